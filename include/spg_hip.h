@@ -1,0 +1,155 @@
+/*
+ * spg_hip.h -- C ABI of libspg_hip.so, the MI355X (gfx950 / CDNA4) implementation of the
+ * superpoint-graph learning hot path of loicland/superpoint_graph:
+ *   PointNet superpoint embedding + edge-conditioned graph convolution (ECC) with GRU update,
+ *   forward and backward.
+ *
+ * The reference has no FFI registry; its boundary to native code is one call site
+ * (learning/ecc/cuda_kernels.py:117-139, invoked from learning/ecc/GraphConvModule.py:78-80,110-112)
+ * plus stock torch.nn calls.  Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer borrowed for the duration of
+ *     the call (the caller -- torch -- owns all memory; the library never allocates device memory);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - return value: 0 on success, a hipError_t (>0) if a launch failed, -1 for an argument error;
+ *     spg_last_error() returns the message (thread local);
+ *   - matrices are row-major fp32 unless stated; index buffers are int64 exactly as
+ *     learning/ecc/GraphConvInfo.py:62-69 produces them.
+ */
+#ifndef SPG_HIP_H
+#define SPG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPG_MAX_LAYERS 8
+#define SPG_VERSION 100
+
+const char* spg_last_error(void);
+int spg_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph structure.  Replaces GraphConvInfo.cuda() (learning/ecc/GraphConvInfo.py:71-76) and the
+ * per-call torch.cumsum(degs) of learning/ecc/cuda_kernels.py:123,135: builds, on the device, the CSR
+ * by target (rowptr, dst) and the reverse CSR by source used by the atomic-free backward.
+ * idxn: int64 [E] source node per edge (edges sorted by target); degs: int64 [N] in-degrees.
+ * ---------------------------------------------------------------------------------------------- */
+size_t spg_graph_workspace_bytes(int N, int E);
+int spg_graph_build(const int64_t* idxn, const int64_t* degs, int N, int E, void* graph_ws, void* stream);
+/* debug / test view: copies of the derived int32 arrays (device pointers, sizes N+1, E, E, N+1, E) */
+int spg_graph_export(const void* graph_ws, int N, int E, int32_t* rowptr, int32_t* src, int32_t* dst,
+                     int32_t* rev_rowptr, int32_t* rev_eid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic ECC operator = GraphConvFunction.forward/backward (learning/ecc/GraphConvModule.py:44-152)
+ * including the segment mean of conv_aggregate_fw/bw (learning/ecc/cuda_kernels.py:55-139).
+ * dtype: 0 = float32, 1 = float64.  x [n_x_rows, cin]; w [n_w_rows, cin, cout] (w_is_matrix) or
+ * [n_w_rows, cin] (cin == cout); idxe: int64 [E] filter index per edge or NULL (identity);
+ * out / grad_out [N, cout]; grad_x [n_x_rows, cin]; grad_w like w.  Results do not depend on the
+ * reference's edge_mem_limit sharding, so there is no such argument.
+ * ---------------------------------------------------------------------------------------------- */
+int spg_ecc_aggregate_fwd(int dtype, const void* x, const void* w, const int64_t* idxe, const void* graph_ws, int N,
+                          int E, int cin, int cout, int w_is_matrix, void* out, void* stream);
+int spg_ecc_aggregate_bwd(int dtype, const void* x, const void* w, const int64_t* idxe, const void* graph_ws, int N,
+                          int E, int n_x_rows, int n_w_rows, int cin, int cout, int w_is_matrix, const void* grad_out,
+                          void* grad_x, void* grad_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GRUCellEx.forward / backward (learning/modules.py:224-251), hidden = input = 32 channels.
+ * params: 6 pointers {weight_ih [96,32], weight_hh [96,32], bias_ih [96], bias_hh [96],
+ * ig.weight [32,32], ig.bias [32]} (the last two may be NULL when ingate == 0).
+ * scratch: >= spg_gru_scratch_floats(n) floats.  grads: 6 pointers like params.
+ * ---------------------------------------------------------------------------------------------- */
+size_t spg_gru_scratch_floats(int n_rows);
+int spg_gru_cell_fwd(const float* input, const float* hidden, int n_rows, const float* const* params, int layernorm,
+                     int ingate, float* out, float* scratch, void* stream);
+int spg_gru_cell_bwd(const float* input, const float* hidden, const float* grad_out, int n_rows,
+                     const float* const* params, int layernorm, int ingate, float* grad_input, float* grad_hidden,
+                     float* const* grads, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused dense layer on the MFMA row-GEMM core (replaces nn.Linear / nn.Conv1d(k=1) + the preceding
+ * BatchNorm/ReLU, e.g. learning/graphnet.py:47-49):  Y = act(X * in_scale + in_shift) @ W^T + bias.
+ * X [M, ldx] (first K columns used), W [N, K], in_scale / in_shift [K] or NULL, Y [M, ldy].
+ * spg_linear_wgrad: dW [N, K] = dY^T @ act(X*in_scale+in_shift); work >= spg_linear_wgrad_work_floats.
+ * ---------------------------------------------------------------------------------------------- */
+int spg_linear_fwd(const float* X, long ldx, int M, int K, const float* W, const float* bias, int N,
+                   const float* in_scale, const float* in_shift, int in_relu, float* Y, long ldy, void* stream);
+size_t spg_linear_wgrad_work_floats(int M, int N, int K);
+int spg_linear_wgrad(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K, const float* in_scale,
+                     const float* in_shift, int in_relu, float* dW, float* work, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PointNet (learning/pointnet.py:16-133): STNkD + per-point MLP + max-pool + FC head, train-mode
+ * BatchNorm statistics over the whole batch, eval mode from the running statistics.
+ * Replaces PointNet.forward / its autograd backward (and the recompute of CloudEmbedder.bw_hook,
+ * learning/pointnet.py:160-176: activations are kept instead, the running statistics are updated
+ * `bn_update_times` times to reproduce the double forward).
+ *
+ * params / grads: one group of 6 pointers per layer, in this layer order:
+ *   stn.convs[0..n_stn_conv), stn.fcs[0..n_stn_fc), stn.proj, convs[0..n_conv), fcs[0..n_fc)
+ * group = {weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var}; absent entries NULL
+ * (grads: {d weight, d bias, d bn.weight, d bn.bias, NULL, NULL}).  With nfeat_stn == 0 the STN
+ * groups are omitted.
+ * clouds [B, nfeat, npts] fp32, clouds_global [B, nfeat_global]; emb [B, fc[n_fc-1]].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct spg_pointnet_cfg {
+  int nfeat, nfeat_stn, nfeat_global, npts;
+  int n_stn_conv, n_stn_fc, n_conv, n_fc;
+  int stn_conv[SPG_MAX_LAYERS], stn_fc[SPG_MAX_LAYERS], conv[SPG_MAX_LAYERS], fc[SPG_MAX_LAYERS];
+  int last_ac;          /* BatchNorm+ReLU after the last FC (PointNet(last_ac=True)) */
+  float bn_eps, bn_momentum;
+} spg_pointnet_cfg;
+
+int spg_pointnet_num_layers(const spg_pointnet_cfg* cfg);
+size_t spg_pointnet_workspace_bytes(const spg_pointnet_cfg* cfg, int B, int training);
+int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
+                         const void* const* params, float* emb, void* workspace, int training, int bn_update_times,
+                         void* stream);
+size_t spg_pointnet_bwd_workspace_bytes(const spg_pointnet_cfg* cfg, int B);
+int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
+                          const void* const* params, const float* grad_emb, void* const* grads, void* workspace,
+                          void* bwd_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RNN-ECC module = RNNGraphConvModule.forward (learning/modules.py:152-183) with a GRUCellEx cell:
+ * filter-generating MLP on the edge features (learning/graphnet.py:17-34, once per forward), then
+ * nrepeats x { ECC aggregate (GraphConvFunction) ; GRU }, states concatenated when cat_all.
+ * params / grads groups (6 pointers each, as above): fnet linear layers [0..n_fnet) (the BatchNorm
+ * after layer `bnidx` lives in that layer's group), then one group for the cell:
+ *   {weight_ih, weight_hh, bias_ih, bias_hh, ig.weight, ig.bias}.
+ * h0 [N, nc] (nc must be 32), edgefeats [E, fnet_widths[0]]; out [N, nc*(nrepeats+1)] (cat_all) or [N, nc].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct spg_eccrnn_cfg {
+  int nc, nrepeats, matrix, layernorm, ingate, cat_all;
+  int n_fnet;                           /* number of Linear layers of the filter network */
+  int fnet_widths[SPG_MAX_LAYERS + 1];  /* n_fnet + 1 entries: input width ... output width */
+  int bnidx, llbias;
+  float bn_eps, bn_momentum;
+} spg_eccrnn_cfg;
+
+size_t spg_eccrnn_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E, int training);
+int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0,
+                       const float* edgefeats, const void* const* params, float* out, void* workspace, int training,
+                       int bn_update_times, void* stream);
+size_t spg_eccrnn_bwd_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E);
+int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
+                        const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
+                        void* workspace, void* bwd_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Instrumentation for bench.py: when enabled, every launch of the row-GEMM kernels is bracketed by
+ * hipEvents on its own stream; spg_prof_read synchronises and returns the accumulated milliseconds,
+ * launch count and algorithmic FLOPs since the last reset.
+ * ---------------------------------------------------------------------------------------------- */
+void spg_prof_enable(int on);
+int spg_prof_read(double* ms, long* launches, double* flops, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPG_HIP_H */

@@ -1,0 +1,278 @@
+// C-ABI entry points of libspg_hip.so that are thin wrappers over the kernels (graph build, generic ECC
+// operator for arbitrary channel counts / fp64, stand-alone GRU cell, fused dense layer).
+// The network-level entry points live in spg_pointnet.hip and spg_eccnet.hip.
+#include "../../include/spg_hip.h"
+#include "spg_ecc.h"
+#include "spg_gemm.h"
+
+extern "C" int spg_version(void) { return SPG_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// graph
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t spg_graph_workspace_bytes(int N, int E) { return spg_graph_bytes(N, E); }
+
+extern "C" int spg_graph_build(const int64_t* idxn, const int64_t* degs, int N, int E, void* graph_ws, void* stream) {
+  SPG_CHECK_ARG(degs && graph_ws && (E == 0 || idxn), "null pointer");
+  return spg_graph_build_impl(idxn, degs, N, E, graph_ws, (hipStream_t)stream);
+}
+
+extern "C" int spg_graph_export(const void* graph_ws, int N, int E, int32_t* rowptr, int32_t* src, int32_t* dst,
+                                int32_t* rev_rowptr, int32_t* rev_eid, void* stream) {
+  SPG_CHECK_ARG(graph_ws != nullptr, "null pointer");
+  SpgGraph g = spg_graph_view(graph_ws, N, E);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipSuccess;
+  if (rowptr) e = hipMemcpyAsync(rowptr, g.rowptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && src && E) e = hipMemcpyAsync(src, g.src, (size_t)E * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && dst && E) e = hipMemcpyAsync(dst, g.dst, (size_t)E * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && rev_rowptr) e = hipMemcpyAsync(rev_rowptr, g.rev_rowptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && rev_eid && E) e = hipMemcpyAsync(rev_eid, g.rev_eid, (size_t)E * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { spg_set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic ECC operator (any channel counts, fp32 / fp64, optional idxe) -- API completeness for
+// GraphConvFunction.apply; the 32-channel fp32 hot path uses the fused kernels of spg_ecc.hip.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void spg_ecc_generic_fwd_kernel(SpgGraph g, const T* __restrict__ x, const T* __restrict__ w,
+                                           const int64_t* __restrict__ idxe, int cin, int cout, int matrix,
+                                           T* __restrict__ out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)g.N * cout) return;
+  const int i = (int)(t / cout), c = (int)(t - (long)i * cout);
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  T acc = 0;
+  for (int e = e0; e < e1; ++e) {
+    const long we = idxe ? (long)idxe[e] : (long)e;
+    const T* xj = x + (long)g.src[e] * cin;
+    if (matrix) {
+      const T* W = w + we * (long)cin * cout;
+      for (int k = 0; k < cin; ++k) acc += xj[k] * W[(long)k * cout + c];
+    } else {
+      acc += xj[c] * w[we * cout + c];
+    }
+  }
+  out[t] = e1 > e0 ? acc / (T)(e1 - e0) : (T)0;
+}
+
+template <typename T>
+__global__ void spg_ecc_generic_bwd_x_kernel(SpgGraph g, const T* __restrict__ w, const int64_t* __restrict__ idxe,
+                                             const T* __restrict__ go, int n_x_rows, int cin, int cout, int matrix,
+                                             T* __restrict__ gx) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n_x_rows * cin) return;
+  const int j = (int)(t / cin), k = (int)(t - (long)j * cin);
+  T acc = 0;
+  if (j < g.N) {
+    for (int q = g.rev_rowptr[j]; q < g.rev_rowptr[j + 1]; ++q) {
+      const int e = g.rev_eid[q];
+      const int d = g.dst[e];
+      const T inv = (T)1 / (T)(g.rowptr[d + 1] - g.rowptr[d]);
+      const long we = idxe ? (long)idxe[e] : (long)e;
+      if (matrix) {
+        const T* W = w + we * (long)cin * cout + (long)k * cout;
+        T s = 0;
+        for (int c = 0; c < cout; ++c) s += go[(long)d * cout + c] * W[c];
+        acc += s * inv;
+      } else {
+        acc += go[(long)d * cout + k] * inv * w[we * cout + k];
+      }
+    }
+  }
+  gx[t] = acc;
+}
+
+template <typename T>
+__global__ void spg_ecc_generic_bwd_w_kernel(SpgGraph g, const T* __restrict__ x, const int64_t* __restrict__ idxe,
+                                             const T* __restrict__ go, int cin, int cout, int matrix,
+                                             T* __restrict__ gw) {
+  const long per = matrix ? (long)cin * cout : (long)cout;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)g.E * per) return;
+  const int e = (int)(t / per);
+  const long rem = t - (long)e * per;
+  const int d = g.dst[e];
+  const T inv = (T)1 / (T)(g.rowptr[d + 1] - g.rowptr[d]);
+  const T* xj = x + (long)g.src[e] * cin;
+  T v;
+  if (matrix) {
+    const int k = (int)(rem / cout), c = (int)(rem - (long)k * cout);
+    v = xj[k] * (go[(long)d * cout + c] * inv);
+  } else {
+    v = xj[rem] * (go[(long)d * cout + rem] * inv);
+  }
+  if (idxe) atomicAdd(&gw[(long)idxe[e] * per + rem], v);   // filter sharing (never used by the SPG path)
+  else gw[t] = v;
+}
+
+template <typename T>
+static int ecc_generic_fwd(const void* x, const void* w, const int64_t* idxe, const SpgGraph& g, int cin, int cout,
+                           int matrix, void* out, hipStream_t st) {
+  const long n = (long)g.N * cout;
+  hipLaunchKernelGGL(spg_ecc_generic_fwd_kernel<T>, dim3(spg_cdiv(n, 256)), dim3(256), 0, st, g, (const T*)x, (const T*)w,
+                     idxe, cin, cout, matrix, (T*)out);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int ecc_generic_bwd(const void* x, const void* w, const int64_t* idxe, const SpgGraph& g, int n_x_rows,
+                           int n_w_rows, int cin, int cout, int matrix, const void* go, void* gx, void* gw,
+                           hipStream_t st) {
+  if (gx) {
+    const long n = (long)n_x_rows * cin;
+    hipLaunchKernelGGL(spg_ecc_generic_bwd_x_kernel<T>, dim3(spg_cdiv(n, 256)), dim3(256), 0, st, g, (const T*)w, idxe,
+                       (const T*)go, n_x_rows, cin, cout, matrix, (T*)gx);
+    SPG_LAUNCH_CHECK();
+  }
+  if (gw) {
+    const long per = matrix ? (long)cin * cout : (long)cout;
+    if (idxe) {
+      hipError_t e = hipMemsetAsync(gw, 0, (size_t)n_w_rows * per * sizeof(T), st);
+      if (e != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    const long n = (long)g.E * per;
+    if (n > 0) {
+      hipLaunchKernelGGL(spg_ecc_generic_bwd_w_kernel<T>, dim3(spg_cdiv(n, 256)), dim3(256), 0, st, g, (const T*)x, idxe,
+                         (const T*)go, cin, cout, matrix, (T*)gw);
+      SPG_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+extern "C" int spg_ecc_aggregate_fwd(int dtype, const void* x, const void* w, const int64_t* idxe, const void* graph_ws,
+                                     int N, int E, int cin, int cout, int w_is_matrix, void* out, void* stream) {
+  SPG_CHECK_ARG(x && out && graph_ws && (E == 0 || w), "null pointer");
+  SPG_CHECK_ARG(dtype == 0 || dtype == 1, "dtype must be 0 (f32) or 1 (f64)");
+  SPG_CHECK_ARG(w_is_matrix || cin == cout, "vector filters need cin == cout");
+  SpgGraph g = spg_graph_view(graph_ws, N, E);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0 && cin == 32 && cout == 32 && idxe == nullptr) {   // hot-path shape: fused wave-per-node kernel
+    SpgEccStepFwd p; memset(&p, 0, sizeof(p));
+    p.g = g; p.W = (const float*)w; p.matrix = w_is_matrix; p.hin = (const float*)x; p.ld = 32;
+    p.agg_save = (float*)out; p.ldagg = 32; p.do_gru = 0;
+    return spg_launch_ecc_step_fwd(p, st);
+  }
+  return dtype == 0 ? ecc_generic_fwd<float>(x, w, idxe, g, cin, cout, w_is_matrix, out, st)
+                    : ecc_generic_fwd<double>(x, w, idxe, g, cin, cout, w_is_matrix, out, st);
+}
+
+extern "C" int spg_ecc_aggregate_bwd(int dtype, const void* x, const void* w, const int64_t* idxe, const void* graph_ws,
+                                     int N, int E, int n_x_rows, int n_w_rows, int cin, int cout, int w_is_matrix,
+                                     const void* grad_out, void* grad_x, void* grad_w, void* stream) {
+  SPG_CHECK_ARG(x && grad_out && graph_ws && (E == 0 || w), "null pointer");
+  SPG_CHECK_ARG(dtype == 0 || dtype == 1, "dtype must be 0 (f32) or 1 (f64)");
+  SpgGraph g = spg_graph_view(graph_ws, N, E);
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == 0 ? ecc_generic_bwd<float>(x, w, idxe, g, n_x_rows, n_w_rows, cin, cout, w_is_matrix, grad_out, grad_x,
+                                             grad_w, st)
+                    : ecc_generic_bwd<double>(x, w, idxe, g, n_x_rows, n_w_rows, cin, cout, w_is_matrix, grad_out,
+                                              grad_x, grad_w, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone GRUCellEx
+// ---------------------------------------------------------------------------------------------
+// scratch layout (floats): w_ih_t 3072 | w_hh_t 3072 | w_ig_t 1024 | dgi n*96 | dgh n*96 | dui n*96 | duh n*96 |
+//                          dpre n*32 | xg n*32 | G n*32 | dhdir n*32 | wgrad work
+static size_t gru_work_floats(int n) { return spg_wgrad_workspace_floats(n, 96, 32); }
+extern "C" size_t spg_gru_scratch_floats(int n) { return 7168 + (size_t)n * (4 * 96 + 4 * 32) + gru_work_floats(n) + 64; }
+
+static int gru_pack(const float* const* params, int layernorm, int ingate, float* scratch, SpgGruParams& G, hipStream_t st) {
+  memset(&G, 0, sizeof(G));
+  G.w_ih = params[0]; G.w_hh = params[1]; G.b_ih = params[2]; G.b_hh = params[3]; G.w_ig = params[4]; G.b_ig = params[5];
+  SPG_CHECK_ARG(G.w_ih && G.w_hh && G.b_ih && G.b_hh, "missing GRU parameters");
+  SPG_CHECK_ARG(!ingate || (G.w_ig && G.b_ig), "missing input-gate parameters");
+  G.layernorm = layernorm; G.ingate = ingate;
+  float* t = scratch;
+  SPG_TRY(spg_launch_transpose(G.w_ih, 96, 32, t, st));
+  SPG_TRY(spg_launch_transpose(G.w_hh, 96, 32, t + 3072, st));
+  if (ingate) SPG_TRY(spg_launch_transpose(G.w_ig, 32, 32, t + 6144, st));
+  G.w_ih_t = t; G.w_hh_t = t + 3072; G.w_ig_t = t + 6144;
+  return 0;
+}
+
+extern "C" int spg_gru_cell_fwd(const float* input, const float* hidden, int n, const float* const* params, int layernorm,
+                                int ingate, float* out, float* scratch, void* stream) {
+  SPG_CHECK_ARG(input && hidden && params && out && scratch && n > 0, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SpgEccStepFwd p; memset(&p, 0, sizeof(p));
+  SPG_TRY(gru_pack(params, layernorm, ingate, scratch, p.gru, st));
+  p.g.N = n; p.agg_in = input; p.ldagg = 32; p.hin = hidden; p.hout = out; p.ld = 32; p.do_gru = 1;
+  return spg_launch_ecc_step_fwd(p, st);
+}
+
+extern "C" int spg_gru_cell_bwd(const float* input, const float* hidden, const float* grad_out, int n,
+                                const float* const* params, int layernorm, int ingate, float* grad_input,
+                                float* grad_hidden, float* const* grads, float* scratch, void* stream) {
+  SPG_CHECK_ARG(input && hidden && grad_out && params && grad_input && grad_hidden && grads && scratch && n > 0,
+                "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SpgEccStepBwd p; memset(&p, 0, sizeof(p));
+  SPG_TRY(gru_pack(params, layernorm, ingate, scratch, p.gru, st));
+  float* f = scratch + 7168;
+  float* dgi = f; f += (size_t)n * 96;
+  float* dgh = f; f += (size_t)n * 96;
+  float* dui = f; f += (size_t)n * 96;
+  float* duh = f; f += (size_t)n * 96;
+  float* dpre = f; f += (size_t)n * 32;
+  float* xg = f; f += (size_t)n * 32;
+  f += (size_t)n * 64;   // (G, dhdir written straight to the outputs)
+  float* work = f;
+  p.g.N = n;   // invdeg == nullptr: no degree scaling
+  p.dcat = grad_out; p.ldc = 32; p.dhdir = grad_hidden; p.use_dhdir = 0;
+  p.hin = hidden; p.ld = 32; p.agg = input; p.ldagg = 32; p.Gcur = grad_input; p.ldg = 32;
+  p.dgi = dgi; p.dgh = dgh; p.dui = dui; p.duh = duh; p.ld96 = 96; p.dpre = dpre; p.xg = xg; p.ld32 = 32;
+  SPG_TRY(spg_launch_ecc_step_bwd(p, st));
+  auto ident = [](const float* X, long ld) { SpgOperand o; memset(&o, 0, sizeof(o)); o.mode = SPG_PRO_IDENT; o.X = X; o.ld = ld; return o; };
+  SpgWgradParams w; memset(&w, 0, sizeof(w));
+  w.M = n; w.N = 96; w.K = 32;
+  if (grads[0]) { w.a = ident(dgi, 96); w.b = ident(xg, 32); SPG_TRY(spg_launch_wgrad(w, grads[0], work, st)); }
+  if (grads[1]) { w.a = ident(dgh, 96); w.b = ident(hidden, 32); SPG_TRY(spg_launch_wgrad(w, grads[1], work, st)); }
+  if (grads[2]) SPG_TRY(spg_launch_colsum(dui, 96, n, 96, grads[2], st));
+  if (grads[3]) SPG_TRY(spg_launch_colsum(duh, 96, n, 96, grads[3], st));
+  if (ingate) {
+    w.N = 32;
+    if (grads[4]) { w.a = ident(dpre, 32); w.b = ident(hidden, 32); SPG_TRY(spg_launch_wgrad(w, grads[4], work, st)); }
+    if (grads[5]) SPG_TRY(spg_launch_colsum(dpre, 32, n, 32, grads[5], st));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused dense layer
+// ---------------------------------------------------------------------------------------------
+static SpgOperand affine_operand(const float* X, long ld, int K, const float* sc, const float* sh, int relu) {
+  SpgOperand o; memset(&o, 0, sizeof(o));
+  if (sc == nullptr && !relu) { o.mode = SPG_PRO_IDENT; }
+  else { o.mode = SPG_PRO_AFFINE; o.c0 = sc; o.c1 = sh; o.relu = relu; o.n_affine = K; }
+  o.X = X; o.ld = ld;
+  return o;
+}
+
+extern "C" int spg_linear_fwd(const float* X, long ldx, int M, int K, const float* W, const float* bias, int N,
+                              const float* in_scale, const float* in_shift, int in_relu, float* Y, long ldy, void* stream) {
+  SPG_CHECK_ARG(X && W && Y, "null pointer");
+  SPG_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale and in_shift go together");
+  SpgGemmParams g; memset(&g, 0, sizeof(g));
+  g.a = affine_operand(X, ldx, K, in_scale, in_shift, in_relu);
+  g.W = W; g.ldw = K; g.bias = bias; g.M = M; g.N = N; g.K = K; g.rows_per_tile = 128; g.epi = SPG_EPI_FWD; g.Y = Y; g.ldy = ldy;
+  return spg_launch_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" size_t spg_linear_wgrad_work_floats(int M, int N, int K) { return spg_wgrad_workspace_floats(M, N, K); }
+
+extern "C" int spg_linear_wgrad(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K,
+                                const float* in_scale, const float* in_shift, int in_relu, float* dW, float* work,
+                                void* stream) {
+  SPG_CHECK_ARG(dY && X && dW && work, "null pointer");
+  SpgWgradParams w; memset(&w, 0, sizeof(w));
+  w.a = affine_operand(dY, lddy, N, nullptr, nullptr, 0);
+  w.b = affine_operand(X, ldx, K, in_scale, in_shift, in_relu);
+  w.M = M; w.N = N; w.K = K;
+  return spg_launch_wgrad(w, dW, work, (hipStream_t)stream);
+}

@@ -1,0 +1,85 @@
+// Internal (C++) interface of the edge-conditioned-convolution / GRU kernels (spg_ecc.hip).
+#pragma once
+#include "spg_common.h"
+
+// Device-side graph structure derived from GraphConvInfo's (idxn, degs)
+// (reference: learning/ecc/GraphConvInfo.py:33-69): CSR by target (edges are already sorted by
+// target) and the reverse CSR by source used by the atomic-free backward.
+struct SpgGraph {
+  int N, E;
+  const int* rowptr;      // [N+1] start of each destination node's in-edge segment
+  const int* src;         // [E]   source node of each edge (= idxn)
+  const int* dst;         // [E]   destination node of each edge
+  const int* rev_rowptr;  // [N+1] start of each source node's out-edge list
+  const int* rev_eid;     // [E]   edge ids grouped by source, increasing inside a group
+  const float* invdeg;    // [N]   1/in-degree, 0 for isolated nodes
+};
+
+size_t spg_graph_bytes(int N, int E);
+SpgGraph spg_graph_view(const void* workspace, int N, int E);
+int spg_graph_build_impl(const int64_t* idxn, const int64_t* degs, int N, int E, void* workspace, hipStream_t stream);
+
+struct SpgGruParams {   // GRUCellEx (learning/modules.py:205-259), hidden = input = 32
+  const float* w_ih;    // [96,32]
+  const float* w_hh;    // [96,32]
+  const float* b_ih;    // [96]
+  const float* b_hh;    // [96]
+  const float* w_ig;    // [32,32]
+  const float* b_ig;    // [32]
+  const float* w_ih_t;  // [32,96] transposed copies (forward: coalesced over outputs)
+  const float* w_hh_t;  // [32,96]
+  const float* w_ig_t;  // [32,32]
+  int layernorm, ingate;
+};
+
+// one RNN-ECC iteration, forward: agg = mean_{in-edges} x_src (.) W_e ; h' = GRU(agg, h)
+struct SpgEccStepFwd {
+  SpgGraph g;
+  const float* W;       // [E,32,32] (matrix) or [E,32] (vector)
+  int matrix;
+  const float* hin;     // h^r   rows of ld floats
+  float* hout;          // h^r+1
+  long ld;
+  const float* agg_in;  // non-null: skip the aggregation (stand-alone GRU cell), [N, ldagg]
+  float* agg_save;      // [N, ldagg] or null
+  long ldagg;
+  int do_gru;           // 0: aggregation only (result in agg_save)
+  SpgGruParams gru;
+};
+int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream);
+
+struct SpgEccStepBwd {
+  SpgGraph g;
+  const float* W;
+  int matrix;
+  // phase 1: dH = dcat + dhdir + sum_{out-edges} W_e . Gnext[dst]
+  const float* dcat;    // [N, ldc] slice (already offset to this state's columns) or null
+  long ldc;
+  const float* Gnext;   // [N, ldg] gradient wrt the aggregate of the NEXT iteration (already / deg), or null
+  long ldg;
+  float* dhdir;         // [N,32] in/out: direct GRU-path gradient wrt the hidden state
+  int use_dhdir;
+  float* gx;            // final_only: output gradient wrt h^0 [N,32]
+  int final_only;
+  // phase 2: GRU backward of this iteration
+  const float* hin;     // h^r
+  long ld;
+  const float* agg;     // aggregate (GRU input before the input gate) of this iteration [N, ldagg]
+  long ldagg;
+  float* Gcur;          // [N, ldg] out: d agg / deg
+  float* dgi;           // [N, ld96] outputs for the deferred weight gradients
+  float* dgh;
+  float* dui;
+  float* duh;
+  long ld96;
+  float* dpre;          // [N, ld32]
+  float* xg;            // [N, ld32]
+  long ld32;
+  SpgGruParams gru;
+};
+int spg_launch_ecc_step_bwd(const SpgEccStepBwd& p, hipStream_t stream);
+
+// dW_e = sum_r h^r_src (x) g^r_dst  (matrix) / h^r_src * g^r_dst (vector), r = 0..R-1
+int spg_launch_ecc_edge_wgrad(const SpgGraph& g, int matrix, const float* states, long lds, const float* G, long ldg,
+                              int R, float* dW, hipStream_t stream);
+int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream);

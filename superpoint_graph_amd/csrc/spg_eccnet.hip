@@ -1,0 +1,336 @@
+// RNN-ECC module (reference: RNNGraphConvModule.forward, learning/modules.py:152-183): filter-generating MLP on
+// the superedge features (learning/graphnet.py:17-34), then nrepeats x {ECC aggregate, GRUCellEx}.
+// Host-side orchestration of the forward / backward kernel sequences and the workspace layout.
+//
+// HBM layout: every per-node quantity that exists once per iteration is stored as [N][R+1][C]
+// (states h^r, aggregates, and in the backward the gate gradients), so that "all iterations" is a plain
+// row-major matrix with (R+1)*N rows for the deferred weight-gradient GEMMs, and a node's history is
+// contiguous for the per-edge filter gradient (summed over the iterations in registers, written once).
+#include "../../include/spg_hip.h"
+#include "spg_ecc.h"
+#include "spg_gemm.h"
+#include <vector>
+
+namespace {
+
+struct FLayer {
+  int cin = 0, cout = 0;
+  bool bn = false, relu = false;
+  const float *W = nullptr, *b = nullptr, *gamma = nullptr, *beta = nullptr;
+  float *rm = nullptr, *rv = nullptr;
+  float* y = nullptr;
+  float *mean = nullptr, *rstd = nullptr, *s = nullptr, *t = nullptr;
+  float *dW = nullptr, *db = nullptr, *dgamma = nullptr, *dbeta = nullptr;
+};
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Plan {
+  spg_eccrnn_cfg cfg;
+  int N = 0, E = 0, R = 0, nout = 0;
+  long ldS = 0;                 // (R+1)*32
+  bool training = false;
+  std::vector<FLayer> F;
+  SpgGruParams gru;
+  float *states = nullptr, *agg = nullptr, *stat = nullptr;
+  float *wih_t = nullptr, *whh_t = nullptr, *wig_t = nullptr;
+  float* cell_grads[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t bytes = 0;
+};
+
+int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, const void* const* params, Plan& pl) {
+  SPG_CHECK_ARG(cfg != nullptr && N > 0 && E >= 0, "cfg / N / E");
+  const spg_eccrnn_cfg& c = *cfg;
+  SPG_CHECK_ARG(c.nc == 32, "the fused RNN-ECC path needs 32 channels");
+  SPG_CHECK_ARG(c.nrepeats >= 1, "nrepeats >= 1");
+  SPG_CHECK_ARG(c.n_fnet >= 1 && c.n_fnet <= SPG_MAX_LAYERS, "n_fnet");
+  SPG_CHECK_ARG(c.bnidx < c.n_fnet - 1 || c.bnidx < 0, "BatchNorm after the last filter layer is not supported");
+  pl.cfg = c; pl.N = N; pl.E = E; pl.R = c.nrepeats; pl.training = training != 0;
+  pl.ldS = (long)(pl.R + 1) * 32;
+  pl.nout = c.matrix ? 1024 : 32;
+  SPG_CHECK_ARG(c.fnet_widths[c.n_fnet] == pl.nout, "filter network output width must be nc*nc (matrix) or nc (vector)");
+  Carver cv(ws);
+  pl.F.assign(c.n_fnet, FLayer());
+  int cmax = 4;
+  for (int i = 0; i < c.n_fnet; ++i) {
+    FLayer& l = pl.F[i];
+    l.cin = c.fnet_widths[i]; l.cout = c.fnet_widths[i + 1];
+    l.bn = (c.bnidx == i); l.relu = i < c.n_fnet - 1;
+    cmax = l.cout > cmax ? l.cout : cmax;
+    if (params) {
+      const void* const* g = params + 6 * i;
+      l.W = (const float*)g[0]; l.b = (const float*)g[1]; l.gamma = (const float*)g[2]; l.beta = (const float*)g[3];
+      l.rm = (float*)g[4]; l.rv = (float*)g[5];
+      SPG_CHECK_ARG(l.W != nullptr, "missing filter-network weight");
+      SPG_CHECK_ARG(!l.bn || (l.rm && l.rv), "missing BatchNorm running statistics");
+    }
+    l.y = cv.take<float>((size_t)(E > 0 ? E : 1) * l.cout);
+    if (l.bn) {
+      l.mean = cv.take<float>(l.cout); l.rstd = cv.take<float>(l.cout);
+      l.s = cv.take<float>(l.cout); l.t = cv.take<float>(l.cout);
+    }
+  }
+  memset(&pl.gru, 0, sizeof(pl.gru));
+  if (params) {
+    const void* const* g = params + 6 * c.n_fnet;
+    pl.gru.w_ih = (const float*)g[0]; pl.gru.w_hh = (const float*)g[1];
+    pl.gru.b_ih = (const float*)g[2]; pl.gru.b_hh = (const float*)g[3];
+    pl.gru.w_ig = (const float*)g[4]; pl.gru.b_ig = (const float*)g[5];
+    SPG_CHECK_ARG(pl.gru.w_ih && pl.gru.w_hh && pl.gru.b_ih && pl.gru.b_hh, "missing GRU parameters");
+    SPG_CHECK_ARG(!c.ingate || (pl.gru.w_ig && pl.gru.b_ig), "missing input-gate parameters");
+  }
+  pl.gru.layernorm = c.layernorm; pl.gru.ingate = c.ingate;
+  pl.wih_t = cv.take<float>(96 * 32); pl.whh_t = cv.take<float>(96 * 32); pl.wig_t = cv.take<float>(32 * 32);
+  pl.gru.w_ih_t = pl.wih_t; pl.gru.w_hh_t = pl.whh_t; pl.gru.w_ig_t = pl.wig_t;
+  pl.states = cv.take<float>((size_t)N * pl.ldS);
+  pl.agg = cv.take<float>((size_t)N * pl.ldS);
+  pl.stat = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, 128) * 2 * cmax);
+  pl.bytes = cv.off + 256;
+  return 0;
+}
+
+SpgOperand op_ident(const float* X, long ld) {
+  SpgOperand o; memset(&o, 0, sizeof(o));
+  o.mode = SPG_PRO_IDENT; o.X = X; o.ld = ld;
+  return o;
+}
+
+SpgOperand fnet_input(const Plan& pl, int i, const float* edgefeats) {
+  if (i == 0) return op_ident(edgefeats, pl.F[0].cin);
+  const FLayer& p = pl.F[i - 1];
+  SpgOperand o; memset(&o, 0, sizeof(o));
+  o.mode = SPG_PRO_AFFINE; o.X = p.y; o.ld = p.cout; o.relu = p.relu ? 1 : 0; o.n_affine = p.cout;
+  if (p.bn) { o.c0 = p.s; o.c1 = p.t; }
+  return o;
+}
+
+SpgOperand op_bnbwd(const float* dz, const float* y, long ld, const float* consts, int C) {
+  SpgOperand o; memset(&o, 0, sizeof(o));
+  o.mode = SPG_PRO_BNBWD; o.X = dz; o.X2 = y; o.ld = ld;
+  o.c0 = consts; o.c1 = consts + C; o.c2 = consts + 2 * C; o.c3 = consts + 3 * C;
+  return o;
+}
+
+int zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (p == nullptr || bytes == 0) return 0;
+  hipError_t e = hipMemsetAsync(p, 0, bytes, st);
+  if (e != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+struct BwdScratch {
+  float *G = nullptr, *dgi = nullptr, *dgh = nullptr, *dui = nullptr, *duh = nullptr, *dpre = nullptr, *xg = nullptr;
+  float *dhdir = nullptr, *dWts = nullptr, *dzA = nullptr, *dzB = nullptr, *Wt = nullptr, *consts = nullptr;
+  float *work = nullptr, *stat = nullptr;
+  size_t zero_bytes = 0;   // the leading region [G .. xg] must be zero-initialised
+  size_t bytes = 0;
+};
+
+void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
+  Carver cv(ws);
+  const size_t rows = (size_t)pl.N * (pl.R + 1);
+  s.G = cv.take<float>(rows * 32);
+  s.dgi = cv.take<float>(rows * 96); s.dgh = cv.take<float>(rows * 96);
+  s.dui = cv.take<float>(rows * 96); s.duh = cv.take<float>(rows * 96);
+  s.dpre = cv.take<float>(rows * 32); s.xg = cv.take<float>(rows * 32);
+  s.zero_bytes = cv.off;
+  s.dhdir = cv.take<float>((size_t)pl.N * 32);
+  const size_t Er = pl.E > 0 ? pl.E : 1;
+  s.dWts = cv.take<float>(Er * pl.nout);
+  int cmax = 4;
+  size_t wmax = 96 * 32, workmax = 16;
+  for (const FLayer& l : pl.F) {
+    cmax = l.cout > cmax ? l.cout : cmax; cmax = l.cin > cmax ? l.cin : cmax;
+    wmax = (size_t)l.cin * l.cout > wmax ? (size_t)l.cin * l.cout : wmax;
+    const size_t w = spg_wgrad_workspace_floats(Er, l.cout, l.cin);
+    workmax = w > workmax ? w : workmax;
+  }
+  {
+    const size_t w = spg_wgrad_workspace_floats((long)rows, 96, 32);
+    workmax = w > workmax ? w : workmax;
+  }
+  int hmax = 4;   // widest hidden activation
+  for (int i = 0; i + 1 < (int)pl.F.size(); ++i) hmax = pl.F[i].cout > hmax ? pl.F[i].cout : hmax;
+  s.dzA = cv.take<float>(Er * hmax); s.dzB = cv.take<float>(Er * hmax);
+  s.Wt = cv.take<float>(wmax);
+  s.consts = cv.take<float>((size_t)4 * cmax);
+  s.work = cv.take<float>(workmax);
+  s.stat = cv.take<float>((size_t)spg_cdiv(Er, 128) * 2 * cmax);
+  s.bytes = cv.off + 256;
+}
+
+}  // namespace
+
+extern "C" size_t spg_eccrnn_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E, int training) {
+  Plan pl;
+  if (make_plan(cfg, N, E, training, nullptr, nullptr, pl) != 0) return 0;
+  return pl.bytes;
+}
+
+extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0,
+                                  const float* edgefeats, const void* const* params, float* out, void* workspace,
+                                  int training, int bn_update_times, void* stream) {
+  SPG_CHECK_ARG(graph_ws && h0 && params && out && workspace, "null pointer");
+  SPG_CHECK_ARG(E == 0 || edgefeats != nullptr, "edgefeats");
+  hipStream_t st = (hipStream_t)stream;
+  Plan pl;
+  SPG_TRY(make_plan(cfg, N, E, training, workspace, params, pl));
+  // ---- filter-generating network (once per forward, shared by all iterations) ----
+  if (E > 0) {
+    for (int i = 0; i < (int)pl.F.size(); ++i) {
+      FLayer& l = pl.F[i];
+      SpgGemmParams g; memset(&g, 0, sizeof(g));
+      g.a = fnet_input(pl, i, edgefeats);
+      g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = E; g.N = l.cout; g.K = l.cin; g.rows_per_tile = 128;
+      g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.cout;
+      g.stat = (l.bn && pl.training) ? pl.stat : nullptr;
+      SPG_TRY(spg_launch_gemm(g, st));
+      if (l.bn) {
+        if (pl.training)
+          SPG_TRY(spg_launch_bn_finalize(pl.stat, spg_cdiv(E, 128), 128, E, l.cout, l.gamma, l.beta, l.rm, l.rv,
+                                         pl.cfg.bn_momentum, pl.cfg.bn_eps, bn_update_times, l.mean, l.rstd, l.s, l.t, st));
+        else
+          SPG_TRY(spg_launch_bn_eval(l.cout, l.gamma, l.beta, l.rm, l.rv, pl.cfg.bn_eps, l.s, l.t, st));
+      }
+    }
+  }
+  // ---- recurrent part ----
+  SPG_TRY(spg_launch_transpose(pl.gru.w_ih, 96, 32, pl.wih_t, st));
+  SPG_TRY(spg_launch_transpose(pl.gru.w_hh, 96, 32, pl.whh_t, st));
+  if (pl.cfg.ingate) SPG_TRY(spg_launch_transpose(pl.gru.w_ig, 32, 32, pl.wig_t, st));
+  SPG_TRY(spg_launch_copy2d(h0, 32, pl.states, pl.ldS, N, 32, st));
+  SpgGraph gr = spg_graph_view(graph_ws, N, E);
+  for (int r = 0; r < pl.R; ++r) {
+    SpgEccStepFwd p; memset(&p, 0, sizeof(p));
+    p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;
+    p.hin = pl.states + (size_t)r * 32; p.hout = pl.states + (size_t)(r + 1) * 32; p.ld = pl.ldS;
+    p.agg_save = pl.training ? pl.agg + (size_t)r * 32 : nullptr; p.ldagg = pl.ldS;
+    p.do_gru = 1; p.gru = pl.gru;
+    SPG_TRY(spg_launch_ecc_step_fwd(p, st));
+  }
+  if (pl.cfg.cat_all) SPG_TRY(spg_launch_copy2d(pl.states, pl.ldS, out, pl.ldS, N, (int)pl.ldS, st));
+  else SPG_TRY(spg_launch_copy2d(pl.states + (size_t)pl.R * 32, pl.ldS, out, 32, N, 32, st));
+  return 0;
+}
+
+extern "C" size_t spg_eccrnn_bwd_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E) {
+  Plan pl;
+  if (make_plan(cfg, N, E, 1, nullptr, nullptr, pl) != 0) return 0;
+  BwdScratch s;
+  carve_bwd(pl, nullptr, s);
+  return s.bytes;
+}
+
+extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
+                                   const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
+                                   void* workspace, void* bwd_workspace, void* stream) {
+  SPG_CHECK_ARG(graph_ws && params && grad_out && grad_h0 && grads && workspace && bwd_workspace, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  Plan pl;
+  SPG_TRY(make_plan(cfg, N, E, 1, workspace, params, pl));
+  for (int i = 0; i < (int)pl.F.size(); ++i) {
+    void* const* g = grads + 6 * i;
+    pl.F[i].dW = (float*)g[0]; pl.F[i].db = (float*)g[1]; pl.F[i].dgamma = (float*)g[2]; pl.F[i].dbeta = (float*)g[3];
+  }
+  for (int k = 0; k < 6; ++k) pl.cell_grads[k] = (float*)grads[6 * pl.F.size() + k];
+  BwdScratch s;
+  carve_bwd(pl, bwd_workspace, s);
+  SPG_TRY(zero_async(bwd_workspace, s.zero_bytes, st));
+  SpgGraph gr = spg_graph_view(graph_ws, N, E);
+  const int R = pl.R;
+  const long ldS = pl.ldS, ld96 = (long)(R + 1) * 96;
+  // ---- back-propagation through the R iterations ----
+  for (int r = R - 1; r >= 0; --r) {
+    SpgEccStepBwd p; memset(&p, 0, sizeof(p));
+    p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;
+    if (pl.cfg.cat_all) { p.dcat = grad_out + (size_t)(r + 1) * 32; p.ldc = ldS; }
+    else if (r == R - 1) { p.dcat = grad_out; p.ldc = 32; }
+    p.Gnext = r < R - 1 ? s.G + (size_t)(r + 1) * 32 : nullptr; p.ldg = ldS;
+    p.dhdir = s.dhdir; p.use_dhdir = r < R - 1;
+    p.hin = pl.states + (size_t)r * 32; p.ld = ldS;
+    p.agg = pl.agg + (size_t)r * 32; p.ldagg = ldS;
+    p.Gcur = s.G + (size_t)r * 32;
+    p.dgi = s.dgi + (size_t)r * 96; p.dgh = s.dgh + (size_t)r * 96;
+    p.dui = s.dui + (size_t)r * 96; p.duh = s.duh + (size_t)r * 96; p.ld96 = ld96;
+    p.dpre = s.dpre + (size_t)r * 32; p.xg = s.xg + (size_t)r * 32; p.ld32 = ldS;
+    p.gru = pl.gru;
+    SPG_TRY(spg_launch_ecc_step_bwd(p, st));
+  }
+  {
+    SpgEccStepBwd p; memset(&p, 0, sizeof(p));
+    p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;
+    if (pl.cfg.cat_all) { p.dcat = grad_out; p.ldc = ldS; }
+    p.Gnext = s.G; p.ldg = ldS; p.dhdir = s.dhdir; p.use_dhdir = 1; p.gx = grad_h0; p.final_only = 1;
+    p.gru = pl.gru;
+    SPG_TRY(spg_launch_ecc_step_bwd(p, st));
+  }
+  // ---- GRU parameter gradients: three weight-gradient GEMMs over all (node, iteration) rows ----
+  const int rows = N * (R + 1);
+  {
+    SpgWgradParams w; memset(&w, 0, sizeof(w));
+    w.a = op_ident(s.dgi, 96); w.b = op_ident(s.xg, 32); w.M = rows; w.N = 96; w.K = 32;
+    SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[0], s.work, st));
+    w.a = op_ident(s.dgh, 96); w.b = op_ident(pl.states, 32);
+    SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[1], s.work, st));
+    SPG_TRY(spg_launch_colsum(s.dui, 96, rows, 96, pl.cell_grads[2], st));
+    SPG_TRY(spg_launch_colsum(s.duh, 96, rows, 96, pl.cell_grads[3], st));
+    if (pl.cfg.ingate) {
+      w.a = op_ident(s.dpre, 32); w.b = op_ident(pl.states, 32); w.N = 32;
+      SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[4], s.work, st));
+      SPG_TRY(spg_launch_colsum(s.dpre, 32, rows, 32, pl.cell_grads[5], st));
+    }
+  }
+  if (E == 0) {   // no edges: the filter network received no gradient
+    for (FLayer& l : pl.F) {
+      SPG_TRY(zero_async(l.dW, (size_t)l.cin * l.cout * 4, st));
+      SPG_TRY(zero_async(l.db, (size_t)l.cout * 4, st));
+      SPG_TRY(zero_async(l.dgamma, (size_t)l.cout * 4, st));
+      SPG_TRY(zero_async(l.dbeta, (size_t)l.cout * 4, st));
+    }
+    return 0;
+  }
+  // ---- per-edge filter gradients (sum over the iterations), then the filter network backward ----
+  SPG_TRY(spg_launch_ecc_edge_wgrad(gr, pl.cfg.matrix, pl.states, ldS, s.G, ldS, R, s.dWts, st));
+  SpgOperand cur = op_ident(s.dWts, pl.nout);
+  float* dz[2] = {s.dzA, s.dzB};
+  int flip = 0;
+  for (int i = (int)pl.F.size() - 1; i >= 0; --i) {
+    FLayer& l = pl.F[i];
+    SpgWgradParams w; memset(&w, 0, sizeof(w));
+    w.a = cur; w.b = fnet_input(pl, i, edgefeats); w.M = E; w.N = l.cout; w.K = l.cin;
+    SPG_TRY(spg_launch_wgrad(w, l.dW, s.work, st));
+    if (l.db) {
+      if (l.bn) SPG_TRY(zero_async(l.db, (size_t)l.cout * 4, st));
+      else SPG_TRY(spg_launch_colsum(cur.X, cur.ld, E, l.cout, l.db, st));
+    }
+    if (i == 0) break;
+    FLayer& prod = pl.F[i - 1];
+    SPG_TRY(spg_launch_transpose(l.W, l.cout, l.cin, s.Wt, st));
+    float* out = dz[flip]; flip ^= 1;
+    SpgGemmParams g; memset(&g, 0, sizeof(g));
+    g.a = cur; g.W = s.Wt; g.ldw = l.cout; g.M = E; g.N = l.cin; g.K = l.cout; g.rows_per_tile = 128;
+    g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.cout;
+    g.mask_relu = prod.relu ? 1 : 0; g.n_mask = prod.cout;
+    if (prod.bn) { g.ms = prod.s; g.mt = prod.t; g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat; }
+    SPG_TRY(spg_launch_gemm(g, st));
+    if (prod.bn) {
+      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(E, 128), l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
+                                         s.consts, prod.dgamma, prod.dbeta, st));
+      cur = op_bnbwd(out, prod.y, prod.cout, s.consts, prod.cout);
+    } else {
+      cur = op_ident(out, l.cin);
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,75 @@
+// Internal (C++) interface of the fused row-GEMM kernels (spg_gemm.hip); used by the PointNet and
+// filter-network orchestration code.  Not part of the C ABI.
+#pragma once
+#include "spg_common.h"
+
+enum { SPG_EPI_FWD = 0, SPG_EPI_BWD = 1 };
+
+// Y[M,N] = prologue(A)[M,K] @ W[N,K]^T (+ bias), with a fused epilogue.
+struct SpgGemmParams {
+  SpgOperand a;
+  const float* W;     // [N, K] row-major
+  long ldw;
+  const float* bias;  // [N] or null
+  int M, N, K;
+  int rows_per_tile;  // <= 128: rows handled by one workgroup (points per superpoint for the 1x1 convs)
+  int epi;
+  float* Y;           // [M, ldy] or null (pool-only forward)
+  long ldy;
+  // SPG_EPI_FWD: per-tile BatchNorm partials (mean, M2) and per-tile max/min pooling of the raw output
+  float* stat;        // [ntile][2][N] or null
+  float* pmax;        // [ntile][N] or null
+  float* pmin;
+  int* imax;
+  int* imin;
+  // SPG_EPI_BWD: columns are the channels of the producer layer; ReLU mask and BatchNorm-backward sums
+  const float* Yp;    // raw output of the producer layer [M, ldyp] (null: no mask / no stats)
+  long ldyp;
+  const float* ms;    // producer BN scale / shift (null: 1 / 0)
+  const float* mt;
+  int mask_relu;
+  int n_mask;         // columns >= n_mask are passed through (concatenated global features)
+  const float* mmean; // producer BN batch mean / rstd (null: no stats)
+  const float* mrstd;
+};
+
+// dW[N,K] = sum_m prologue_a(dY)[m, n] * prologue_b(A)[m, k]
+struct SpgWgradParams {
+  SpgOperand a;       // channels -> rows of dW
+  SpgOperand b;       // channels -> columns of dW
+  int M, N, K;
+  int rows_per_split; // multiple of 32
+  float* partial;     // [nsplit][N][K]
+};
+
+int spg_gemm_ntiles(const SpgGemmParams& p);
+int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream);
+
+// workspace (floats) needed by spg_launch_wgrad for a problem of this size
+size_t spg_wgrad_workspace_floats(long M, int N, int K);
+// dW (dense [N,K], ld = K) = reduction; `work` holds the split partials
+int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t stream);
+
+// BatchNorm forward statistics: partials [ntile][2][N] -> mean, rstd, scale s = gamma*rstd, shift t = beta - mean*s;
+// running stats updated `update_times` times (run_full_monger re-runs the forward, learning/pointnet.py:167,173)
+int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                           int update_times, float* mean, float* rstd, float* s, float* t, hipStream_t stream);
+// eval mode: s, t from the running statistics
+int spg_launch_bn_eval(int N, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* s, float* t, hipStream_t stream);
+// BatchNorm backward: partials [ntile][2][N] (sum dz, sum dz*xhat) -> consts[4][N] = {s, c1, mean, s*c2*rstd},
+// dgamma, dbeta
+int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long count, int N, const float* s,
+                               const float* mean, const float* rstd, float* consts, float* dgamma, float* dbeta,
+                               hipStream_t stream);
+// max-pool selection after the BN statistics are known: out[g, c] = s[c] >= 0 ? pmax : pmin  (+ argidx),
+// out[g, N + e] = extra[g, e]; aidx uses the same leading dimension ldo as out
+int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,
+                           int G, int N, const float* extra, int nextra, float* out, long ldo, int* aidx,
+                           hipStream_t stream);
+int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, hipStream_t stream);
+int spg_launch_transpose(const float* W, int N, int K, float* Wt, hipStream_t stream);
+// dT[g, 2a+b] = sum_p clouds[g, a, p] * dxy[g*P + p, b]   (gradient of the 2x2 STN transform, pointnet.py:123)
+int spg_launch_stn_dT(const float* clouds, int Ctot, int P, int G, const float* dxy, long ldd, float* dT,
+                      hipStream_t stream);

@@ -1,0 +1,582 @@
+// Fused row-GEMM kernels for gfx950: the dense contractions of the PointNet 1x1 convolutions / FC layers
+// and of the filter-generating network (reference: learning/pointnet.py:27-49,83-118,
+// learning/graphnet.py:17-34), forward, data-gradient and weight-gradient, on v_mfma_f32_32x32x2_f32
+// (exact fp32, equal to an fmaf chain) with
+//   * the producer's BatchNorm+ReLU (forward) / BatchNorm-backward formula (backward) fused into the
+//     LDS staging of the consumer, so normalised activations never exist in HBM;
+//   * per-workgroup BatchNorm partial statistics (mean / M2 for Chan's combination; sum dz, sum dz*xhat
+//     in the backward), the max-pool over the points of a superpoint and the ReLU mask fused into the
+//     epilogue.
+// One workgroup = 4 wavefronts (one per SIMD); tile = 128 rows x JT columns, reduction staged through
+// LDS in chunks of 32 in the [k/4][row][4] layout of spg_common.h.
+#include "spg_gemm.h"
+#include <float.h>
+#include <limits.h>
+#include <stdarg.h>
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+extern "C" const char* spg_last_error(void) { return g_err; }
+void spg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// optional instrumentation (bench.py): hipEvents around every MFMA GEMM launch, on the launch stream
+// ---------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+struct ProfScope {
+  hipStream_t st; bool on; ProfRec r;
+  ProfScope(hipStream_t s, double flops) : st(s), on(g_prof_on) {
+    if (on) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.flops = flops; (void)hipEventRecord(r.a, st); }
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); } }
+};
+}  // namespace
+extern "C" void spg_prof_enable(int on) { g_prof_on = on != 0; }
+extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int reset) {
+  double t = 0.0, f = 0.0;
+  for (ProfRec& r : g_prof) {
+    (void)hipEventSynchronize(r.b);
+    float dt = 0.f;
+    (void)hipEventElapsedTime(&dt, r.a, r.b);
+    t += dt; f += r.flops;
+  }
+  if (ms) *ms = t;
+  if (launches) *launches = (long)g_prof.size();
+  if (flops) *flops = f;
+  if (reset) {
+    for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ---------------------------------------------------------------------------------------------
+template <int JT, int WI, int WJ>
+__global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmParams p) {
+  constexpr int IT = 128;
+  constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
+  static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
+  extern __shared__ f32x4 smem[];
+  f32x4* As = smem;
+  f32x4* Bs = smem + (SPG_KC / 4) * (IT + 1);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int tile = blockIdx.x;
+  const long m0 = (long)tile * p.rows_per_tile;
+  const int mvalid = (int)min((long)p.rows_per_tile, (long)p.M - m0);
+  const int n0 = blockIdx.y * JT;
+  const bool vecA = spg_operand_vec_ok(p.a) && (p.K & 3) == 0;
+  const bool vecW = (p.K & 3) == 0 && (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
+    spg_stage_rows<IT>(p.a, m0, mvalid, k0, p.K, As, vecA);
+    spg_stage_weight<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bs, vecW);
+    __syncthreads();
+    spg_mfma_chunk<TI, TJ>(As, Bs, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+    __syncthreads();
+  }
+
+  float* red = reinterpret_cast<float*>(smem);  // LDS is free again after the last barrier
+  const int colw = wj * (JT / WJ);
+  const int roww = wi * (IT / WI);
+
+  if (p.epi == SPG_EPI_FWD) {
+    // ---- bias + store ----
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + colw + 32 * j + r;
+      const bool colok = col < p.N;
+      const float bv = (p.bias != nullptr && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = roww + 32 * i + spg_acc_row(q, h);
+          acc[i][j][q] += bv;
+          if (p.Y != nullptr && colok && row < mvalid) p.Y[(m0 + row) * p.ldy + col] = acc[i][j][q];
+        }
+    }
+    // ---- BatchNorm partials of this tile: column mean and M2 = sum (y - mean)^2 over the valid rows ----
+    if (p.stat != nullptr) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (roww + 32 * i + spg_acc_row(q, h) < mvalid) s += acc[i][j][q];
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) red[wi * JT + colw + 32 * j + r] = s;
+      }
+      __syncthreads();
+      if (tid < JT) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < WI; ++w) tot += red[w * JT + tid];
+        red[WI * JT + tid] = tot / (float)mvalid;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const float mean = red[WI * JT + colw + 32 * j + r];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (roww + 32 * i + spg_acc_row(q, h) < mvalid) {
+              const float d = acc[i][j][q] - mean;
+              s = fmaf(d, d, s);
+            }
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) red[wi * JT + colw + 32 * j + r] = s;
+      }
+      __syncthreads();
+      if (tid < JT && n0 + tid < p.N) {
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WI; ++w) m2 += red[w * JT + tid];
+        p.stat[((long)tile * 2 + 0) * p.N + n0 + tid] = red[WI * JT + tid];
+        p.stat[((long)tile * 2 + 1) * p.N + n0 + tid] = m2;
+      }
+      __syncthreads();
+    }
+    // ---- max / min over the rows of the tile (= the points of one superpoint), first index wins ties ----
+    if (p.pmax != nullptr) {
+      float* rmx = red;
+      float* rmn = red + WI * JT;
+      int* rix = reinterpret_cast<int*>(red + 2 * WI * JT);
+      int* rin = reinterpret_cast<int*>(red + 3 * WI * JT);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        float vmx = -FLT_MAX, vmn = FLT_MAX;
+        int imx = INT_MAX, imn = INT_MAX;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = roww + 32 * i + spg_acc_row(q, h);
+            const float v = acc[i][j][q];
+            if (row < mvalid) {
+              if (v > vmx || (v == vmx && row < imx)) { vmx = v; imx = row; }
+              if (v < vmn || (v == vmn && row < imn)) { vmn = v; imn = row; }
+            }
+          }
+        {
+          const float ov = __shfl_xor(vmx, 32, 64);
+          const int oi = __shfl_xor(imx, 32, 64);
+          if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
+          const float pv = __shfl_xor(vmn, 32, 64);
+          const int pi = __shfl_xor(imn, 32, 64);
+          if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
+        }
+        if (h == 0) {
+          const int c = wi * JT + colw + 32 * j + r;
+          rmx[c] = vmx; rix[c] = imx; rmn[c] = vmn; rin[c] = imn;
+        }
+      }
+      __syncthreads();
+      if (tid < JT && n0 + tid < p.N) {
+        float vmx = rmx[tid], vmn = rmn[tid];
+        int imx = rix[tid], imn = rin[tid];
+#pragma unroll
+        for (int w = 1; w < WI; ++w) {
+          const float ov = rmx[w * JT + tid];
+          const int oi = rix[w * JT + tid];
+          if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
+          const float pv = rmn[w * JT + tid];
+          const int pi = rin[w * JT + tid];
+          if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
+        }
+        const long o = (long)tile * p.N + n0 + tid;
+        p.pmax[o] = vmx; p.imax[o] = imx; p.pmin[o] = vmn; p.imin[o] = imn;
+      }
+    }
+  } else {
+    // ---- SPG_EPI_BWD: ReLU mask of the producer layer, store dz, BatchNorm-backward partial sums ----
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + colw + 32 * j + r;
+      const bool colok = col < p.N;
+      const bool masked = p.mask_relu && colok && col < p.n_mask && p.Yp != nullptr;
+      const float sc = (p.ms != nullptr && colok && col < p.n_mask) ? p.ms[col] : 1.f;
+      const float sh = (p.mt != nullptr && colok && col < p.n_mask) ? p.mt[col] : 0.f;
+      const bool stats = p.stat != nullptr && p.mmean != nullptr && colok && col < p.n_mask;
+      const float mean = stats ? p.mmean[col] : 0.f;
+      const float rstd = stats ? p.mrstd[col] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = roww + 32 * i + spg_acc_row(q, h);
+          if (colok && row < mvalid) {
+            float v = acc[i][j][q];
+            float yv = 0.f;
+            if (masked || stats) yv = p.Yp[(m0 + row) * p.ldyp + col];
+            if (masked && !(fmaf(yv, sc, sh) > 0.f)) v = 0.f;
+            p.Y[(m0 + row) * p.ldy + col] = v;
+            if (stats) {
+              s1 += v;
+              s2 = fmaf(v, (yv - mean) * rstd, s2);
+            }
+          }
+        }
+      if (p.stat != nullptr) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+          red[wi * JT + colw + 32 * j + r] = s1;
+          red[(WI + wi) * JT + colw + 32 * j + r] = s2;
+        }
+      }
+    }
+    if (p.stat != nullptr) {
+      __syncthreads();
+      if (tid < JT && n0 + tid < p.N) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WI; ++w) {
+          a += red[w * JT + tid];
+          b += red[(WI + w) * JT + tid];
+        }
+        p.stat[((long)tile * 2 + 0) * p.N + n0 + tid] = a;
+        p.stat[((long)tile * 2 + 1) * p.N + n0 + tid] = b;
+      }
+    }
+  }
+}
+
+int spg_gemm_ntiles(const SpgGemmParams& p) { return spg_cdiv(p.M, p.rows_per_tile); }
+
+template <int JT, int WI, int WJ>
+static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)(SPG_KC / 4) * (128 + 1 + JT + 1) * sizeof(f32x4);
+  dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
+  ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
+  hipLaunchKernelGGL((spg_rowgemm_kernel<JT, WI, WJ>), grid, dim3(SPG_THREADS), lds, stream, p);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream) {
+  SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
+  SPG_CHECK_ARG(p.rows_per_tile >= 1 && p.rows_per_tile <= 128, "rows_per_tile must be in [1,128]");
+  SPG_CHECK_ARG(p.epi == SPG_EPI_FWD || p.Y != nullptr, "backward epilogue needs an output");
+  if (p.N <= 32) return launch_gemm_t<32, 4, 1>(p, stream);
+  if (p.N <= 64) return launch_gemm_t<64, 2, 2>(p, stream);
+  if (p.N <= 128) return launch_gemm_t<128, 2, 2>(p, stream);
+  return launch_gemm_t<256, 2, 2>(p, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight-gradient kernel: reduction over the rows (points / superpoints / edges / nodes)
+// ---------------------------------------------------------------------------------------------
+template <int IT, int JT, int WI, int WJ>
+__global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradParams p) {
+  constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
+  static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
+  extern __shared__ f32x4 smem[];
+  f32x4* As = smem;
+  f32x4* Bs = smem + (SPG_KC / 4) * (IT + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int split = blockIdx.x;
+  const int i0 = blockIdx.y * IT, j0 = blockIdx.z * JT;
+  const long ms = (long)split * p.rows_per_split;
+  const long me = min((long)p.M, ms + p.rows_per_split);
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  for (long m = ms; m < me; m += SPG_KC) {
+    spg_stage_cols<IT>(p.a, m, me, i0, p.N, As);
+    spg_stage_cols<JT>(p.b, m, me, j0, p.K, Bs);
+    __syncthreads();
+    spg_mfma_chunk<TI, TJ>(As, Bs, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int k = j0 + wj * (JT / WJ) + 32 * j + r;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n = i0 + wi * (IT / WI) + 32 * i + spg_acc_row(q, h);
+        if (n < p.N && k < p.K) p.partial[((long)split * p.N + n) * p.K + k] = acc[i][j][q];
+      }
+  }
+}
+
+__global__ void spg_reduce_partials_kernel(const float* __restrict__ partial, int nsplit, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + i];   // fixed order: deterministic
+  out[i] = s;
+}
+
+static void wgrad_plan(long M, int N, int K, int* IT, int* JT, int* nsplit, int* rps) {
+  int jt = K <= 32 ? 32 : (K <= 64 ? 64 : 128);
+  int it;
+  if (jt == 32) it = 128;
+  else if (jt == 64) it = N <= 64 ? 64 : 128;
+  else it = N <= 128 ? 128 : 256;
+  const int tiles = spg_cdiv(N, it) * spg_cdiv(K, jt);
+  int target = 512 / tiles;
+  if (target < 1) target = 1;
+  long rows = (M + target - 1) / target;
+  rows = ((rows + SPG_KC - 1) / SPG_KC) * SPG_KC;
+  if (rows < SPG_KC) rows = SPG_KC;
+  *IT = it; *JT = jt; *rps = (int)rows; *nsplit = spg_cdiv(M, rows);
+}
+
+size_t spg_wgrad_workspace_floats(long M, int N, int K) {
+  int it, jt, ns, rps;
+  wgrad_plan(M, N, K, &it, &jt, &ns, &rps);
+  return (size_t)ns * N * K;
+}
+
+template <int IT, int JT, int WI, int WJ>
+static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t stream) {
+  const size_t lds = (size_t)(SPG_KC / 4) * (IT + 1 + JT + 1) * sizeof(f32x4);
+  dim3 grid(nsplit, spg_cdiv(p.N, IT), spg_cdiv(p.K, JT));
+  ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
+  hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ>), grid, dim3(SPG_THREADS), lds, stream, p);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t stream) {
+  SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty wgrad");
+  int it, jt, ns, rps;
+  wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
+  p.rows_per_split = rps;
+  p.partial = (ns == 1) ? dW : work;
+  int rc;
+  if (jt == 32) rc = launch_wgrad_t<128, 32, 4, 1>(p, ns, stream);
+  else if (jt == 64 && it == 64) rc = launch_wgrad_t<64, 64, 2, 2>(p, ns, stream);
+  else if (jt == 64) rc = launch_wgrad_t<128, 64, 2, 2>(p, ns, stream);
+  else if (it == 128) rc = launch_wgrad_t<128, 128, 2, 2>(p, ns, stream);
+  else rc = launch_wgrad_t<256, 128, 2, 2>(p, ns, stream);
+  if (rc) return rc;
+  if (ns > 1) {
+    const long n = (long)p.N * p.K;
+    hipLaunchKernelGGL(spg_reduce_partials_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, work, ns, n, dW);
+    SPG_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics
+// ---------------------------------------------------------------------------------------------
+__global__ void spg_bn_finalize_kernel(const float* __restrict__ stat, int ntile, int rows_per_tile, long M, int N,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* running_mean, float* running_var, float momentum, float eps,
+                                       int update_times, float* mean_o, float* rstd_o, float* s_o, float* t_o) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  // Chan et al. pairwise combination of (count, mean, M2), accumulated in fp64 (torch CPU BatchNorm
+  // accumulates float statistics in double as well).
+  double tot = 0.0;
+  for (int b = 0; b < ntile; ++b) {
+    const long nb = min((long)rows_per_tile, M - (long)b * rows_per_tile);
+    tot += (double)nb * (double)stat[((long)b * 2) * N + c];
+  }
+  const double mean = tot / (double)M;
+  double m2 = 0.0;
+  for (int b = 0; b < ntile; ++b) {
+    const long nb = min((long)rows_per_tile, M - (long)b * rows_per_tile);
+    const double d = (double)stat[((long)b * 2) * N + c] - mean;
+    m2 += (double)stat[((long)b * 2 + 1) * N + c] + (double)nb * d * d;
+  }
+  const double var = m2 / (double)M;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+  mean_o[c] = (float)mean;
+  rstd_o[c] = (float)rstd;
+  s_o[c] = (float)(g * rstd);
+  t_o[c] = (float)(be - mean * g * rstd);
+  if (running_mean != nullptr && update_times > 0) {
+    const double uvar = M > 1 ? m2 / (double)(M - 1) : var;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int u = 0; u < update_times; ++u) {
+      rm = (1.f - momentum) * rm + momentum * (float)mean;
+      rv = (1.f - momentum) * rv + momentum * (float)uvar;
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+}
+
+int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                           int update_times, float* mean, float* rstd, float* s, float* t, hipStream_t stream) {
+  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(spg_cdiv(N, 64)), dim3(64), 0, stream, stat, ntile, rows_per_tile, M,
+                     N, gamma, beta, running_mean, running_var, momentum, eps, update_times, mean, rstd, s, t);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void spg_bn_eval_kernel(int N, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                   float eps, float* s, float* t) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const double rstd = 1.0 / sqrt((double)rv[c] + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+  s[c] = (float)(g * rstd);
+  t[c] = (float)(be - (double)rm[c] * g * rstd);
+}
+
+int spg_launch_bn_eval(int N, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* s, float* t, hipStream_t stream) {
+  hipLaunchKernelGGL(spg_bn_eval_kernel, dim3(spg_cdiv(N, 64)), dim3(64), 0, stream, N, gamma, beta, running_mean,
+                     running_var, eps, s, t);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void spg_bn_bwd_finalize_kernel(const float* __restrict__ stat, int ntile, int ldstat, long count, int N,
+                                           const float* __restrict__ s, const float* __restrict__ mean,
+                                           const float* __restrict__ rstd, float* consts, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  double a = 0.0, b = 0.0;
+  for (int t = 0; t < ntile; ++t) {
+    a += (double)stat[((long)t * 2) * ldstat + c];
+    b += (double)stat[((long)t * 2 + 1) * ldstat + c];
+  }
+  if (dbeta) dbeta[c] = (float)a;
+  if (dgamma) dgamma[c] = (float)b;
+  const double c1 = a / (double)count, c2 = b / (double)count;
+  consts[0 * N + c] = s[c];
+  consts[1 * N + c] = (float)c1;
+  consts[2 * N + c] = mean[c];
+  consts[3 * N + c] = (float)((double)s[c] * c2 * (double)rstd[c]);
+}
+
+int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long count, int N, const float* s,
+                               const float* mean, const float* rstd, float* consts, float* dgamma, float* dbeta,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(spg_bn_bwd_finalize_kernel, dim3(spg_cdiv(N, 64)), dim3(64), 0, stream, stat, ntile, ldstat, count, N, s,
+                     mean, rstd, consts, dgamma, dbeta);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void spg_pool_select_kernel(const float* pmax, const float* pmin, const int* imax, const int* imin,
+                                       const float* s, int G, int N, const float* extra, int nextra, float* out,
+                                       long ldo, int* aidx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = N + nextra;
+  if (i >= (long)G * W) return;
+  const long g = i / W;
+  const int c = (int)(i - g * W);
+  if (c < N) {
+    const bool up = s[c] >= 0.f;
+    out[g * ldo + c] = up ? pmax[g * N + c] : pmin[g * N + c];
+    aidx[g * ldo + c] = up ? imax[g * N + c] : imin[g * N + c];   // aidx shares the leading dimension of `out`
+  } else {
+    out[g * ldo + c] = extra[g * nextra + (c - N)];
+  }
+}
+
+int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,
+                           int G, int N, const float* extra, int nextra, float* out, long ldo, int* aidx,
+                           hipStream_t stream) {
+  const long n = (long)G * (N + nextra);
+  hipLaunchKernelGGL(spg_pool_select_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, pmax, pmin, imax, imin, s,
+                     G, N, extra, nextra, out, ldo, aidx);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void spg_colsum_kernel(const float* __restrict__ X, long ld, long M, int N, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < N)
+    for (long m = g; m < M; m += 4) s += X[m * ld + c];
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(spg_colsum_kernel, dim3(spg_cdiv(N, 64)), dim3(256), 0, stream, X, ld, M, N, out);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void spg_transpose_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ Wt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * K) return;
+  const int k = (int)(i / N), n = (int)(i - (long)k * N);   // consecutive threads -> consecutive Wt elements
+  Wt[i] = W[(long)n * K + k];
+}
+
+int spg_launch_transpose(const float* W, int N, int K, float* Wt, hipStream_t stream) {
+  const long n = (long)N * K;
+  hipLaunchKernelGGL(spg_transpose_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, W, N, K, Wt);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void spg_stn_dT_kernel(const float* __restrict__ clouds, int Ctot, int P, int G, const float* __restrict__ dxy,
+                                  long ldd, float* __restrict__ dT) {
+  // one wavefront per superpoint
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (g >= G) return;
+  float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+  for (int p = lane; p < P; p += 64) {
+    const float x = clouds[((long)g * Ctot + 0) * P + p], y = clouds[((long)g * Ctot + 1) * P + p];
+    const float d0 = dxy[((long)g * P + p) * ldd + 0], d1 = dxy[((long)g * P + p) * ldd + 1];
+    a00 = fmaf(x, d0, a00); a01 = fmaf(x, d1, a01); a10 = fmaf(y, d0, a10); a11 = fmaf(y, d1, a11);
+  }
+  a00 = spg_wave_sum(a00); a01 = spg_wave_sum(a01); a10 = spg_wave_sum(a10); a11 = spg_wave_sum(a11);
+  if (lane == 0) {
+    dT[(long)g * 4 + 0] = a00; dT[(long)g * 4 + 1] = a01; dT[(long)g * 4 + 2] = a10; dT[(long)g * 4 + 3] = a11;
+  }
+}
+
+int spg_launch_stn_dT(const float* clouds, int Ctot, int P, int G, const float* dxy, long ldd, float* dT,
+                      hipStream_t stream) {
+  hipLaunchKernelGGL(spg_stn_dT_kernel, dim3(spg_cdiv(G, 4)), dim3(256), 0, stream, clouds, Ctot, P, G, dxy, ldd, dT);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,406 @@
+// PointNet superpoint embedder on the fused row-GEMM kernels: host-side orchestration (kernel sequence,
+// workspace layout) of the forward and backward passes.  Reference: learning/pointnet.py:16-133
+// (STNkD, PointNet); CloudEmbedder's recompute-in-backward (pointnet.py:160-176) is replaced by keeping
+// the raw layer outputs in HBM (288 GB per GPU), the BatchNorm running statistics are updated as many
+// times as the reference's double forward would.
+//
+// Data layout in HBM
+//   clouds         [B, nfeat, P]    as the loader produces them (channel-major per superpoint)
+//   y_l            [B*P, C_l]       raw (pre-BatchNorm) output of 1x1-conv layer l, row = b*P + p
+//   y_fc           [B, C]           raw output of an FC layer
+//   BatchNorm(+ReLU) is applied by the CONSUMER while staging its tile into LDS (scale s, shift t per
+//   channel), so normalised activations are never written.
+//   The max-pool over the points is fused into the epilogue of the last conv (per-superpoint max AND
+//   min of the raw output: after the batch statistics are known, sign(s) decides which one is the
+//   max of the normalised value -- BatchNorm is monotone per channel).
+#include "../../include/spg_hip.h"
+#include "spg_gemm.h"
+#include <vector>
+
+namespace {
+
+struct Layer {
+  int cin = 0, cout = 0;
+  bool bn = false;
+  bool conv = false;            // rows = points (B*P) instead of superpoints (B)
+  const float *W = nullptr, *b = nullptr, *gamma = nullptr, *beta = nullptr;
+  float *rm = nullptr, *rv = nullptr;
+  float* y = nullptr;           // raw output (workspace or external)
+  long ldy = 0;
+  float *mean = nullptr, *rstd = nullptr, *s = nullptr, *t = nullptr;   // BN batch constants
+  float *dW = nullptr, *db = nullptr, *dgamma = nullptr, *dbeta = nullptr;
+};
+
+struct Segment {           // convs (BN+ReLU each) -> max-pool (+concat) -> fcs (BN+ReLU each, last one plain)
+  std::vector<int> convs, fcs;
+  float* pooled = nullptr;  // [B, C_lastconv + nextra] selected raw max / min (+ concatenated global features)
+  long ldpool = 0;
+  int* aidx = nullptr;      // [B, C_lastconv]
+  int nextra = 0;
+  const float* extra = nullptr;
+};
+
+struct Plan {
+  spg_pointnet_cfg cfg;
+  int B = 0, P = 0;
+  long M = 0;
+  bool training = false;
+  std::vector<Layer> L;
+  Segment stn, main;
+  bool has_stn = false;
+  // shared scratch
+  float *stat = nullptr, *pmax = nullptr, *pmin = nullptr;
+  int *imax = nullptr, *imin = nullptr;
+  size_t bytes = 0;
+};
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+int num_layers(const spg_pointnet_cfg& c) {
+  return (c.nfeat_stn > 0 ? c.n_stn_conv + c.n_stn_fc + 1 : 0) + c.n_conv + c.n_fc;
+}
+
+// builds the layer table and carves the forward workspace (base may be null: size query)
+int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const void* const* params, float* emb,
+              Plan& pl) {
+  SPG_CHECK_ARG(cfg != nullptr && B > 0, "cfg / B");
+  const spg_pointnet_cfg& c = *cfg;
+  SPG_CHECK_ARG(c.npts >= 1 && c.npts <= 128, "npts must be in [1,128]");
+  SPG_CHECK_ARG(c.n_conv >= 1 && c.n_fc >= 1 && c.n_conv <= SPG_MAX_LAYERS && c.n_fc <= SPG_MAX_LAYERS, "layer counts");
+  SPG_CHECK_ARG(c.last_ac == 0, "last_ac=True is not supported");
+  SPG_CHECK_ARG(c.nfeat_stn == 0 || (c.nfeat_stn >= 2 && c.nfeat_stn <= c.nfeat && c.n_stn_conv >= 1 && c.n_stn_fc >= 1),
+                "STN configuration");
+  SPG_CHECK_ARG(c.nfeat >= 1 && c.nfeat <= 32, "nfeat must be <= 32");
+  pl.cfg = c; pl.B = B; pl.P = c.npts; pl.M = (long)B * c.npts; pl.training = training != 0;
+  pl.has_stn = c.nfeat_stn > 0;
+  pl.L.clear();
+  auto add = [&](int cin, int cout, bool bn, bool conv) {
+    Layer l; l.cin = cin; l.cout = cout; l.bn = bn; l.conv = conv;
+    pl.L.push_back(l);
+    return (int)pl.L.size() - 1;
+  };
+  pl.stn = Segment(); pl.main = Segment();
+  if (pl.has_stn) {
+    for (int i = 0; i < c.n_stn_conv; ++i) pl.stn.convs.push_back(add(i ? c.stn_conv[i - 1] : c.nfeat_stn, c.stn_conv[i], true, true));
+    for (int i = 0; i < c.n_stn_fc; ++i)
+      pl.stn.fcs.push_back(add(i ? c.stn_fc[i - 1] : c.stn_conv[c.n_stn_conv - 1], c.stn_fc[i], true, false));
+    pl.stn.fcs.push_back(add(c.stn_fc[c.n_stn_fc - 1], 4, false, false));   // proj
+  }
+  for (int i = 0; i < c.n_conv; ++i) pl.main.convs.push_back(add(i ? c.conv[i - 1] : c.nfeat, c.conv[i], true, true));
+  for (int i = 0; i < c.n_fc; ++i)
+    pl.main.fcs.push_back(add(i ? c.fc[i - 1] : c.conv[c.n_conv - 1] + c.nfeat_global, c.fc[i], i < c.n_fc - 1, false));
+  pl.main.nextra = c.nfeat_global;
+
+  Carver cv(ws);
+  int cmax = 4;
+  for (size_t i = 0; i < pl.L.size(); ++i) {
+    Layer& l = pl.L[i];
+    if (params) {
+      const void* const* g = params + 6 * i;
+      l.W = (const float*)g[0]; l.b = (const float*)g[1]; l.gamma = (const float*)g[2]; l.beta = (const float*)g[3];
+      l.rm = (float*)g[4]; l.rv = (float*)g[5];
+      SPG_CHECK_ARG(l.W != nullptr, "missing layer weight");
+      SPG_CHECK_ARG(!l.bn || (l.rm != nullptr && l.rv != nullptr), "missing BatchNorm running statistics");
+    }
+    cmax = l.cout > cmax ? l.cout : cmax;
+    if (l.bn) {
+      l.mean = cv.take<float>(l.cout); l.rstd = cv.take<float>(l.cout);
+      l.s = cv.take<float>(l.cout); l.t = cv.take<float>(l.cout);
+    }
+  }
+  auto carve_segment = [&](Segment& sg, float* final_out) {
+    for (size_t k = 0; k < sg.convs.size(); ++k) {
+      Layer& l = pl.L[sg.convs[k]];
+      const bool last = k + 1 == sg.convs.size();
+      l.ldy = l.cout;
+      // the pooled layer's dense output is only needed by the backward pass
+      l.y = (!last || pl.training) ? cv.take<float>((size_t)pl.M * l.cout) : nullptr;
+    }
+    const Layer& lc = pl.L[sg.convs.back()];
+    sg.ldpool = lc.cout + sg.nextra;
+    sg.pooled = cv.take<float>((size_t)B * sg.ldpool);
+    sg.aidx = cv.take<int>((size_t)B * sg.ldpool);
+    for (size_t k = 0; k < sg.fcs.size(); ++k) {
+      Layer& l = pl.L[sg.fcs[k]];
+      const bool last = k + 1 == sg.fcs.size();
+      l.ldy = l.cout;
+      l.y = (last && final_out) ? final_out : cv.take<float>((size_t)B * l.cout);
+    }
+  };
+  if (pl.has_stn) carve_segment(pl.stn, nullptr);
+  carve_segment(pl.main, emb);
+  pl.stat = cv.take<float>((size_t)B * 2 * cmax);
+  pl.pmax = cv.take<float>((size_t)B * cmax); pl.pmin = cv.take<float>((size_t)B * cmax);
+  pl.imax = cv.take<int>((size_t)B * cmax); pl.imin = cv.take<int>((size_t)B * cmax);
+  pl.bytes = cv.off + 256;
+  return 0;
+}
+
+SpgOperand op_affine(const Layer& prod, const float* X, long ld, int n_affine) {
+  SpgOperand o; memset(&o, 0, sizeof(o));
+  o.mode = SPG_PRO_AFFINE; o.X = X; o.ld = ld; o.c0 = prod.s; o.c1 = prod.t; o.relu = 1; o.n_affine = n_affine;
+  return o;
+}
+SpgOperand op_cloud(const Plan& pl, const float* clouds, const float* stnT) {
+  SpgOperand o; memset(&o, 0, sizeof(o));
+  o.mode = SPG_PRO_CLOUD; o.X = clouds; o.Ctot = pl.cfg.nfeat; o.P = pl.P; o.stnT = stnT;
+  return o;
+}
+SpgOperand op_ident(const float* X, long ld) {
+  SpgOperand o; memset(&o, 0, sizeof(o));
+  o.mode = SPG_PRO_IDENT; o.X = X; o.ld = ld;
+  return o;
+}
+
+// the operand through which layer `k` of the segment reads its input in the forward pass
+SpgOperand input_operand(const Plan& pl, const Segment& sg, bool is_fc, size_t k, const float* clouds, const float* stnT) {
+  if (!is_fc) {
+    if (k == 0) return op_cloud(pl, clouds, stnT);
+    const Layer& p = pl.L[sg.convs[k - 1]];
+    return op_affine(p, p.y, p.ldy, p.cout);
+  }
+  if (k == 0) {
+    const Layer& p = pl.L[sg.convs.back()];
+    return op_affine(p, sg.pooled, sg.ldpool, p.cout);
+  }
+  const Layer& p = pl.L[sg.fcs[k - 1]];
+  return op_affine(p, p.y, p.ldy, p.cout);
+}
+
+int bn_stats(const Plan& pl, Layer& l, int ntile, int rows_per_tile, long M, int update_times, hipStream_t st) {
+  if (pl.training)
+    return spg_launch_bn_finalize(pl.stat, ntile, rows_per_tile, M, l.cout, l.gamma, l.beta, l.rm, l.rv,
+                                  pl.cfg.bn_momentum, pl.cfg.bn_eps, update_times, l.mean, l.rstd, l.s, l.t, st);
+  return spg_launch_bn_eval(l.cout, l.gamma, l.beta, l.rm, l.rv, pl.cfg.bn_eps, l.s, l.t, st);
+}
+
+int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stnT, int update_times, hipStream_t st) {
+  for (size_t k = 0; k < sg.convs.size(); ++k) {
+    Layer& l = pl.L[sg.convs[k]];
+    const bool last = k + 1 == sg.convs.size();
+    SpgGemmParams g; memset(&g, 0, sizeof(g));
+    g.a = input_operand(pl, sg, false, k, clouds, stnT);
+    g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = (int)pl.M; g.N = l.cout; g.K = l.cin;
+    g.rows_per_tile = pl.P; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
+    g.stat = pl.training ? pl.stat : nullptr;
+    if (last) { g.pmax = pl.pmax; g.pmin = pl.pmin; g.imax = pl.imax; g.imin = pl.imin; }
+    SPG_TRY(spg_launch_gemm(g, st));
+    SPG_TRY(bn_stats(pl, l, pl.B, pl.P, pl.M, update_times, st));
+    if (last)
+      SPG_TRY(spg_launch_pool_select(pl.pmax, pl.pmin, pl.imax, pl.imin, l.s, pl.B, l.cout, sg.extra, sg.nextra,
+                                     sg.pooled, sg.ldpool, sg.aidx, st));
+  }
+  for (size_t k = 0; k < sg.fcs.size(); ++k) {
+    Layer& l = pl.L[sg.fcs[k]];
+    SpgGemmParams g; memset(&g, 0, sizeof(g));
+    g.a = input_operand(pl, sg, true, k, clouds, stnT);
+    g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = pl.B; g.N = l.cout; g.K = l.cin;
+    g.rows_per_tile = 128; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
+    g.stat = (pl.training && l.bn) ? pl.stat : nullptr;
+    SPG_TRY(spg_launch_gemm(g, st));
+    if (l.bn) SPG_TRY(bn_stats(pl, l, spg_cdiv(pl.B, 128), 128, pl.B, update_times, st));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct BwdScratch {
+  float *dzA = nullptr, *dzB = nullptr;     // [M, cmax_conv] ping-pong for the dense conv gradients
+  float *fzA = nullptr, *fzB = nullptr;     // [B, cmax_fc]
+  float* Wt = nullptr;                      // transposed weight of the current layer
+  float* consts = nullptr;                  // [4][cmax]
+  float* work = nullptr;                    // wgrad split partials
+  float* stat = nullptr;                    // [ntile][2][cmax]
+  float* dxy = nullptr;                     // [M, 2]
+  float* dT = nullptr;                      // [B, 4]
+  size_t bytes = 0;
+};
+
+void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
+  Carver cv(ws);
+  int cconv = 4, cfc = 4, cmax = 4;
+  size_t wmax = 16, workmax = 16;
+  for (const Layer& l : pl.L) {
+    if (l.conv) { cconv = l.cin > cconv ? l.cin : cconv; }
+    else { cfc = l.cin > cfc ? l.cin : cfc; }
+    cmax = l.cout > cmax ? l.cout : cmax; cmax = l.cin > cmax ? l.cin : cmax;
+    wmax = (size_t)l.cin * l.cout > wmax ? (size_t)l.cin * l.cout : wmax;
+    const size_t w = spg_wgrad_workspace_floats(l.conv ? pl.M : pl.B, l.cout, l.cin);
+    workmax = w > workmax ? w : workmax;
+  }
+  s.dzA = cv.take<float>((size_t)pl.M * cconv); s.dzB = cv.take<float>((size_t)pl.M * cconv);
+  s.fzA = cv.take<float>((size_t)pl.B * cfc); s.fzB = cv.take<float>((size_t)pl.B * cfc);
+  s.Wt = cv.take<float>(wmax);
+  s.consts = cv.take<float>((size_t)4 * cmax);
+  s.work = cv.take<float>(workmax);
+  s.stat = cv.take<float>((size_t)pl.B * 2 * cmax);
+  s.dxy = cv.take<float>((size_t)pl.M * 2);
+  s.dT = cv.take<float>((size_t)pl.B * 4);
+  s.bytes = cv.off + 256;
+}
+
+SpgOperand op_bnbwd(const float* dz, const float* y, long ld, const float* consts, int C) {
+  SpgOperand o; memset(&o, 0, sizeof(o));
+  o.mode = SPG_PRO_BNBWD; o.X = dz; o.X2 = y; o.ld = ld;
+  o.c0 = consts; o.c1 = consts + C; o.c2 = consts + 2 * C; o.c3 = consts + 3 * C;
+  return o;
+}
+
+int zero_async(float* p, size_t n, hipStream_t st) {
+  if (p == nullptr || n == 0) return 0;
+  hipError_t e = hipMemsetAsync(p, 0, n * sizeof(float), st);
+  if (e != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+// Backward of one segment.  `cur` is the gradient wrt the raw output of the segment's last fc layer
+// (IDENT operand).  If want_dxy, the gradient wrt the first two input channels of conv 0 is left in s.dxy.
+int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgOperand cur, const float* clouds, const float* stnT,
+                     bool want_dxy, hipStream_t st) {
+  const int B = pl.B;
+  // ---- fc head ----
+  float* fz[2] = {s.fzA, s.fzB};
+  int flip = 0;
+  for (int k = (int)sg.fcs.size() - 1; k >= 0; --k) {
+    Layer& l = pl.L[sg.fcs[k]];
+    SpgWgradParams w; memset(&w, 0, sizeof(w));
+    w.a = cur; w.b = input_operand(pl, sg, true, k, clouds, stnT); w.M = B; w.N = l.cout; w.K = l.cin;
+    SPG_TRY(spg_launch_wgrad(w, l.dW, s.work, st));
+    if (l.db) {
+      if (l.bn) SPG_TRY(zero_async(l.db, l.cout, st));   // a bias in front of train-mode BatchNorm has zero gradient
+      else SPG_TRY(spg_launch_colsum(cur.X, cur.ld, B, l.cout, l.db, st));
+    }
+    // data gradient -> producer of this layer's input
+    const bool first = k == 0;
+    Layer& prod = first ? pl.L[sg.convs.back()] : pl.L[sg.fcs[k - 1]];
+    SPG_TRY(spg_launch_transpose(l.W, l.cout, l.cin, s.Wt, st));
+    float* out = fz[flip]; flip ^= 1;
+    SpgGemmParams g; memset(&g, 0, sizeof(g));
+    g.a = cur; g.W = s.Wt; g.ldw = l.cout; g.M = B; g.N = l.cin; g.K = l.cout; g.rows_per_tile = 128;
+    g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin;
+    g.Yp = first ? sg.pooled : prod.y; g.ldyp = first ? sg.ldpool : prod.ldy;
+    g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
+    g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
+    SPG_TRY(spg_launch_gemm(g, st));
+    // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
+    const int C = prod.cout;
+    SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(B, 128), l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
+                                       prod.rstd, s.consts, prod.dgamma, prod.dbeta, st));
+    if (!first) {
+      cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, C);
+    } else {
+      memset(&cur, 0, sizeof(cur));
+      cur.mode = SPG_PRO_POOLBWD; cur.X = out; cur.ldg = (int)sg.ldpool; cur.aidx = sg.aidx; cur.P = pl.P;
+      cur.X2 = prod.y; cur.ld = prod.ldy;
+      cur.c0 = s.consts; cur.c1 = s.consts + C; cur.c2 = s.consts + 2 * C; cur.c3 = s.consts + 3 * C;
+    }
+  }
+  // ---- conv stack ----
+  float* dz[2] = {s.dzA, s.dzB};
+  flip = 0;
+  for (int k = (int)sg.convs.size() - 1; k >= 0; --k) {
+    Layer& l = pl.L[sg.convs[k]];
+    SpgWgradParams w; memset(&w, 0, sizeof(w));
+    w.a = cur; w.b = input_operand(pl, sg, false, k, clouds, stnT); w.M = (int)pl.M; w.N = l.cout; w.K = l.cin;
+    SPG_TRY(spg_launch_wgrad(w, l.dW, s.work, st));
+    if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
+    if (k > 0) {
+      Layer& prod = pl.L[sg.convs[k - 1]];
+      SPG_TRY(spg_launch_transpose(l.W, l.cout, l.cin, s.Wt, st));
+      float* out = dz[flip]; flip ^= 1;
+      SpgGemmParams g; memset(&g, 0, sizeof(g));
+      g.a = cur; g.W = s.Wt; g.ldw = l.cout; g.M = (int)pl.M; g.N = l.cin; g.K = l.cout; g.rows_per_tile = pl.P;
+      g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.ldy;
+      g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
+      g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
+      SPG_TRY(spg_launch_gemm(g, st));
+      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, B, l.cin, pl.M, prod.cout, prod.s, prod.mean, prod.rstd, s.consts,
+                                         prod.dgamma, prod.dbeta, st));
+      cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, prod.cout);
+    } else if (want_dxy) {
+      // gradient wrt the transformed xy only (learning/pointnet.py:123-124): 2 output columns
+      SPG_TRY(spg_launch_transpose(l.W, l.cout, l.cin, s.Wt, st));
+      SpgGemmParams g; memset(&g, 0, sizeof(g));
+      g.a = cur; g.W = s.Wt; g.ldw = l.cout; g.M = (int)pl.M; g.N = 2; g.K = l.cout; g.rows_per_tile = pl.P;
+      g.epi = SPG_EPI_BWD; g.Y = s.dxy; g.ldy = 2;
+      SPG_TRY(spg_launch_gemm(g, st));
+    }
+  }
+  return 0;
+}
+
+void bind_grads(Plan& pl, void* const* grads) {
+  for (size_t i = 0; i < pl.L.size(); ++i) {
+    void* const* g = grads + 6 * i;
+    pl.L[i].dW = (float*)g[0]; pl.L[i].db = (float*)g[1]; pl.L[i].dgamma = (float*)g[2]; pl.L[i].dbeta = (float*)g[3];
+  }
+}
+
+}  // namespace
+
+extern "C" int spg_pointnet_num_layers(const spg_pointnet_cfg* cfg) { return cfg ? num_layers(*cfg) : -1; }
+
+extern "C" size_t spg_pointnet_workspace_bytes(const spg_pointnet_cfg* cfg, int B, int training) {
+  Plan pl;
+  if (make_plan(cfg, B, training, nullptr, nullptr, nullptr, pl) != 0) return 0;
+  return pl.bytes;
+}
+
+extern "C" int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
+                                    const void* const* params, float* emb, void* workspace, int training,
+                                    int bn_update_times, void* stream) {
+  SPG_CHECK_ARG(clouds && params && emb && workspace, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  Plan pl;
+  SPG_TRY(make_plan(cfg, B, training, workspace, params, emb, pl));
+  SPG_CHECK_ARG(pl.cfg.nfeat_global == 0 || clouds_global != nullptr, "clouds_global is required");
+  pl.main.extra = clouds_global;
+  const float* stnT = nullptr;
+  if (pl.has_stn) {
+    SPG_TRY(forward_segment(pl, pl.stn, clouds, nullptr, bn_update_times, st));
+    stnT = pl.L[pl.stn.fcs.back()].y;
+  }
+  SPG_TRY(forward_segment(pl, pl.main, clouds, stnT, bn_update_times, st));
+  return 0;
+}
+
+extern "C" size_t spg_pointnet_bwd_workspace_bytes(const spg_pointnet_cfg* cfg, int B) {
+  Plan pl;
+  if (make_plan(cfg, B, 1, nullptr, nullptr, nullptr, pl) != 0) return 0;
+  BwdScratch s;
+  carve_bwd(pl, nullptr, s);
+  return s.bytes;
+}
+
+extern "C" int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
+                                     const void* const* params, const float* grad_emb, void* const* grads,
+                                     void* workspace, void* bwd_workspace, void* stream) {
+  SPG_CHECK_ARG(clouds && params && grad_emb && grads && workspace && bwd_workspace, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  Plan pl;
+  // the forward wrote the last fc output to `emb`; it is not needed by the backward, so pass a dummy
+  SPG_TRY(make_plan(cfg, B, 1, workspace, params, (float*)grad_emb /*unused as y*/, pl));
+  pl.main.extra = clouds_global;
+  bind_grads(pl, grads);
+  BwdScratch s;
+  carve_bwd(pl, bwd_workspace, s);
+  const float* stnT = pl.has_stn ? pl.L[pl.stn.fcs.back()].y : nullptr;
+  const int cout = pl.L[pl.main.fcs.back()].cout;
+  SPG_TRY(backward_segment(pl, pl.main, s, op_ident(grad_emb, cout), clouds, stnT, pl.has_stn, st));
+  if (pl.has_stn) {
+    SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, s.dT, st));
+    SPG_TRY(backward_segment(pl, pl.stn, s, op_ident(s.dT, 4), clouds, nullptr, false, st));
+  }
+  return 0;
+}
