@@ -110,6 +110,9 @@ size_t spg_pointnet_workspace_bytes(const spg_pointnet_cfg* cfg, int B, int trai
 int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
                          const void* const* params, float* emb, void* workspace, int training, int bn_update_times,
                          void* stream);
+/* test helper: byte offset of a layer's buffer inside the forward workspace (what: 0 raw output, 1 BN scale,
+ * 2 BN shift, 3 batch mean, 4 batch rstd; layer -1 / -2: pooled buffer of the STN / main segment); -1 if absent */
+long spg_pointnet_debug_offset(const spg_pointnet_cfg* cfg, int B, int training, int layer, int what);
 size_t spg_pointnet_bwd_workspace_bytes(const spg_pointnet_cfg* cfg, int B);
 int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
                           const void* const* params, const float* grad_emb, void* const* grads, void* workspace,

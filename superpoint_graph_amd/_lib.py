@@ -1,0 +1,102 @@
+"""ctypes loader of libspg_hip.so (the C-ABI boundary declared in include/spg_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent, importing the
+kernels raises.  torch must be imported before the library so that the HIP runtime bundled with
+torch (libamdhip64) is the one the library binds to.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libspg_hip.so')
+
+SPG_MAX_LAYERS = 8
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+class PointNetCfg(ctypes.Structure):
+    _fields_ = [('nfeat', ctypes.c_int), ('nfeat_stn', ctypes.c_int), ('nfeat_global', ctypes.c_int), ('npts', ctypes.c_int),
+                ('n_stn_conv', ctypes.c_int), ('n_stn_fc', ctypes.c_int), ('n_conv', ctypes.c_int), ('n_fc', ctypes.c_int),
+                ('stn_conv', ctypes.c_int * SPG_MAX_LAYERS), ('stn_fc', ctypes.c_int * SPG_MAX_LAYERS),
+                ('conv', ctypes.c_int * SPG_MAX_LAYERS), ('fc', ctypes.c_int * SPG_MAX_LAYERS),
+                ('last_ac', ctypes.c_int), ('bn_eps', ctypes.c_float), ('bn_momentum', ctypes.c_float)]
+
+
+class EccRnnCfg(ctypes.Structure):
+    _fields_ = [('nc', ctypes.c_int), ('nrepeats', ctypes.c_int), ('matrix', ctypes.c_int), ('layernorm', ctypes.c_int),
+                ('ingate', ctypes.c_int), ('cat_all', ctypes.c_int), ('n_fnet', ctypes.c_int),
+                ('fnet_widths', ctypes.c_int * (SPG_MAX_LAYERS + 1)), ('bnidx', ctypes.c_int), ('llbias', ctypes.c_int),
+                ('bn_eps', ctypes.c_float), ('bn_momentum', ctypes.c_float)]
+
+
+_i, _l, _p, _sz = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes): every symbol include/spg_hip.h declares
+SIGNATURES = {
+    'spg_last_error': (ctypes.c_char_p, []),
+    'spg_version': (_i, []),
+    'spg_graph_workspace_bytes': (_sz, [_i, _i]),
+    'spg_graph_build': (_i, [_p, _p, _i, _i, _p, _p]),
+    'spg_graph_export': (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'spg_ecc_aggregate_fwd': (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'spg_ecc_aggregate_bwd': (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'spg_gru_scratch_floats': (_sz, [_i]),
+    'spg_gru_cell_fwd': (_i, [_p, _p, _i, c_void_pp, _i, _i, _p, _p, _p]),
+    'spg_gru_cell_bwd': (_i, [_p, _p, _p, _i, c_void_pp, _i, _i, _p, _p, c_void_pp, _p, _p]),
+    'spg_linear_fwd': (_i, [_p, _l, _i, _i, _p, _p, _i, _p, _p, _i, _p, _l, _p]),
+    'spg_linear_wgrad_work_floats': (_sz, [_i, _i, _i]),
+    'spg_linear_wgrad': (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
+    'spg_pointnet_num_layers': (_i, [ctypes.POINTER(PointNetCfg)]),
+    'spg_pointnet_workspace_bytes': (_sz, [ctypes.POINTER(PointNetCfg), _i, _i]),
+    'spg_pointnet_forward': (_i, [ctypes.POINTER(PointNetCfg), _i, _p, _p, c_void_pp, _p, _p, _i, _i, _p]),
+    'spg_pointnet_debug_offset': (_l, [ctypes.POINTER(PointNetCfg), _i, _i, _i, _i]),
+    'spg_pointnet_bwd_workspace_bytes': (_sz, [ctypes.POINTER(PointNetCfg), _i]),
+    'spg_pointnet_backward': (_i, [ctypes.POINTER(PointNetCfg), _i, _p, _p, c_void_pp, _p, c_void_pp, _p, _p, _p]),
+    'spg_eccrnn_workspace_bytes': (_sz, [ctypes.POINTER(EccRnnCfg), _i, _i, _i]),
+    'spg_eccrnn_forward': (_i, [ctypes.POINTER(EccRnnCfg), _i, _i, _p, _p, _p, c_void_pp, _p, _p, _i, _i, _p]),
+    'spg_eccrnn_bwd_workspace_bytes': (_sz, [ctypes.POINTER(EccRnnCfg), _i, _i]),
+    'spg_eccrnn_backward': (_i, [ctypes.POINTER(EccRnnCfg), _i, _i, _p, _p, c_void_pp, _p, _p, c_void_pp, _p, _p, _p]),
+    'spg_prof_enable': (None, [_i]),
+    'spg_prof_read': (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double), _i]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(['make', '-C', CSRC, '-j8'], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError('building libspg_hip.so failed:\n' + out.stdout[-4000:] + out.stderr[-4000:])
+    if verbose:
+        print(out.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} not found: the HIP extension is not built '
+                               f'(run `python -c "import __graft_entry__ as g; g.build()"` or `make -C {CSRC}`). '
+                               'There is no CPU fallback for the product path.')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = lib().spg_last_error()
+        raise RuntimeError(f'libspg_hip {what} failed (rc={rc}): {msg.decode() if msg else ""}')

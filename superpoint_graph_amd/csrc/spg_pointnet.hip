@@ -375,6 +375,25 @@ extern "C" int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const fl
   return 0;
 }
 
+// debug / test helper: byte offset inside the forward workspace of a layer's buffers
+//   what: 0 raw output y, 1 BN scale s, 2 BN shift t, 3 batch mean, 4 batch rstd;
+//   layer == -1 / -2: pooled (selected raw max/min + globals) of the STN / main segment (what ignored).
+extern "C" long spg_pointnet_debug_offset(const spg_pointnet_cfg* cfg, int B, int training, int layer, int what) {
+  Plan pl;
+  char* fake = (char*)(uintptr_t)4096;
+  if (make_plan(cfg, B, training, fake, nullptr, (float*)(uintptr_t)8, pl) != 0) return -1;
+  const void* p = nullptr;
+  if (layer == -1) p = pl.has_stn ? pl.stn.pooled : nullptr;
+  else if (layer == -2) p = pl.main.pooled;
+  else if (layer >= 0 && layer < (int)pl.L.size()) {
+    const Layer& l = pl.L[layer];
+    p = what == 0 ? (const void*)l.y : what == 1 ? l.s : what == 2 ? l.t : what == 3 ? l.mean : l.rstd;
+    if (what == 0 && l.y == (float*)(uintptr_t)8) return -1;
+  }
+  if (p == nullptr) return -1;
+  return (long)((const char*)p - fake);
+}
+
 extern "C" size_t spg_pointnet_bwd_workspace_bytes(const spg_pointnet_cfg* cfg, int B) {
   Plan pl;
   if (make_plan(cfg, B, 1, nullptr, nullptr, nullptr, pl) != 0) return 0;

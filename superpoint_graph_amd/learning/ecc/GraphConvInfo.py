@@ -1,0 +1,76 @@
+"""GraphConvInfo: host-side batching of graphs into flat index buffers, same contract as the reference
+(learning/ecc/GraphConvInfo.py:16-86): edges sorted by target, `idxn` = source node per edge, `degs` =
+in-degree per node, edge features in the same order.  Integer outputs are bit-exact with the reference.
+`.cuda()` additionally builds the device-side CSR / reverse-CSR used by the HIP kernels."""
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+
+class GraphConvInfo(object):
+    def __init__(self, *args, **kwargs):
+        self._idxn = None
+        self._idxe = None
+        self._degrees = None
+        self._degrees_gpu = None
+        self._edgefeats = None
+        self._edge_indexes = None
+        self._graph = None          # superpoint_graph_amd.ops.DeviceGraph after .cuda()
+        if len(args) > 0 or len(kwargs) > 0:
+            self.set_batch(*args, **kwargs)
+
+    def set_batch(self, graphs, edge_feat_func):
+        """graphs: igraph-like objects (get_edgelist(), es[...], es.attributes(), indegree(), vcount())."""
+        graphs = graphs if isinstance(graphs, (list, tuple)) else [graphs]
+        p = 0
+        idxn, degrees, edge_indexes = [], [], []
+        edgeattrs = defaultdict(list)
+        for G in graphs:
+            E = np.array(G.get_edgelist()).reshape(-1, 2)
+            idx = E[:, 1].argsort()                      # sort by target (numpy default kind, as the reference)
+            idxn.append(p + E[idx, 0])
+            edgeseq = G.es[idx.tolist()]
+            for a in G.es.attributes():
+                edgeattrs[a] += edgeseq.get_attribute_values(a)
+            degrees += G.indegree(G.vs, loops=True)
+            edge_indexes.append(np.asarray(p + E[idx]))
+            p += G.vcount()
+        self._edgefeats, self._idxe = edge_feat_func(edgeattrs)
+        self._idxn = torch.LongTensor(np.concatenate(idxn))
+        if self._idxe is not None:
+            assert self._idxe.numel() == self._idxn.numel()
+        self._degrees = torch.LongTensor(degrees)
+        self._degrees_gpu = None
+        self._edge_indexes = torch.LongTensor(np.concatenate(edge_indexes).T)
+        self._graph = None
+
+    @classmethod
+    def from_buffers(cls, idxn, degs, edgefeats, idxe=None, edge_indexes=None):
+        """Build directly from already-batched buffers (synthetic scenes, tests)."""
+        gi = cls()
+        gi._idxn, gi._degrees, gi._edgefeats, gi._idxe, gi._edge_indexes = idxn, degs, edgefeats, idxe, edge_indexes
+        return gi
+
+    def cuda(self):
+        from ... import ops
+        self._idxn = self._idxn.cuda()
+        if self._idxe is not None:
+            self._idxe = self._idxe.cuda()
+        self._degrees_gpu = self._degrees.cuda()
+        self._edgefeats = self._edgefeats.cuda()
+        if self._edge_indexes is not None:
+            self._edge_indexes = self._edge_indexes.cuda()
+        self._graph = ops.DeviceGraph(self._idxn, self._degrees_gpu)
+
+    def device_graph(self):
+        if self._graph is None:
+            raise RuntimeError('GraphConvInfo.cuda() must be called before the HIP graph convolution '
+                               '(GraphNetwork.set_info(gc_infos, cuda=True) does it)')
+        return self._graph
+
+    def get_buffers(self):
+        return self._idxn, self._idxe, self._degrees, self._degrees_gpu, self._edgefeats
+
+    def get_pyg_buffers(self):
+        return self._edge_indexes

@@ -1,0 +1,152 @@
+"""RNN-ECC module and GRU cell with the reference's module API (learning/modules.py:128-259)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class GRUCellEx(nn.GRUCell):
+    """GRU cell extended with row normalisation of the gate pre-activations and an input gate (reference
+    learning/modules.py:205-259; same parameters: weight_ih, weight_hh, bias_ih, bias_hh, ig.*).
+    forward/backward run in one fused HIP kernel each (32 channels)."""
+
+    def __init__(self, input_size, hidden_size, bias=True, layernorm=True, ingate=True):
+        super(GRUCellEx, self).__init__(input_size, hidden_size, bias)
+        self._layernorm = layernorm
+        self._ingate = ingate
+        if layernorm:
+            self.add_module('ini', nn.InstanceNorm1d(1, eps=1e-5, affine=False, track_running_stats=False))
+            self.add_module('inh', nn.InstanceNorm1d(1, eps=1e-5, affine=False, track_running_stats=False))
+        if ingate:
+            self.add_module('ig', nn.Linear(hidden_size, input_size, bias=True))
+
+    def param_tensors(self):
+        ig = self._modules['ig'] if self._ingate else None
+        return (self.weight_ih, self.weight_hh, self.bias_ih, self.bias_hh,
+                None if ig is None else ig.weight, None if ig is None else ig.bias)
+
+    def forward(self, input, hidden):
+        if not input.is_cuda:
+            raise RuntimeError('superpoint_graph_amd.GRUCellEx has no CPU path')
+        if self.input_size != 32 or self.hidden_size != 32 or self.bias_ih is None:
+            raise NotImplementedError('the HIP GRU cell is specialised for 32 channels with bias')
+        params = [p for p in self.param_tensors() if p is not None]
+        return _GRUCellFunction.apply(self, input.contiguous(), hidden.contiguous(), *params)
+
+    def __repr__(self):
+        s = super(GRUCellEx, self).__repr__() + '('
+        if self._ingate:
+            s += 'ingate'
+        if self._layernorm:
+            s += ' layernorm'
+        return s + ')'
+
+
+class _GRUCellFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cell, input, hidden, *params):
+        ctx.cell = cell
+        ctx.save_for_backward(input, hidden)
+        return ops.gru_cell_fwd(input, hidden, cell.param_tensors(), cell._layernorm, cell._ingate)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        input, hidden = ctx.saved_tensors
+        cell = ctx.cell
+        gi, gh, grads = ops.gru_cell_bwd(input, hidden, grad_out, cell.param_tensors(), cell._layernorm, cell._ingate)
+        return (None, gi, gh) + tuple(g for g in grads if g is not None)
+
+
+def _fnet_groups(fnet):
+    """(Linear, BatchNorm-or-None) pairs of a create_fnet() Sequential, plus its bnidx."""
+    groups, bnidx, mods = [], -1, list(fnet)
+    for i, m in enumerate(mods):
+        if isinstance(m, nn.Linear):
+            bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+            if bn is not None:
+                bnidx = len(groups)
+            groups.append((m, bn))
+        elif not isinstance(m, (nn.BatchNorm1d, nn.ReLU)):
+            raise NotImplementedError(f'unsupported filter-network module {type(m).__name__}')
+    return groups, bnidx
+
+
+class _EccRnnFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, hx, edgefeats, graph, training, *flat_params):
+        cfg, groups = module._cfg_and_groups()
+        out, state = ops.eccrnn_forward(cfg, graph, hx.contiguous(), edgefeats, groups, training, 1)
+        ctx.module, ctx.state, ctx.groups = module, state, groups
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad_h0, gg = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out)
+        nf = ctx.state.cfg.n_fnet
+        flat = []
+        for li, g in enumerate(gg):
+            flat += list(g[:4]) if li < nf else list(g)
+        flat = [t for t in flat if t is not None]
+        return (None, grad_h0, None, None, None) + tuple(flat)
+
+
+class RNNGraphConvModule(nn.Module):
+    """Recurrent graph convolution: filter-generating network once, then nrepeats x {ECC, RNN cell}
+    (reference learning/modules.py:128-183; same constructor signature, `_cell` / `_fnet` attribute names).
+    With a GRUCellEx cell and 32 channels the whole module is one C call (spg_eccrnn_forward)."""
+
+    def __init__(self, cell, filter_net, nfeat=None, vv=True, gc_info=None, nrepeats=1, cat_all=False,
+                 edge_mem_limit=1e20, use_pyg=True, cuda=True):
+        super(RNNGraphConvModule, self).__init__()
+        self._cell = cell
+        self._isLSTM = 'LSTM' in type(cell).__name__
+        self._fnet = filter_net
+        self._nrepeats = nrepeats
+        self._cat_all = cat_all
+        self._edge_mem_limit = edge_mem_limit
+        self._vv = vv
+        self.set_info(gc_info)
+        self.use_pyg = use_pyg
+        if use_pyg:
+            raise NotImplementedError('--use_pyg 1 (torch_geometric NNConv) is out of scope of the HIP path; use --use_pyg 0')
+        if self._isLSTM:
+            raise NotImplementedError('lstm_* model configs are not implemented on the HIP path yet (gru_* are)')
+
+    def set_info(self, gc_info):
+        self._gci = gc_info
+
+    def _cfg_and_groups(self):
+        fg, bnidx = _fnet_groups(self._fnet)
+        widths = [fg[0][0].in_features] + [lin.out_features for lin, _ in fg]
+        nc = self._cell.hidden_size
+        matrix = widths[-1] == nc * nc and widths[-1] != nc
+        bn = next((b for _, b in fg if b is not None), None)
+        cfg = ops.make_eccrnn_cfg(nc, self._nrepeats, matrix, self._cell._layernorm, self._cell._ingate, self._cat_all,
+                                  widths, bnidx, fg[-1][0].bias is not None,
+                                  1e-5 if bn is None else bn.eps, 0.1 if bn is None or bn.momentum is None else bn.momentum)
+        groups = []
+        for lin, b in fg:
+            groups.append((lin.weight, lin.bias, None if b is None else b.weight, None if b is None else b.bias,
+                           None if b is None else b.running_mean, None if b is None else b.running_var))
+        groups.append(self._cell.param_tensors())
+        return cfg, groups
+
+    def _flat_params(self):
+        flat = []
+        for lin, b in _fnet_groups(self._fnet)[0]:
+            flat += [lin.weight, lin.bias] + ([b.weight, b.bias] if b is not None else [])
+        flat += list(self._cell.param_tensors())
+        return [p for p in flat if p is not None]
+
+    def forward(self, hx):
+        if not hx.is_cuda:
+            raise RuntimeError('superpoint_graph_amd.RNNGraphConvModule has no CPU path')
+        idxn, idxe, degs, degs_gpu, edgefeats = self._gci.get_buffers()
+        if idxe is not None:
+            raise NotImplementedError('filter sharing (idxe) is not supported by the fused RNN-ECC path')
+        if self.training:
+            for m in self._fnet:
+                if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None:
+                    m.num_batches_tracked += 1
+        return _EccRnnFunction.apply(self, hx, edgefeats.contiguous().float(), self._gci.device_graph(), self.training,
+                                     *self._flat_params())

@@ -1,0 +1,207 @@
+"""PointNet superpoint embedder with the reference's module API (learning/pointnet.py:16-180).
+
+The classes own the SAME parameters under the SAME state_dict keys as the reference (they are built from
+the same nn.Conv1d / nn.BatchNorm1d / nn.Linear containers in the same order, so initialisation under a
+given seed is identical and reference checkpoints load), but `forward` hands the parameter pointers to
+libspg_hip (spg_pointnet_forward / spg_pointnet_backward): fused 1x1-conv + BatchNorm + ReLU + max-pool
+MFMA kernels instead of cuDNN/cuBLAS calls."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def _seq_groups(seq):
+    """(weight, bias, bn.weight, bn.bias, running_mean, running_var) per parametric layer of a
+    Sequential[Conv1d|Linear, (BatchNorm1d), ReLU, ...]."""
+    groups, mods = [], list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, (nn.Conv1d, nn.Linear)):
+            bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+            groups.append((m, bn))
+        elif not isinstance(m, (nn.BatchNorm1d, nn.ReLU, nn.Dropout)):
+            raise NotImplementedError(f'{type(m).__name__} is not supported by the HIP PointNet (norm must be "batch")')
+        i += 1
+    return groups
+
+
+def _tensors(lin, bn):
+    w = lin.weight
+    return (w, lin.bias, None if bn is None else bn.weight, None if bn is None else bn.bias,
+            None if bn is None else bn.running_mean, None if bn is None else bn.running_var)
+
+
+class STNkD(nn.Module):
+    """Spatial Transformer Net producing a KxK transformation matrix (reference learning/pointnet.py:16-61).
+    Inside PointNet it is evaluated by the fused HIP pipeline; called on its own it runs the same kernels
+    through a PointNet-less plan (K must be 2)."""
+
+    def __init__(self, nfeat, nf_conv, nf_fc, K=2, norm='batch', affine=True, n_group=1):
+        super(STNkD, self).__init__()
+        if norm != 'batch':
+            raise NotImplementedError('only norm="batch" is implemented on the HIP path')
+        modules = []
+        for i in range(len(nf_conv)):
+            modules.append(nn.Conv1d(nf_conv[i - 1] if i > 0 else nfeat, nf_conv[i], 1))
+            modules.append(nn.BatchNorm1d(nf_conv[i]))
+            modules.append(nn.ReLU(True))
+        self.convs = nn.Sequential(*modules)
+        modules = []
+        for i in range(len(nf_fc)):
+            modules.append(nn.Linear(nf_fc[i - 1] if i > 0 else nf_conv[-1], nf_fc[i]))
+            modules.append(nn.BatchNorm1d(nf_fc[i]))
+            modules.append(nn.ReLU(True))
+        self.fcs = nn.Sequential(*modules)
+        self.proj = nn.Linear(nf_fc[-1], K * K)
+        nn.init.constant_(self.proj.weight, 0)
+        nn.init.constant_(self.proj.bias, 0)
+        self.eye = torch.eye(K).unsqueeze(0)
+        self._nfeat, self._nf_conv, self._nf_fc, self._K = nfeat, list(nf_conv), list(nf_fc), K
+
+    def layer_groups(self):
+        return _seq_groups(self.convs) + _seq_groups(self.fcs) + [(self.proj, None)]
+
+
+class _PointNetFunction(torch.autograd.Function):
+    """autograd node around spg_pointnet_forward / spg_pointnet_backward; parameters are passed as inputs
+    so that autograd delivers their gradients."""
+
+    @staticmethod
+    def forward(ctx, module, clouds, clouds_global, training, bn_update_times, *flat_params):
+        groups = module._groups_tensors()
+        emb, state = ops.pointnet_forward(module._cfg(clouds.shape[2]), clouds, clouds_global, groups, training, bn_update_times)
+        ctx.module, ctx.state, ctx.groups = module, state, groups
+        return emb
+
+    @staticmethod
+    def backward(ctx, grad_emb):
+        gg = ops.pointnet_backward(ctx.state, ctx.groups, grad_emb)
+        flat = []
+        for (gw, gb, ggam, gbet) in gg:
+            flat += [gw, gb, ggam, gbet]
+        flat = [g for g in flat if g is not None]
+        return (None, None, None, None, None) + tuple(flat)
+
+
+class PointNet(nn.Module):
+    """PointNet with one spatial transformer and a "global" input concatenated after the max-pool
+    (reference learning/pointnet.py:63-133; same constructor signature)."""
+
+    def __init__(self, nf_conv, nf_fc, nf_conv_stn, nf_fc_stn, nfeat, nfeat_stn=2, nfeat_global=1, prelast_do=0.5,
+                 last_ac=False, is_res=False, norm='batch', affine=True, n_group=1, last_bn=False):
+        super(PointNet, self).__init__()
+        if norm != 'batch':
+            raise NotImplementedError('only norm="batch" is implemented on the HIP path')
+        torch.manual_seed(0)          # reference learning/pointnet.py:78
+        if nfeat_stn > 0:
+            self.stn = STNkD(nfeat_stn, nf_conv_stn, nf_fc_stn, norm=norm, n_group=n_group)
+        self.nfeat_stn = nfeat_stn
+        modules = []
+        for i in range(len(nf_conv)):
+            modules.append(nn.Conv1d(nf_conv[i - 1] if i > 0 else nfeat, nf_conv[i], 1))
+            modules.append(nn.BatchNorm1d(nf_conv[i]))
+            modules.append(nn.ReLU(True))
+        self.convs = nn.Sequential(*modules)
+        modules = []
+        for i in range(len(nf_fc)):
+            modules.append(nn.Linear(nf_fc[i - 1] if i > 0 else nf_conv[-1] + nfeat_global, nf_fc[i]))
+            if i < len(nf_fc) - 1 or last_ac:
+                modules.append(nn.BatchNorm1d(nf_fc[i]))
+                modules.append(nn.ReLU(True))
+            if i == len(nf_fc) - 2 and prelast_do > 0:
+                modules.append(nn.Dropout(prelast_do))
+        if is_res:
+            nn.init.normal_(modules[-1].weight, mean=0, std=1e-2)
+            nn.init.normal_(modules[-1].bias, mean=0, std=1e-2)
+        self.fcs = nn.Sequential(*modules)
+        self._nfeat, self._nfeat_global, self._last_ac, self._prelast_do = nfeat, nfeat_global, last_ac, prelast_do
+        self._nf_conv, self._nf_fc = list(nf_conv), list(nf_fc)
+
+    # ---- parameter plumbing ----
+    def layer_groups(self):
+        g = self.stn.layer_groups() if self.nfeat_stn > 0 else []
+        return g + _seq_groups(self.convs) + _seq_groups(self.fcs)
+
+    def _groups_tensors(self):
+        return [_tensors(lin, bn) for lin, bn in self.layer_groups()]
+
+    def _flat_params(self):
+        flat = []
+        for lin, bn in self.layer_groups():
+            flat += [lin.weight, lin.bias] + ([bn.weight, bn.bias] if bn is not None else [])
+        return [p for p in flat if p is not None]
+
+    def _cfg(self, npts):
+        stn_conv = self.stn._nf_conv if self.nfeat_stn > 0 else []
+        stn_fc = self.stn._nf_fc if self.nfeat_stn > 0 else []
+        bn0 = self.convs[1]
+        return ops.make_pointnet_cfg(self._nfeat, self.nfeat_stn, self._nfeat_global, npts, stn_conv, stn_fc,
+                                     self._nf_conv, self._nf_fc, self._last_ac, bn0.eps,
+                                     0.1 if bn0.momentum is None else bn0.momentum)
+
+    def _bump_batches_tracked(self, times):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None:
+                m.num_batches_tracked += times
+
+    def forward(self, input, input_global, bn_update_times=1):
+        if not input.is_cuda:
+            raise RuntimeError('superpoint_graph_amd.PointNet has no CPU path; move the model and inputs to the GPU')
+        if self.training and self._prelast_do > 0:
+            raise NotImplementedError('ptn_prelast_do > 0 (dropout before the last layer) is not implemented on the HIP path')
+        if self.nfeat_stn > 0 and self.stn._K != 2:
+            raise NotImplementedError('the fused STN applies a 2x2 transform (K=2), as PointNet.forward does')
+        input = input.contiguous().float()
+        if self.training:
+            self._bump_batches_tracked(bn_update_times)
+        return _PointNetFunction.apply(self, input, input_global, self.training, bn_update_times, *self._flat_params())
+
+
+class CloudEmbedder():
+    """Evaluates PointNet on superpoints; too small superpoints get zero embeddings (reference
+    learning/pointnet.py:138-180).  `ptn_mem_monger` keeps its observable semantics (autograd is cut after
+    the embeddings, `bw_hook()` back-propagates into PointNet, BatchNorm running statistics advance twice
+    per step) but nothing is recomputed: the raw layer outputs stay in HBM."""
+
+    def __init__(self, args):
+        self.args = args
+        self.bw_hook = lambda: None
+        self.run = self.run_full_monger if args.ptn_mem_monger else self.run_full
+
+    @staticmethod
+    def _to_device(clouds_flag, clouds, clouds_global):
+        dev = torch.device('cuda', torch.cuda.current_device())
+        idx_valid = torch.nonzero(clouds_flag.eq(0)).reshape(-1).to(dev)
+        return idx_valid, clouds.to(dev, non_blocking=True), clouds_global.to(dev, non_blocking=True)
+
+    def run_full(self, model, clouds_meta, clouds_flag, clouds, clouds_global):
+        if not self.args.cuda:
+            raise RuntimeError('superpoint_graph_amd has no CPU path (--cuda 1 required)')
+        idx_valid, clouds, clouds_global = self._to_device(clouds_flag, clouds, clouds_global)
+        out = model.ptn(clouds, clouds_global)
+        descriptors = out.new_zeros(clouds_flag.size(0), out.size(1))
+        return descriptors.index_copy(0, idx_valid, out)
+
+    def run_full_monger(self, model, clouds_meta, clouds_flag, clouds, clouds_global):
+        if not self.args.cuda:
+            raise RuntimeError('superpoint_graph_amd has no CPU path (--cuda 1 required)')
+        idx_valid, clouds, clouds_global = self._to_device(clouds_flag, clouds, clouds_global)
+        ptn = model.ptn
+        if not model.training:
+            with torch.no_grad():
+                out = ptn(clouds, clouds_global)
+            self.bw_hook = lambda: None
+        else:
+            # one forward that keeps its activations; the running statistics advance as in the reference's
+            # forward + re-forward (learning/pointnet.py:167,173)
+            live = ptn(clouds, clouds_global, bn_update_times=2)
+            out = live.detach().requires_grad_(True)
+
+            def bw_hook():
+                if out.grad is not None:
+                    live.backward(out.grad)
+            self.bw_hook = bw_hook
+        descriptors = out.new_zeros(clouds_flag.size(0), out.size(1))
+        return descriptors.index_copy(0, idx_valid, out)

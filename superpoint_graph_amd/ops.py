@@ -1,0 +1,269 @@
+"""Tensor-level wrappers over the C ABI (include/spg_hip.h): torch owns device memory and streams, the HIP
+library does the arithmetic.  Every function here requires CUDA(ROCm) tensors and raises otherwise --
+there is no CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import EccRnnCfg, PointNetCfg, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype=None, name='tensor'):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must live on the GPU: the superpoint_graph_amd kernels have no CPU path')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    return t
+
+
+def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+# --------------------------------------------------------------------------------------------------
+# graph structure
+# --------------------------------------------------------------------------------------------------
+class DeviceGraph:
+    """CSR-by-target + reverse CSR built on the device from GraphConvInfo's (idxn, degs)."""
+
+    def __init__(self, idxn: torch.Tensor, degs: torch.Tensor):
+        _req(idxn, torch.int64, 'idxn'); _req(degs, torch.int64, 'degs')
+        self.N, self.E = int(degs.numel()), int(idxn.numel())
+        nbytes = lib().spg_graph_workspace_bytes(self.N, self.E)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=idxn.device)
+        self.idxn, self.degs = idxn, degs
+        check(lib().spg_graph_build(_ptr(idxn) if self.E else None, _ptr(degs), self.N, self.E, _ptr(self.ws), _stream()),
+              'spg_graph_build')
+
+    def export(self):
+        dev = self.ws.device
+        rowptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
+        rev_rowptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
+        src = torch.empty(self.E, dtype=torch.int32, device=dev)
+        dst = torch.empty(self.E, dtype=torch.int32, device=dev)
+        rev = torch.empty(self.E, dtype=torch.int32, device=dev)
+        check(lib().spg_graph_export(_ptr(self.ws), self.N, self.E, _ptr(rowptr), _ptr(src), _ptr(dst), _ptr(rev_rowptr),
+                                     _ptr(rev), _stream()), 'spg_graph_export')
+        return rowptr, src, dst, rev_rowptr, rev
+
+
+# --------------------------------------------------------------------------------------------------
+# generic ECC operator
+# --------------------------------------------------------------------------------------------------
+_DT = {torch.float32: 0, torch.float64: 1}
+
+
+def ecc_aggregate_fwd(x, w, graph: DeviceGraph, idxe=None, cin=None, cout=None):
+    _req(x, name='input'); _req(w, x.dtype, 'weights')
+    matrix = w.dim() == 3
+    cin = x.shape[1] if cin is None else cin
+    cout = (w.shape[2] if matrix else w.shape[1]) if cout is None else cout
+    out = torch.empty(graph.N, cout, dtype=x.dtype, device=x.device)
+    check(lib().spg_ecc_aggregate_fwd(_DT[x.dtype], _ptr(x), _ptr(w), _ptr(idxe), _ptr(graph.ws), graph.N, graph.E, cin, cout,
+                                      int(matrix), _ptr(out), _stream()), 'spg_ecc_aggregate_fwd')
+    return out
+
+
+def ecc_aggregate_bwd(x, w, grad_out, graph: DeviceGraph, idxe=None, need_x=True, need_w=True):
+    matrix = w.dim() == 3
+    cin = x.shape[1]
+    cout = w.shape[2] if matrix else w.shape[1]
+    grad_out = grad_out.contiguous()
+    gx = torch.empty_like(x) if need_x else None
+    gw = torch.empty_like(w) if need_w else None
+    check(lib().spg_ecc_aggregate_bwd(_DT[x.dtype], _ptr(x), _ptr(w), _ptr(idxe), _ptr(graph.ws), graph.N, graph.E,
+                                      x.shape[0], w.shape[0], cin, cout, int(matrix), _ptr(grad_out), _ptr(gx), _ptr(gw),
+                                      _stream()), 'spg_ecc_aggregate_bwd')
+    return gx, gw
+
+
+# --------------------------------------------------------------------------------------------------
+# GRU cell
+# --------------------------------------------------------------------------------------------------
+def gru_cell_fwd(inp, hidden, params: Sequence[Optional[torch.Tensor]], layernorm: bool, ingate: bool):
+    _req(inp, torch.float32, 'input'); _req(hidden, torch.float32, 'hidden')
+    n = inp.shape[0]
+    out = torch.empty_like(hidden)
+    scratch = torch.empty(lib().spg_gru_scratch_floats(n), dtype=torch.float32, device=inp.device)
+    check(lib().spg_gru_cell_fwd(_ptr(inp), _ptr(hidden), n, _ptr_array(params), int(layernorm), int(ingate), _ptr(out),
+                                 _ptr(scratch), _stream()), 'spg_gru_cell_fwd')
+    return out
+
+
+def gru_cell_bwd(inp, hidden, grad_out, params, layernorm: bool, ingate: bool):
+    n = inp.shape[0]
+    grad_out = grad_out.contiguous()
+    gi, gh = torch.empty_like(inp), torch.empty_like(hidden)
+    grads = [None if p is None else torch.empty_like(p) for p in params]
+    scratch = torch.empty(lib().spg_gru_scratch_floats(n), dtype=torch.float32, device=inp.device)
+    check(lib().spg_gru_cell_bwd(_ptr(inp), _ptr(hidden), _ptr(grad_out), n, _ptr_array(params), int(layernorm), int(ingate),
+                                 _ptr(gi), _ptr(gh), _ptr_array(grads), _ptr(scratch), _stream()), 'spg_gru_cell_bwd')
+    return gi, gh, grads
+
+
+# --------------------------------------------------------------------------------------------------
+# dense layer
+# --------------------------------------------------------------------------------------------------
+def linear_fwd(x, w, bias=None, in_scale=None, in_shift=None, in_relu=False):
+    _req(x, torch.float32, 'x'); _req(w, torch.float32, 'w')
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    check(lib().spg_linear_fwd(_ptr(x), K, M, K, _ptr(w), _ptr(bias), N, _ptr(in_scale), _ptr(in_shift), int(in_relu), _ptr(y),
+                               N, _stream()), 'spg_linear_fwd')
+    return y
+
+
+def linear_wgrad(dy, x, in_scale=None, in_shift=None, in_relu=False):
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    work = torch.empty(max(1, lib().spg_linear_wgrad_work_floats(M, N, K)), dtype=torch.float32, device=x.device)
+    check(lib().spg_linear_wgrad(_ptr(dy), N, _ptr(x), K, M, N, K, _ptr(in_scale), _ptr(in_shift), int(in_relu), _ptr(dw),
+                                 _ptr(work), _stream()), 'spg_linear_wgrad')
+    return dw
+
+
+# --------------------------------------------------------------------------------------------------
+# PointNet
+# --------------------------------------------------------------------------------------------------
+def make_pointnet_cfg(nfeat, nfeat_stn, nfeat_global, npts, stn_conv, stn_fc, conv, fc, last_ac=False,
+                      bn_eps=1e-5, bn_momentum=0.1) -> PointNetCfg:
+    c = PointNetCfg()
+    c.nfeat, c.nfeat_stn, c.nfeat_global, c.npts = nfeat, nfeat_stn, nfeat_global, npts
+    c.n_stn_conv, c.n_stn_fc, c.n_conv, c.n_fc = len(stn_conv), len(stn_fc), len(conv), len(fc)
+    for dst, src in ((c.stn_conv, stn_conv), (c.stn_fc, stn_fc), (c.conv, conv), (c.fc, fc)):
+        if len(src) > _lib.SPG_MAX_LAYERS:
+            raise ValueError('too many layers')
+        for i, v in enumerate(src):
+            dst[i] = int(v)
+    c.last_ac, c.bn_eps, c.bn_momentum = int(last_ac), bn_eps, bn_momentum
+    return c
+
+
+class PointNetState:
+    """Saved forward state (workspace with the raw layer outputs and BatchNorm constants)."""
+
+    def __init__(self, cfg, B, clouds, clouds_global, ws):
+        self.cfg, self.B, self.clouds, self.clouds_global, self.ws = cfg, B, clouds, clouds_global, ws
+
+
+def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Sequence[Optional[torch.Tensor]]],
+                     training: bool, bn_update_times: int = 1):
+    """groups: one 6-tuple (weight, bias, bn.weight, bn.bias, running_mean, running_var) per layer in the order
+    of include/spg_hip.h.  Returns (emb [B, D], PointNetState)."""
+    _req(clouds, torch.float32, 'clouds')
+    B = clouds.shape[0]
+    if clouds.shape[1] != cfg.nfeat or clouds.shape[2] != cfg.npts:
+        raise ValueError(f'clouds must be [B, {cfg.nfeat}, {cfg.npts}], got {tuple(clouds.shape)}')
+    if clouds_global is not None:
+        clouds_global = _req(clouds_global.reshape(B, -1).contiguous(), torch.float32, 'clouds_global')
+        if clouds_global.shape[1] != cfg.nfeat_global:
+            raise ValueError('clouds_global width does not match nfeat_global')
+    nbytes = lib().spg_pointnet_workspace_bytes(ctypes.byref(cfg), B, int(training))
+    if nbytes == 0:
+        raise RuntimeError('spg_pointnet_workspace_bytes: ' + lib().spg_last_error().decode())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=clouds.device)
+    D = cfg.fc[cfg.n_fc - 1]
+    emb = torch.empty(B, D, dtype=torch.float32, device=clouds.device)
+    flat = [t for g in groups for t in g]
+    check(lib().spg_pointnet_forward(ctypes.byref(cfg), B, _ptr(clouds), _ptr(clouds_global), _ptr_array(flat), _ptr(emb),
+                                     _ptr(ws), int(training), int(bn_update_times), _stream()), 'spg_pointnet_forward')
+    return emb, PointNetState(cfg, B, clouds, clouds_global, ws)
+
+
+def pointnet_backward(state: PointNetState, groups, grad_emb):
+    """Returns a list of 4-tuples (d weight, d bias, d bn.weight, d bn.bias) per layer."""
+    cfg, B = state.cfg, state.B
+    grad_emb = _req(grad_emb.contiguous(), torch.float32, 'grad_emb')
+    nbytes = lib().spg_pointnet_bwd_workspace_bytes(ctypes.byref(cfg), B)
+    bws = torch.empty(nbytes, dtype=torch.uint8, device=grad_emb.device)
+    gg, flatg = [], []
+    for g in groups:
+        d = [None if g[k] is None else torch.empty_like(g[k]) for k in range(4)]
+        gg.append(tuple(d))
+        flatg += d + [None, None]
+    flat = [t for g in groups for t in g]
+    check(lib().spg_pointnet_backward(ctypes.byref(cfg), B, _ptr(state.clouds), _ptr(state.clouds_global), _ptr_array(flat),
+                                      _ptr(grad_emb), _ptr_array(flatg), _ptr(state.ws), _ptr(bws), _stream()),
+          'spg_pointnet_backward')
+    return gg
+
+
+# --------------------------------------------------------------------------------------------------
+# RNN-ECC module
+# --------------------------------------------------------------------------------------------------
+def make_eccrnn_cfg(nc, nrepeats, matrix, layernorm, ingate, cat_all, fnet_widths, bnidx, llbias, bn_eps=1e-5,
+                    bn_momentum=0.1) -> EccRnnCfg:
+    c = EccRnnCfg()
+    c.nc, c.nrepeats, c.matrix, c.layernorm, c.ingate, c.cat_all = nc, nrepeats, int(matrix), int(layernorm), int(ingate), int(cat_all)
+    c.n_fnet = len(fnet_widths) - 1
+    if c.n_fnet > _lib.SPG_MAX_LAYERS:
+        raise ValueError('filter network too deep')
+    for i, v in enumerate(fnet_widths):
+        c.fnet_widths[i] = int(v)
+    c.bnidx, c.llbias, c.bn_eps, c.bn_momentum = bnidx, int(llbias), bn_eps, bn_momentum
+    return c
+
+
+class EccRnnState:
+    def __init__(self, cfg, graph, edgefeats, ws):
+        self.cfg, self.graph, self.edgefeats, self.ws = cfg, graph, edgefeats, ws
+
+
+def eccrnn_forward(cfg: EccRnnCfg, graph: DeviceGraph, h0, edgefeats, groups, training: bool, bn_update_times: int = 1):
+    _req(h0, torch.float32, 'input'); _req(edgefeats, torch.float32, 'edgefeats')
+    N, E = graph.N, graph.E
+    if h0.shape[0] != N or h0.shape[1] != cfg.nc:
+        raise ValueError(f'input must be [{N}, {cfg.nc}], got {tuple(h0.shape)}')
+    nbytes = lib().spg_eccrnn_workspace_bytes(ctypes.byref(cfg), N, E, int(training))
+    if nbytes == 0:
+        raise RuntimeError('spg_eccrnn_workspace_bytes: ' + lib().spg_last_error().decode())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h0.device)
+    width = cfg.nc * (cfg.nrepeats + 1) if cfg.cat_all else cfg.nc
+    out = torch.empty(N, width, dtype=torch.float32, device=h0.device)
+    flat = [t for g in groups for t in g]
+    check(lib().spg_eccrnn_forward(ctypes.byref(cfg), N, E, _ptr(graph.ws), _ptr(h0), _ptr(edgefeats), _ptr_array(flat),
+                                   _ptr(out), _ptr(ws), int(training), int(bn_update_times), _stream()), 'spg_eccrnn_forward')
+    return out, EccRnnState(cfg, graph, edgefeats, ws)
+
+
+def eccrnn_backward(state: EccRnnState, groups, grad_out):
+    cfg, graph = state.cfg, state.graph
+    N, E = graph.N, graph.E
+    grad_out = _req(grad_out.contiguous(), torch.float32, 'grad_out')
+    bws = torch.empty(lib().spg_eccrnn_bwd_workspace_bytes(ctypes.byref(cfg), N, E), dtype=torch.uint8, device=grad_out.device)
+    grad_h0 = torch.empty(N, cfg.nc, dtype=torch.float32, device=grad_out.device)
+    gg, flatg = [], []
+    nf = cfg.n_fnet
+    for li, g in enumerate(groups):
+        if li < nf:
+            d = [None if g[k] is None else torch.empty_like(g[k]) for k in range(4)] + [None, None]
+        else:
+            d = [None if g[k] is None else torch.empty_like(g[k]) for k in range(6)]
+        gg.append(tuple(d))
+        flatg += d
+    flat = [t for g in groups for t in g]
+    check(lib().spg_eccrnn_backward(ctypes.byref(cfg), N, E, _ptr(graph.ws), _ptr(state.edgefeats), _ptr_array(flat),
+                                    _ptr(grad_out), _ptr(grad_h0), _ptr_array(flatg), _ptr(state.ws), _ptr(bws), _stream()),
+          'spg_eccrnn_backward')
+    return grad_h0, gg

@@ -1,0 +1,69 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(tag):
+    """-> (spec, batch dict of torch tensors, state0 dict, npz)"""
+    from oracle import spg_oracle as O
+    g = np.load(os.path.join(GOLDEN, tag + '.npz'))
+    ints = g['spec/ints']
+    spec = O.ModelSpec(model_config=str(g['spec/model_config']), node_feats=int(ints[0]), edge_feats=int(ints[1]),
+                       ptn_widths=(tuple(int(v) for v in g['spec/ptn_widths0']), tuple(int(v) for v in g['spec/ptn_widths1'])),
+                       ptn_widths_stn=(tuple(int(v) for v in g['spec/ptn_widths_stn0']), tuple(int(v) for v in g['spec/ptn_widths_stn1'])),
+                       ptn_nfeat_stn=int(ints[2]), fnet_widths=tuple(int(v) for v in g['spec/fnet_widths']),
+                       fnet_llbias=int(ints[3]), fnet_orthoinit=int(ints[4]), fnet_bnidx=int(ints[5]), ptn_npts=int(ints[6]))
+    batch = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('batch/')}
+    state0 = {k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('state0/')}
+    return spec, batch, state0, g
+
+
+def build_model(spec, state=None, n_classes=None):
+    """The product model (superpoint_graph_amd.learning) for a ModelSpec, as learning/main.py:create_model does."""
+    from superpoint_graph_amd.learning import graphnet, pointnet
+    model = torch.nn.Module()
+    nfeat = spec.ptn_widths[1][-1]
+    model.ecc = graphnet.GraphNetwork(spec.model_config, nfeat, [spec.edge_feats] + list(spec.fnet_widths),
+                                      spec.fnet_orthoinit, spec.fnet_llbias, spec.fnet_bnidx, 30000, use_pyg=0, cuda=1)
+    model.ptn = pointnet.PointNet(list(spec.ptn_widths[0]), list(spec.ptn_widths[1]), list(spec.ptn_widths_stn[0]),
+                                  list(spec.ptn_widths_stn[1]), spec.node_feats, spec.ptn_nfeat_stn,
+                                  prelast_do=spec.ptn_prelast_do)
+    if state is not None:
+        model.load_state_dict(state)
+    return model
+
+
+def maxrel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope='session')
+def hip():
+    """The loaded HIP library; building it first if the .so is absent (build container)."""
+    from superpoint_graph_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()

@@ -1,0 +1,141 @@
+"""GPU parity tests of the whole hot path (PointNet embedding + RNN-ECC, forward and backward) through the
+reference's module API (superpoint_graph_amd.learning.*), against the golden vectors produced by the
+imported reference (tests/golden, oracle/validate_against_reference.py) and the fp64 oracle; plus
+size-independent properties at the BASELINE scene size."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import build_model, load_golden, maxrel
+from oracle import spg_oracle as O
+from superpoint_graph_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 1e-4          # north star: fp32 embeddings / logits within 1e-4 relative of the reference CPU path
+
+
+def _gci(batch):
+    from superpoint_graph_amd.learning import ecc
+    return ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone(),
+                                          None, batch['edge_indexes'].clone() if 'edge_indexes' in batch else None)
+
+
+def _run(model, batch, monger=1):
+    from superpoint_graph_amd.learning import pointnet
+    args = types.SimpleNamespace(cuda=1, ptn_mem_monger=monger)
+    model.ecc.set_info([_gci(batch)], 1)
+    emb_er = pointnet.CloudEmbedder(args)
+    emb = emb_er.run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])
+    return emb, model.ecc(emb), emb_er
+
+
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small'])
+def test_eval_forward_matches_reference(hip, tag):
+    spec, batch, state0, g = load_golden(tag)
+    model = build_model(spec, state0).to(DEV).eval()
+    emb, logits, _ = _run(model, batch)
+    assert maxrel(emb, torch.from_numpy(g['eval/emb'])) < TOL
+    assert maxrel(logits, torch.from_numpy(g['eval/logits'])) < TOL
+    invalid = (batch['clouds_flag'] != 0).nonzero().reshape(-1)
+    assert float(emb[invalid.to(DEV)].abs().max()) == 0.0              # too-small superpoints: exactly zero rows
+    assert torch.equal(logits.argmax(1).cpu(), torch.from_numpy(g['eval/logits']).argmax(1))
+
+
+@pytest.mark.parametrize('monger', [1, 0])
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small'])
+def test_train_step_matches_reference(hip, tag, monger):
+    spec, batch, state0, g = load_golden(tag)
+    model = build_model(spec, state0).to(DEV).train()
+    cw = torch.from_numpy(g['class_weights']).to(DEV)
+    emb, logits, embedder = _run(model, batch, monger)
+    loss = F.cross_entropy(logits, batch['label_mode'].to(DEV), weight=cw)
+    model.zero_grad()
+    loss.backward()
+    embedder.bw_hook()
+    assert maxrel(emb, torch.from_numpy(g['train/emb'])) < TOL
+    assert maxrel(logits, torch.from_numpy(g['train/logits'])) < TOL
+    assert maxrel(loss, torch.from_numpy(g['train/loss'])) < TOL
+    worst = {}
+    for k, p in model.named_parameters():
+        ref = torch.from_numpy(g['grad/' + k])
+        assert p.grad is not None, k
+        if float(ref.abs().max()) < 1e-6:      # bias in front of a train-mode BatchNorm: analytically zero
+            assert float(p.grad.abs().max()) < 1e-5, k
+            continue
+        worst[k] = maxrel(p.grad, ref)
+    bad = {k: v for k, v in worst.items() if v > 5e-4}
+    assert not bad, bad
+    if monger:                                  # golden state1 was produced with ptn_mem_monger=1 (double BN update)
+        sd = model.state_dict()
+        for k in [k[7:] for k in g.files if k.startswith('state1/')]:
+            assert maxrel(sd[k].double(), torch.from_numpy(g['state1/' + k]).double()) < 1e-5, k
+
+
+def test_train_forward_vs_fp64_oracle(hip):
+    """both fp32 paths (reference on CPU, HIP) are compared with the fp64 oracle: HIP must be as close as the reference."""
+    spec, batch, state0, g = load_golden('s3dis_gru10_matrix')
+    model = build_model(spec, state0).to(DEV).train()
+    emb, logits, _ = _run(model, batch)
+    e64, l64 = torch.from_numpy(g['train/emb_fp64']), torch.from_numpy(g['train/logits_fp64'])
+    ref_err = maxrel(torch.from_numpy(g['train/logits']), l64)
+    assert maxrel(logits, l64) < max(10 * ref_err, 2e-5)
+    assert maxrel(emb, e64) < 2e-5
+
+
+def _unit_batch(seeds, n_sp=1000, n_edges=5000):
+    scenes = [synth.scene(s, n_sp=n_sp, n_edges=n_edges) for s in seeds]
+    col = synth.collate_numpy(scenes)
+    idxn, degs, ef, ei = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    return dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+
+
+def test_baseline_size_properties(hip):
+    """BASELINE-size scenes (1000 superpoints x 128 points, 5000 superedges): size-independent properties."""
+    spec = O.ModelSpec()
+    torch.manual_seed(1)
+    model = build_model(spec).to(DEV)
+    with torch.no_grad():                       # non-trivial BN statistics / STN
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.8, 1.2); m.weight.normal_(1, 0.2); m.bias.normal_(0, 0.1)
+        model.ptn.stn.proj.weight.normal_(0, 0.02)
+    ba, bb, bab = _unit_batch([0]), _unit_batch([1]), _unit_batch([0, 1])
+    model.eval()
+    with torch.no_grad():
+        ea, la, _ = _run(model, ba)
+        eb, lb, _ = _run(model, bb)
+        eab, lab, _ = _run(model, bab)
+        ea2, la2, _ = _run(model, ba)
+    # idempotence / determinism: bit-identical on repetition (no atomics anywhere)
+    assert torch.equal(ea, ea2) and torch.equal(la, la2)
+    # eval mode decouples scenes: the disjoint union gives exactly the per-scene results
+    assert torch.equal(eab, torch.cat([ea, eb])) and torch.equal(lab, torch.cat([la, lb]))
+    assert float(ea[(ba['clouds_flag'] != 0).to(DEV)].abs().sum()) == 0.0
+    # against the CPU oracle at full size (seconds)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    eo, lo = O.model_forward(ba, spec, P, False)
+    assert maxrel(ea, eo) < TOL and maxrel(la, lo) < TOL
+    # training step at full size: finite, deterministic gradients, and equal to the oracle's
+    model.train()
+    def step():
+        model.zero_grad()
+        emb, logits, embedder = _run(model, ba)
+        loss = F.cross_entropy(logits, ba['label_mode'].to(DEV))
+        loss.backward(); embedder.bw_hook()
+        return loss.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    l1, g1 = step()
+    model.load_state_dict(sd0)
+    l2, g2 = step()
+    assert torch.equal(l1, l2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+    st = {k: v.detach().cpu().clone() for k, v in sd0.items()}
+    lo, _, _, go = O.train_step(ba, spec, st, None)
+    assert maxrel(l1, lo) < TOL
+    bad = {k: maxrel(g1[k], go[k]) for k in g1 if float(go[k].abs().max()) > 1e-6 and maxrel(g1[k], go[k]) > 2e-3}
+    assert not bad, bad

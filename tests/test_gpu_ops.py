@@ -1,0 +1,136 @@
+"""GPU parity tests of the individual HIP operators, called through the C ABI (superpoint_graph_amd.ops /
+the learning.* module API) and checked against the oracle and the golden vectors of the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, maxrel
+from oracle import spg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _random_graph(n, e, seed, zero_deg=True):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, e)
+    dst = np.sort(rng.integers(0, n, e))
+    if zero_deg:
+        dst[dst == 3 % n] = (4 % n)           # node 3 gets no in-edges
+        dst = np.sort(dst)
+    degs = np.bincount(dst, minlength=n).astype(np.int64)
+    return torch.from_numpy(src.astype(np.int64)), torch.from_numpy(degs)
+
+
+def test_graph_build_bit_exact(hip):
+    from superpoint_graph_amd import ops
+    for n, e, seed in ((5, 50, 0), (1000, 5000, 1), (10000, 50000, 2), (7, 0, 3)):
+        idxn, degs = _random_graph(n, e, seed) if e else (torch.zeros(0, dtype=torch.long), torch.zeros(n, dtype=torch.long))
+        g = ops.DeviceGraph(idxn.to(DEV), degs.to(DEV))
+        rowptr, src, dst, rrp, rev = [t.cpu().numpy() for t in g.export()]
+        assert np.array_equal(rowptr, O.csr_by_target(degs.numpy()))
+        assert np.array_equal(src, idxn.numpy()) and np.array_equal(dst, O.edge_targets(degs.numpy()))
+        rp, order = O.csr_by_source(idxn.numpy(), n)
+        assert np.array_equal(rrp, rp) and np.array_equal(rev, order)
+
+
+def test_generic_ecc_fp64_golden_and_gradcheck(hip):
+    from superpoint_graph_amd.learning import ecc
+    g = np.load(os.path.join(GOLDEN, 'ops.npz'))
+    x, w = torch.from_numpy(g['ecc_x']).to(DEV), torch.from_numpy(g['ecc_w']).to(DEV)
+    idxn, degs = torch.from_numpy(g['ecc_idxn']).to(DEV), torch.from_numpy(g['ecc_degs'])
+    out = ecc.GraphConvFunction.apply(x, w, 10, 15, idxn, None, degs, degs.to(DEV), 30)
+    assert maxrel(out, torch.from_numpy(g['ecc_out'])) < 1e-13
+    assert float(out[1].abs().max()) == 0.0
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    o = ecc.GraphConvFunction.apply(xg, wg, 10, 15, idxn, None, degs, degs.to(DEV), 1)
+    o.backward(torch.ones_like(o))
+    assert maxrel(xg.grad, torch.from_numpy(g['ecc_gx_ones'])) < 1e-13 and maxrel(wg.grad, torch.from_numpy(g['ecc_gw_ones'])) < 1e-13
+    # the reference's own test: fp64 gradcheck, with and without filter sharing (test_GraphConvModule.py:23-57)
+    dg = degs.to(DEV)
+    assert torch.autograd.gradcheck(lambda a, b: ecc.GraphConvFunction.apply(a, b, 10, 15, idxn, None, degs, dg, 30), (xg, wg))
+    gen = torch.Generator().manual_seed(1)
+    idxe = torch.randint(0, 30, (50,), generator=gen).to(DEV)
+    w30 = torch.randn(30, 10, 15, generator=gen, dtype=torch.float64).to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, b: ecc.GraphConvFunction.apply(a, b, 10, 15, idxn, idxe, degs, dg, 30), (xg, w30))
+    # vector filters
+    xv, wv = torch.from_numpy(g['eccv_x']).to(DEV).requires_grad_(True), torch.from_numpy(g['eccv_w']).to(DEV).requires_grad_(True)
+    ov = ecc.GraphConvFunction.apply(xv, wv, 12, 12, idxn, None, degs, dg, 1e10)
+    assert maxrel(ov, torch.from_numpy(g['eccv_out'])) < 1e-13
+    ov.backward(torch.from_numpy(g['eccv_go']).to(DEV))
+    assert maxrel(xv.grad, torch.from_numpy(g['eccv_gx'])) < 1e-13 and maxrel(wv.grad, torch.from_numpy(g['eccv_gw'])) < 1e-13
+
+
+@pytest.mark.parametrize('matrix', [True, False])
+@pytest.mark.parametrize('n,e', [(40, 150), (1000, 5000)])
+def test_fused_ecc_32_channels(hip, matrix, n, e):
+    """hot-path shape through spg_ecc_aggregate_fwd's fused wave-per-node kernel + the generic backward."""
+    from superpoint_graph_amd.learning import ecc
+    idxn, degs = _random_graph(n, e, 7)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(n, 32, generator=gen)
+    w = torch.randn(e, 32, 32, generator=gen) if matrix else torch.randn(e, 32, generator=gen)
+    go = torch.randn(n, 32, generator=gen)
+    ref = O.ecc_forward(x.double(), w.double(), idxn, degs)
+    gx_ref, gw_ref = O.ecc_backward(x.double(), w.double(), go.double(), idxn, degs)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    out = ecc.GraphConvFunction.apply(xg, wg, 32, 32, idxn.to(DEV), None, degs, degs.to(DEV), 30000)
+    assert maxrel(out, ref) < 2e-6
+    assert float(out[3].abs().max()) == 0.0
+    out.backward(go.to(DEV))
+    assert maxrel(xg.grad, gx_ref) < 2e-6 and maxrel(wg.grad, gw_ref) < 2e-6
+
+
+@pytest.mark.parametrize('layernorm,ingate', [(True, True), (False, False), (True, False)])
+def test_gru_cell(hip, layernorm, ingate):
+    from superpoint_graph_amd.learning import modules
+    g = np.load(os.path.join(GOLDEN, 'ops.npz'))
+    torch.manual_seed(5)
+    cell = modules.GRUCellEx(32, 32, bias=True, layernorm=layernorm, ingate=ingate)
+    if layernorm and ingate:
+        cell.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('gru_p/')})
+    cell = cell.to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    n = 9 if (layernorm and ingate) else 333
+    inp = torch.from_numpy(g['gru_in']) if n == 9 else torch.randn(n, 32, generator=gen)
+    hid = torch.from_numpy(g['gru_h']) if n == 9 else torch.randn(n, 32, generator=gen)
+    xi, xh = inp.to(DEV).requires_grad_(True), hid.to(DEV).requires_grad_(True)
+    out = cell(xi, xh)
+    if n == 9:
+        assert maxrel(out, torch.from_numpy(g['gru_out'])) < 2e-6        # the reference's own output
+    # fp64 oracle forward + autograd backward
+    P = {'c.' + k: v.detach().cpu().double().requires_grad_(True) for k, v in cell.state_dict().items()}
+    oi, oh = inp.double().requires_grad_(True), hid.double().requires_grad_(True)
+    ref = O.gru_cell_ex(oi, oh, P, 'c', layernorm, ingate)
+    assert maxrel(out, ref) < 2e-6
+    go = torch.randn(n, 32, generator=gen)
+    out.backward(go.to(DEV))
+    ref.backward(go.double())
+    assert maxrel(xi.grad, oi.grad) < 5e-6 and maxrel(xh.grad, oh.grad) < 5e-6
+    for k, p in cell.named_parameters():
+        assert maxrel(p.grad, P['c.' + k].grad) < 5e-6, k
+
+
+@pytest.mark.parametrize('M,K,N', [(300, 14, 64), (129, 13, 32), (1000, 64, 64), (517, 64, 128), (256, 128, 256),
+                                   (300, 257, 256), (100, 64, 4), (640, 64, 1024), (77, 352, 13), (128, 32, 96)])
+def test_linear_forward_and_wgrad(hip, M, K, N):
+    from superpoint_graph_amd import ops
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    sc, sh = torch.rand(K, generator=gen) + 0.5, torch.randn(K, generator=gen) * 0.3
+    sc[0] = -sc[0]
+    dy = torch.randn(M, N, generator=gen)
+    X, W, Bv, SC, SH, DY = [t.to(DEV) for t in (x, w, b, sc, sh, dy)]
+    y = ops.linear_fwd(X, W, Bv)
+    assert maxrel(y, x.double() @ w.double().t() + b.double()) < 2e-6
+    a = torch.relu(x.double() * sc.double() + sh.double())
+    y2 = ops.linear_fwd(X, W, None, SC, SH, True)
+    assert maxrel(y2, a @ w.double().t()) < 2e-6
+    dw = ops.linear_wgrad(DY, X)
+    assert maxrel(dw, dy.double().t() @ x.double()) < 2e-6
+    dw2 = ops.linear_wgrad(DY, X, SC, SH, True)
+    assert maxrel(dw2, dy.double().t() @ a) < 2e-6

@@ -1,0 +1,82 @@
+"""CPU: the oracle (oracle/spg_oracle.py) against the golden vectors generated from the imported reference
+(oracle/validate_against_reference.py), plus the reference's own property tests restated
+(learning/ecc/test_GraphConvModule.py:23-75)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, maxrel
+from oracle import spg_oracle as O
+
+
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small'])
+def test_oracle_eval_forward_matches_reference(tag):
+    spec, batch, state0, g = load_golden(tag)
+    emb, logits = O.model_forward(batch, spec, {k: v.clone() for k, v in state0.items()}, False)
+    assert maxrel(emb, torch.from_numpy(g['eval/emb'])) < 2e-6
+    assert maxrel(logits, torch.from_numpy(g['eval/logits'])) < 5e-6
+
+
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small'])
+def test_oracle_train_step_matches_reference(tag):
+    spec, batch, state0, g = load_golden(tag)
+    st = {k: v.clone() for k, v in state0.items()}
+    cw = torch.from_numpy(g['class_weights'])
+    loss, logits, emb, grads = O.train_step(batch, spec, st, cw)
+    assert maxrel(emb, torch.from_numpy(g['train/emb'])) < 2e-5
+    assert maxrel(logits, torch.from_numpy(g['train/logits'])) < 5e-5
+    assert maxrel(loss, torch.from_numpy(g['train/loss'])) < 1e-5
+    for k in [k[5:] for k in g.files if k.startswith('grad/')]:
+        ref = torch.from_numpy(g['grad/' + k])
+        if float(ref.abs().max()) < 1e-6:      # bias in front of a train-mode BatchNorm: rounding noise on both sides
+            continue
+        assert maxrel(grads[k], ref) < 2e-4, k
+    for k in [k[7:] for k in g.files if k.startswith('state1/')]:
+        assert maxrel(st[k].double(), torch.from_numpy(g['state1/' + k]).double()) < 1e-5, k
+
+
+def test_index_contract_bit_exact():
+    for tag in ('s3dis_gru10_matrix', 'vector_gru4_small'):
+        spec, batch, state0, g = load_golden(tag)
+        n_graphs = len([k for k in g.files if k.startswith('graph/') and k.endswith('/n')])
+        el = [g[f'graph/{i}/edges'] for i in range(n_graphs)]
+        vc = [int(g[f'graph/{i}/n']) for i in range(n_graphs)]
+        ef = [g[f'graph/{i}/feats'] for i in range(n_graphs)]
+        idxn, degs, edgefeats, edge_indexes = O.set_batch(el, vc, ef)
+        assert np.array_equal(idxn, g['batch/idxn']) and np.array_equal(degs, g['batch/degs'])
+        assert np.array_equal(edge_indexes, g['batch/edge_indexes']) and np.array_equal(edgefeats, g['batch/edgefeats'])
+        rp = O.csr_by_target(degs)
+        assert rp[-1] == len(idxn)
+        rrp, order = O.csr_by_source(idxn, len(degs))
+        assert np.array_equal(np.sort(order), np.arange(len(idxn)))
+        for j in range(len(degs)):
+            seg = order[rrp[j]:rrp[j + 1]]
+            assert np.all(idxn[seg] == j) and np.all(np.diff(seg) > 0)
+
+
+def test_ops_golden():
+    g = np.load('tests/golden/ops.npz') if False else np.load(__import__('os').path.join(__import__('conftest').GOLDEN, 'ops.npz'))
+    x, w = torch.from_numpy(g['ecc_x']), torch.from_numpy(g['ecc_w'])
+    idxn, degs = torch.from_numpy(g['ecc_idxn']), torch.from_numpy(g['ecc_degs'])
+    out = O.ecc_forward(x, w, idxn, degs)
+    assert maxrel(out, torch.from_numpy(g['ecc_out'])) < 1e-14
+    assert float(out[1].abs().max()) == 0.0                 # zero in-degree row is exactly zero
+    gx, gw = O.ecc_backward(torch.from_numpy(g['eccv_x']), torch.from_numpy(g['eccv_w']), torch.from_numpy(g['eccv_go']), idxn, degs)
+    assert maxrel(gx, torch.from_numpy(g['eccv_gx'])) < 1e-14 and maxrel(gw, torch.from_numpy(g['eccv_gw'])) < 1e-14
+    P = {'c.' + k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('gru_p/')}
+    hy = O.gru_cell_ex(torch.from_numpy(g['gru_in']), torch.from_numpy(g['gru_h']), P, 'c')
+    assert maxrel(hy, torch.from_numpy(g['gru_out'])) < 2e-6
+
+
+def test_gradcheck_and_shard_invariance():
+    # learning/ecc/test_GraphConvModule.py:29-36 fixture
+    gen = torch.Generator().manual_seed(0)
+    n, e, cin, cout = 20, 50, 10, 15
+    x = torch.randn(n, cin, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(e, cin, cout, generator=gen, dtype=torch.float64, requires_grad=True)
+    idxn = torch.randint(0, n, (e,), generator=gen)
+    degs = torch.LongTensor([5, 0, 15, 20, 10])
+    assert torch.autograd.gradcheck(lambda a, b: O.EccFunction.apply(a, b, cin, cout, idxn, None, degs, None, 30), (x, w))
+    for lim in (1, 30, 1e10):
+        sh = O.get_edge_shards(degs.numpy(), lim)
+        assert sum(a for a, _ in sh) == 5 and sum(b for _, b in sh) == 50

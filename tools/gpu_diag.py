@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""GPU diagnostic (not a test): layer-by-layer comparison of the HIP pipeline with the fp64 oracle on the
+golden fixtures, printing one error figure per intermediate tensor / gradient so that a numerical problem
+can be localised from a single gpurun call.  Output: stdout and gpurun_out/diag.txt."""
+import ctypes
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from conftest import build_model, load_golden, maxrel          # noqa: E402
+from oracle import spg_oracle as O                             # noqa: E402
+from superpoint_graph_amd import _lib, ops                     # noqa: E402
+
+OUT = []
+
+
+def say(*a):
+    s = ' '.join(str(x) for x in a)
+    print(s, flush=True)
+    OUT.append(s)
+
+
+def oracle_ptn_layers(batch, spec, P, training, dt=torch.float64):
+    """raw (pre-BatchNorm) output of every parametric layer in the C layer order."""
+    clouds = batch['clouds'].to(dt)
+    B, Fe, Pn = clouds.shape
+    ys = []
+    def bn_relu(y, pfx):
+        return torch.relu(O.batch_norm(y, pfx, P, training))
+    def seg(x0, pfx, convw, fcw, extra=None, last_plain=True, proj=None):
+        h = x0
+        for i in range(len(convw)):
+            y = O._lin(h, P, f'{pfx}.convs.{3*i}'); ys.append(y); h = bn_relu(y, f'{pfx}.convs.{3*i+1}')
+        h = h.reshape(B, Pn, -1).max(1)[0]
+        if extra is not None:
+            h = torch.cat([h, extra], 1)
+        idx = 0
+        for i in range(len(fcw)):
+            y = O._lin(h, P, f'{pfx}.fcs.{idx}'); ys.append(y); idx += 1
+            if proj is not None or i < len(fcw) - 1:
+                h = bn_relu(y, f'{pfx}.fcs.{idx}'); idx += 2
+            else:
+                h = y
+        if proj is not None:
+            y = O._lin(h, P, proj); ys.append(y); h = y
+        return h
+    x = clouds.permute(0, 2, 1).reshape(B * Pn, Fe)
+    if spec.ptn_nfeat_stn > 0:
+        t = seg(x[:, :spec.ptn_nfeat_stn], 'ptn.stn', spec.ptn_widths_stn[0], spec.ptn_widths_stn[1], proj='ptn.stn.proj')
+        T = t.view(-1, 2, 2) + torch.eye(2, dtype=dt)
+        xy = torch.bmm(clouds[:, :2, :].transpose(1, 2), T).transpose(1, 2)
+        clouds2 = torch.cat([xy, clouds[:, 2:, :]], 1)
+        x = clouds2.permute(0, 2, 1).reshape(B * Pn, Fe)
+    emb = seg(x, 'ptn', spec.ptn_widths[0], spec.ptn_widths[1], extra=batch['clouds_global'].to(dt).view(B, -1))
+    return ys, emb
+
+
+def diag_pointnet(tag, training):
+    spec, batch, state0, g = load_golden(tag)
+    say(f'--- pointnet {tag} training={training}')
+    model = build_model(spec, state0).cuda()
+    model.train(training)
+    ptn = model.ptn
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in state0.items()}
+    ys, emb_o = oracle_ptn_layers(batch, spec, P64, training)
+    cfg = ptn._cfg(batch['clouds'].shape[2])
+    groups = ptn._groups_tensors()
+    clouds, cg = batch['clouds'].cuda(), batch['clouds_global'].cuda()
+    emb, st = ops.pointnet_forward(cfg, clouds, cg, groups, training, 1)
+    torch.cuda.synchronize()
+    B = clouds.shape[0]
+    L = _lib.lib()
+    nl = L.spg_pointnet_num_layers(ctypes.byref(cfg))
+    for li in range(nl):
+        off = L.spg_pointnet_debug_offset(ctypes.byref(cfg), B, int(training), li, 0)
+        ref = ys[li]
+        if off < 0:
+            say(f'  layer {li:2d} [{tuple(ref.shape)}] raw output not materialised')
+            continue
+        n = ref.numel()
+        got = st.ws[off:off + 4 * n].view(torch.float32).view(ref.shape)
+        say(f'  layer {li:2d} {tuple(ref.shape)} raw output maxrel = {maxrel(got, ref):.3e}')
+    say(f'  embedding maxrel vs fp64 oracle = {maxrel(emb, emb_o):.3e}')
+    return spec, batch, state0, g, model
+
+
+def diag_train(tag):
+    import types
+    from superpoint_graph_amd.learning import ecc, pointnet
+    spec, batch, state0, g = load_golden(tag)
+    say(f'--- train step {tag}')
+    model = build_model(spec, state0).cuda().train()
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+    emb_er = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
+    emb = emb_er.run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])
+    say(f'  train emb vs reference   {maxrel(emb, torch.from_numpy(g["train/emb"])):.3e}')
+    # ECC alone, fed with the REFERENCE embeddings (isolates the ECC/GRU part)
+    emb_ref = torch.from_numpy(g['train/emb']).cuda().requires_grad_(True)
+    out_ref_in = model.ecc(emb_ref)
+    say(f'  logits (reference emb in) vs reference {maxrel(out_ref_in, torch.from_numpy(g["train/logits"])):.3e}')
+    logits = model.ecc(emb)
+    say(f'  logits vs reference      {maxrel(logits, torch.from_numpy(g["train/logits"])):.3e}')
+    cw = torch.from_numpy(g['class_weights']).cuda()
+    loss = F.cross_entropy(logits, batch['label_mode'].cuda(), weight=cw)
+    say(f'  loss {float(loss):.6f} vs reference {float(g["train/loss"]):.6f}')
+    model.zero_grad()
+    loss.backward()
+    emb_er.bw_hook()
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        ref = torch.from_numpy(g['grad/' + k])
+        if p.grad is None:
+            say(f'  grad {k:34s} MISSING')
+            continue
+        say(f'  grad {k:34s} maxrel {maxrel(p.grad, ref):.3e}   |ref|max {float(ref.abs().max()):.3e}  |got|max {float(p.grad.abs().max()):.3e}')
+
+
+def main():
+    torch.manual_seed(0)
+    say('device:', torch.cuda.get_device_name(0))
+    for fn, args in ((diag_pointnet, ('s3dis_gru10_matrix', False)), (diag_pointnet, ('s3dis_gru10_matrix', True)),
+                     (diag_pointnet, ('vector_gru4_small', True)), (diag_train, ('s3dis_gru10_matrix',)),
+                     (diag_train, ('vector_gru4_small',))):
+        try:
+            fn(*args)
+        except Exception:
+            say('EXCEPTION in', fn.__name__, args)
+            say(traceback.format_exc())
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'diag.txt'), 'w') as f:
+        f.write('\n'.join(OUT) + '\n')
+
+
+if __name__ == '__main__':
+    main()
