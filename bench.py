@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- superpoints/sec of the superpoint-graph learning hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic S3DIS-shaped scenes that are already resident
+in HBM: zero_grad -> CloudEmbedder.run (PointNet) -> model.ecc (filter MLP + 10 x {ECC, GRU} + classifier) ->
+weighted cross entropy -> backward -> bw_hook (PointNet backward) -> [N>1: ONE flat-bucket RCCL all-reduce]
+-> element-wise gradient clamp -> Adam step      (the reference's trainer window, learning/main.py:199-213).
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches it with torch.distributed.run (one rank per GPU, RANK/LOCAL_RANK/WORLD_SIZE in
+the environment); every rank holds its own scene(s) (weak scaling), no data-path collective besides the
+gradient all-reduce.  Rank 0 prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+
+
+def build_model(model_config, device):
+    """create_model of learning/main.py:414-431 with the S3DIS production flags (S3DIS.md:26-28)."""
+    from superpoint_graph_amd.learning import graphnet, pointnet
+    torch.manual_seed(1)
+    model = torch.nn.Module()
+    model.ecc = graphnet.GraphNetwork(model_config, 32, [13, 32, 128, 64], 1, 0, 2, 30000, use_pyg=0, cuda=1)
+    model.ptn = pointnet.PointNet([64, 64, 128, 128, 256], [256, 64, 32], [64, 64, 128], [128, 64], 14, 14, prelast_do=0)
+    return model.to(device)
+
+
+def make_batch(seeds, n_sp, n_edges):
+    from superpoint_graph_amd import synth
+    from superpoint_graph_amd.learning import spg
+    scenes = [synth.scene(s, n_sp=n_sp, n_edges=n_edges) for s in seeds]
+    targets, GIs, (meta, flag, clouds, diam) = spg.eccpc_collate([spg.sample_from_scene(s, f'scene{i}') for i, s in enumerate(scenes)])
+    return targets, GIs, flag, clouds, diam, scenes
+
+
+def cpu_baseline(model_config, scenes, state, max_seconds=25.0):
+    """The oracle (CPU restatement of the reference, kind "port") timed on this host's cores on the same scene.
+    This is the only place bench.py touches oracle/ -- as the reported CPU baseline, never as the measured path."""
+    from oracle import spg_oracle as O
+    from superpoint_graph_amd import synth
+    spec = O.ModelSpec(model_config=model_config)
+    torch.set_num_threads(os.cpu_count() or 1)
+    col = synth.collate_numpy(scenes[:1])
+    idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    st = {k: v.detach().cpu().clone() for k, v in state.items()}
+    O.train_step(batch, spec, st, None)           # warm-up
+    times = []
+    t_begin = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_begin) < max_seconds:
+        t0 = time.perf_counter()
+        O.train_step(batch, spec, st, None)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    n = int(batch['clouds_flag'].numel())
+    return {'value': n / med, 'unit': 'superpoints/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{len(times)} fwd+bwd steps of one {n}-superpoint scene (median {med * 1e3:.0f} ms/step), '
+                      'oracle/spg_oracle.py train_step on torch-CPU'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--scenes', type=int, default=1, help='scenes per GPU per step')
+    ap.add_argument('--n-sp', type=int, default=1000)
+    ap.add_argument('--n-edges', type=int, default=5000)
+    ap.add_argument('--model-config', default='gru_10_0,f_13')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from superpoint_graph_amd import _lib, dist as spd
+    from superpoint_graph_amd.learning import pointnet
+    rank, local, world = spd.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    model = build_model(args.model_config, dev)
+    model.train()
+    seeds = [rank * args.scenes + i for i in range(args.scenes)]          # every rank its own scenes (weak scaling)
+    targets, GIs, flag, clouds, diam, scenes = make_batch(seeds, args.n_sp, args.n_edges)
+    # inputs resident in HBM before the timed region
+    clouds_d, diam_d = clouds.to(dev), diam.to(dev)
+    label_mode = targets[:, 0].to(dev)
+    model.ecc.set_info(GIs, 1)                                             # H2D of the index buffers + device CSR build
+    embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=0.0)
+    bucket = spd.GradBucket(model.parameters())
+    w_local = spd.loss_weight(label_mode)
+    state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    n_sp_step = int(flag.numel())
+
+    def step():
+        optimizer.zero_grad(set_to_none=False)
+        emb = embedder.run(model, None, flag, clouds_d, diam_d)
+        out = model.ecc(emb)
+        loss = F.cross_entropy(out, label_mode)
+        loss.backward()
+        embedder.bw_hook()
+        if world > 1:
+            bucket.allreduce(w_local)
+        for p in model.parameters():
+            p.grad.clamp_(-1.0, 1.0)
+        optimizer.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = n_sp_step * world * args.steps / dt
+
+    result = {
+        'metric': 'superpoints/sec (embed+ECC fwd+bwd), S3DIS-shaped SPG', 'value': value, 'unit': 'superpoints/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x 14 feats, '
+                               f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config} (S3DIS production model, '
+                               'matrix filters, 10 GRU iterations), train step fwd+bwd+Adam',
+                   'superpoints_per_step': n_sp_step * world, 'parallelism': f'dp{world} (one scene shard per GPU, one flat-bucket '
+                                                                              'RCCL all-reduce)' if world > 1 else 'single GPU'},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernels = the MFMA row-GEMMs (PointNet convs/FCs + filter net, fwd/dgrad/wgrad): each launch bracketed by
+        # hipEvents on its stream in a separate instrumented pass of the SAME step (events inside the timed region would
+        # perturb `value`).
+        L = _lib.lib()
+        import ctypes
+        torch.cuda.synchronize()
+        L.spg_prof_enable(1)
+        nprof = 3
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        ms, launches, flops = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+        L.spg_prof_read(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flops), 1)
+        L.spg_prof_enable(0)
+        ach = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                              'kernel': 'spg_rowgemm_kernel + spg_wgrad_kernel (fp32 MFMA 32x32x2)',
+                              'launches_per_step': launches.value / nprof, 'gemm_ms_per_step': ms.value / nprof,
+                              'algorithmic_gflop_per_step': flops.value / nprof / 1e9}
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.model_config, scenes, state0)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

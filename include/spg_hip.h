@@ -37,12 +37,15 @@ int spg_version(void);
  * per-call torch.cumsum(degs) of learning/ecc/cuda_kernels.py:123,135: builds, on the device, the CSR
  * by target (rowptr, dst) and the reverse CSR by source used by the atomic-free backward.
  * idxn: int64 [E] source node per edge (edges sorted by target); degs: int64 [N] in-degrees.
+ * n_src >= N: number of rows of the INPUT feature matrix (GraphConvFunction allows more input rows than
+ * output nodes; for superpoint graphs n_src == N).  Indices outside [0, n_src) raise the header's error flag.
  * ---------------------------------------------------------------------------------------------- */
-size_t spg_graph_workspace_bytes(int N, int E);
-int spg_graph_build(const int64_t* idxn, const int64_t* degs, int N, int E, void* graph_ws, void* stream);
-/* debug / test view: copies of the derived int32 arrays (device pointers, sizes N+1, E, E, N+1, E) */
-int spg_graph_export(const void* graph_ws, int N, int E, int32_t* rowptr, int32_t* src, int32_t* dst,
-                     int32_t* rev_rowptr, int32_t* rev_eid, void* stream);
+size_t spg_graph_workspace_bytes(int N, int n_src, int E);
+int spg_graph_build(const int64_t* idxn, const int64_t* degs, int N, int n_src, int E, void* graph_ws, void* stream);
+/* debug / test view: copies of the derived int32 arrays (device pointers, sizes N+1, E, E, n_src+1, E) and of the
+ * header {N, n_src, E, error flag} */
+int spg_graph_export(const void* graph_ws, int N, int n_src, int E, int32_t* rowptr, int32_t* src, int32_t* dst,
+                     int32_t* rev_rowptr, int32_t* rev_eid, int32_t* hdr, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Generic ECC operator = GraphConvFunction.forward/backward (learning/ecc/GraphConvModule.py:44-152)

@@ -41,9 +41,9 @@ _i, _l, _p, _sz = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_size_t
 SIGNATURES = {
     'spg_last_error': (ctypes.c_char_p, []),
     'spg_version': (_i, []),
-    'spg_graph_workspace_bytes': (_sz, [_i, _i]),
-    'spg_graph_build': (_i, [_p, _p, _i, _i, _p, _p]),
-    'spg_graph_export': (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'spg_graph_workspace_bytes': (_sz, [_i, _i, _i]),
+    'spg_graph_build': (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    'spg_graph_export': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     'spg_ecc_aggregate_fwd': (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     'spg_ecc_aggregate_bwd': (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     'spg_gru_scratch_floats': (_sz, [_i]),

@@ -10,15 +10,16 @@ extern "C" int spg_version(void) { return SPG_VERSION; }
 // ---------------------------------------------------------------------------------------------
 // graph
 // ---------------------------------------------------------------------------------------------
-extern "C" size_t spg_graph_workspace_bytes(int N, int E) { return spg_graph_bytes(N, E); }
+extern "C" size_t spg_graph_workspace_bytes(int N, int n_src, int E) { return spg_graph_bytes(N, n_src, E); }
 
-extern "C" int spg_graph_build(const int64_t* idxn, const int64_t* degs, int N, int E, void* graph_ws, void* stream) {
+extern "C" int spg_graph_build(const int64_t* idxn, const int64_t* degs, int N, int n_src, int E, void* graph_ws,
+                               void* stream) {
   SPG_CHECK_ARG(degs && graph_ws && (E == 0 || idxn), "null pointer");
-  return spg_graph_build_impl(idxn, degs, N, E, graph_ws, (hipStream_t)stream);
+  return spg_graph_build_impl(idxn, degs, N, n_src, E, graph_ws, (hipStream_t)stream);
 }
 
-extern "C" int spg_graph_export(const void* graph_ws, int N, int E, int32_t* rowptr, int32_t* src, int32_t* dst,
-                                int32_t* rev_rowptr, int32_t* rev_eid, void* stream) {
+extern "C" int spg_graph_export(const void* graph_ws, int N, int n_src, int E, int32_t* rowptr, int32_t* src, int32_t* dst,
+                                int32_t* rev_rowptr, int32_t* rev_eid, int32_t* hdr, void* stream) {
   SPG_CHECK_ARG(graph_ws != nullptr, "null pointer");
   SpgGraph g = spg_graph_view(graph_ws, N, E);
   hipStream_t st = (hipStream_t)stream;
@@ -26,7 +27,9 @@ extern "C" int spg_graph_export(const void* graph_ws, int N, int E, int32_t* row
   if (rowptr) e = hipMemcpyAsync(rowptr, g.rowptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess && src && E) e = hipMemcpyAsync(src, g.src, (size_t)E * 4, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess && dst && E) e = hipMemcpyAsync(dst, g.dst, (size_t)E * 4, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess && rev_rowptr) e = hipMemcpyAsync(rev_rowptr, g.rev_rowptr, (size_t)(N + 1) * 4, hipMemcpyDeviceToDevice, st);
+  if (n_src < N) n_src = N;
+  if (e == hipSuccess && rev_rowptr) e = hipMemcpyAsync(rev_rowptr, g.rev_rowptr, (size_t)(n_src + 1) * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && hdr) e = hipMemcpyAsync(hdr, g.hdr, 16, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess && rev_eid && E) e = hipMemcpyAsync(rev_eid, g.rev_eid, (size_t)E * 4, hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) { spg_set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
@@ -66,7 +69,7 @@ __global__ void spg_ecc_generic_bwd_x_kernel(SpgGraph g, const T* __restrict__ w
   if (t >= (long)n_x_rows * cin) return;
   const int j = (int)(t / cin), k = (int)(t - (long)j * cin);
   T acc = 0;
-  if (j < g.N) {
+  if (j < g.hdr[1]) {   // hdr[1] = number of source rows the reverse CSR was built for
     for (int q = g.rev_rowptr[j]; q < g.rev_rowptr[j + 1]; ++q) {
       const int e = g.rev_eid[q];
       const int d = g.dst[e];

@@ -7,17 +7,18 @@
 // target) and the reverse CSR by source used by the atomic-free backward.
 struct SpgGraph {
   int N, E;
+  const int* hdr;         // [4] device header {N, Ns (number of source rows >= N), E, error flag}
   const int* rowptr;      // [N+1] start of each destination node's in-edge segment
   const int* src;         // [E]   source node of each edge (= idxn)
   const int* dst;         // [E]   destination node of each edge
-  const int* rev_rowptr;  // [N+1] start of each source node's out-edge list
+  const int* rev_rowptr;  // [Ns+1] start of each source node's out-edge list
   const int* rev_eid;     // [E]   edge ids grouped by source, increasing inside a group
   const float* invdeg;    // [N]   1/in-degree, 0 for isolated nodes
 };
 
-size_t spg_graph_bytes(int N, int E);
+size_t spg_graph_bytes(int N, int Ns, int E);
 SpgGraph spg_graph_view(const void* workspace, int N, int E);
-int spg_graph_build_impl(const int64_t* idxn, const int64_t* degs, int N, int E, void* workspace, hipStream_t stream);
+int spg_graph_build_impl(const int64_t* idxn, const int64_t* degs, int N, int Ns, int E, void* workspace, hipStream_t stream);
 
 struct SpgGruParams {   // GRUCellEx (learning/modules.py:205-259), hidden = input = 32
   const float* w_ih;    // [96,32]

@@ -18,28 +18,32 @@
 static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 struct GraphLayout {
-  size_t rowptr, src, dst, rev_rowptr, rev_eid, invdeg, cursor, total;
+  size_t hdr, rowptr, src, dst, rev_eid, invdeg, rev_rowptr, cursor, total;
 };
-static GraphLayout graph_layout(int N, int E) {
+// target-side arrays first (their offsets depend on N and E only); the source-side arrays, whose length is
+// the number of SOURCE rows Ns >= N (GraphConvFunction allows more input rows than output nodes), come last.
+static GraphLayout graph_layout(int N, int Ns, int E) {
   GraphLayout L;
   size_t o = 0;
+  L.hdr = o; o += 16;
   L.rowptr = o; o += al16((size_t)(N + 1) * 4);
   L.src = o; o += al16((size_t)(E + 1) * 4);
   L.dst = o; o += al16((size_t)(E + 1) * 4);
-  L.rev_rowptr = o; o += al16((size_t)(N + 1) * 4);
   L.rev_eid = o; o += al16((size_t)(E + 1) * 4);
   L.invdeg = o; o += al16((size_t)(N + 1) * 4);
-  L.cursor = o; o += al16((size_t)(N + 1) * 4);
+  L.rev_rowptr = o; o += al16((size_t)(Ns + 1) * 4);
+  L.cursor = o; o += al16((size_t)(Ns + 1) * 4);
   L.total = o;
   return L;
 }
-size_t spg_graph_bytes(int N, int E) { return graph_layout(N, E).total; }
+size_t spg_graph_bytes(int N, int Ns, int E) { return graph_layout(N, Ns < N ? N : Ns, E).total; }
 
 SpgGraph spg_graph_view(const void* ws, int N, int E) {
-  GraphLayout L = graph_layout(N, E);
+  GraphLayout L = graph_layout(N, N, E);
   const char* b = (const char*)ws;
   SpgGraph g;
   g.N = N; g.E = E;
+  g.hdr = (const int*)(b + L.hdr);
   g.rowptr = (const int*)(b + L.rowptr);
   g.src = (const int*)(b + L.src);
   g.dst = (const int*)(b + L.dst);
@@ -73,21 +77,30 @@ __global__ __launch_bounds__(1024) void spg_scan_kernel(const TIn* __restrict__ 
   if (t == 1023) out[n] = (int)part[1023];
 }
 
-__global__ void spg_graph_nodes_kernel(const int64_t* __restrict__ degs, const int* __restrict__ rowptr, int N,
-                                       int* __restrict__ dst, float* __restrict__ invdeg, int* __restrict__ cursor) {
+__global__ void spg_graph_nodes_kernel(const int64_t* __restrict__ degs, const int* __restrict__ rowptr, int N, int Ns,
+                                       int E, int* __restrict__ hdr, int* __restrict__ dst, float* __restrict__ invdeg,
+                                       int* __restrict__ cursor) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { hdr[0] = N; hdr[1] = Ns; hdr[2] = E; hdr[3] = 0; }
+  if (i < Ns) cursor[i] = 0;
   if (i >= N) return;
   const int d = (int)degs[i];
   invdeg[i] = d > 0 ? 1.0f / (float)d : 0.f;
-  cursor[i] = 0;
   const int e0 = rowptr[i];
   for (int k = 0; k < d; ++k) dst[e0 + k] = i;
 }
 
-__global__ void spg_graph_edges_kernel(const int64_t* __restrict__ idxn, int E, int* __restrict__ src, int* __restrict__ cnt) {
+__global__ void spg_graph_edges_kernel(const int64_t* __restrict__ idxn, int E, int Ns, int* __restrict__ src,
+                                       int* __restrict__ cnt, int* __restrict__ hdr) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const int j = (int)idxn[e];
+  const int64_t j64 = idxn[e];
+  if (j64 < 0 || j64 >= Ns) {   // malformed index buffer: flag it, never write out of bounds
+    src[e] = 0;
+    atomicOr(&hdr[3], 1);
+    return;
+  }
+  const int j = (int)j64;
   src[e] = j;
   atomicAdd(&cnt[j], 1);   // integer count only: the result is order-independent
 }
@@ -113,9 +126,10 @@ __global__ void spg_graph_revsort_kernel(const int* __restrict__ rev_rowptr, int
   }
 }
 
-int spg_graph_build_impl(const int64_t* idxn, const int64_t* degs, int N, int E, void* ws, hipStream_t stream) {
+int spg_graph_build_impl(const int64_t* idxn, const int64_t* degs, int N, int Ns, int E, void* ws, hipStream_t stream) {
   SPG_CHECK_ARG(N > 0 && E >= 0, "graph needs N > 0");
-  GraphLayout L = graph_layout(N, E);
+  if (Ns < N) Ns = N;
+  GraphLayout L = graph_layout(N, Ns, E);
   char* b = (char*)ws;
   int* rowptr = (int*)(b + L.rowptr);
   int* src = (int*)(b + L.src);
@@ -124,24 +138,25 @@ int spg_graph_build_impl(const int64_t* idxn, const int64_t* degs, int N, int E,
   int* rev_eid = (int*)(b + L.rev_eid);
   float* invdeg = (float*)(b + L.invdeg);
   int* cursor = (int*)(b + L.cursor);
+  int* hdr = (int*)(b + L.hdr);
   hipLaunchKernelGGL(spg_scan_kernel<int64_t>, dim3(1), dim3(1024), 0, stream, degs, N, rowptr);
   SPG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(spg_graph_nodes_kernel, dim3(spg_cdiv(N, 256)), dim3(256), 0, stream, degs, rowptr, N, dst, invdeg,
-                     cursor);
+  hipLaunchKernelGGL(spg_graph_nodes_kernel, dim3(spg_cdiv(Ns, 256)), dim3(256), 0, stream, degs, rowptr, N, Ns, E, hdr, dst,
+                     invdeg, cursor);
   SPG_LAUNCH_CHECK();
   if (E > 0) {
-    hipLaunchKernelGGL(spg_graph_edges_kernel, dim3(spg_cdiv(E, 256)), dim3(256), 0, stream, idxn, E, src, cursor);
+    hipLaunchKernelGGL(spg_graph_edges_kernel, dim3(spg_cdiv(E, 256)), dim3(256), 0, stream, idxn, E, Ns, src, cursor, hdr);
     SPG_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(spg_scan_kernel<int>, dim3(1), dim3(1024), 0, stream, (const int*)cursor, N, rev_rowptr);
+  hipLaunchKernelGGL(spg_scan_kernel<int>, dim3(1), dim3(1024), 0, stream, (const int*)cursor, Ns, rev_rowptr);
   SPG_LAUNCH_CHECK();
-  hipError_t me = hipMemsetAsync(cursor, 0, (size_t)N * 4, stream);
+  hipError_t me = hipMemsetAsync(cursor, 0, (size_t)Ns * 4, stream);
   if (me != hipSuccess) { spg_set_error("hipMemsetAsync failed: %s", hipGetErrorString(me)); return (int)me; }
   if (E > 0) {
     hipLaunchKernelGGL(spg_graph_revfill_kernel, dim3(spg_cdiv(E, 256)), dim3(256), 0, stream, (const int*)src, E,
                        (const int*)rev_rowptr, cursor, rev_eid);
     SPG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(spg_graph_revsort_kernel, dim3(spg_cdiv(N, 256)), dim3(256), 0, stream, (const int*)rev_rowptr, N,
+    hipLaunchKernelGGL(spg_graph_revsort_kernel, dim3(spg_cdiv(Ns, 256)), dim3(256), 0, stream, (const int*)rev_rowptr, Ns,
                        rev_eid);
     SPG_LAUNCH_CHECK();
   }

@@ -11,15 +11,15 @@ from ... import ops
 _graph_cache = {}
 
 
-def _graph_for(idxn, degs_gpu):
+def _graph_for(idxn, degs_gpu, n_src):
     """Device CSR for (idxn, degs) buffers handed to GraphConvFunction.apply directly (GraphConvInfo.cuda()
     normally builds it once per batch); cached by buffer identity."""
-    key = (idxn.data_ptr(), degs_gpu.data_ptr(), idxn.numel(), degs_gpu.numel())
+    key = (idxn.data_ptr(), degs_gpu.data_ptr(), idxn.numel(), degs_gpu.numel(), n_src)
     g = _graph_cache.get(key)
     if g is None or g.idxn is not idxn:
         if len(_graph_cache) > 8:
             _graph_cache.clear()
-        g = ops.DeviceGraph(idxn, degs_gpu)
+        g = ops.DeviceGraph(idxn, degs_gpu, n_src)
         _graph_cache[key] = g
     return g
 
@@ -36,7 +36,7 @@ class GraphConvFunction(Function):
         assert full or (in_channels == out_channels and weights.size(1) == in_channels)
         if degs_gpu is None:
             degs_gpu = degs.to(input.device)
-        graph = degs_gpu if isinstance(degs_gpu, ops.DeviceGraph) else _graph_for(idxn, degs_gpu)
+        graph = degs_gpu if isinstance(degs_gpu, ops.DeviceGraph) else _graph_for(idxn, degs_gpu, input.shape[0])
         input, weights = input.contiguous(), weights.contiguous()
         ctx.save_for_backward(input, weights)
         ctx._graph, ctx._idxe = graph, idxe

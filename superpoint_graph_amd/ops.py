@@ -45,24 +45,27 @@ def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
 class DeviceGraph:
     """CSR-by-target + reverse CSR built on the device from GraphConvInfo's (idxn, degs)."""
 
-    def __init__(self, idxn: torch.Tensor, degs: torch.Tensor):
+    def __init__(self, idxn: torch.Tensor, degs: torch.Tensor, n_src: Optional[int] = None):
+        """n_src: number of rows of the input feature matrix (>= number of output nodes; equal for superpoint graphs)."""
         _req(idxn, torch.int64, 'idxn'); _req(degs, torch.int64, 'degs')
         self.N, self.E = int(degs.numel()), int(idxn.numel())
-        nbytes = lib().spg_graph_workspace_bytes(self.N, self.E)
+        self.n_src = max(self.N, int(n_src) if n_src is not None else self.N)
+        nbytes = lib().spg_graph_workspace_bytes(self.N, self.n_src, self.E)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=idxn.device)
         self.idxn, self.degs = idxn, degs
-        check(lib().spg_graph_build(_ptr(idxn) if self.E else None, _ptr(degs), self.N, self.E, _ptr(self.ws), _stream()),
-              'spg_graph_build')
+        check(lib().spg_graph_build(_ptr(idxn) if self.E else None, _ptr(degs), self.N, self.n_src, self.E, _ptr(self.ws),
+                                    _stream()), 'spg_graph_build')
 
     def export(self):
         dev = self.ws.device
         rowptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
-        rev_rowptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
+        rev_rowptr = torch.empty(self.n_src + 1, dtype=torch.int32, device=dev)
         src = torch.empty(self.E, dtype=torch.int32, device=dev)
         dst = torch.empty(self.E, dtype=torch.int32, device=dev)
         rev = torch.empty(self.E, dtype=torch.int32, device=dev)
-        check(lib().spg_graph_export(_ptr(self.ws), self.N, self.E, _ptr(rowptr), _ptr(src), _ptr(dst), _ptr(rev_rowptr),
-                                     _ptr(rev), _stream()), 'spg_graph_export')
+        self.hdr = torch.empty(4, dtype=torch.int32, device=dev)
+        check(lib().spg_graph_export(_ptr(self.ws), self.N, self.n_src, self.E, _ptr(rowptr), _ptr(src), _ptr(dst),
+                                     _ptr(rev_rowptr), _ptr(rev), _ptr(self.hdr), _stream()), 'spg_graph_export')
         return rowptr, src, dst, rev_rowptr, rev
 
 
@@ -74,6 +77,8 @@ _DT = {torch.float32: 0, torch.float64: 1}
 
 def ecc_aggregate_fwd(x, w, graph: DeviceGraph, idxe=None, cin=None, cout=None):
     _req(x, name='input'); _req(w, x.dtype, 'weights')
+    if x.shape[0] > graph.n_src:
+        raise ValueError(f'graph was built for {graph.n_src} input rows, input has {x.shape[0]}')
     matrix = w.dim() == 3
     cin = x.shape[1] if cin is None else cin
     cout = (w.shape[2] if matrix else w.shape[1]) if cout is None else cout

@@ -1,0 +1,65 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient bucket (superpoint_graph_amd/dist.py) reproduces the
+single-process gradient of the whole batch (weighted by the per-rank loss normalisers)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _make(seed=0):
+    torch.manual_seed(seed)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 5))
+    x = torch.randn(23, 6)
+    y = torch.randint(0, 5, (23,))
+    y[::7] = -100
+    cw = torch.linspace(0.5, 1.5, 5)
+    return model, x, y, cw
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from superpoint_graph_amd import dist as spd
+    r, l, w = spd.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    model, x, y, cw = _make()
+    cut = 9                                   # unequal shards: 9 vs 14 "superpoints"
+    xs, ys = (x[:cut], y[:cut]) if rank == 0 else (x[cut:], y[cut:])
+    loss = F.cross_entropy(model(xs), ys, weight=cw)
+    loss.backward()
+    bucket = spd.GradBucket(model.parameters())
+    wtot = bucket.allreduce(spd.loss_weight(ys, cw))
+    ret[rank] = ([p.grad.clone() for p in model.parameters()], float(wtot))
+    torch.distributed.destroy_process_group()
+
+
+def test_weighted_gradient_allreduce_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    model, x, y, cw = _make()
+    F.cross_entropy(model(x), y, weight=cw).backward()
+    ref = [p.grad for p in model.parameters()]
+    from superpoint_graph_amd import dist as spd
+    assert abs(ret[0][1] - spd.loss_weight(y, cw)) < 1e-5
+    for r in (0, 1):
+        for a, b in zip(ret[r][0], ref):
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+
+
+def test_bucket_world1_is_identity_and_sharding():
+    from superpoint_graph_amd import dist as spd
+    model, x, y, cw = _make(1)
+    F.cross_entropy(model(x), y, weight=cw).backward()
+    before = [p.grad.clone() for p in model.parameters()]
+    spd.GradBucket(model.parameters()).allreduce(spd.loss_weight(y, cw))
+    for a, b in zip(before, [p.grad for p in model.parameters()]):
+        assert torch.allclose(a, b, atol=1e-7, rtol=1e-6)
+    assert spd.shard_scenes(8, 3, 8) == [3] and spd.shard_scenes(10, 0, 4) == [0, 1, 2] and spd.shard_scenes(10, 3, 4) == [8, 9]
+    assert sorted(sum((spd.shard_scenes(13, r, 4) for r in range(4)), [])) == list(range(13))

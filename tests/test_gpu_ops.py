@@ -30,10 +30,20 @@ def test_graph_build_bit_exact(hip):
         idxn, degs = _random_graph(n, e, seed) if e else (torch.zeros(0, dtype=torch.long), torch.zeros(n, dtype=torch.long))
         g = ops.DeviceGraph(idxn.to(DEV), degs.to(DEV))
         rowptr, src, dst, rrp, rev = [t.cpu().numpy() for t in g.export()]
+        assert g.hdr.cpu().tolist() == [n, n, e, 0]
         assert np.array_equal(rowptr, O.csr_by_target(degs.numpy()))
         assert np.array_equal(src, idxn.numpy()) and np.array_equal(dst, O.edge_targets(degs.numpy()))
         rp, order = O.csr_by_source(idxn.numpy(), n)
         assert np.array_equal(rrp, rp) and np.array_equal(rev, order)
+    # more input rows than output nodes (the reference's test fixture) and a malformed index buffer
+    idxn, degs = torch.tensor([7, 0, 19, 3, 3]), torch.tensor([2, 0, 3])
+    g = ops.DeviceGraph(idxn.to(DEV), degs.to(DEV), n_src=20)
+    rowptr, src, dst, rrp, rev = [t.cpu().numpy() for t in g.export()]
+    rp, order = O.csr_by_source(idxn.numpy(), 20)
+    assert np.array_equal(rrp, rp) and np.array_equal(rev, order) and g.hdr.cpu().tolist() == [3, 20, 5, 0]
+    g = ops.DeviceGraph(idxn.to(DEV), degs.to(DEV))            # n_src defaults to N=3: indices 7, 19 are out of range
+    g.export()
+    assert g.hdr.cpu().tolist()[3] == 1
 
 
 def test_generic_ecc_fp64_golden_and_gradcheck(hip):

@@ -35,7 +35,7 @@ def test_size_queries(hip):
     assert hip.spg_pointnet_workspace_bytes(ctypes.byref(bad), 10, 1) == 0 and b'npts' in hip.spg_last_error()
     c2 = ops.make_eccrnn_cfg(32, 10, True, True, True, True, [13, 32, 128, 64, 1024], 2, False)
     assert hip.spg_eccrnn_workspace_bytes(ctypes.byref(c2), 1000, 5000, 1) > 0
-    assert hip.spg_graph_workspace_bytes(1000, 5000) >= 4 * (2 * 1001 + 3 * 5000)
+    assert hip.spg_graph_workspace_bytes(1000, 1000, 5000) >= 4 * (2 * 1001 + 3 * 5000)
 
 
 def test_graphconvinfo_bit_exact_and_collate():
