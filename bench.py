@@ -52,7 +52,11 @@ def cpu_baseline(model_config, scenes, state, max_seconds=25.0):
     from oracle import spg_oracle as O
     from superpoint_graph_amd import synth
     spec = O.ModelSpec(model_config=model_config)
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 64)))
     col = synth.collate_numpy(scenes[:1])
     idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
     batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
@@ -86,6 +90,14 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(240, exit=False, file=sys.stderr)     # if anything hangs, say where
+
+    def log(msg):
+        print(f'[bench +{time.perf_counter() - T0:.1f}s] {msg}', file=sys.stderr, flush=True)
+
+    T0 = time.perf_counter()
     from superpoint_graph_amd import _lib, dist as spd
     from superpoint_graph_amd.learning import pointnet
     rank, local, world = spd.init_from_env()
@@ -129,9 +141,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log('model and batch ready')
     for _ in range(args.warmup):
         step()
     barrier()
+    log('warm-up done')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -143,6 +157,7 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = n_sp_step * world * args.steps / dt
+    log(f'timed region done: {ms_per_step:.3f} ms/step')
 
     result = {
         'metric': 'superpoints/sec (embed+ECC fwd+bwd), S3DIS-shaped SPG', 'value': value, 'unit': 'superpoints/s',
@@ -170,6 +185,7 @@ def main():
         ms, launches, flops = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
         L.spg_prof_read(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flops), 1)
         L.spg_prof_enable(0)
+        log('instrumented pass done')
         ach = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
@@ -182,6 +198,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.model_config, scenes, state0)
         print(json.dumps(result), flush=True)
+    faulthandler.cancel_dump_traceback_later()
     if world > 1:
         dist.destroy_process_group()
 

@@ -64,7 +64,9 @@ def test_generic_ecc_fp64_golden_and_gradcheck(hip):
     gen = torch.Generator().manual_seed(1)
     idxe = torch.randint(0, 30, (50,), generator=gen).to(DEV)
     w30 = torch.randn(30, 10, 15, generator=gen, dtype=torch.float64).to(DEV).requires_grad_(True)
-    assert torch.autograd.gradcheck(lambda a, b: ecc.GraphConvFunction.apply(a, b, 10, 15, idxn, idxe, degs, dg, 30), (xg, w30))
+    # filter sharing accumulates grad_weights with fp64 atomics (order-dependent in the last bits): nondet_tol
+    assert torch.autograd.gradcheck(lambda a, b: ecc.GraphConvFunction.apply(a, b, 10, 15, idxn, idxe, degs, dg, 30), (xg, w30),
+                                    nondet_tol=1e-10)
     # vector filters
     xv, wv = torch.from_numpy(g['eccv_x']).to(DEV).requires_grad_(True), torch.from_numpy(g['eccv_w']).to(DEV).requires_grad_(True)
     ov = ecc.GraphConvFunction.apply(xv, wv, 12, 12, idxn, None, degs, dg, 1e10)

@@ -123,12 +123,59 @@ def diag_train(tag):
         say(f'  grad {k:34s} maxrel {maxrel(p.grad, ref):.3e}   |ref|max {float(ref.abs().max()):.3e}  |got|max {float(p.grad.abs().max()):.3e}')
 
 
+def diag_fullsize():
+    """BASELINE-size scene: HIP gradients and the fp32 CPU oracle's, both against the fp64 oracle."""
+    import time
+    import types
+    from superpoint_graph_amd import synth
+    from superpoint_graph_amd.learning import ecc, pointnet
+    say('--- full-size scene (1000 superpoints): gradients vs the fp64 oracle')
+    try:
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+    except Exception:
+        pass
+    spec = O.ModelSpec()
+    torch.manual_seed(1)
+    model = build_model(spec).cuda().train()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.normal_(1, 0.2); m.bias.normal_(0, 0.1)
+        model.ptn.stn.proj.weight.normal_(0, 0.02)
+    sc = synth.scene(0)
+    col = synth.collate_numpy([sc])
+    idxn, degs, ef, ei = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+    emb_er = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
+    emb = emb_er.run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])
+    logits = model.ecc(emb)
+    loss = F.cross_entropy(logits, batch['label_mode'].cuda())
+    model.zero_grad(); loss.backward(); emb_er.bw_hook(); torch.cuda.synchronize()
+    t0 = time.time()
+    l32, lg32, e32, g32 = O.train_step(batch, spec, {k: v.clone() for k, v in sd0.items()}, None, update_running_stats=False)
+    t1 = time.time()
+    l64, lg64, e64, g64 = O.train_step(batch, spec, {k: v.clone() for k, v in sd0.items()}, None, dtype=torch.float64,
+                                        update_running_stats=False)
+    say(f'  oracle fp32 {t1 - t0:.1f}s, fp64 {time.time() - t1:.1f}s;  loss hip {float(loss):.7f} o32 {float(l32):.7f} o64 {float(l64):.7f}')
+    say(f'  emb    hip-vs-64 {maxrel(emb, e64):.3e}   o32-vs-64 {maxrel(e32, e64):.3e}')
+    say(f'  logits hip-vs-64 {maxrel(logits, lg64):.3e}   o32-vs-64 {maxrel(lg32, lg64):.3e}')
+    for k, p in model.named_parameters():
+        if float(g64[k].abs().max()) < 1e-6:
+            continue
+        say(f'  grad {k:34s} hip-vs-64 {maxrel(p.grad, g64[k]):.3e}   o32-vs-64 {maxrel(g32[k], g64[k]):.3e}')
+
+
 def main():
     torch.manual_seed(0)
     say('device:', torch.cuda.get_device_name(0))
     for fn, args in ((diag_pointnet, ('s3dis_gru10_matrix', False)), (diag_pointnet, ('s3dis_gru10_matrix', True)),
                      (diag_pointnet, ('vector_gru4_small', True)), (diag_train, ('s3dis_gru10_matrix',)),
-                     (diag_train, ('vector_gru4_small',))):
+                     (diag_train, ('vector_gru4_small',)), (diag_fullsize, ())):
         try:
             fn(*args)
         except Exception:
