@@ -122,8 +122,13 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     n_sp_step = int(flag.numel())
 
+    params = [p for p in model.parameters()]
+
+    def grads_of(ps):
+        return [p.grad for p in ps if p.grad is not None]
+
     def step():
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad(set_to_none=True)
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
         loss = F.cross_entropy(out, label_mode)
@@ -131,8 +136,7 @@ def main():
         embedder.bw_hook()
         if world > 1:
             bucket.allreduce(w_local)
-        for p in model.parameters():
-            p.grad.clamp_(-1.0, 1.0)
+        torch._foreach_clamp_(grads_of(params), -1.0, 1.0)              # p.grad.clamp_(-clip, clip), learning/main.py:210-212
         optimizer.step()
         return loss
 

@@ -236,12 +236,12 @@ extern "C" int spg_gru_cell_bwd(const float* input, const float* hidden, const f
   w.M = n; w.N = 96; w.K = 32;
   if (grads[0]) { w.a = ident(dgi, 96); w.b = ident(xg, 32); SPG_TRY(spg_launch_wgrad(w, grads[0], work, st)); }
   if (grads[1]) { w.a = ident(dgh, 96); w.b = ident(hidden, 32); SPG_TRY(spg_launch_wgrad(w, grads[1], work, st)); }
-  if (grads[2]) SPG_TRY(spg_launch_colsum(dui, 96, n, 96, grads[2], st));
-  if (grads[3]) SPG_TRY(spg_launch_colsum(duh, 96, n, 96, grads[3], st));
+  if (grads[2]) SPG_TRY(spg_launch_colsum(dui, 96, n, 96, grads[2], work, st));
+  if (grads[3]) SPG_TRY(spg_launch_colsum(duh, 96, n, 96, grads[3], work, st));
   if (ingate) {
     w.N = 32;
     if (grads[4]) { w.a = ident(dpre, 32); w.b = ident(hidden, 32); SPG_TRY(spg_launch_wgrad(w, grads[4], work, st)); }
-    if (grads[5]) SPG_TRY(spg_launch_colsum(dpre, 32, n, 32, grads[5], st));
+    if (grads[5]) SPG_TRY(spg_launch_colsum(dpre, 32, n, 32, grads[5], work, st));
   }
   return 0;
 }

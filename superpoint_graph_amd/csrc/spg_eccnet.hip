@@ -283,12 +283,12 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[0], s.work, st));
     w.a = op_ident(s.dgh, 96); w.b = op_ident(pl.states, 32);
     SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[1], s.work, st));
-    SPG_TRY(spg_launch_colsum(s.dui, 96, rows, 96, pl.cell_grads[2], st));
-    SPG_TRY(spg_launch_colsum(s.duh, 96, rows, 96, pl.cell_grads[3], st));
+    SPG_TRY(spg_launch_colsum(s.dui, 96, rows, 96, pl.cell_grads[2], s.work, st));
+    SPG_TRY(spg_launch_colsum(s.duh, 96, rows, 96, pl.cell_grads[3], s.work, st));
     if (pl.cfg.ingate) {
       w.a = op_ident(s.dpre, 32); w.b = op_ident(pl.states, 32); w.N = 32;
       SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[4], s.work, st));
-      SPG_TRY(spg_launch_colsum(s.dpre, 32, rows, 32, pl.cell_grads[5], st));
+      SPG_TRY(spg_launch_colsum(s.dpre, 32, rows, 32, pl.cell_grads[5], s.work, st));
     }
   }
   if (E == 0) {   // no edges: the filter network received no gradient
@@ -312,7 +312,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     SPG_TRY(spg_launch_wgrad(w, l.dW, s.work, st));
     if (l.db) {
       if (l.bn) SPG_TRY(zero_async(l.db, (size_t)l.cout * 4, st));
-      else SPG_TRY(spg_launch_colsum(cur.X, cur.ld, E, l.cout, l.db, st));
+      else SPG_TRY(spg_launch_colsum(cur.X, cur.ld, E, l.cout, l.db, s.work, st));
     }
     if (i == 0) break;
     FLayer& prod = pl.F[i - 1];

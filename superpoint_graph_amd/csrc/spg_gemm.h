@@ -68,7 +68,9 @@ int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long co
 int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,
                            int G, int N, const float* extra, int nextra, float* out, long ldo, int* aidx,
                            hipStream_t stream);
-int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, hipStream_t stream);
+// work: >= spg_colsum_workspace_floats(N) floats (spg_wgrad_workspace_floats(., N, .) is always large enough)
+size_t spg_colsum_workspace_floats(int N);
+int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, float* work, hipStream_t stream);
 int spg_launch_transpose(const float* W, int N, int K, float* Wt, hipStream_t stream);
 // dT[g, 2a+b] = sum_p clouds[g, a, p] * dxy[g*P + p, b]   (gradient of the 2x2 STN transform, pointnet.py:123)
 int spg_launch_stn_dT(const float* clouds, int Ctot, int P, int G, const float* dxy, long ldd, float* dT,

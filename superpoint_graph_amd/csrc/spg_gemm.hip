@@ -337,12 +337,23 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   }
 }
 
-__global__ void spg_reduce_partials_kernel(const float* __restrict__ partial, int nsplit, long n, float* __restrict__ out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] = sum_k partial[k][i]: 64 elements x 16 split-groups per workgroup, fixed summation order (deterministic)
+__global__ __launch_bounds__(1024) void spg_reduce_partials_kernel(const float* __restrict__ partial, int nsplit, long n,
+                                                                   float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + tx;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + i];   // fixed order: deterministic
-  out[i] = s;
+  if (i < n)
+    for (int k = ty; k < nsplit; k += 16) s += partial[(long)k * n + i];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][tx];
+    out[i] = t;
+  }
 }
 
 static void wgrad_plan(long M, int N, int K, int* IT, int* JT, int* nsplit, int* rps) {
@@ -363,7 +374,8 @@ static void wgrad_plan(long M, int N, int K, int* IT, int* JT, int* nsplit, int*
 size_t spg_wgrad_workspace_floats(long M, int N, int K) {
   int it, jt, ns, rps;
   wgrad_plan(M, N, K, &it, &jt, &ns, &rps);
-  return (size_t)ns * N * K;
+  const size_t w = (size_t)ns * N * K, c = (size_t)64 * N;   // also large enough for spg_launch_colsum over N columns
+  return w > c ? w : c;
 }
 
 template <int IT, int JT, int WI, int WJ>
@@ -391,7 +403,7 @@ int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t strea
   if (rc) return rc;
   if (ns > 1) {
     const long n = (long)p.N * p.K;
-    hipLaunchKernelGGL(spg_reduce_partials_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, work, ns, n, dW);
+    hipLaunchKernelGGL(spg_reduce_partials_kernel, dim3(spg_cdiv(n, 64)), dim3(1024), 0, stream, work, ns, n, dW);
     SPG_LAUNCH_CHECK();
   }
   return 0;
@@ -400,26 +412,35 @@ int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t strea
 // ---------------------------------------------------------------------------------------------
 // BatchNorm statistics
 // ---------------------------------------------------------------------------------------------
-__global__ void spg_bn_finalize_kernel(const float* __restrict__ stat, int ntile, int rows_per_tile, long M, int N,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* running_mean, float* running_var, float momentum, float eps,
-                                       int update_times, float* mean_o, float* rstd_o, float* s_o, float* t_o) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  // Chan et al. pairwise combination of (count, mean, M2), accumulated in fp64 (torch CPU BatchNorm
-  // accumulates float statistics in double as well).
-  double tot = 0.0;
-  for (int b = 0; b < ntile; ++b) {
-    const long nb = min((long)rows_per_tile, M - (long)b * rows_per_tile);
-    tot += (double)nb * (double)stat[((long)b * 2) * N + c];
-  }
-  const double mean = tot / (double)M;
-  double m2 = 0.0;
-  for (int b = 0; b < ntile; ++b) {
-    const long nb = min((long)rows_per_tile, M - (long)b * rows_per_tile);
-    const double d = (double)stat[((long)b * 2) * N + c] - mean;
-    m2 += (double)stat[((long)b * 2 + 1) * N + c] + (double)nb * d * d;
-  }
+// 32 channels x 32 tile-groups per workgroup; single pass in fp64:
+//   mean = sum n_b m_b / M ;  M2 = sum M2_b + sum n_b m_b^2 - M mean^2   (Chan et al.; torch CPU BatchNorm also
+//   accumulates float statistics in double)
+__global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __restrict__ stat, int ntile, int rows_per_tile,
+                                                               long M, int N, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* running_mean,
+                                                               float* running_var, float momentum, float eps,
+                                                               int update_times, float* mean_o, float* rstd_o, float* s_o,
+                                                               float* t_o) {
+  __shared__ double r0[32][33], r1[32][33], r2[32][33];
+  const int cx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (c < N)
+    for (int b = ty; b < ntile; b += 32) {
+      const double nb = (double)min((long)rows_per_tile, M - (long)b * rows_per_tile);
+      const double mb = (double)stat[((long)b * 2) * N + c];
+      a0 += nb * mb;
+      a1 += nb * mb * mb;
+      a2 += (double)stat[((long)b * 2 + 1) * N + c];
+    }
+  r0[ty][cx] = a0; r1[ty][cx] = a1; r2[ty][cx] = a2;
+  __syncthreads();
+  if (ty != 0 || c >= N) return;
+  a0 = a1 = a2 = 0.0;
+  for (int k = 0; k < 32; ++k) { a0 += r0[k][cx]; a1 += r1[k][cx]; a2 += r2[k][cx]; }
+  const double mean = a0 / (double)M;
+  double m2 = a2 + a1 - (double)M * mean * mean;
+  if (m2 < 0.0) m2 = 0.0;
   const double var = m2 / (double)M;
   const double rstd = 1.0 / sqrt(var + (double)eps);
   const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
@@ -442,7 +463,7 @@ __global__ void spg_bn_finalize_kernel(const float* __restrict__ stat, int ntile
 int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                            int update_times, float* mean, float* rstd, float* s, float* t, hipStream_t stream) {
-  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(spg_cdiv(N, 64)), dim3(64), 0, stream, stat, ntile, rows_per_tile, M,
+  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(spg_cdiv(N, 32)), dim3(1024), 0, stream, stat, ntile, rows_per_tile, M,
                      N, gamma, beta, running_mean, running_var, momentum, eps, update_times, mean, rstd, s, t);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -466,16 +487,25 @@ int spg_launch_bn_eval(int N, const float* gamma, const float* beta, const float
   return 0;
 }
 
-__global__ void spg_bn_bwd_finalize_kernel(const float* __restrict__ stat, int ntile, int ldstat, long count, int N,
-                                           const float* __restrict__ s, const float* __restrict__ mean,
-                                           const float* __restrict__ rstd, float* consts, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+__global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* __restrict__ stat, int ntile, int ldstat,
+                                                                   long count, int N, const float* __restrict__ s,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, float* consts,
+                                                                   float* dgamma, float* dbeta) {
+  __shared__ double r0[32][33], r1[32][33];
+  const int cx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   double a = 0.0, b = 0.0;
-  for (int t = 0; t < ntile; ++t) {
-    a += (double)stat[((long)t * 2) * ldstat + c];
-    b += (double)stat[((long)t * 2 + 1) * ldstat + c];
-  }
+  if (c < N)
+    for (int t = ty; t < ntile; t += 32) {
+      a += (double)stat[((long)t * 2) * ldstat + c];
+      b += (double)stat[((long)t * 2 + 1) * ldstat + c];
+    }
+  r0[ty][cx] = a; r1[ty][cx] = b;
+  __syncthreads();
+  if (ty != 0 || c >= N) return;
+  a = b = 0.0;
+  for (int k = 0; k < 32; ++k) { a += r0[k][cx]; b += r1[k][cx]; }
   if (dbeta) dbeta[c] = (float)a;
   if (dgamma) dgamma[c] = (float)b;
   const double c1 = a / (double)count, c2 = b / (double)count;
@@ -488,7 +518,7 @@ __global__ void spg_bn_bwd_finalize_kernel(const float* __restrict__ stat, int n
 int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long count, int N, const float* s,
                                const float* mean, const float* rstd, float* consts, float* dgamma, float* dbeta,
                                hipStream_t stream) {
-  hipLaunchKernelGGL(spg_bn_bwd_finalize_kernel, dim3(spg_cdiv(N, 64)), dim3(64), 0, stream, stat, ntile, ldstat, count, N, s,
+  hipLaunchKernelGGL(spg_bn_bwd_finalize_kernel, dim3(spg_cdiv(N, 32)), dim3(1024), 0, stream, stat, ntile, ldstat, count, N, s,
                      mean, rstd, consts, dgamma, dbeta);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -524,21 +554,42 @@ int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax
   return 0;
 }
 
-__global__ void spg_colsum_kernel(const float* __restrict__ X, long ld, long M, int N, float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
+// column sums in two deterministic stages: 64 columns x 16 row-groups per workgroup over a slice of the rows,
+// then the slice partials are summed in a fixed order
+#define SPG_COLSUM_SLICES 64
+__global__ __launch_bounds__(1024) void spg_colsum_kernel(const float* __restrict__ X, long ld, long M, int N,
+                                                          long rows_per_slice, float* __restrict__ part) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const long m0 = (long)blockIdx.y * rows_per_slice, m1 = min(M, m0 + rows_per_slice);
   float s = 0.f;
   if (c < N)
-    for (long m = g; m < M; m += 4) s += X[m * ld + c];
-  red[g][threadIdx.x & 63] = s;
+    for (long m = m0 + ty; m < m1; m += 16) s += X[m * ld + c];
+  red[ty][tx] = s;
   __syncthreads();
-  if (g == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (ty == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][tx];
+    part[(long)blockIdx.y * N + c] = t;
+  }
 }
 
-int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(spg_colsum_kernel, dim3(spg_cdiv(N, 64)), dim3(256), 0, stream, X, ld, M, N, out);
+size_t spg_colsum_workspace_floats(int N) { return (size_t)SPG_COLSUM_SLICES * N; }
+
+int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, float* work, hipStream_t stream) {
+  long rps = (M + SPG_COLSUM_SLICES - 1) / SPG_COLSUM_SLICES;
+  if (rps < 16) rps = 16;
+  const int slices = spg_cdiv(M, rps);
+  hipLaunchKernelGGL(spg_colsum_kernel, dim3(spg_cdiv(N, 64), slices), dim3(1024), 0, stream, X, ld, M, N, rps,
+                     slices == 1 ? out : work);
   SPG_LAUNCH_CHECK();
+  if (slices > 1) {
+    hipLaunchKernelGGL(spg_reduce_partials_kernel, dim3(spg_cdiv(N, 64)), dim3(1024), 0, stream, (const float*)work, slices,
+                       (long)N, out);
+    SPG_LAUNCH_CHECK();
+  }
   return 0;
 }
 

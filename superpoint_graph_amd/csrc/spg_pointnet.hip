@@ -279,7 +279,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgOperand cur, const
     SPG_TRY(spg_launch_wgrad(w, l.dW, s.work, st));
     if (l.db) {
       if (l.bn) SPG_TRY(zero_async(l.db, l.cout, st));   // a bias in front of train-mode BatchNorm has zero gradient
-      else SPG_TRY(spg_launch_colsum(cur.X, cur.ld, B, l.cout, l.db, st));
+      else SPG_TRY(spg_launch_colsum(cur.X, cur.ld, B, l.cout, l.db, s.work, st));
     }
     // data gradient -> producer of this layer's input
     const bool first = k == 0;
