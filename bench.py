@@ -136,7 +136,9 @@ def main():
         embedder.bw_hook()
         if world > 1:
             bucket.allreduce(w_local)
-        torch._foreach_clamp_(grads_of(params), -1.0, 1.0)              # p.grad.clamp_(-clip, clip), learning/main.py:210-212
+        g = grads_of(params)                                             # p.grad.clamp_(-clip, clip), learning/main.py:210-212
+        torch._foreach_clamp_min_(g, -1.0)
+        torch._foreach_clamp_max_(g, 1.0)
         optimizer.step()
         return loss
 

