@@ -263,7 +263,7 @@ extern "C" int spg_linear_fwd(const float* X, long ldx, int M, int K, const floa
   SPG_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale and in_shift go together");
   SpgGemmParams g; memset(&g, 0, sizeof(g));
   g.a = affine_operand(X, ldx, K, in_scale, in_shift, in_relu);
-  g.W = W; g.ldw = K; g.bias = bias; g.M = M; g.N = N; g.K = K; g.rows_per_tile = 128; g.epi = SPG_EPI_FWD; g.Y = Y; g.ldy = ldy;
+  g.W = W; g.ldw = K; g.bias = bias; g.M = M; g.N = N; g.K = K; g.rows_per_tile = M <= 8192 ? SPG_FC_ROWS : 128; g.epi = SPG_EPI_FWD; g.Y = Y; g.ldy = ldy;
   return spg_launch_gemm(g, (hipStream_t)stream);
 }
 

@@ -114,44 +114,101 @@ __device__ __forceinline__ float spg_fetch(const SpgOperand& d, long m, int c) {
   }
 }
 
-// 4 consecutive channels c..c+3 of one row; caller guarantees 16-byte alignment of the row segment
-// and that the mode is IDENT / AFFINE / BNBWD.
-__device__ __forceinline__ f32x4 spg_fetch4(const SpgOperand& d, long m, int c) {
-  f32x4 v = *reinterpret_cast<const f32x4*>(d.X + m * d.ld + c);
+// ----------------------------------------------------------------------------------------------
+// Vectorised fetch: 4 consecutive channels of one row with the per-channel constants hoisted into
+// registers (SpgQuad) -- they are loaded once per K-chunk (forward / dgrad) or once per kernel
+// (weight gradient, where a thread keeps the same channel quad for all rows).
+// ----------------------------------------------------------------------------------------------
+struct SpgQuad {
+  f32x4 a, b, c, d;
+  int nvalid;    // number of valid channels in this quad (0..4); the others are forced to zero
+};
+
+__host__ __device__ inline bool spg_operand_vec_ok(const SpgOperand& d) {
+  if (d.mode == SPG_PRO_CLOUD) return false;
+  if ((d.ld & 3) != 0 || (((uintptr_t)d.X) & 15) != 0) return false;
+  if ((d.mode == SPG_PRO_BNBWD || d.mode == SPG_PRO_POOLBWD) && (((uintptr_t)d.X2) & 15) != 0) return false;
+  if (d.mode == SPG_PRO_POOLBWD && ((d.ldg & 3) != 0 || (((uintptr_t)d.aidx) & 15) != 0)) return false;
+  return true;
+}
+
+__device__ __forceinline__ float spg_ldc(const float* p, int c, int n, float dflt) { return (p != nullptr && c < n) ? p[c] : dflt; }
+
+// constants of channels c..c+3 (nch = number of channels of the operand)
+__device__ __forceinline__ SpgQuad spg_quad_consts(const SpgOperand& d, int c, int nch) {
+  SpgQuad q;
+  q.nvalid = nch - c < 0 ? 0 : (nch - c > 4 ? 4 : nch - c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    q.a[i] = 1.f; q.b[i] = 0.f; q.c[i] = 0.f; q.d[i] = 0.f;
+  }
   if (d.mode == SPG_PRO_AFFINE) {
-    if (d.c0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (c + i < d.n_affine) v[i] = fmaf(v[i], d.c0[c + i], d.c1[c + i]);
+    for (int i = 0; i < 4; ++i) {
+      const bool aff = c + i < d.n_affine && c + i < nch;
+      q.a[i] = aff ? spg_ldc(d.c0, c + i, nch, 1.f) : 1.f;
+      q.b[i] = aff ? spg_ldc(d.c1, c + i, nch, 0.f) : 0.f;
+      q.c[i] = (aff && d.relu) ? 0.f : -3.0e38f;          // lower clamp: ReLU or none
     }
-    if (d.relu) {
+  } else if (d.mode == SPG_PRO_BNBWD || d.mode == SPG_PRO_POOLBWD) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (c + i < d.n_affine) v[i] = fmaxf(v[i], 0.f);
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = c + i < nch;
+      q.a[i] = ok ? d.c0[c + i] : 0.f;
+      q.b[i] = ok ? d.c1[c + i] : 0.f;
+      q.c[i] = ok ? d.c2[c + i] : 0.f;
+      q.d[i] = ok ? d.c3[c + i] : 0.f;
     }
-  } else if (d.mode == SPG_PRO_BNBWD) {
-    f32x4 y = *reinterpret_cast<const f32x4*>(d.X2 + m * d.ld + c);
+  }
+  return q;
+}
+
+// row m, channels c..c+3 (the row segment must be readable as one aligned 16-byte load: ld % 4 == 0)
+__device__ __forceinline__ f32x4 spg_fetch4q(const SpgOperand& d, const SpgQuad& q, long m, int c) {
+  f32x4 v;
+  if (d.mode == SPG_PRO_IDENT) {
+    v = *reinterpret_cast<const f32x4*>(d.X + m * d.ld + c);
+  } else if (d.mode == SPG_PRO_AFFINE) {
+    v = *reinterpret_cast<const f32x4*>(d.X + m * d.ld + c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = d.c0[c + i] * (v[i] - d.c1[c + i]) - (y[i] - d.c2[c + i]) * d.c3[c + i];
+    for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(v[i], q.a[i], q.b[i]), q.c[i]);
+  } else {
+    f32x4 dz;
+    if (d.mode == SPG_PRO_BNBWD) {
+      dz = *reinterpret_cast<const f32x4*>(d.X + m * d.ld + c);
+    } else {   // POOLBWD: gradient of the max-pool goes to the winning row of each (group, channel)
+      const long g = m / d.P;
+      const int p = (int)(m - g * d.P);
+      const f32x4 dp = *reinterpret_cast<const f32x4*>(d.X + g * d.ldg + c);
+      const int4 ai = *reinterpret_cast<const int4*>(d.aidx + g * d.ldg + c);
+      dz[0] = ai.x == p ? dp[0] : 0.f; dz[1] = ai.y == p ? dp[1] : 0.f;
+      dz[2] = ai.z == p ? dp[2] : 0.f; dz[3] = ai.w == p ? dp[3] : 0.f;
+    }
+    const f32x4 y = *reinterpret_cast<const f32x4*>(d.X2 + m * d.ld + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = q.a[i] * (dz[i] - q.b[i]) - (y[i] - q.c[i]) * q.d[i];
+  }
+  if (q.nvalid < 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i >= q.nvalid) v[i] = 0.f;
   }
   return v;
 }
 
-__host__ __device__ inline bool spg_operand_vec_ok(const SpgOperand& d) {
-  if (!(d.mode == SPG_PRO_IDENT || d.mode == SPG_PRO_AFFINE || d.mode == SPG_PRO_BNBWD)) return false;
-  if ((d.ld & 3) != 0 || (((uintptr_t)d.X) & 15) != 0) return false;
-  if (d.mode == SPG_PRO_BNBWD && (((uintptr_t)d.X2) & 15) != 0) return false;
-  return true;
-}
-
 // ----------------------------------------------------------------------------------------------
-// LDS tile layout shared by every MFMA kernel here:  tile[q][row][4]  (q = reduction index / 4,
-// `rows`+1 16-byte slots per plane).  A lane (row r = lane&31, half h = lane>>5) reads ONE
-// ds_read_b128 per 8 reduction steps: plane 2g+h gives it 4 consecutive reduction indices, used as
-// the A (or B) operand of 4 successive v_mfma_f32_32x32x2_f32 -- both operands use the same
-// (plane, component) -> reduction-index map, so the pairing inside each MFMA is consistent.
-// Consecutive rows are consecutive 16-byte slots: conflict-free for ds_read_b128 and ds_write_b128;
-// the odd plane stride (rows+1) keeps the 8 planes of one row on distinct banks for the writes.
+// LDS tile layouts.
+//  "out-major"  tile[q][row][4]  (q = reduction index / 4, rows+1 16-byte slots per plane): natural when the
+//     global matrix is [row][reduction] (forward / dgrad A operand, forward weights).  A lane (row r = lane&31,
+//     half h = lane>>5) reads ONE ds_read_b128 per 8 reduction steps: plane 2g+h holds reduction indices
+//     8g+4h+{0..3}, used as the operand of 4 successive v_mfma_f32_32x32x2_f32.  Conflict-free b128 reads and
+//     writes (consecutive rows = consecutive slots; odd plane stride).
+//  "red-major"  tile[red][ch] row-major floats (stride = channels + pad): natural when the global matrix is
+//     [reduction][channel] (both operands of the weight gradient, the untransposed weights of the dgrad).
+//     Written with ds_write_b128 exactly as loaded (float4 along the channels), read with one ds_read_b32 per
+//     MFMA operand (32 consecutive channels = 32 consecutive banks).  LDS bandwidth is irrelevant here: a
+//     wave issues TI+TJ dword reads per TI*TJ MFMAs of 64 cycles each.
+// Both layouts use the same reduction-index <-> (MFMA k-slot, lane half) map, so they can be mixed.
 // ----------------------------------------------------------------------------------------------
 template <int TI, int TJ>
 __device__ __forceinline__ void spg_mfma_chunk(const f32x4* __restrict__ As, const f32x4* __restrict__ Bs,
@@ -174,8 +231,52 @@ __device__ __forceinline__ void spg_mfma_chunk(const f32x4* __restrict__ As, con
   }
 }
 
-// Stage a [nrows_tile x SPG_KC] tile, element (row, k) = operand(m0+row, k0+k), rows >= mvalid and
-// channels >= nch are zero.  (forward / dgrad A operand: LDS row = matrix row, reduction = channel)
+// A out-major, B red-major
+template <int TI, int TJ>
+__device__ __forceinline__ void spg_mfma_chunk_or(const f32x4* __restrict__ As, const float* __restrict__ Bs,
+                                                  int strideA, int strideB, int rowA, int colB, int h,
+                                                  f32x16 (&acc)[TI][TJ]) {
+#pragma unroll
+  for (int g = 0; g < SPG_KC / 8; ++g) {
+    f32x4 a[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) a[i] = As[(2 * g + h) * strideA + rowA + 32 * i];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float b[TJ];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b[j] = Bs[(8 * g + 4 * h + s) * strideB + colB + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
+// both operands red-major
+template <int TI, int TJ>
+__device__ __forceinline__ void spg_mfma_chunk_rr(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                  int strideA, int strideB, int colA, int colB, int h,
+                                                  f32x16 (&acc)[TI][TJ]) {
+#pragma unroll
+  for (int kk = 0; kk < SPG_KC / 2; ++kk) {
+    float a[TI], b[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) a[i] = As[(2 * kk + h) * strideA + colA + 32 * i];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) b[j] = Bs[(2 * kk + h) * strideB + colB + 32 * j];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// Out-major staging of a [ROWS x SPG_KC] tile: element (row, k) = operand(m0+row, k0+k); rows >= mvalid and
+// channels >= nch are zero.
 template <int ROWS>
 __device__ __forceinline__ void spg_stage_rows(const SpgOperand& d, long m0, int mvalid, int k0, int nch,
                                                f32x4* __restrict__ lds, bool vec) {
@@ -184,10 +285,11 @@ __device__ __forceinline__ void spg_stage_rows(const SpgOperand& d, long m0, int
     // 8 float4 per row; a thread keeps the same k-quad for all its rows
     const int kq = tid & 7;
     const int c = k0 + 4 * kq;
+    const SpgQuad q = spg_quad_consts(d, c, nch);
 #pragma unroll 4
     for (int row = tid >> 3; row < ROWS; row += SPG_THREADS / 8) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < mvalid && c < nch) v = spg_fetch4(d, m0 + row, c);   // nch % 4 == 0 on this path
+      if (row < mvalid && q.nvalid > 0) v = spg_fetch4q(d, q, m0 + row, c);
       lds[kq * (ROWS + 1) + row] = v;
     }
   } else if (d.mode == SPG_PRO_CLOUD) {
@@ -210,29 +312,45 @@ __device__ __forceinline__ void spg_stage_rows(const SpgOperand& d, long m0, int
   }
 }
 
-// Stage a [CH x SPG_KC] tile of the TRANSPOSED operand: LDS row = channel (c0+ch), reduction index =
-// matrix row (m0 + k).  Used by the weight-gradient kernel (reduction over points/edges/nodes).
-// Each thread gathers 4 consecutive rows of one channel (4 coalesced 4-byte loads across the wave)
-// and writes one 16-byte slot.
+// Red-major staging of a [SPG_KC rows x CH channels] tile: LDS[r][ch] = operand(m0 + r, c0 + ch), rows >= mend
+// and channels >= nch are zero.  `stride` (floats): CH+4 on the vector path (16-byte aligned rows), CH+1 for the
+// channel-major cloud source (conflict-free dword writes with the points along the lanes).
 template <int CH>
-__device__ __forceinline__ void spg_stage_cols(const SpgOperand& d, long m0, long mend, int c0, int nch,
-                                               f32x4* __restrict__ lds) {
+__device__ __forceinline__ int spg_red_stride(const SpgOperand& d) { return d.mode == SPG_PRO_CLOUD ? CH + 1 : CH + 4; }
+
+template <int CH>
+__device__ __forceinline__ void spg_stage_red(const SpgOperand& d, const SpgQuad& q, long m0, long mend, int c0, int nch,
+                                              float* __restrict__ lds, bool vec) {
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < CH * (SPG_KC / 4); idx += SPG_THREADS) {
-    const int ch = idx % CH, mq = idx / CH;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (c0 + ch < nch) {
+  constexpr int QUADS = CH / 4;
+  if (vec) {
+    constexpr int RPP = SPG_THREADS / QUADS;          // rows per pass
+    const int cq = tid % QUADS;                       // fixed channel quad of this thread (q holds its constants)
+    const int c = c0 + 4 * cq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        long m = m0 + 4 * mq + i;
-        if (m < mend) v[i] = spg_fetch(d, m, c0 + ch);
-      }
+    for (int r = tid / QUADS; r < SPG_KC; r += RPP) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m0 + r < mend && q.nvalid > 0) v = spg_fetch4q(d, q, m0 + r, c);
+      *reinterpret_cast<f32x4*>(lds + r * (CH + 4) + 4 * cq) = v;
     }
-    lds[mq * (CH + 1) + ch] = v;
+  } else if (d.mode == SPG_PRO_CLOUD) {
+    for (int idx = tid; idx < CH * SPG_KC; idx += SPG_THREADS) {
+      const int r = idx % SPG_KC, ch = idx / SPG_KC;
+      float v = 0.f;
+      if (m0 + r < mend && c0 + ch < nch) v = spg_fetch(d, m0 + r, c0 + ch);
+      lds[r * (CH + 1) + ch] = v;
+    }
+  } else {
+    for (int idx = tid; idx < CH * SPG_KC; idx += SPG_THREADS) {
+      const int ch = idx % CH, r = idx / CH;
+      float v = 0.f;
+      if (m0 + r < mend && c0 + ch < nch) v = spg_fetch(d, m0 + r, c0 + ch);
+      lds[r * (CH + 4) + ch] = v;
+    }
   }
 }
 
-// Weight tile: W [nout, kred] row-major (ld), LDS row = output channel n0+j, reduction = k0+k.
+// Out-major weight tile: W [nout, kred] row-major (ld), LDS row = output channel n0+j, reduction = k0+k.
 template <int JT>
 __device__ __forceinline__ void spg_stage_weight(const float* __restrict__ W, long ld, int n0, int nout, int k0,
                                                  int kred, f32x4* __restrict__ lds, bool vec) {
@@ -253,6 +371,35 @@ __device__ __forceinline__ void spg_stage_weight(const float* __restrict__ W, lo
       float v = 0.f;
       if (n0 + j < nout && k0 + k < kred) v = W[(long)(n0 + j) * ld + k0 + k];
       l[((k >> 2) * (JT + 1) + j) * 4 + (k & 3)] = v;
+    }
+  }
+}
+
+// Red-major weight tile for the data gradient: W [nred, nout] row-major (ld) read UNTRANSPOSED:
+// LDS[r][j] = W[k0 + r][n0 + j]   (reduction over the rows of W = output channels of the forward layer)
+template <int JT>
+__device__ __forceinline__ void spg_stage_weight_red(const float* __restrict__ W, long ld, int n0, int nout, int k0,
+                                                     int kred, float* __restrict__ lds, bool vec) {
+  const int tid = threadIdx.x;
+  constexpr int QUADS = JT / 4;
+  if (vec) {
+    constexpr int RPP = SPG_THREADS / QUADS;
+    const int cq = tid % QUADS;
+    const int c = n0 + 4 * cq;
+#pragma unroll
+    for (int r = tid / QUADS; r < SPG_KC; r += RPP) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k0 + r < kred && c < nout) {     // nout % 4 == 0 on this path
+        v = *reinterpret_cast<const f32x4*>(W + (long)(k0 + r) * ld + c);
+      }
+      *reinterpret_cast<f32x4*>(lds + r * (JT + 4) + 4 * cq) = v;
+    }
+  } else {
+    for (int idx = tid; idx < JT * SPG_KC; idx += SPG_THREADS) {
+      const int j = idx % JT, r = idx / JT;
+      float v = 0.f;
+      if (k0 + r < kred && n0 + j < nout) v = W[(long)(k0 + r) * ld + n0 + j];
+      lds[r * (JT + 4) + j] = v;
     }
   }
 }

@@ -95,7 +95,7 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
   pl.gru.w_ih_t = pl.wih_t; pl.gru.w_hh_t = pl.whh_t; pl.gru.w_ig_t = pl.wig_t;
   pl.states = cv.take<float>((size_t)N * pl.ldS);
   pl.agg = cv.take<float>((size_t)N * pl.ldS);
-  pl.stat = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, 128) * 2 * cmax);
+  pl.stat = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, SPG_FC_ROWS) * 2 * cmax);
   pl.bytes = cv.off + 256;
   return 0;
 }
@@ -163,10 +163,9 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   int hmax = 4;   // widest hidden activation
   for (int i = 0; i + 1 < (int)pl.F.size(); ++i) hmax = pl.F[i].cout > hmax ? pl.F[i].cout : hmax;
   s.dzA = cv.take<float>(Er * hmax); s.dzB = cv.take<float>(Er * hmax);
-  s.Wt = cv.take<float>(wmax);
   s.consts = cv.take<float>((size_t)4 * cmax);
   s.work = cv.take<float>(workmax);
-  s.stat = cv.take<float>((size_t)spg_cdiv(Er, 128) * 2 * cmax);
+  s.stat = cv.take<float>((size_t)spg_cdiv(Er, SPG_FC_ROWS) * 2 * cmax);
   s.bytes = cv.off + 256;
 }
 
@@ -192,13 +191,13 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
       FLayer& l = pl.F[i];
       SpgGemmParams g; memset(&g, 0, sizeof(g));
       g.a = fnet_input(pl, i, edgefeats);
-      g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = E; g.N = l.cout; g.K = l.cin; g.rows_per_tile = 128;
+      g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = E; g.N = l.cout; g.K = l.cin; g.rows_per_tile = SPG_FC_ROWS;
       g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.cout;
       g.stat = (l.bn && pl.training) ? pl.stat : nullptr;
       SPG_TRY(spg_launch_gemm(g, st));
       if (l.bn) {
         if (pl.training)
-          SPG_TRY(spg_launch_bn_finalize(pl.stat, spg_cdiv(E, 128), 128, E, l.cout, l.gamma, l.beta, l.rm, l.rv,
+          SPG_TRY(spg_launch_bn_finalize(pl.stat, spg_cdiv(E, SPG_FC_ROWS), SPG_FC_ROWS, E, l.cout, l.gamma, l.beta, l.rm, l.rv,
                                          pl.cfg.bn_momentum, pl.cfg.bn_eps, bn_update_times, l.mean, l.rstd, l.s, l.t, st));
         else
           SPG_TRY(spg_launch_bn_eval(l.cout, l.gamma, l.beta, l.rm, l.rv, pl.cfg.bn_eps, l.s, l.t, st));
@@ -316,16 +315,16 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     }
     if (i == 0) break;
     FLayer& prod = pl.F[i - 1];
-    SPG_TRY(spg_launch_transpose(l.W, l.cout, l.cin, s.Wt, st));
     float* out = dz[flip]; flip ^= 1;
     SpgGemmParams g; memset(&g, 0, sizeof(g));
-    g.a = cur; g.W = s.Wt; g.ldw = l.cout; g.M = E; g.N = l.cin; g.K = l.cout; g.rows_per_tile = 128;
+    g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;
+    g.M = E; g.N = l.cin; g.K = l.cout; g.rows_per_tile = SPG_FC_ROWS;
     g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.cout;
     g.mask_relu = prod.relu ? 1 : 0; g.n_mask = prod.cout;
     if (prod.bn) { g.ms = prod.s; g.mt = prod.t; g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat; }
     SPG_TRY(spg_launch_gemm(g, st));
     if (prod.bn) {
-      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(E, 128), l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
+      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(E, SPG_FC_ROWS), l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
                                          s.consts, prod.dgamma, prod.dbeta, st));
       cur = op_bnbwd(out, prod.y, prod.cout, s.consts, prod.cout);
     } else {

@@ -4,12 +4,14 @@
 #include "spg_common.h"
 
 enum { SPG_EPI_FWD = 0, SPG_EPI_BWD = 1 };
+#define SPG_FC_ROWS 32   // rows per workgroup for the few-row GEMMs (FC layers over superpoints, filter net over edges)
 
 // Y[M,N] = prologue(A)[M,K] @ W[N,K]^T (+ bias), with a fused epilogue.
 struct SpgGemmParams {
   SpgOperand a;
-  const float* W;     // [N, K] row-major
+  const float* W;     // [N, K] row-major (w_red == 0) or [K, N] row-major (w_red == 1: the untransposed weight of a dgrad)
   long ldw;
+  int w_red;
   const float* bias;  // [N] or null
   int M, N, K;
   int rows_per_tile;  // <= 128: rows handled by one workgroup (points per superpoint for the 1x1 convs)

@@ -62,14 +62,14 @@ extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int rese
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ---------------------------------------------------------------------------------------------
-template <int JT, int WI, int WJ>
+template <int IT, int JT, int WI, int WJ, bool WRED>
 __global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmParams p) {
-  constexpr int IT = 128;
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
   extern __shared__ f32x4 smem[];
   f32x4* As = smem;
   f32x4* Bs = smem + (SPG_KC / 4) * (IT + 1);
+  float* Bsr = reinterpret_cast<float*>(Bs);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -78,8 +78,9 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmP
   const long m0 = (long)tile * p.rows_per_tile;
   const int mvalid = (int)min((long)p.rows_per_tile, (long)p.M - m0);
   const int n0 = blockIdx.y * JT;
-  const bool vecA = spg_operand_vec_ok(p.a) && (p.K & 3) == 0;
-  const bool vecW = (p.K & 3) == 0 && (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0;
+  const bool vecA = spg_operand_vec_ok(p.a);
+  const bool vecW = WRED ? ((p.N & 3) == 0 && (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0)
+                         : ((p.K & 3) == 0 && (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0);
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -91,9 +92,11 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmP
 
   for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
     spg_stage_rows<IT>(p.a, m0, mvalid, k0, p.K, As, vecA);
-    spg_stage_weight<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bs, vecW);
+    if (WRED) spg_stage_weight_red<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bsr, vecW);
+    else spg_stage_weight<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bs, vecW);
     __syncthreads();
-    spg_mfma_chunk<TI, TJ>(As, Bs, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+    if (WRED) spg_mfma_chunk_or<TI, TJ>(As, Bsr, IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+    else spg_mfma_chunk<TI, TJ>(As, Bs, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
     __syncthreads();
   }
 
@@ -271,24 +274,34 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmP
 
 int spg_gemm_ntiles(const SpgGemmParams& p) { return spg_cdiv(p.M, p.rows_per_tile); }
 
-template <int JT, int WI, int WJ>
+template <int IT, int JT, int WI, int WJ, bool WRED>
 static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)(SPG_KC / 4) * (128 + 1 + JT + 1) * sizeof(f32x4);
+  // A tile (out-major) + weight tile (out-major [8][JT+1] float4 or red-major [32][JT+4] floats); the epilogue
+  // reuses the region for its reductions (<= 4*WI*JT floats)
+  size_t lds = (size_t)(SPG_KC / 4) * (IT + 1) * sizeof(f32x4) +
+               (WRED ? (size_t)SPG_KC * (JT + 4) * sizeof(float) : (size_t)(SPG_KC / 4) * (JT + 1) * sizeof(f32x4));
+  const size_t epi = (size_t)4 * WI * JT * sizeof(float);
+  if (lds < epi) lds = epi;
   dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-  hipLaunchKernelGGL((spg_rowgemm_kernel<JT, WI, WJ>), grid, dim3(SPG_THREADS), lds, stream, p);
+  hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
+}
+
+template <bool WRED>
+static int launch_gemm_w(const SpgGemmParams& p, hipStream_t stream) {
+  if (p.rows_per_tile <= 32) return launch_gemm_t<32, 128, 1, 4, WRED>(p, stream);   // few rows (FC layers, filter net)
+  if (p.N <= 32) return launch_gemm_t<128, 32, 4, 1, WRED>(p, stream);
+  if (p.N <= 64) return launch_gemm_t<128, 64, 2, 2, WRED>(p, stream);
+  return launch_gemm_t<128, 128, 2, 2, WRED>(p, stream);                                // wider outputs: grid.y column tiles
 }
 
 int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream) {
   SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   SPG_CHECK_ARG(p.rows_per_tile >= 1 && p.rows_per_tile <= 128, "rows_per_tile must be in [1,128]");
   SPG_CHECK_ARG(p.epi == SPG_EPI_FWD || p.Y != nullptr, "backward epilogue needs an output");
-  if (p.N <= 32) return launch_gemm_t<32, 4, 1>(p, stream);
-  if (p.N <= 64) return launch_gemm_t<64, 2, 2>(p, stream);
-  if (p.N <= 128) return launch_gemm_t<128, 2, 2>(p, stream);
-  return launch_gemm_t<256, 2, 2>(p, stream);
+  return p.w_red ? launch_gemm_w<true>(p, stream) : launch_gemm_w<false>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,8 +312,8 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
   extern __shared__ f32x4 smem[];
-  f32x4* As = smem;
-  f32x4* Bs = smem + (SPG_KC / 4) * (IT + 1);
+  float* As = reinterpret_cast<float*>(smem);          // red-major [32][IT + pad]
+  float* Bs = As + SPG_KC * (IT + 4);                   // red-major [32][JT + pad]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
@@ -308,6 +321,11 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   const int i0 = blockIdx.y * IT, j0 = blockIdx.z * JT;
   const long ms = (long)split * p.rows_per_split;
   const long me = min((long)p.M, ms + p.rows_per_split);
+  const bool vecA = spg_operand_vec_ok(p.a), vecB = spg_operand_vec_ok(p.b);
+  const int sa = spg_red_stride<IT>(p.a), sb = spg_red_stride<JT>(p.b);
+  // a thread keeps the same channel quad for every row: per-channel constants are loaded once
+  const SpgQuad qa = spg_quad_consts(p.a, i0 + 4 * (tid % (IT / 4)), p.N);
+  const SpgQuad qb = spg_quad_consts(p.b, j0 + 4 * (tid % (JT / 4)), p.K);
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -318,10 +336,10 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   for (long m = ms; m < me; m += SPG_KC) {
-    spg_stage_cols<IT>(p.a, m, me, i0, p.N, As);
-    spg_stage_cols<JT>(p.b, m, me, j0, p.K, Bs);
+    spg_stage_red<IT>(p.a, qa, m, me, i0, p.N, As, vecA);
+    spg_stage_red<JT>(p.b, qb, m, me, j0, p.K, Bs, vecB);
     __syncthreads();
-    spg_mfma_chunk<TI, TJ>(As, Bs, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+    spg_mfma_chunk_rr<TI, TJ>(As, Bs, sa, sb, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
     __syncthreads();
   }
 #pragma unroll
@@ -380,7 +398,7 @@ size_t spg_wgrad_workspace_floats(long M, int N, int K) {
 
 template <int IT, int JT, int WI, int WJ>
 static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t stream) {
-  const size_t lds = (size_t)(SPG_KC / 4) * (IT + 1 + JT + 1) * sizeof(f32x4);
+  const size_t lds = (size_t)SPG_KC * (IT + 4 + JT + 4) * sizeof(float);
   dim3 grid(nsplit, spg_cdiv(p.N, IT), spg_cdiv(p.K, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
   hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ>), grid, dim3(SPG_THREADS), lds, stream, p);

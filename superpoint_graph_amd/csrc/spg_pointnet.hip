@@ -128,7 +128,7 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
       l.y = (!last || pl.training) ? cv.take<float>((size_t)pl.M * l.cout) : nullptr;
     }
     const Layer& lc = pl.L[sg.convs.back()];
-    sg.ldpool = lc.cout + sg.nextra;
+    sg.ldpool = (lc.cout + sg.nextra + 3) & ~3;      // padded: rows readable as aligned float4
     sg.pooled = cv.take<float>((size_t)B * sg.ldpool);
     sg.aidx = cv.take<int>((size_t)B * sg.ldpool);
     for (size_t k = 0; k < sg.fcs.size(); ++k) {
@@ -206,10 +206,10 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     SpgGemmParams g; memset(&g, 0, sizeof(g));
     g.a = input_operand(pl, sg, true, k, clouds, stnT);
     g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = pl.B; g.N = l.cout; g.K = l.cin;
-    g.rows_per_tile = 128; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
+    g.rows_per_tile = SPG_FC_ROWS; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
     g.stat = (pl.training && l.bn) ? pl.stat : nullptr;
     SPG_TRY(spg_launch_gemm(g, st));
-    if (l.bn) SPG_TRY(bn_stats(pl, l, spg_cdiv(pl.B, 128), 128, pl.B, update_times, st));
+    if (l.bn) SPG_TRY(bn_stats(pl, l, spg_cdiv(pl.B, SPG_FC_ROWS), SPG_FC_ROWS, pl.B, update_times, st));
   }
   return 0;
 }
@@ -218,7 +218,6 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
 struct BwdScratch {
   float *dzA = nullptr, *dzB = nullptr;     // [M, cmax_conv] ping-pong for the dense conv gradients
   float *fzA = nullptr, *fzB = nullptr;     // [B, cmax_fc]
-  float* Wt = nullptr;                      // transposed weight of the current layer
   float* consts = nullptr;                  // [4][cmax]
   float* work = nullptr;                    // wgrad split partials
   float* stat = nullptr;                    // [ntile][2][cmax]
@@ -233,7 +232,7 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   size_t wmax = 16, workmax = 16;
   for (const Layer& l : pl.L) {
     if (l.conv) { cconv = l.cin > cconv ? l.cin : cconv; }
-    else { cfc = l.cin > cfc ? l.cin : cfc; }
+    else { cfc = l.cin + 4 > cfc ? l.cin + 4 : cfc; }
     cmax = l.cout > cmax ? l.cout : cmax; cmax = l.cin > cmax ? l.cin : cmax;
     wmax = (size_t)l.cin * l.cout > wmax ? (size_t)l.cin * l.cout : wmax;
     const size_t w = spg_wgrad_workspace_floats(l.conv ? pl.M : pl.B, l.cout, l.cin);
@@ -241,7 +240,6 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   }
   s.dzA = cv.take<float>((size_t)pl.M * cconv); s.dzB = cv.take<float>((size_t)pl.M * cconv);
   s.fzA = cv.take<float>((size_t)pl.B * cfc); s.fzB = cv.take<float>((size_t)pl.B * cfc);
-  s.Wt = cv.take<float>(wmax);
   s.consts = cv.take<float>((size_t)4 * cmax);
   s.work = cv.take<float>(workmax);
   s.stat = cv.take<float>((size_t)pl.B * 2 * cmax);
@@ -284,18 +282,18 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgOperand cur, const
     // data gradient -> producer of this layer's input
     const bool first = k == 0;
     Layer& prod = first ? pl.L[sg.convs.back()] : pl.L[sg.fcs[k - 1]];
-    SPG_TRY(spg_launch_transpose(l.W, l.cout, l.cin, s.Wt, st));
     float* out = fz[flip]; flip ^= 1;
     SpgGemmParams g; memset(&g, 0, sizeof(g));
-    g.a = cur; g.W = s.Wt; g.ldw = l.cout; g.M = B; g.N = l.cin; g.K = l.cout; g.rows_per_tile = 128;
-    g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin;
+    g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;   // dz_prev = dy @ W, W read untransposed
+    g.M = B; g.N = l.cin; g.K = l.cout; g.rows_per_tile = SPG_FC_ROWS;
+    g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = first ? sg.ldpool : l.cin;
     g.Yp = first ? sg.pooled : prod.y; g.ldyp = first ? sg.ldpool : prod.ldy;
     g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
     g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
     SPG_TRY(spg_launch_gemm(g, st));
     // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
     const int C = prod.cout;
-    SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(B, 128), l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
+    SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(B, SPG_FC_ROWS), l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
                                        prod.rstd, s.consts, prod.dgamma, prod.dbeta, st));
     if (!first) {
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, C);
@@ -317,10 +315,10 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgOperand cur, const
     if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
     if (k > 0) {
       Layer& prod = pl.L[sg.convs[k - 1]];
-      SPG_TRY(spg_launch_transpose(l.W, l.cout, l.cin, s.Wt, st));
       float* out = dz[flip]; flip ^= 1;
       SpgGemmParams g; memset(&g, 0, sizeof(g));
-      g.a = cur; g.W = s.Wt; g.ldw = l.cout; g.M = (int)pl.M; g.N = l.cin; g.K = l.cout; g.rows_per_tile = pl.P;
+      g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;
+      g.M = (int)pl.M; g.N = l.cin; g.K = l.cout; g.rows_per_tile = pl.P;
       g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.ldy;
       g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
       g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
@@ -330,9 +328,9 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgOperand cur, const
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, prod.cout);
     } else if (want_dxy) {
       // gradient wrt the transformed xy only (learning/pointnet.py:123-124): 2 output columns
-      SPG_TRY(spg_launch_transpose(l.W, l.cout, l.cin, s.Wt, st));
       SpgGemmParams g; memset(&g, 0, sizeof(g));
-      g.a = cur; g.W = s.Wt; g.ldw = l.cout; g.M = (int)pl.M; g.N = 2; g.K = l.cout; g.rows_per_tile = pl.P;
+      g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;
+      g.M = (int)pl.M; g.N = 2; g.K = l.cout; g.rows_per_tile = pl.P;
       g.epi = SPG_EPI_BWD; g.Y = s.dxy; g.ldy = 2;
       SPG_TRY(spg_launch_gemm(g, st));
     }
