@@ -115,13 +115,17 @@ __device__ __forceinline__ float spg_fetch(const SpgOperand& d, long m, int c) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// Vectorised fetch: 4 consecutive channels of one row with the per-channel constants hoisted into
-// registers (SpgQuad) -- they are loaded once per K-chunk (forward / dgrad) or once per kernel
-// (weight gradient, where a thread keeps the same channel quad for all rows).
+// Vectorised fetch: 4 consecutive channels of one row with the per-channel constants hoisted into registers
+// (SpgQuad): loaded once per K-chunk (forward / dgrad) or once per kernel (weight gradient, where a thread keeps
+// the same channel quad for all rows).  The operand mode is a TEMPLATE parameter on this path: the main loops
+// must be straight-line code (no per-item branches) so that the compiler can keep the global loads of the
+// next chunk in flight behind the MFMAs of the current one with counted s_waitcnt.
 // ----------------------------------------------------------------------------------------------
 struct SpgQuad {
   f32x4 a, b, c, d;
   int nvalid;    // number of valid channels in this quad (0..4); the others are forced to zero
+  int naff;      // AFFINE: number of leading channels of the quad that get scale/shift(/ReLU); the rest pass through
+  int relu;
 };
 
 __host__ __device__ inline bool spg_operand_vec_ok(const SpgOperand& d) {
@@ -132,67 +136,96 @@ __host__ __device__ inline bool spg_operand_vec_ok(const SpgOperand& d) {
   return true;
 }
 
-__device__ __forceinline__ float spg_ldc(const float* p, int c, int n, float dflt) { return (p != nullptr && c < n) ? p[c] : dflt; }
-
-// constants of channels c..c+3 (nch = number of channels of the operand)
+// constants of channels c..c+3 (nch = number of channels of the operand).  All loads are unconditional (clamped
+// indices) and NOT consumed here, so they travel with the data loads of the chunk; masking happens in
+// spg_finish_raw.
+template <int MODE>
 __device__ __forceinline__ SpgQuad spg_quad_consts(const SpgOperand& d, int c, int nch) {
   SpgQuad q;
   q.nvalid = nch - c < 0 ? 0 : (nch - c > 4 ? 4 : nch - c);
+  q.naff = 0; q.relu = 0;
+  if (MODE == SPG_PRO_AFFINE) {
+    const int lim = d.n_affine < nch ? d.n_affine : nch;
+    q.naff = lim - c < 0 ? 0 : (lim - c > 4 ? 4 : lim - c);
+    q.relu = d.relu;
+    if (d.c0 != nullptr) {                                  // wave-uniform
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    q.a[i] = 1.f; q.b[i] = 0.f; q.c[i] = 0.f; q.d[i] = 0.f;
-  }
-  if (d.mode == SPG_PRO_AFFINE) {
+      for (int i = 0; i < 4; ++i) {
+        const int ci = c + i < lim ? c + i : 0;
+        q.a[i] = d.c0[ci];
+        q.b[i] = d.c1[ci];
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool aff = c + i < d.n_affine && c + i < nch;
-      q.a[i] = aff ? spg_ldc(d.c0, c + i, nch, 1.f) : 1.f;
-      q.b[i] = aff ? spg_ldc(d.c1, c + i, nch, 0.f) : 0.f;
-      q.c[i] = (aff && d.relu) ? 0.f : -3.0e38f;          // lower clamp: ReLU or none
+      for (int i = 0; i < 4; ++i) { q.a[i] = 1.f; q.b[i] = 0.f; }
     }
-  } else if (d.mode == SPG_PRO_BNBWD || d.mode == SPG_PRO_POOLBWD) {
+  } else if (MODE == SPG_PRO_BNBWD || MODE == SPG_PRO_POOLBWD) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = c + i < nch;
-      q.a[i] = ok ? d.c0[c + i] : 0.f;
-      q.b[i] = ok ? d.c1[c + i] : 0.f;
-      q.c[i] = ok ? d.c2[c + i] : 0.f;
-      q.d[i] = ok ? d.c3[c + i] : 0.f;
+      const int ci = c + i < nch ? c + i : 0;
+      q.a[i] = d.c0[ci]; q.b[i] = d.c1[ci]; q.c[i] = d.c2[ci]; q.d[i] = d.c3[ci];
     }
   }
   return q;
 }
 
-// row m, channels c..c+3 (the row segment must be readable as one aligned 16-byte load: ld % 4 == 0)
-__device__ __forceinline__ f32x4 spg_fetch4q(const SpgOperand& d, const SpgQuad& q, long m, int c) {
-  f32x4 v;
-  if (d.mode == SPG_PRO_IDENT) {
-    v = *reinterpret_cast<const f32x4*>(d.X + m * d.ld + c);
-  } else if (d.mode == SPG_PRO_AFFINE) {
-    v = *reinterpret_cast<const f32x4*>(d.X + m * d.ld + c);
+// Raw (un-processed) global data of one quad: the loads are issued early (software pipelining: they are in flight
+// while the MFMAs of the previous chunk run) and finished -- prologue arithmetic -- right before the LDS write.
+struct SpgRaw {
+  f32x4 x, y;
+};
+
+// rows m[i] (already clamped into the matrix), channels c..c+3 (clamped; each row segment must be readable as one
+// aligned 16-byte load: ld % 4 == 0).  All loads are unconditional.  Load order: primary loads (and, for the
+// max-pool backward, the tiny per-group arg-max rows), then the secondary loads; the arg-max mask is resolved
+// while the secondary loads are still in flight.
+template <int MODE, int NI>
+__device__ __forceinline__ void spg_load_raw(const SpgOperand& d, const long (&m)[NI], int c, SpgRaw (&r)[NI]) {
+  if (MODE == SPG_PRO_POOLBWD) {
+    int4 ai[NI];
+    int pp[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(v[i], q.a[i], q.b[i]), q.c[i]);
-  } else {
-    f32x4 dz;
-    if (d.mode == SPG_PRO_BNBWD) {
-      dz = *reinterpret_cast<const f32x4*>(d.X + m * d.ld + c);
-    } else {   // POOLBWD: gradient of the max-pool goes to the winning row of each (group, channel)
-      const long g = m / d.P;
-      const int p = (int)(m - g * d.P);
-      const f32x4 dp = *reinterpret_cast<const f32x4*>(d.X + g * d.ldg + c);
-      const int4 ai = *reinterpret_cast<const int4*>(d.aidx + g * d.ldg + c);
-      dz[0] = ai.x == p ? dp[0] : 0.f; dz[1] = ai.y == p ? dp[1] : 0.f;
-      dz[2] = ai.z == p ? dp[2] : 0.f; dz[3] = ai.w == p ? dp[3] : 0.f;
+    for (int i = 0; i < NI; ++i) {
+      const unsigned mu = (unsigned)m[i], P = (unsigned)d.P;
+      const unsigned g = mu / P;
+      pp[i] = (int)(mu - g * P);
+      r[i].x = *reinterpret_cast<const f32x4*>(d.X + (long)g * d.ldg + c);
+      ai[i] = *reinterpret_cast<const int4*>(d.aidx + (long)g * d.ldg + c);
     }
-    const f32x4 y = *reinterpret_cast<const f32x4*>(d.X2 + m * d.ld + c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = q.a[i] * (dz[i] - q.b[i]) - (y[i] - q.c[i]) * q.d[i];
-  }
-  if (q.nvalid < 4) {
+    for (int i = 0; i < NI; ++i) r[i].y = *reinterpret_cast<const f32x4*>(d.X2 + m[i] * d.ld + c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i >= q.nvalid) v[i] = 0.f;
+    for (int i = 0; i < NI; ++i) {   // gradient of the max-pool goes to the winning row of each (group, channel)
+      r[i].x[0] = ai[i].x == pp[i] ? r[i].x[0] : 0.f; r[i].x[1] = ai[i].y == pp[i] ? r[i].x[1] : 0.f;
+      r[i].x[2] = ai[i].z == pp[i] ? r[i].x[2] : 0.f; r[i].x[3] = ai[i].w == pp[i] ? r[i].x[3] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) r[i].x = *reinterpret_cast<const f32x4*>(d.X + m[i] * d.ld + c);
+    if (MODE == SPG_PRO_BNBWD) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) r[i].y = *reinterpret_cast<const f32x4*>(d.X2 + m[i] * d.ld + c);
+    }
   }
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4 spg_finish_raw(const SpgQuad& q, const SpgRaw& r, bool valid) {
+  f32x4 v;
+  if (MODE == SPG_PRO_IDENT) {
+    v = r.x;
+  } else if (MODE == SPG_PRO_AFFINE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = fmaf(r.x[i], q.a[i], q.b[i]);
+      v[i] = i < q.naff ? (q.relu ? fmaxf(t, 0.f) : t) : r.x[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = q.a[i] * (r.x[i] - q.b[i]) - (r.y[i] - q.c[i]) * q.d[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (valid && i < q.nvalid) ? v[i] : 0.f;
   return v;
 }
 
@@ -275,26 +308,16 @@ __device__ __forceinline__ void spg_mfma_chunk_rr(const float* __restrict__ As, 
   }
 }
 
-// Out-major staging of a [ROWS x SPG_KC] tile: element (row, k) = operand(m0+row, k0+k); rows >= mvalid and
-// channels >= nch are zero.
+// Generic (runtime-mode, scalar) out-major staging of a [ROWS x SPG_KC] tile: element (row, k) =
+// operand(m0+row, k0+k); rows >= mvalid and channels >= nch are zero.  Used when the vector path does not apply
+// (channel-major clouds, unaligned leading dimensions); those GEMMs are tiny.
 template <int ROWS>
 __device__ __forceinline__ void spg_stage_rows(const SpgOperand& d, long m0, int mvalid, int k0, int nch,
-                                               f32x4* __restrict__ lds, bool vec) {
+                                               f32x4* __restrict__ lds) {
   const int tid = threadIdx.x;
-  if (vec) {
-    // 8 float4 per row; a thread keeps the same k-quad for all its rows
-    const int kq = tid & 7;
-    const int c = k0 + 4 * kq;
-    const SpgQuad q = spg_quad_consts(d, c, nch);
-#pragma unroll 4
-    for (int row = tid >> 3; row < ROWS; row += SPG_THREADS / 8) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < mvalid && q.nvalid > 0) v = spg_fetch4q(d, q, m0 + row, c);
-      lds[kq * (ROWS + 1) + row] = v;
-    }
-  } else if (d.mode == SPG_PRO_CLOUD) {
+  float* l = reinterpret_cast<float*>(lds);
+  if (d.mode == SPG_PRO_CLOUD) {
     // channel-major source: consecutive lanes take consecutive points (coalesced along p)
-    float* l = reinterpret_cast<float*>(lds);
     for (int idx = tid; idx < ROWS * SPG_KC; idx += SPG_THREADS) {
       const int row = idx % ROWS, k = idx / ROWS;
       float v = 0.f;
@@ -302,7 +325,6 @@ __device__ __forceinline__ void spg_stage_rows(const SpgOperand& d, long m0, int
       l[((k >> 2) * (ROWS + 1) + row) * 4 + (k & 3)] = v;
     }
   } else {
-    float* l = reinterpret_cast<float*>(lds);
     for (int idx = tid; idx < ROWS * SPG_KC; idx += SPG_THREADS) {
       const int row = idx / SPG_KC, k = idx % SPG_KC;
       float v = 0.f;
@@ -312,28 +334,17 @@ __device__ __forceinline__ void spg_stage_rows(const SpgOperand& d, long m0, int
   }
 }
 
-// Red-major staging of a [SPG_KC rows x CH channels] tile: LDS[r][ch] = operand(m0 + r, c0 + ch), rows >= mend
-// and channels >= nch are zero.  `stride` (floats): CH+4 on the vector path (16-byte aligned rows), CH+1 for the
-// channel-major cloud source (conflict-free dword writes with the points along the lanes).
+// Generic (scalar) red-major staging of a [SPG_KC rows x CH channels] tile: LDS[r][ch] = operand(m0 + r, c0 + ch).
+// `stride` (floats): CH+4 normally (16-byte aligned rows for the vector path), CH+1 for the channel-major cloud
+// source (conflict-free dword writes with the points along the lanes).
 template <int CH>
 __device__ __forceinline__ int spg_red_stride(const SpgOperand& d) { return d.mode == SPG_PRO_CLOUD ? CH + 1 : CH + 4; }
 
 template <int CH>
-__device__ __forceinline__ void spg_stage_red(const SpgOperand& d, const SpgQuad& q, long m0, long mend, int c0, int nch,
-                                              float* __restrict__ lds, bool vec) {
+__device__ __forceinline__ void spg_stage_red(const SpgOperand& d, long m0, long mend, int c0, int nch,
+                                              float* __restrict__ lds) {
   const int tid = threadIdx.x;
-  constexpr int QUADS = CH / 4;
-  if (vec) {
-    constexpr int RPP = SPG_THREADS / QUADS;          // rows per pass
-    const int cq = tid % QUADS;                       // fixed channel quad of this thread (q holds its constants)
-    const int c = c0 + 4 * cq;
-#pragma unroll
-    for (int r = tid / QUADS; r < SPG_KC; r += RPP) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + r < mend && q.nvalid > 0) v = spg_fetch4q(d, q, m0 + r, c);
-      *reinterpret_cast<f32x4*>(lds + r * (CH + 4) + 4 * cq) = v;
-    }
-  } else if (d.mode == SPG_PRO_CLOUD) {
+  if (d.mode == SPG_PRO_CLOUD) {
     for (int idx = tid; idx < CH * SPG_KC; idx += SPG_THREADS) {
       const int r = idx % SPG_KC, ch = idx / SPG_KC;
       float v = 0.f;
@@ -350,59 +361,136 @@ __device__ __forceinline__ void spg_stage_red(const SpgOperand& d, const SpgQuad
   }
 }
 
-// Out-major weight tile: W [nout, kred] row-major (ld), LDS row = output channel n0+j, reduction = k0+k.
+// Generic (scalar) out-major weight tile: W [nout, kred] row-major (ld), LDS row = output channel n0+j.
 template <int JT>
 __device__ __forceinline__ void spg_stage_weight(const float* __restrict__ W, long ld, int n0, int nout, int k0,
-                                                 int kred, f32x4* __restrict__ lds, bool vec) {
-  const int tid = threadIdx.x;
-  if (vec) {
-    const int kq = tid & 7;
-    const int k = k0 + 4 * kq;
-#pragma unroll 4
-    for (int j = tid >> 3; j < JT; j += SPG_THREADS / 8) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + j < nout && k < kred) v = *reinterpret_cast<const f32x4*>(W + (long)(n0 + j) * ld + k);
-      lds[kq * (JT + 1) + j] = v;
-    }
-  } else {
-    float* l = reinterpret_cast<float*>(lds);
-    for (int idx = tid; idx < JT * SPG_KC; idx += SPG_THREADS) {
-      const int j = idx / SPG_KC, k = idx % SPG_KC;
-      float v = 0.f;
-      if (n0 + j < nout && k0 + k < kred) v = W[(long)(n0 + j) * ld + k0 + k];
-      l[((k >> 2) * (JT + 1) + j) * 4 + (k & 3)] = v;
-    }
+                                                 int kred, f32x4* __restrict__ lds) {
+  float* l = reinterpret_cast<float*>(lds);
+  for (int idx = threadIdx.x; idx < JT * SPG_KC; idx += SPG_THREADS) {
+    const int j = idx / SPG_KC, k = idx % SPG_KC;
+    float v = 0.f;
+    if (n0 + j < nout && k0 + k < kred) v = W[(long)(n0 + j) * ld + k0 + k];
+    l[((k >> 2) * (JT + 1) + j) * 4 + (k & 3)] = v;
   }
 }
 
-// Red-major weight tile for the data gradient: W [nred, nout] row-major (ld) read UNTRANSPOSED:
+// Generic (scalar) red-major weight tile for the data gradient: W [kred, nout] row-major (ld) read UNTRANSPOSED:
 // LDS[r][j] = W[k0 + r][n0 + j]   (reduction over the rows of W = output channels of the forward layer)
 template <int JT>
 __device__ __forceinline__ void spg_stage_weight_red(const float* __restrict__ W, long ld, int n0, int nout, int k0,
-                                                     int kred, float* __restrict__ lds, bool vec) {
-  const int tid = threadIdx.x;
-  constexpr int QUADS = JT / 4;
-  if (vec) {
-    constexpr int RPP = SPG_THREADS / QUADS;
-    const int cq = tid % QUADS;
-    const int c = n0 + 4 * cq;
-#pragma unroll
-    for (int r = tid / QUADS; r < SPG_KC; r += RPP) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (k0 + r < kred && c < nout) {     // nout % 4 == 0 on this path
-        v = *reinterpret_cast<const f32x4*>(W + (long)(k0 + r) * ld + c);
-      }
-      *reinterpret_cast<f32x4*>(lds + r * (JT + 4) + 4 * cq) = v;
-    }
-  } else {
-    for (int idx = tid; idx < JT * SPG_KC; idx += SPG_THREADS) {
-      const int j = idx % JT, r = idx / JT;
-      float v = 0.f;
-      if (k0 + r < kred && n0 + j < nout) v = W[(long)(k0 + r) * ld + n0 + j];
-      lds[r * (JT + 4) + j] = v;
-    }
+                                                     int kred, float* __restrict__ lds) {
+  for (int idx = threadIdx.x; idx < JT * SPG_KC; idx += SPG_THREADS) {
+    const int j = idx % JT, r = idx / JT;
+    float v = 0.f;
+    if (k0 + r < kred && n0 + j < nout) v = W[(long)(k0 + r) * ld + n0 + j];
+    lds[r * (JT + 4) + j] = v;
   }
 }
+
+// ----------------------------------------------------------------------------------------------
+// Software-pipelined staging (vector paths only): `load` issues the global loads of a chunk into registers,
+// `store` finishes them (prologue arithmetic) and writes the LDS tile.  The kernels call load(c+1) before the
+// MFMAs of chunk c and store(c+1) after them, into the other LDS buffer: HBM/L2 latency hides under the MFMAs.
+// ----------------------------------------------------------------------------------------------
+template <int MODE, int ROWS>
+struct SpgRowsPipe {          // out-major [ROWS x 32] tile of an operand
+  static constexpr int NI = ROWS / 32;
+  SpgRaw raw[NI];
+  SpgQuad q;
+  unsigned vmask;             // bit i: row i of this thread is inside the tile
+  __device__ __forceinline__ void load(const SpgOperand& d, long m0, int mvalid, int k0, int nch) {
+    const int tid = threadIdx.x, c = k0 + 4 * (tid & 7);
+    q = spg_quad_consts<MODE>(d, c, nch);
+    long m[NI];
+    vmask = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const bool ok = row < mvalid;
+      m[i] = m0 + (ok ? row : 0);                           // clamped: loads are unconditional
+      vmask |= ok ? (1u << i) : 0u;
+    }
+    spg_load_raw<MODE, NI>(d, m, q.nvalid > 0 ? c : 0, raw);
+  }
+  __device__ __forceinline__ void store(f32x4* __restrict__ lds) const {
+    const int tid = threadIdx.x, kq = tid & 7;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      lds[kq * (ROWS + 1) + (tid >> 3) + 32 * i] = spg_finish_raw<MODE>(q, raw[i], (vmask >> i) & 1u);
+  }
+};
+
+template <int MODE, int CH>
+struct SpgRedPipe {           // red-major [32 x CH] tile of an operand (the thread's channel quad is fixed: q set once)
+  static constexpr int QUADS = CH / 4, RPP = SPG_THREADS / QUADS, NI = SPG_KC / RPP;
+  SpgRaw raw[NI];
+  unsigned vmask;
+  __device__ __forceinline__ void load(const SpgOperand& d, const SpgQuad& q, long m0, long mend, int c0) {
+    const int tid = threadIdx.x, c = c0 + 4 * (tid % QUADS);
+    long m[NI];
+    vmask = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const long mm = m0 + tid / QUADS + RPP * i;
+      const bool ok = mm < mend;
+      m[i] = ok ? mm : m0;
+      vmask |= ok ? (1u << i) : 0u;
+    }
+    spg_load_raw<MODE, NI>(d, m, q.nvalid > 0 ? c : 0, raw);
+  }
+  __device__ __forceinline__ void store(const SpgQuad& q, float* __restrict__ lds) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      *reinterpret_cast<f32x4*>(lds + (tid / QUADS + RPP * i) * (CH + 4) + 4 * (tid % QUADS)) =
+          spg_finish_raw<MODE>(q, raw[i], (vmask >> i) & 1u);
+  }
+};
+
+template <int JT>
+struct SpgWeightPipe {        // out-major [JT x 32] weight tile: W [nout, kred]
+  static constexpr int NI = JT / 32;
+  f32x4 raw[NI];
+  __device__ __forceinline__ void load(const float* __restrict__ W, long ld, int n0, int nout, int k0, int kred) {
+    const int tid = threadIdx.x, k = k0 + 4 * (tid & 7);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = (tid >> 3) + 32 * i;
+      const bool ok = n0 + j < nout && k < kred;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(W + (ok ? (long)(n0 + j) * ld + k : 0));   // unconditional, clamped
+#pragma unroll
+      for (int e = 0; e < 4; ++e) raw[i][e] = ok ? v[e] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(f32x4* __restrict__ lds) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) lds[(tid & 7) * (JT + 1) + (tid >> 3) + 32 * i] = raw[i];
+  }
+};
+
+template <int JT>
+struct SpgWeightRedPipe {     // red-major [32 x JT] weight tile: W [kred, nout] read untransposed
+  static constexpr int QUADS = JT / 4, RPP = SPG_THREADS / QUADS, NI = SPG_KC / RPP;
+  f32x4 raw[NI];
+  __device__ __forceinline__ void load(const float* __restrict__ W, long ld, int n0, int nout, int k0, int kred) {
+    const int tid = threadIdx.x, c = n0 + 4 * (tid % QUADS);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = tid / QUADS + RPP * i;
+      const bool ok = k0 + r < kred && c < nout;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(W + (ok ? (long)(k0 + r) * ld + c : 0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) raw[i][e] = ok ? v[e] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      *reinterpret_cast<f32x4*>(lds + (tid / QUADS + RPP * i) * (JT + 4) + 4 * (tid % QUADS)) = raw[i];
+  }
+};
 
 // C/D fragment of v_mfma_f32_32x32x2_f32: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int spg_acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }

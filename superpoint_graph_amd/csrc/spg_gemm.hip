@@ -62,12 +62,223 @@ extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int rese
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ---------------------------------------------------------------------------------------------
-template <int IT, int JT, int WI, int WJ, bool WRED>
+// Epilogues.  FULL: the tile is completely inside the matrix (and, for the backward, inside the masked channel
+// range), so every load / store is unconditional: straight-line code without per-element exec-mask branches and the
+// conservative s_waitcnt the compiler puts at their joins.
+template <int IT, int JT, int WI, int WJ, bool FULL>
+__device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
+                                                 float* __restrict__ red, int tile, long m0, int mvalid, int n0) {
+  constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int colw = wj * (JT / WJ), roww = wi * (IT / WI);
+  // ---- bias + store ----
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + colw + 32 * j + r;
+    const bool colok = FULL || col < p.N;
+    float bv = 0.f;
+    if (p.bias != nullptr) {   // uniform
+      const float t = p.bias[colok ? col : 0];
+      bv = colok ? t : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] += bv;
+    if (p.Y != nullptr) {      // uniform
+      float* yb = p.Y + (m0 + roww) * p.ldy + col;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = 32 * i + spg_acc_row(q, h);
+          if (FULL || (colok && roww + row < mvalid)) yb[(long)row * p.ldy] = acc[i][j][q];
+        }
+    }
+  }
+  // ---- BatchNorm partials of this tile: column mean and M2 = sum (y - mean)^2 over the valid rows ----
+  if (p.stat != nullptr) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (FULL || roww + 32 * i + spg_acc_row(q, h) < mvalid) s += acc[i][j][q];
+      s += __shfl_xor(s, 32, 64);
+      if (h == 0) red[wi * JT + colw + 32 * j + r] = s;
+    }
+    __syncthreads();
+    if (tid < JT) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < WI; ++w) tot += red[w * JT + tid];
+      red[WI * JT + tid] = tot / (float)mvalid;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const float mean = red[WI * JT + colw + 32 * j + r];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (FULL || roww + 32 * i + spg_acc_row(q, h) < mvalid) {
+            const float d = acc[i][j][q] - mean;
+            s = fmaf(d, d, s);
+          }
+      s += __shfl_xor(s, 32, 64);
+      if (h == 0) red[wi * JT + colw + 32 * j + r] = s;
+    }
+    __syncthreads();
+    if (tid < JT && n0 + tid < p.N) {
+      float m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WI; ++w) m2 += red[w * JT + tid];
+      p.stat[((long)tile * 2 + 0) * p.N + n0 + tid] = red[WI * JT + tid];
+      p.stat[((long)tile * 2 + 1) * p.N + n0 + tid] = m2;
+    }
+    __syncthreads();
+  }
+  // ---- max / min over the rows of the tile (= the points of one superpoint), first index wins ties ----
+  if (p.pmax != nullptr) {
+    float* rmx = red;
+    float* rmn = red + WI * JT;
+    int* rix = reinterpret_cast<int*>(red + 2 * WI * JT);
+    int* rin = reinterpret_cast<int*>(red + 3 * WI * JT);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      float vmx = -FLT_MAX, vmn = FLT_MAX;
+      int imx = INT_MAX, imn = INT_MAX;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = roww + 32 * i + spg_acc_row(q, h);
+          const float v = acc[i][j][q];
+          if (FULL || row < mvalid) {
+            if (v > vmx || (v == vmx && row < imx)) { vmx = v; imx = row; }
+            if (v < vmn || (v == vmn && row < imn)) { vmn = v; imn = row; }
+          }
+        }
+      {
+        const float ov = __shfl_xor(vmx, 32, 64);
+        const int oi = __shfl_xor(imx, 32, 64);
+        if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
+        const float pv = __shfl_xor(vmn, 32, 64);
+        const int pi = __shfl_xor(imn, 32, 64);
+        if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
+      }
+      if (h == 0) {
+        const int c = wi * JT + colw + 32 * j + r;
+        rmx[c] = vmx; rix[c] = imx; rmn[c] = vmn; rin[c] = imn;
+      }
+    }
+    __syncthreads();
+    if (tid < JT && n0 + tid < p.N) {
+      float vmx = rmx[tid], vmn = rmn[tid];
+      int imx = rix[tid], imn = rin[tid];
+#pragma unroll
+      for (int w = 1; w < WI; ++w) {
+        const float ov = rmx[w * JT + tid];
+        const int oi = rix[w * JT + tid];
+        if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
+        const float pv = rmn[w * JT + tid];
+        const int pi = rin[w * JT + tid];
+        if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
+      }
+      const long o = (long)tile * p.N + n0 + tid;
+      p.pmax[o] = vmx; p.imax[o] = imx; p.pmin[o] = vmn; p.imin[o] = imn;
+    }
+  }
+}
+
+// backward: ReLU mask of the producer layer, store dz, BatchNorm-backward partial sums (sum dz, sum dz*xhat)
+template <int IT, int JT, int WI, int WJ, bool FULL>
+__device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
+                                                 float* __restrict__ red, int tile, long m0, int mvalid, int n0) {
+  constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int colw = wj * (JT / WJ), roww = wi * (IT / WI);
+  const bool do_stats = p.stat != nullptr && p.mmean != nullptr;           // uniform
+  const bool do_mask = p.mask_relu != 0 && p.Yp != nullptr;                // uniform
+  const bool use_y = p.Yp != nullptr && (do_stats || do_mask);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + colw + 32 * j + r;
+    const bool colok = FULL || col < p.N;
+    const bool inm = FULL || col < p.n_mask;                               // channel of the producer layer
+    const int cc = (colok && inm) ? col : 0;
+    float sc = 1.f, sh = 0.f, mean = 0.f, rstd = 0.f;
+    if (p.ms != nullptr) { sc = p.ms[cc]; sh = p.mt[cc]; }
+    if (do_stats) { mean = p.mmean[cc]; rstd = p.mrstd[cc]; }
+    const float* yp = p.Yp + (m0 + roww) * p.ldyp + (colok ? col : 0);
+    float* yo = p.Y + (m0 + roww) * p.ldy + col;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      float yv[16];
+      if (use_y) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = 32 * i + spg_acc_row(q, h);
+          const bool ok = FULL || (colok && roww + row < mvalid);
+          yv[q] = yp[ok ? (long)row * p.ldyp : 0];                         // unconditional (clamped) load
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 32 * i + spg_acc_row(q, h);
+        const bool ok = FULL || (colok && roww + row < mvalid);
+        float v = acc[i][j][q];
+        const float y = use_y ? yv[q] : 0.f;
+        if (do_mask && inm && !(fmaf(y, sc, sh) > 0.f)) v = 0.f;
+        if (FULL || ok) yo[(long)row * p.ldy] = v;
+        if (do_stats) {
+          const float w = (ok && inm) ? v : 0.f;
+          s1 += w;
+          s2 = fmaf(w, (y - mean) * rstd, s2);
+        }
+      }
+    }
+    if (p.stat != nullptr) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        red[wi * JT + colw + 32 * j + r] = s1;
+        red[(WI + wi) * JT + colw + 32 * j + r] = s2;
+      }
+    }
+  }
+  if (p.stat != nullptr) {
+    __syncthreads();
+    if (tid < JT && n0 + tid < p.N) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WI; ++w) {
+        a += red[w * JT + tid];
+        b += red[(WI + w) * JT + tid];
+      }
+      p.stat[((long)tile * 2 + 0) * p.N + n0 + tid] = a;
+      p.stat[((long)tile * 2 + 1) * p.N + n0 + tid] = b;
+    }
+  }
+}
+
+// AMODE >= 0: operand mode of A known at compile time, vector + software-pipelined main loop (host guarantees the
+// alignment conditions); AMODE < 0: generic scalar staging (channel-major clouds, unaligned leading dimensions).
+template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE>
 __global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
   extern __shared__ f32x4 smem[];
-  f32x4* As = smem;
+  f32x4* As = smem;                                   // buffer b: A at smem + b*(A_F4+B_F4), weights right behind it
   f32x4* Bs = smem + (SPG_KC / 4) * (IT + 1);
   float* Bsr = reinterpret_cast<float*>(Bs);
 
@@ -78,10 +289,6 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmP
   const long m0 = (long)tile * p.rows_per_tile;
   const int mvalid = (int)min((long)p.rows_per_tile, (long)p.M - m0);
   const int n0 = blockIdx.y * JT;
-  const bool vecA = spg_operand_vec_ok(p.a);
-  const bool vecW = WRED ? ((p.N & 3) == 0 && (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0)
-                         : ((p.K & 3) == 0 && (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0);
-
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -90,224 +297,115 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmP
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
-    spg_stage_rows<IT>(p.a, m0, mvalid, k0, p.K, As, vecA);
-    if (WRED) spg_stage_weight_red<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bsr, vecW);
-    else spg_stage_weight<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bs, vecW);
+  constexpr int A_F4 = (SPG_KC / 4) * (IT + 1);                                  // float4 slots of one A buffer
+  constexpr int B_F4 = WRED ? SPG_KC * (JT + 4) / 4 : (SPG_KC / 4) * (JT + 1);   // float4 slots of one weight buffer
+  if constexpr (AMODE >= 0) {
+    // software-pipelined main loop, two LDS buffers, ONE barrier per chunk
+    SpgRowsPipe<AMODE, IT> pa;
+    SpgWeightPipe<JT> pw;
+    SpgWeightRedPipe<JT> pwr;
+    pa.load(p.a, m0, mvalid, 0, p.K);
+    if (WRED) pwr.load(p.W, p.ldw, n0, p.N, 0, p.K); else pw.load(p.W, p.ldw, n0, p.N, 0, p.K);
+    pa.store(As);
+    if (WRED) pwr.store(Bsr); else pw.store(Bs);
     __syncthreads();
-    if (WRED) spg_mfma_chunk_or<TI, TJ>(As, Bsr, IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
-    else spg_mfma_chunk<TI, TJ>(As, Bs, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
-    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
+      const bool more = k0 + SPG_KC < p.K;
+      if (more) {
+        pa.load(p.a, m0, mvalid, k0 + SPG_KC, p.K);
+        if (WRED) pwr.load(p.W, p.ldw, n0, p.N, k0 + SPG_KC, p.K); else pw.load(p.W, p.ldw, n0, p.N, k0 + SPG_KC, p.K);
+      }
+      const f32x4* Ac = As + buf * (A_F4 + B_F4);
+      const f32x4* Bc = Bs + buf * (A_F4 + B_F4);
+      if (WRED) spg_mfma_chunk_or<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      else spg_mfma_chunk<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      if (more) {
+        f32x4* An = As + (buf ^ 1) * (A_F4 + B_F4);
+        f32x4* Bn = Bs + (buf ^ 1) * (A_F4 + B_F4);
+        pa.store(An);
+        if (WRED) pwr.store(reinterpret_cast<float*>(Bn)); else pw.store(Bn);
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
+      spg_stage_rows<IT>(p.a, m0, mvalid, k0, p.K, As);
+      if (WRED) spg_stage_weight_red<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bsr);
+      else spg_stage_weight<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bs);
+      __syncthreads();
+      if (WRED) spg_mfma_chunk_or<TI, TJ>(As, Bsr, IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      else spg_mfma_chunk<TI, TJ>(As, Bs, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      __syncthreads();
+    }
   }
 
   float* red = reinterpret_cast<float*>(smem);  // LDS is free again after the last barrier
-  const int colw = wj * (JT / WJ);
-  const int roww = wi * (IT / WI);
-
-  if (p.epi == SPG_EPI_FWD) {
-    // ---- bias + store ----
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int col = n0 + colw + 32 * j + r;
-      const bool colok = col < p.N;
-      const float bv = (p.bias != nullptr && colok) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = roww + 32 * i + spg_acc_row(q, h);
-          acc[i][j][q] += bv;
-          if (p.Y != nullptr && colok && row < mvalid) p.Y[(m0 + row) * p.ldy + col] = acc[i][j][q];
-        }
-    }
-    // ---- BatchNorm partials of this tile: column mean and M2 = sum (y - mean)^2 over the valid rows ----
-    if (p.stat != nullptr) {
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            if (roww + 32 * i + spg_acc_row(q, h) < mvalid) s += acc[i][j][q];
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) red[wi * JT + colw + 32 * j + r] = s;
-      }
-      __syncthreads();
-      if (tid < JT) {
-        float tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < WI; ++w) tot += red[w * JT + tid];
-        red[WI * JT + tid] = tot / (float)mvalid;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const float mean = red[WI * JT + colw + 32 * j + r];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            if (roww + 32 * i + spg_acc_row(q, h) < mvalid) {
-              const float d = acc[i][j][q] - mean;
-              s = fmaf(d, d, s);
-            }
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) red[wi * JT + colw + 32 * j + r] = s;
-      }
-      __syncthreads();
-      if (tid < JT && n0 + tid < p.N) {
-        float m2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WI; ++w) m2 += red[w * JT + tid];
-        p.stat[((long)tile * 2 + 0) * p.N + n0 + tid] = red[WI * JT + tid];
-        p.stat[((long)tile * 2 + 1) * p.N + n0 + tid] = m2;
-      }
-      __syncthreads();
-    }
-    // ---- max / min over the rows of the tile (= the points of one superpoint), first index wins ties ----
-    if (p.pmax != nullptr) {
-      float* rmx = red;
-      float* rmn = red + WI * JT;
-      int* rix = reinterpret_cast<int*>(red + 2 * WI * JT);
-      int* rin = reinterpret_cast<int*>(red + 3 * WI * JT);
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        float vmx = -FLT_MAX, vmn = FLT_MAX;
-        int imx = INT_MAX, imn = INT_MAX;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int row = roww + 32 * i + spg_acc_row(q, h);
-            const float v = acc[i][j][q];
-            if (row < mvalid) {
-              if (v > vmx || (v == vmx && row < imx)) { vmx = v; imx = row; }
-              if (v < vmn || (v == vmn && row < imn)) { vmn = v; imn = row; }
-            }
-          }
-        {
-          const float ov = __shfl_xor(vmx, 32, 64);
-          const int oi = __shfl_xor(imx, 32, 64);
-          if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
-          const float pv = __shfl_xor(vmn, 32, 64);
-          const int pi = __shfl_xor(imn, 32, 64);
-          if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
-        }
-        if (h == 0) {
-          const int c = wi * JT + colw + 32 * j + r;
-          rmx[c] = vmx; rix[c] = imx; rmn[c] = vmn; rin[c] = imn;
-        }
-      }
-      __syncthreads();
-      if (tid < JT && n0 + tid < p.N) {
-        float vmx = rmx[tid], vmn = rmn[tid];
-        int imx = rix[tid], imn = rin[tid];
-#pragma unroll
-        for (int w = 1; w < WI; ++w) {
-          const float ov = rmx[w * JT + tid];
-          const int oi = rix[w * JT + tid];
-          if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
-          const float pv = rmn[w * JT + tid];
-          const int pi = rin[w * JT + tid];
-          if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
-        }
-        const long o = (long)tile * p.N + n0 + tid;
-        p.pmax[o] = vmx; p.imax[o] = imx; p.pmin[o] = vmn; p.imin[o] = imn;
-      }
-    }
+  if constexpr (!WRED) {      // forward kernels: weights [N,K]; backward (dgrad) kernels: untransposed weights [K,N]
+    if (mvalid == IT && n0 + JT <= p.N) spg_epilogue_fwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
+    else spg_epilogue_fwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
   } else {
-    // ---- SPG_EPI_BWD: ReLU mask of the producer layer, store dz, BatchNorm-backward partial sums ----
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int col = n0 + colw + 32 * j + r;
-      const bool colok = col < p.N;
-      const bool masked = p.mask_relu && colok && col < p.n_mask && p.Yp != nullptr;
-      const float sc = (p.ms != nullptr && colok && col < p.n_mask) ? p.ms[col] : 1.f;
-      const float sh = (p.mt != nullptr && colok && col < p.n_mask) ? p.mt[col] : 0.f;
-      const bool stats = p.stat != nullptr && p.mmean != nullptr && colok && col < p.n_mask;
-      const float mean = stats ? p.mmean[col] : 0.f;
-      const float rstd = stats ? p.mrstd[col] : 0.f;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = roww + 32 * i + spg_acc_row(q, h);
-          if (colok && row < mvalid) {
-            float v = acc[i][j][q];
-            float yv = 0.f;
-            if (masked || stats) yv = p.Yp[(m0 + row) * p.ldyp + col];
-            if (masked && !(fmaf(yv, sc, sh) > 0.f)) v = 0.f;
-            p.Y[(m0 + row) * p.ldy + col] = v;
-            if (stats) {
-              s1 += v;
-              s2 = fmaf(v, (yv - mean) * rstd, s2);
-            }
-          }
-        }
-      if (p.stat != nullptr) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (h == 0) {
-          red[wi * JT + colw + 32 * j + r] = s1;
-          red[(WI + wi) * JT + colw + 32 * j + r] = s2;
-        }
-      }
-    }
-    if (p.stat != nullptr) {
-      __syncthreads();
-      if (tid < JT && n0 + tid < p.N) {
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int w = 0; w < WI; ++w) {
-          a += red[w * JT + tid];
-          b += red[(WI + w) * JT + tid];
-        }
-        p.stat[((long)tile * 2 + 0) * p.N + n0 + tid] = a;
-        p.stat[((long)tile * 2 + 1) * p.N + n0 + tid] = b;
-      }
-    }
+    const bool full = mvalid == IT && n0 + JT <= p.N && (n0 + JT <= p.n_mask || (p.stat == nullptr && !p.mask_relu));
+    if (full) spg_epilogue_bwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
+    else spg_epilogue_bwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
   }
 }
 
 int spg_gemm_ntiles(const SpgGemmParams& p) { return spg_cdiv(p.M, p.rows_per_tile); }
 
-template <int IT, int JT, int WI, int WJ, bool WRED>
+template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE>
 static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
-  // A tile (out-major) + weight tile (out-major [8][JT+1] float4 or red-major [32][JT+4] floats); the epilogue
-  // reuses the region for its reductions (<= 4*WI*JT floats)
+  // A tile (out-major) + weight tile (out-major [8][JT+1] float4 or red-major [32][JT+4] floats), double-buffered;
+  // the epilogue reuses the region for its reductions (<= 4*WI*JT floats)
   size_t lds = (size_t)(SPG_KC / 4) * (IT + 1) * sizeof(f32x4) +
                (WRED ? (size_t)SPG_KC * (JT + 4) * sizeof(float) : (size_t)(SPG_KC / 4) * (JT + 1) * sizeof(f32x4));
+  if (AMODE >= 0) lds *= 2;
   const size_t epi = (size_t)4 * WI * JT * sizeof(float);
   if (lds < epi) lds = epi;
   dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-  hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED>), grid, dim3(SPG_THREADS), lds, stream, p);
+  hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
 }
 
-template <bool WRED>
-static int launch_gemm_w(const SpgGemmParams& p, hipStream_t stream) {
-  if (p.rows_per_tile <= 32) return launch_gemm_t<32, 128, 1, 4, WRED>(p, stream);   // few rows (FC layers, filter net)
-  if (p.N <= 32) return launch_gemm_t<128, 32, 4, 1, WRED>(p, stream);
-  if (p.N <= 64) return launch_gemm_t<128, 64, 2, 2, WRED>(p, stream);
-  return launch_gemm_t<128, 128, 2, 2, WRED>(p, stream);                                // wider outputs: grid.y column tiles
+template <bool WRED, int AMODE>
+static int launch_gemm_shape(const SpgGemmParams& p, hipStream_t stream) {
+  if (p.rows_per_tile <= 32) return launch_gemm_t<32, 128, 1, 4, WRED, AMODE>(p, stream);   // few rows (FC layers, filter net)
+  if (p.N <= 32) return launch_gemm_t<128, 32, 4, 1, WRED, AMODE>(p, stream);
+  if (p.N <= 64) return launch_gemm_t<128, 64, 2, 2, WRED, AMODE>(p, stream);
+  return launch_gemm_t<128, 128, 2, 2, WRED, AMODE>(p, stream);                                // wider outputs: grid.y column tiles
 }
 
 int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream) {
   SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   SPG_CHECK_ARG(p.rows_per_tile >= 1 && p.rows_per_tile <= 128, "rows_per_tile must be in [1,128]");
   SPG_CHECK_ARG(p.epi == SPG_EPI_FWD || p.Y != nullptr, "backward epilogue needs an output");
-  return p.w_red ? launch_gemm_w<true>(p, stream) : launch_gemm_w<false>(p, stream);
+  SPG_CHECK_ARG((p.epi == SPG_EPI_BWD) == (p.w_red != 0), "forward epilogue <-> [N,K] weights, backward epilogue <-> [K,N] weights");
+  const bool walign = (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0;
+  const bool vec = spg_operand_vec_ok(p.a) && walign && ((p.w_red ? p.N : p.K) & 3) == 0;
+  const int mode = vec ? p.a.mode : -1;
+  if (!p.w_red) {
+    switch (mode) {
+      case SPG_PRO_IDENT: return launch_gemm_shape<false, SPG_PRO_IDENT>(p, stream);
+      case SPG_PRO_AFFINE: return launch_gemm_shape<false, SPG_PRO_AFFINE>(p, stream);
+      default: return launch_gemm_shape<false, -1>(p, stream);
+    }
+  }
+  switch (mode) {
+    case SPG_PRO_IDENT: return launch_gemm_shape<true, SPG_PRO_IDENT>(p, stream);
+    case SPG_PRO_BNBWD: return launch_gemm_shape<true, SPG_PRO_BNBWD>(p, stream);
+    case SPG_PRO_POOLBWD: return launch_gemm_shape<true, SPG_PRO_POOLBWD>(p, stream);
+    default: return launch_gemm_shape<true, -1>(p, stream);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // weight-gradient kernel: reduction over the rows (points / superpoints / edges / nodes)
 // ---------------------------------------------------------------------------------------------
-template <int IT, int JT, int WI, int WJ>
+// AMODE / BMODE >= 0: compile-time operand modes, vector + software-pipelined loop; < 0: generic scalar staging.
+template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE>
 __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
@@ -321,12 +419,6 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   const int i0 = blockIdx.y * IT, j0 = blockIdx.z * JT;
   const long ms = (long)split * p.rows_per_split;
   const long me = min((long)p.M, ms + p.rows_per_split);
-  const bool vecA = spg_operand_vec_ok(p.a), vecB = spg_operand_vec_ok(p.b);
-  const int sa = spg_red_stride<IT>(p.a), sb = spg_red_stride<JT>(p.b);
-  // a thread keeps the same channel quad for every row: per-channel constants are loaded once
-  const SpgQuad qa = spg_quad_consts(p.a, i0 + 4 * (tid % (IT / 4)), p.N);
-  const SpgQuad qb = spg_quad_consts(p.b, j0 + 4 * (tid % (JT / 4)), p.K);
-
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -335,12 +427,43 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  for (long m = ms; m < me; m += SPG_KC) {
-    spg_stage_red<IT>(p.a, qa, m, me, i0, p.N, As, vecA);
-    spg_stage_red<JT>(p.b, qb, m, me, j0, p.K, Bs, vecB);
+  if constexpr (AMODE >= 0 && BMODE >= 0) {
+    // software-pipelined: global loads of chunk c+1 fly during the MFMAs of chunk c; two LDS buffers, one barrier.
+    // A thread keeps the same channel quad for every row: the per-channel constants are loaded once.
+    constexpr int BUF = SPG_KC * (IT + 4 + JT + 4);
+    const SpgQuad qa = spg_quad_consts<AMODE>(p.a, i0 + 4 * (tid % (IT / 4)), p.N);
+    const SpgQuad qb = spg_quad_consts<BMODE>(p.b, j0 + 4 * (tid % (JT / 4)), p.K);
+    SpgRedPipe<AMODE, IT> pa;
+    SpgRedPipe<BMODE, JT> pb;
+    pa.load(p.a, qa, ms, me, i0);
+    pb.load(p.b, qb, ms, me, j0);
+    pa.store(qa, As);
+    pb.store(qb, Bs);
     __syncthreads();
-    spg_mfma_chunk_rr<TI, TJ>(As, Bs, sa, sb, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
-    __syncthreads();
+    int buf = 0;
+    for (long m = ms; m < me; m += SPG_KC) {
+      const bool more = m + SPG_KC < me;
+      if (more) {
+        pa.load(p.a, qa, m + SPG_KC, me, i0);
+        pb.load(p.b, qb, m + SPG_KC, me, j0);
+      }
+      spg_mfma_chunk_rr<TI, TJ>(As + buf * BUF, Bs + buf * BUF, IT + 4, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      if (more) {
+        pa.store(qa, As + (buf ^ 1) * BUF);
+        pb.store(qb, Bs + (buf ^ 1) * BUF);
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    const int sa = spg_red_stride<IT>(p.a), sb = spg_red_stride<JT>(p.b);
+    for (long m = ms; m < me; m += SPG_KC) {
+      spg_stage_red<IT>(p.a, m, me, i0, p.N, As);
+      spg_stage_red<JT>(p.b, m, me, j0, p.K, Bs);
+      __syncthreads();
+      spg_mfma_chunk_rr<TI, TJ>(As, Bs, sa, sb, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
@@ -379,7 +502,7 @@ static void wgrad_plan(long M, int N, int K, int* IT, int* JT, int* nsplit, int*
   int it;
   if (jt == 32) it = 128;
   else if (jt == 64) it = N <= 64 ? 64 : 128;
-  else it = N <= 128 ? 128 : 256;
+  else it = 128;
   const int tiles = spg_cdiv(N, it) * spg_cdiv(K, jt);
   int target = 512 / tiles;
   if (target < 1) target = 1;
@@ -396,14 +519,31 @@ size_t spg_wgrad_workspace_floats(long M, int N, int K) {
   return w > c ? w : c;
 }
 
-template <int IT, int JT, int WI, int WJ>
+template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE>
 static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t stream) {
-  const size_t lds = (size_t)SPG_KC * (IT + 4 + JT + 4) * sizeof(float);
+  const size_t lds = (size_t)((AMODE >= 0 && BMODE >= 0) ? 2 : 1) * SPG_KC * (IT + 4 + JT + 4) * sizeof(float);
   dim3 grid(nsplit, spg_cdiv(p.N, IT), spg_cdiv(p.K, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-  hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ>), grid, dim3(SPG_THREADS), lds, stream, p);
+  hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
+}
+
+template <int AMODE, int BMODE>
+static int launch_wgrad_shape(const SpgWgradParams& p, int it, int jt, int ns, hipStream_t stream) {
+  if (jt == 32) return launch_wgrad_t<128, 32, 4, 1, AMODE, BMODE>(p, ns, stream);
+  if (jt == 64 && it == 64) return launch_wgrad_t<64, 64, 2, 2, AMODE, BMODE>(p, ns, stream);
+  if (jt == 64) return launch_wgrad_t<128, 64, 2, 2, AMODE, BMODE>(p, ns, stream);
+  return launch_wgrad_t<128, 128, 2, 2, AMODE, BMODE>(p, ns, stream);
+}
+
+template <int AMODE>
+static int launch_wgrad_b(const SpgWgradParams& p, int it, int jt, int ns, hipStream_t stream) {
+  switch (p.b.mode) {
+    case SPG_PRO_IDENT: return launch_wgrad_shape<AMODE, SPG_PRO_IDENT>(p, it, jt, ns, stream);
+    case SPG_PRO_AFFINE: return launch_wgrad_shape<AMODE, SPG_PRO_AFFINE>(p, it, jt, ns, stream);
+    default: return launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
+  }
 }
 
 int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t stream) {
@@ -412,12 +552,15 @@ int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t strea
   wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
   p.rows_per_split = rps;
   p.partial = (ns == 1) ? dW : work;
+  // the vector path needs whole channel quads inside the matrices (N, K multiples of 4 are guaranteed by padded
+  // leading dimensions: quads past the last channel are masked, but must be addressable)
+  const bool vec = spg_operand_vec_ok(p.a) && spg_operand_vec_ok(p.b) && p.a.ld >= ((p.N + 3) & ~3) && p.b.ld >= ((p.K + 3) & ~3);
   int rc;
-  if (jt == 32) rc = launch_wgrad_t<128, 32, 4, 1>(p, ns, stream);
-  else if (jt == 64 && it == 64) rc = launch_wgrad_t<64, 64, 2, 2>(p, ns, stream);
-  else if (jt == 64) rc = launch_wgrad_t<128, 64, 2, 2>(p, ns, stream);
-  else if (it == 128) rc = launch_wgrad_t<128, 128, 2, 2>(p, ns, stream);
-  else rc = launch_wgrad_t<256, 128, 2, 2>(p, ns, stream);
+  if (!vec) rc = launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
+  else if (p.a.mode == SPG_PRO_IDENT) rc = launch_wgrad_b<SPG_PRO_IDENT>(p, it, jt, ns, stream);
+  else if (p.a.mode == SPG_PRO_BNBWD) rc = launch_wgrad_b<SPG_PRO_BNBWD>(p, it, jt, ns, stream);
+  else if (p.a.mode == SPG_PRO_POOLBWD) rc = launch_wgrad_b<SPG_PRO_POOLBWD>(p, it, jt, ns, stream);
+  else rc = launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
   if (rc) return rc;
   if (ns > 1) {
     const long n = (long)p.N * p.K;
