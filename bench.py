@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--model-config', default='gru_10_0,f_13')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
     args = ap.parse_args()
 
     import faulthandler
@@ -116,7 +117,7 @@ def main():
     label_mode = targets[:, 0].to(dev)
     model.ecc.set_info(GIs, 1)                                             # H2D of the index buffers + device CSR build
     embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=0.0)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=0.0, capturable=bool(args.hipgraph))
     bucket = spd.GradBucket(model.parameters())
     w_local = spd.loss_weight(label_mode)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -127,20 +128,51 @@ def main():
     def grads_of(ps):
         return [p.grad for p in ps if p.grad is not None]
 
-    def step():
+    def fwd_bwd():
         optimizer.zero_grad(set_to_none=True)
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
         loss = F.cross_entropy(out, label_mode)
         loss.backward()
         embedder.bw_hook()
-        if world > 1:
-            bucket.allreduce(w_local)
+
+    def update():
         g = grads_of(params)                                             # p.grad.clamp_(-clip, clip), learning/main.py:210-212
         torch._foreach_clamp_min_(g, -1.0)
         torch._foreach_clamp_max_(g, 1.0)
         optimizer.step()
-        return loss
+
+    def eager_step():
+        fwd_bwd()
+        if world > 1:
+            bucket.allreduce(w_local)
+        update()
+
+    step = eager_step
+    if args.hipgraph:
+        # HIP graph capture of the launch-bound step (~230 dependent kernel launches): the forward/backward and the
+        # clamp+Adam update are captured separately so that the RCCL all-reduce between them stays an eager call.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g_fb):
+            fwd_bwd()
+        with torch.cuda.graph(g_up):
+            update()
+
+        def graph_step():
+            g_fb.replay()
+            if world > 1:
+                bucket.allreduce(w_local)
+            g_up.replay()
+        step = graph_step
+        log('hipGraph captured')
 
     def barrier():
         if world > 1:
@@ -172,7 +204,7 @@ def main():
         'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x 14 feats, '
                                f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config} (S3DIS production model, '
                                'matrix filters, 10 GRU iterations), train step fwd+bwd+Adam',
-                   'superpoints_per_step': n_sp_step * world, 'parallelism': f'dp{world} (one scene shard per GPU, one flat-bucket '
+                   'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'parallelism': f'dp{world} (one scene shard per GPU, one flat-bucket '
                                                                               'RCCL all-reduce)' if world > 1 else 'single GPU'},
     }
 
@@ -186,7 +218,7 @@ def main():
         L.spg_prof_enable(1)
         nprof = 3
         for _ in range(nprof):
-            step()
+            eager_step()                     # instrumented launches cannot be replayed from a graph
         torch.cuda.synchronize()
         ms, launches, flops = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
         L.spg_prof_read(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flops), 1)

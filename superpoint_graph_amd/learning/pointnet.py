@@ -142,9 +142,10 @@ class PointNet(nn.Module):
                                      0.1 if bn0.momentum is None else bn0.momentum)
 
     def _bump_batches_tracked(self, times):
-        for m in self.modules():
-            if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None:
-                m.num_batches_tracked += times
+        nbt = [m.num_batches_tracked for m in self.modules()
+               if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None]
+        if nbt:
+            torch._foreach_add_(nbt, times)          # one launch for all BatchNorm layers
 
     def forward(self, input, input_global, bn_update_times=1):
         if not input.is_cuda:
