@@ -117,19 +117,15 @@ def main():
     label_mode = targets[:, 0].to(dev)
     model.ecc.set_info(GIs, 1)                                             # H2D of the index buffers + device CSR build
     embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=0.0, capturable=bool(args.hipgraph))
-    bucket = spd.GradBucket(model.parameters())
+    from superpoint_graph_amd.flat import FlatParameters
+    arena = FlatParameters(model)                    # parameters / gradients as views of one flat buffer each
+    optimizer = torch.optim.Adam([arena.flat], lr=1e-2, weight_decay=0.0, capturable=bool(args.hipgraph))
     w_local = spd.loss_weight(label_mode)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     n_sp_step = int(flag.numel())
 
-    params = [p for p in model.parameters()]
-
-    def grads_of(ps):
-        return [p.grad for p in ps if p.grad is not None]
-
     def fwd_bwd():
-        optimizer.zero_grad(set_to_none=True)
+        arena.zero_grad()
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
         loss = F.cross_entropy(out, label_mode)
@@ -137,15 +133,13 @@ def main():
         embedder.bw_hook()
 
     def update():
-        g = grads_of(params)                                             # p.grad.clamp_(-clip, clip), learning/main.py:210-212
-        torch._foreach_clamp_min_(g, -1.0)
-        torch._foreach_clamp_max_(g, 1.0)
+        arena.clamp_grad_(1.0)                                           # p.grad.clamp_(-clip, clip), learning/main.py:210-212
         optimizer.step()
 
     def eager_step():
         fwd_bwd()
         if world > 1:
-            bucket.allreduce(w_local)
+            arena.allreduce(w_local)
         update()
 
     step = eager_step
@@ -160,7 +154,6 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(g_fb):
             fwd_bwd()
         with torch.cuda.graph(g_up):
@@ -169,7 +162,7 @@ def main():
         def graph_step():
             g_fb.replay()
             if world > 1:
-                bucket.allreduce(w_local)
+                arena.allreduce(w_local)
             g_up.replay()
         step = graph_step
         log('hipGraph captured')

@@ -191,11 +191,8 @@ static int gru_pack(const float* const* params, int layernorm, int ingate, float
   SPG_CHECK_ARG(G.w_ih && G.w_hh && G.b_ih && G.b_hh, "missing GRU parameters");
   SPG_CHECK_ARG(!ingate || (G.w_ig && G.b_ig), "missing input-gate parameters");
   G.layernorm = layernorm; G.ingate = ingate;
-  float* t = scratch;
-  SPG_TRY(spg_launch_transpose(G.w_ih, 96, 32, t, st));
-  SPG_TRY(spg_launch_transpose(G.w_hh, 96, 32, t + 3072, st));
-  if (ingate) SPG_TRY(spg_launch_transpose(G.w_ig, 32, 32, t + 6144, st));
-  G.w_ih_t = t; G.w_hh_t = t + 3072; G.w_ig_t = t + 6144;
+  SPG_CHECK_ARG((((uintptr_t)G.w_ih | (uintptr_t)G.w_hh | (uintptr_t)G.w_ig) & 15) == 0, "GRU weights must be 16-byte aligned");
+  (void)scratch; (void)st;
   return 0;
 }
 

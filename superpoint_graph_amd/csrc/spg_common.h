@@ -165,6 +165,8 @@ __device__ __forceinline__ SpgQuad spg_quad_consts(const SpgOperand& d, int c, i
       const int ci = c + i < nch ? c + i : 0;
       q.a[i] = d.c0[ci]; q.b[i] = d.c1[ci]; q.c[i] = d.c2[ci]; q.d[i] = d.c3[ci];
     }
+  } else if (MODE == SPG_PRO_CLOUD) {
+    q.naff = (d.stnT != nullptr && c == 0) ? 1 : 0;         // this quad holds x, y: apply the 2x2 STN transform
   }
   return q;
 }
@@ -180,8 +182,19 @@ struct SpgRaw {
 // max-pool backward, the tiny per-group arg-max rows), then the secondary loads; the arg-max mask is resolved
 // while the secondary loads are still in flight.
 template <int MODE, int NI>
-__device__ __forceinline__ void spg_load_raw(const SpgOperand& d, const long (&m)[NI], int c, SpgRaw (&r)[NI]) {
-  if (MODE == SPG_PRO_POOLBWD) {
+__device__ __forceinline__ void spg_load_raw(const SpgOperand& d, const long (&m)[NI], int c, int nvalid, SpgRaw (&r)[NI]) {
+  if (MODE == SPG_PRO_CLOUD) {
+    // channel-major clouds [G, Ctot, P]: four dword loads per quad (the caller maps lanes to consecutive points)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const unsigned mu = (unsigned)m[i], P = (unsigned)d.P;
+      const unsigned g = mu / P;
+      const float* base = d.X + ((long)g * d.Ctot) * d.P + (mu - g * P);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[i].x[e] = base[(long)(e < nvalid ? c + e : 0) * d.P];
+      if (d.stnT != nullptr) r[i].y = *reinterpret_cast<const f32x4*>(d.stnT + (long)g * 4);   // wave-uniform branch
+    }
+  } else if (MODE == SPG_PRO_POOLBWD) {
     int4 ai[NI];
     int pp[NI];
 #pragma unroll
@@ -214,6 +227,13 @@ __device__ __forceinline__ f32x4 spg_finish_raw(const SpgQuad& q, const SpgRaw& 
   f32x4 v;
   if (MODE == SPG_PRO_IDENT) {
     v = r.x;
+  } else if (MODE == SPG_PRO_CLOUD) {
+    v = r.x;
+    if (q.naff) {   // learning/pointnet.py:123  [x y] @ (proj.view(2,2) + I); same expression as spg_fetch
+      const float x = r.x[0], y = r.x[1];
+      v[0] = fmaf(x, r.y[0] + 1.f, y * r.y[2]);
+      v[1] = fmaf(x, r.y[1], y * (r.y[3] + 1.f));
+    }
   } else if (MODE == SPG_PRO_AFFINE) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -410,7 +430,7 @@ struct SpgRowsPipe {          // out-major [ROWS x 32] tile of an operand
       m[i] = m0 + (ok ? row : 0);                           // clamped: loads are unconditional
       vmask |= ok ? (1u << i) : 0u;
     }
-    spg_load_raw<MODE, NI>(d, m, q.nvalid > 0 ? c : 0, raw);
+    spg_load_raw<MODE, NI>(d, m, q.nvalid > 0 ? c : 0, q.nvalid, raw);
   }
   __device__ __forceinline__ void store(f32x4* __restrict__ lds) const {
     const int tid = threadIdx.x, kq = tid & 7;
@@ -425,25 +445,34 @@ struct SpgRedPipe {           // red-major [32 x CH] tile of an operand (the thr
   static constexpr int QUADS = CH / 4, RPP = SPG_THREADS / QUADS, NI = SPG_KC / RPP;
   SpgRaw raw[NI];
   unsigned vmask;
+  // row-major sources: consecutive lanes take consecutive channel quads of one row (16-byte loads, coalesced along
+  // the channels); channel-major clouds: consecutive lanes take consecutive points of one channel quad.
+  static __device__ __forceinline__ int quad_of(int tid) { return MODE == SPG_PRO_CLOUD ? tid / SPG_KC : tid % QUADS; }
+  static __device__ __forceinline__ int row_of(int tid, int i) {
+    return MODE == SPG_PRO_CLOUD ? (tid % SPG_KC) : tid / QUADS + RPP * i;
+  }
+  static constexpr int NITEMS = MODE == SPG_PRO_CLOUD ? (QUADS * SPG_KC + SPG_THREADS - 1) / SPG_THREADS : NI;
   __device__ __forceinline__ void load(const SpgOperand& d, const SpgQuad& q, long m0, long mend, int c0) {
-    const int tid = threadIdx.x, c = c0 + 4 * (tid % QUADS);
+    const int tid = threadIdx.x, c = c0 + 4 * quad_of(tid);
     long m[NI];
     vmask = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const long mm = m0 + tid / QUADS + RPP * i;
-      const bool ok = mm < mend;
+      const long mm = m0 + row_of(tid, i);
+      const bool ok = mm < mend && (MODE != SPG_PRO_CLOUD || (i == 0 && quad_of(tid) < QUADS));
       m[i] = ok ? mm : m0;
       vmask |= ok ? (1u << i) : 0u;
     }
-    spg_load_raw<MODE, NI>(d, m, q.nvalid > 0 ? c : 0, raw);
+    spg_load_raw<MODE, NI>(d, m, q.nvalid > 0 ? c : 0, q.nvalid, raw);
   }
   __device__ __forceinline__ void store(const SpgQuad& q, float* __restrict__ lds) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      *reinterpret_cast<f32x4*>(lds + (tid / QUADS + RPP * i) * (CH + 4) + 4 * (tid % QUADS)) =
+    for (int i = 0; i < NI; ++i) {
+      if (MODE == SPG_PRO_CLOUD && (i > 0 || quad_of(tid) >= QUADS)) continue;   // 32 rows x QUADS quads <= 256 threads
+      *reinterpret_cast<f32x4*>(lds + row_of(tid, i) * (CH + 4) + 4 * quad_of(tid)) =
           spg_finish_raw<MODE>(q, raw[i], (vmask >> i) & 1u);
+    }
   }
 };
 

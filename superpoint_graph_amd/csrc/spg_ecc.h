@@ -27,9 +27,6 @@ struct SpgGruParams {   // GRUCellEx (learning/modules.py:205-259), hidden = inp
   const float* b_hh;    // [96]
   const float* w_ig;    // [32,32]
   const float* b_ig;    // [32]
-  const float* w_ih_t;  // [32,96] transposed copies (forward: coalesced over outputs)
-  const float* w_hh_t;  // [32,96]
-  const float* w_ig_t;  // [32,32]
   int layernorm, ingate;
 };
 

@@ -179,17 +179,34 @@ __device__ __forceinline__ void spg_aggregate_node(const SpgGraph& g, const floa
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   if (matrix) {
     const int kb = lane >> 3;
-    for (int e = e0; e < e1; ++e) {
-      const float* xj = hin + (long)g.src[e] * ld;
-      const f32x4* We = reinterpret_cast<const f32x4*>(W + (long)e * 1024);
+    // 4 edges per batch: all index / filter / state loads of a batch are issued before any of them is consumed
+    for (int e = e0; e < e1; e += 4) {
+      int sidx[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = We[lane + 64 * q];      // row k = kb + 8q, columns 4*(lane&7)..+3 of W_e[in][out]
-        const float xk = xj[kb + 8 * q];
-        a4[0] = fmaf(xk, w[0], a4[0]);
-        a4[1] = fmaf(xk, w[1], a4[1]);
-        a4[2] = fmaf(xk, w[2], a4[2]);
-        a4[3] = fmaf(xk, w[3], a4[3]);
+      for (int u = 0; u < 4; ++u) sidx[u] = g.src[min(e + u, e1 - 1)];
+      f32x4 w[4][4];
+      float xk[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4* We = reinterpret_cast<const f32x4*>(W + (long)min(e + u, e1 - 1) * 1024);
+        const float* xj = hin + (long)sidx[u] * ld;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          w[u][q] = We[lane + 64 * q];          // row k = kb + 8q, columns 4*(lane&7)..+3 of W_e[in][out]
+          xk[u][q] = xj[kb + 8 * q];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float on = (e + u < e1) ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float xv = xk[u][q] * on;
+          a4[0] = fmaf(xv, w[u][q][0], a4[0]);
+          a4[1] = fmaf(xv, w[u][q][1], a4[1]);
+          a4[2] = fmaf(xv, w[u][q][2], a4[2]);
+          a4[3] = fmaf(xv, w[u][q][3], a4[3]);
+        }
       }
     }
 #pragma unroll
@@ -220,34 +237,55 @@ struct GruFwdState {
   float r, z, n;         // gates (lanes 0..31; z was shuffled from lanes 32..63)
 };
 
-__device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, const float* __restrict__ sa,
+// Rows of the GRU weight matrices held in registers: lane l owns gate rows l (first value) and 64 + (l & 31)
+// (second value) of W_ih / W_hh and row (l & 31) of the input-gate matrix.  They are loaded at kernel entry --
+// independent of the graph data -- so their latency overlaps the edge gather.
+struct GruRows {
+  f32x4 ih1[8], hh1[8], ih2[8], hh2[8], ig[8];
+};
+
+__device__ __forceinline__ void spg_gru_load_rows(const SpgGruParams& G, int lane, GruRows& w) {
+  const f32x4* pih = reinterpret_cast<const f32x4*>(G.w_ih);
+  const f32x4* phh = reinterpret_cast<const f32x4*>(G.w_hh);
+  const int r1 = lane, r2 = 64 + (lane & 31);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    w.ih1[q] = pih[r1 * 8 + q]; w.hh1[q] = phh[r1 * 8 + q];
+    w.ih2[q] = pih[r2 * 8 + q]; w.hh2[q] = phh[r2 * 8 + q];
+  }
+  if (G.ingate) {
+    const f32x4* pig = reinterpret_cast<const f32x4*>(G.w_ig);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w.ig[q] = pig[(lane & 31) * 8 + q];
+  }
+}
+
+__device__ __forceinline__ float spg_dot32(const f32x4 (&w)[8], const float* __restrict__ v) {
+  float a0 = 0.f, a1 = 0.f;    // k-order 0..31 split over two chains (exact order is immaterial at 1e-6)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(v + 4 * q);   // LDS broadcast read
+    a0 = fmaf(w[q][0], x[0], a0); a1 = fmaf(w[q][1], x[1], a1);
+    a0 = fmaf(w[q][2], x[2], a0); a1 = fmaf(w[q][3], x[3], a1);
+  }
+  return a0 + a1;
+}
+
+__device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, const GruRows& w, const float* __restrict__ sa,
                                                      const float* __restrict__ sh, float* __restrict__ sx, int lane,
                                                      GruFwdState& st) {
   // input gate: x = sigmoid(W_ig h + b_ig) * a      (learning/modules.py:225-226)
   float gin = 1.f, x = 0.f;
   if (lane < 32) {
-    if (G.ingate) {
-      float pre = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) pre = fmaf(G.w_ig_t[k * 32 + lane], sh[k], pre);
-      gin = spg_sigmoid(pre + G.b_ig[lane]);
-    }
+    if (G.ingate) gin = spg_sigmoid(spg_dot32(w.ig, sh) + G.b_ig[lane]);
     x = gin * sa[lane];
     sx[lane] = x;
   }
   st.gin = gin; st.x = x;
   __syncthreads();
-  float gi1 = 0.f, gh1 = 0.f, gi2 = 0.f, gh2 = 0.f;
-#pragma unroll 8
-  for (int k = 0; k < 32; ++k) {
-    const float xv = sx[k], hv = sh[k];
-    gi1 = fmaf(G.w_ih_t[k * 96 + lane], xv, gi1);
-    gh1 = fmaf(G.w_hh_t[k * 96 + lane], hv, gh1);
-    if (lane < 32) {
-      gi2 = fmaf(G.w_ih_t[k * 96 + 64 + lane], xv, gi2);
-      gh2 = fmaf(G.w_hh_t[k * 96 + 64 + lane], hv, gh2);
-    }
-  }
+  float gi1 = spg_dot32(w.ih1, sx), gh1 = spg_dot32(w.hh1, sh);
+  float gi2 = 0.f, gh2 = 0.f;
+  if (lane < 32) { gi2 = spg_dot32(w.ih2, sx); gh2 = spg_dot32(w.hh2, sh); }
   st.rstd_i = 1.f; st.rstd_h = 1.f;
   if (G.layernorm) {   // per-row (x - mean)/sqrt(var_biased + eps) over the 96 values (learning/modules.py:218-222)
     const float mi = spg_wave_sum(gi1 + (lane < 32 ? gi2 : 0.f)) * (1.f / 96.f);
@@ -272,10 +310,12 @@ __device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, cons
 // forward step
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void spg_ecc_step_fwd_kernel(const SpgEccStepFwd p) {
-  __shared__ float lds[4][3][32];
+  __shared__ __attribute__((aligned(16))) float lds[4][3][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
   const bool active = i < p.g.N;
+  GruRows wr;
+  if (p.do_gru) spg_gru_load_rows(p.gru, lane, wr);
   float* sa = lds[wave][0];
   float* sh = lds[wave][1];
   float* sx = lds[wave][2];
@@ -301,7 +341,7 @@ __global__ __launch_bounds__(256) void spg_ecc_step_fwd_kernel(const SpgEccStepF
   if (active && p.agg_save != nullptr && lane < 32) p.agg_save[(long)i * p.ldagg + lane] = sa[lane];
   if (!p.do_gru) return;
   GruFwdState st;
-  spg_gru_forward_node(p.gru, sa, sh, sx, lane, st);
+  spg_gru_forward_node(p.gru, wr, sa, sh, sx, lane, st);
   if (active && lane < 32) {
     const float h = sh[lane];
     p.hout[(long)i * p.ld + lane] = st.n + st.z * (h - st.n);   // hy = newgate + inputgate*(hidden - newgate)
@@ -318,7 +358,7 @@ int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
 // backward step
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepBwd p) {
-  __shared__ float lds[4][5][96];
+  __shared__ __attribute__((aligned(16))) float lds[4][5][96];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 4 + wave;
   const bool active = j < p.g.N;
@@ -337,14 +377,27 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
       const int b = p.g.rev_rowptr[j], e_ = p.g.rev_rowptr[j + 1];
       if (p.matrix) {
         float pq[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = b; t < e_; ++t) {
-          const int e = p.g.rev_eid[t];
-          const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.Gnext + (long)p.g.dst[e] * p.ldg + 4 * (lane & 7));
-          const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)e * 1024);
+        for (int t = b; t < e_; t += 4) {      // 4 out-edges per batch, loads first
+          int eid[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 w = We[lane + 64 * q];
-            pq[q] += (w[0] * g4[0] + w[1] * g4[1]) + (w[2] * g4[2] + w[3] * g4[3]);
+          for (int u = 0; u < 4; ++u) eid[u] = p.g.rev_eid[min(t + u, e_ - 1)];
+          int did[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) did[u] = p.g.dst[eid[u]];
+          f32x4 w[4][4], g4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            g4[u] = *reinterpret_cast<const f32x4*>(p.Gnext + (long)did[u] * p.ldg + 4 * (lane & 7));
+            const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)eid[u] * 1024);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[u][q] = We[lane + 64 * q];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float on = (t + u < e_) ? 1.f : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              pq[q] += on * ((w[u][q][0] * g4[u][0] + w[u][q][1] * g4[u][1]) + (w[u][q][2] * g4[u][2] + w[u][q][3] * g4[u][3]));
           }
         }
 #pragma unroll
@@ -384,7 +437,11 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
   __syncthreads();
   const SpgGruParams& G = p.gru;
   GruFwdState st;
-  spg_gru_forward_node(G, sa, sh, sx, lane, st);
+  {
+    GruRows wr;
+    spg_gru_load_rows(G, lane, wr);
+    spg_gru_forward_node(G, wr, sa, sh, sx, lane, st);
+  }
   const float a_in = lane < 32 ? sa[lane] : 0.f;
   const float h_in = lane < 32 ? sh[lane] : 0.f;
   // gate backward on lanes 0..31 (channel = lane)

@@ -44,7 +44,6 @@ struct Plan {
   std::vector<FLayer> F;
   SpgGruParams gru;
   float *states = nullptr, *agg = nullptr, *stat = nullptr;
-  float *wih_t = nullptr, *whh_t = nullptr, *wig_t = nullptr;
   float* cell_grads[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t bytes = 0;
 };
@@ -91,8 +90,6 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
     SPG_CHECK_ARG(!c.ingate || (pl.gru.w_ig && pl.gru.b_ig), "missing input-gate parameters");
   }
   pl.gru.layernorm = c.layernorm; pl.gru.ingate = c.ingate;
-  pl.wih_t = cv.take<float>(96 * 32); pl.whh_t = cv.take<float>(96 * 32); pl.wig_t = cv.take<float>(32 * 32);
-  pl.gru.w_ih_t = pl.wih_t; pl.gru.w_hh_t = pl.whh_t; pl.gru.w_ig_t = pl.wig_t;
   pl.states = cv.take<float>((size_t)N * pl.ldS);
   pl.agg = cv.take<float>((size_t)N * pl.ldS);
   pl.stat = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, SPG_FC_ROWS) * 2 * cmax);
@@ -205,9 +202,6 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
     }
   }
   // ---- recurrent part ----
-  SPG_TRY(spg_launch_transpose(pl.gru.w_ih, 96, 32, pl.wih_t, st));
-  SPG_TRY(spg_launch_transpose(pl.gru.w_hh, 96, 32, pl.whh_t, st));
-  if (pl.cfg.ingate) SPG_TRY(spg_launch_transpose(pl.gru.w_ig, 32, 32, pl.wig_t, st));
   SPG_TRY(spg_launch_copy2d(h0, 32, pl.states, pl.ldS, N, 32, st));
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
   for (int r = 0; r < pl.R; ++r) {

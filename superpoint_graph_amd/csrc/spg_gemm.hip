@@ -431,10 +431,10 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
     // software-pipelined: global loads of chunk c+1 fly during the MFMAs of chunk c; two LDS buffers, one barrier.
     // A thread keeps the same channel quad for every row: the per-channel constants are loaded once.
     constexpr int BUF = SPG_KC * (IT + 4 + JT + 4);
-    const SpgQuad qa = spg_quad_consts<AMODE>(p.a, i0 + 4 * (tid % (IT / 4)), p.N);
-    const SpgQuad qb = spg_quad_consts<BMODE>(p.b, j0 + 4 * (tid % (JT / 4)), p.K);
     SpgRedPipe<AMODE, IT> pa;
     SpgRedPipe<BMODE, JT> pb;
+    const SpgQuad qa = spg_quad_consts<AMODE>(p.a, i0 + 4 * pa.quad_of(tid), p.N);
+    const SpgQuad qb = spg_quad_consts<BMODE>(p.b, j0 + 4 * pb.quad_of(tid), p.K);
     pa.load(p.a, qa, ms, me, i0);
     pb.load(p.b, qb, ms, me, j0);
     pa.store(qa, As);
@@ -542,6 +542,9 @@ static int launch_wgrad_b(const SpgWgradParams& p, int it, int jt, int ns, hipSt
   switch (p.b.mode) {
     case SPG_PRO_IDENT: return launch_wgrad_shape<AMODE, SPG_PRO_IDENT>(p, it, jt, ns, stream);
     case SPG_PRO_AFFINE: return launch_wgrad_shape<AMODE, SPG_PRO_AFFINE>(p, it, jt, ns, stream);
+    case SPG_PRO_CLOUD:   // raw clouds (first conv of a segment): at most 32 input channels, one column tile
+      if (jt == 32) return launch_wgrad_t<128, 32, 4, 1, AMODE, SPG_PRO_CLOUD>(p, ns, stream);
+      return launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
     default: return launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
   }
 }
@@ -554,7 +557,8 @@ int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t strea
   p.partial = (ns == 1) ? dW : work;
   // the vector path needs whole channel quads inside the matrices (N, K multiples of 4 are guaranteed by padded
   // leading dimensions: quads past the last channel are masked, but must be addressable)
-  const bool vec = spg_operand_vec_ok(p.a) && spg_operand_vec_ok(p.b) && p.a.ld >= ((p.N + 3) & ~3) && p.b.ld >= ((p.K + 3) & ~3);
+  const bool b_ok = p.b.mode == SPG_PRO_CLOUD ? (p.K <= 32) : (spg_operand_vec_ok(p.b) && p.b.ld >= ((p.K + 3) & ~3));
+  const bool vec = spg_operand_vec_ok(p.a) && p.a.ld >= ((p.N + 3) & ~3) && b_ok;
   int rc;
   if (!vec) rc = launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
   else if (p.a.mode == SPG_PRO_IDENT) rc = launch_wgrad_b<SPG_PRO_IDENT>(p, it, jt, ns, stream);

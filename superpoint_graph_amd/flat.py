@@ -1,0 +1,58 @@
+"""FlatParameters: every trainable parameter of a model (and its gradient) becomes a view into ONE flat fp32 buffer.
+
+Why (MI355X-first, launch-bound regime): a training step of the 279k-parameter model is ~230 dependent kernel
+launches; with 69 separate parameter tensors the reference-style update adds 69 gradient accumulations, a
+multi-tensor Adam and 69 clamps on top.  With flat storage
+  * the HIP backward kernels write the gradients straight into their final location (no per-parameter allocation,
+    accumulation or zero-fill launches; one fill per step zeroes the whole arena),
+  * the element-wise clamp (learning/main.py:210-212) and Adam are ONE launch sequence over one tensor,
+  * the data-parallel all-reduce (superpoint_graph_amd/dist.py) runs on the arena itself: no flatten/unflatten.
+The arithmetic is unchanged (clamp and Adam are element-wise), `state_dict()` keys / shapes are unchanged."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FlatParameters:
+    def __init__(self, model: torch.nn.Module):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError('model has no trainable parameters')
+        dev, dt = self.params[0].device, self.params[0].dtype
+        # every parameter starts on a 256-byte boundary: the kernels' 16-byte vector paths need aligned bases
+        self._offsets, off = [], 0
+        for p in self.params:
+            self._offsets.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        self.numel = off
+        data = torch.zeros(self.numel, dtype=dt, device=dev)
+        self._gbuf = torch.zeros(self.numel + 1, dtype=dt, device=dev)       # +1: loss-weight slot of the all-reduce
+        for p, off in zip(self.params, self._offsets):
+            n = p.numel()
+            data[off:off + n].copy_(p.data.reshape(-1))
+            p.data = data[off:off + n].view(p.shape)
+            p.grad = self._gbuf[off:off + n].view(p.shape)
+        self.flat = torch.nn.Parameter(data)             # hand THIS to the optimizer
+        self.flat.grad = self._gbuf[:self.numel]
+        for m in model.modules():
+            m._spg_direct_grads = True                   # the HIP autograd Functions then write into p.grad directly
+
+    def zero_grad(self):
+        self._gbuf.zero_()
+
+    def clamp_grad_(self, clip: float):
+        if clip > 0:
+            self.flat.grad.clamp_(-clip, clip)
+
+    def allreduce(self, local_weight: float = 1.0, group=None):
+        """Weighted data-parallel mean of the gradients (see superpoint_graph_amd/dist.py), in place on the arena."""
+        if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        self.flat.grad.mul_(float(local_weight))
+        self._gbuf[self.numel] = float(local_weight)
+        dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
+        self.flat.grad.div_(self._gbuf[self.numel])

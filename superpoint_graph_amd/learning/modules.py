@@ -81,8 +81,14 @@ class _EccRnnFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        grad_h0, gg = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out)
         nf = ctx.state.cfg.n_fnet
+        from .pointnet import _direct_grad_targets
+        d_f = _direct_grad_targets(ctx.module, ctx.groups[:nf], 4)
+        d_c = _direct_grad_targets(ctx.module, ctx.groups[nf:], 6)
+        if d_f is not None and d_c is not None:
+            grad_h0, _ = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out, d_f + d_c)
+            return (None, grad_h0, None, None, None) + (None,) * len(ctx.module._flat_params())
+        grad_h0, gg = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out)
         flat = []
         for li, g in enumerate(gg):
             flat += list(g[:4]) if li < nf else list(g)

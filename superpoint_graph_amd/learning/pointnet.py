@@ -64,6 +64,28 @@ class STNkD(nn.Module):
         return _seq_groups(self.convs) + _seq_groups(self.fcs) + [(self.proj, None)]
 
 
+def _direct_grad_targets(module, groups, nparam):
+    """When the module was wrapped by superpoint_graph_amd.flat.FlatParameters every parameter owns a .grad view
+    into one flat, pre-zeroed gradient buffer: return those views (structure of `groups`; `None` for the bias in
+    front of a BatchNorm, whose gradient is exactly zero) so that the kernels write into them directly."""
+    if not getattr(module, '_spg_direct_grads', False):
+        return None
+    out = []
+    for g in groups:
+        has_bn = nparam == 4 and g[2] is not None
+        row = []
+        for k in range(nparam):
+            t = g[k]
+            if t is None or (has_bn and k == 1):
+                row.append(None)
+                continue
+            if t.grad is None or not t.grad.is_contiguous():
+                return None
+            row.append(t.grad)
+        out.append(tuple(row))
+    return out
+
+
 class _PointNetFunction(torch.autograd.Function):
     """autograd node around spg_pointnet_forward / spg_pointnet_backward; parameters are passed as inputs
     so that autograd delivers their gradients."""
@@ -77,6 +99,10 @@ class _PointNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_emb):
+        direct = _direct_grad_targets(ctx.module, ctx.groups, 4)
+        if direct is not None:      # gradients are written straight into the pre-assigned .grad views (FlatParameters)
+            ops.pointnet_backward(ctx.state, ctx.groups, grad_emb, direct)
+            return (None,) * (5 + len(ctx.module._flat_params()))
         gg = ops.pointnet_backward(ctx.state, ctx.groups, grad_emb)
         flat = []
         for (gw, gb, ggam, gbet) in gg:

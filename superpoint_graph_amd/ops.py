@@ -196,15 +196,21 @@ def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Seque
     return emb, PointNetState(cfg, B, clouds, clouds_global, ws)
 
 
-def pointnet_backward(state: PointNetState, groups, grad_emb):
-    """Returns a list of 4-tuples (d weight, d bias, d bn.weight, d bn.bias) per layer."""
+def pointnet_backward(state: PointNetState, groups, grad_emb, out_grads=None):
+    """Returns a list of 4-tuples (d weight, d bias, d bn.weight, d bn.bias) per layer.
+    out_grads: optional pre-allocated destination tensors in the same structure (written, not accumulated); a
+    `None` entry is skipped by the library (used for the analytically-zero biases in front of a BatchNorm when the
+    destination is a pre-zeroed flat gradient buffer)."""
     cfg, B = state.cfg, state.B
     grad_emb = _req(grad_emb.contiguous(), torch.float32, 'grad_emb')
     nbytes = lib().spg_pointnet_bwd_workspace_bytes(ctypes.byref(cfg), B)
     bws = torch.empty(nbytes, dtype=torch.uint8, device=grad_emb.device)
     gg, flatg = [], []
-    for g in groups:
-        d = [None if g[k] is None else torch.empty_like(g[k]) for k in range(4)]
+    for li, g in enumerate(groups):
+        if out_grads is not None:
+            d = list(out_grads[li][:4])
+        else:
+            d = [None if g[k] is None else torch.empty_like(g[k]) for k in range(4)]
         gg.append(tuple(d))
         flatg += d + [None, None]
     flat = [t for g in groups for t in g]
@@ -252,7 +258,8 @@ def eccrnn_forward(cfg: EccRnnCfg, graph: DeviceGraph, h0, edgefeats, groups, tr
     return out, EccRnnState(cfg, graph, edgefeats, ws)
 
 
-def eccrnn_backward(state: EccRnnState, groups, grad_out):
+def eccrnn_backward(state: EccRnnState, groups, grad_out, out_grads=None):
+    """out_grads: see pointnet_backward."""
     cfg, graph = state.cfg, state.graph
     N, E = graph.N, graph.E
     grad_out = _req(grad_out.contiguous(), torch.float32, 'grad_out')
@@ -261,7 +268,9 @@ def eccrnn_backward(state: EccRnnState, groups, grad_out):
     gg, flatg = [], []
     nf = cfg.n_fnet
     for li, g in enumerate(groups):
-        if li < nf:
+        if out_grads is not None:
+            d = (list(out_grads[li][:4]) + [None, None]) if li < nf else list(out_grads[li][:6])
+        elif li < nf:
             d = [None if g[k] is None else torch.empty_like(g[k]) for k in range(4)] + [None, None]
         else:
             d = [None if g[k] is None else torch.empty_like(g[k]) for k in range(6)]

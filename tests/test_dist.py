@@ -63,3 +63,55 @@ def test_bucket_world1_is_identity_and_sharding():
         assert torch.allclose(a, b, atol=1e-7, rtol=1e-6)
     assert spd.shard_scenes(8, 3, 8) == [3] and spd.shard_scenes(10, 0, 4) == [0, 1, 2] and spd.shard_scenes(10, 3, 4) == [8, 9]
     assert sorted(sum((spd.shard_scenes(13, r, 4) for r in range(4)), [])) == list(range(13))
+
+
+def _flat_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from superpoint_graph_amd import dist as spd
+    from superpoint_graph_amd.flat import FlatParameters
+    spd.init_from_env('gloo')
+    model, x, y, cw = _make()
+    arena = FlatParameters(model)
+    cut = 9
+    xs, ys = (x[:cut], y[:cut]) if rank == 0 else (x[cut:], y[cut:])
+    arena.zero_grad()
+    F.cross_entropy(model(xs), ys, weight=cw).backward()
+    arena.allreduce(spd.loss_weight(ys, cw))
+    arena.clamp_grad_(0.05)
+    opt = torch.optim.Adam([arena.flat], lr=1e-2)
+    opt.step()
+    ret[rank] = ([p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()])
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_parameters_world2_matches_single_process():
+    """arena all-reduce + clamp + Adam over the flat buffer == reference-style per-parameter clamp + Adam on the whole batch"""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_flat_worker, args=(2, port, ret), nprocs=2, join=True)
+    model, x, y, cw = _make()
+    F.cross_entropy(model(x), y, weight=cw).backward()
+    for p in model.parameters():
+        p.grad.data.clamp_(-0.05, 0.05)                      # learning/main.py:210-212
+    ref_g = [p.grad.clone() for p in model.parameters()]
+    torch.optim.Adam(model.parameters(), lr=1e-2).step()
+    for r in (0, 1):
+        for a, b in zip(ret[r][0], ref_g):
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+        for a, b in zip(ret[r][1], model.parameters()):
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+
+
+def test_flat_parameters_keeps_state_dict():
+    from superpoint_graph_amd.flat import FlatParameters
+    model, x, y, cw = _make(3)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    arena = FlatParameters(model)
+    assert arena.numel >= sum(v.numel() for v in sd0.values()) and arena.numel % 64 == 0
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd0[k]) and v.shape == sd0[k].shape
+    with torch.no_grad():
+        arena.flat.add_(1.0)                                 # the module parameters are views of the arena
+    for k, v in model.state_dict().items():
+        assert torch.allclose(v, sd0[k] + 1.0)

@@ -75,6 +75,31 @@ def test_train_step_matches_reference(hip, tag, monger):
             assert maxrel(sd[k].double(), torch.from_numpy(g['state1/' + k]).double()) < 1e-5, k
 
 
+def test_flat_parameters_direct_gradients(hip):
+    """FlatParameters: the HIP backward writes into the flat gradient arena; same gradients as the reference."""
+    from superpoint_graph_amd.flat import FlatParameters
+    spec, batch, state0, g = load_golden('s3dis_gru10_matrix')
+    model = build_model(spec, state0).to(DEV).train()
+    arena = FlatParameters(model)
+    cw = torch.from_numpy(g['class_weights']).to(DEV)
+    for _ in range(2):                              # twice: the arena is re-zeroed and overwritten, never accumulated
+        arena.zero_grad()
+        emb, logits, embedder = _run(model, batch, 1)
+        loss = F.cross_entropy(logits, batch['label_mode'].to(DEV), weight=cw)
+        loss.backward()
+        embedder.bw_hook()
+        model.load_state_dict(state0)               # undo the BatchNorm running-stat update
+    assert maxrel(loss, torch.from_numpy(g['train/loss'])) < TOL
+    for k, p in model.named_parameters():
+        ref = torch.from_numpy(g['grad/' + k])
+        assert p.grad.data_ptr() >= arena.flat.grad.data_ptr()          # still a view of the arena
+        if float(ref.abs().max()) < 1e-6:
+            assert float(p.grad.abs().max()) < 1e-5, k
+        else:
+            assert maxrel(p.grad, ref) < 5e-4, k
+    assert sorted(model.state_dict().keys()) == sorted(state0.keys())
+
+
 def test_train_forward_vs_fp64_oracle(hip):
     """both fp32 paths (reference on CPU, HIP) are compared with the fp64 oracle: HIP must be as close as the reference."""
     spec, batch, state0, g = load_golden('s3dis_gru10_matrix')
