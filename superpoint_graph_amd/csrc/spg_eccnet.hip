@@ -130,6 +130,7 @@ struct BwdScratch {
   float *G = nullptr, *dgi = nullptr, *dgh = nullptr, *dui = nullptr, *duh = nullptr, *dpre = nullptr, *xg = nullptr;
   float *dhdir = nullptr, *dWts = nullptr, *dzA = nullptr, *dzB = nullptr, *Wt = nullptr, *consts = nullptr;
   float *work = nullptr, *stat = nullptr;
+  size_t work_floats = 0;
   size_t zero_bytes = 0;   // the leading region [G .. xg] must be zero-initialised
   size_t bytes = 0;
 };
@@ -150,18 +151,15 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   for (const FLayer& l : pl.F) {
     cmax = l.cout > cmax ? l.cout : cmax; cmax = l.cin > cmax ? l.cin : cmax;
     wmax = (size_t)l.cin * l.cout > wmax ? (size_t)l.cin * l.cout : wmax;
-    const size_t w = spg_wgrad_workspace_floats(Er, l.cout, l.cin);
-    workmax = w > workmax ? w : workmax;
+    workmax += ((spg_wgrad_workspace_floats(Er, l.cout, l.cin) + 63) & ~(size_t)63) + 64 * (size_t)l.cout + 128;
   }
-  {
-    const size_t w = spg_wgrad_workspace_floats((long)rows, 96, 32);
-    workmax = w > workmax ? w : workmax;
-  }
+  // GRU: three weight gradients + three bias column sums over all (node, iteration) rows
+  workmax += 3 * (((spg_wgrad_workspace_floats((long)rows, 96, 32) + 63) & ~(size_t)63) + 64 * 96 + 128);
   int hmax = 4;   // widest hidden activation
   for (int i = 0; i + 1 < (int)pl.F.size(); ++i) hmax = pl.F[i].cout > hmax ? pl.F[i].cout : hmax;
   s.dzA = cv.take<float>(Er * hmax); s.dzB = cv.take<float>(Er * hmax);
   s.consts = cv.take<float>((size_t)4 * cmax);
-  s.work = cv.take<float>(workmax);
+  s.work = cv.take<float>(workmax); s.work_floats = workmax;
   s.stat = cv.take<float>((size_t)spg_cdiv(Er, SPG_FC_ROWS) * 2 * cmax);
   s.bytes = cv.off + 256;
 }
@@ -240,6 +238,8 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
   BwdScratch s;
   carve_bwd(pl, bwd_workspace, s);
   SPG_TRY(zero_async(bwd_workspace, s.zero_bytes, st));
+  SpgReduceQueue rq;
+  rq.arena = s.work; rq.arena_floats = s.work_floats;
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
   const int R = pl.R;
   const long ldS = pl.ldS, ld96 = (long)(R + 1) * 96;
@@ -273,15 +273,15 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
   {
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = op_ident(s.dgi, 96); w.b = op_ident(s.xg, 32); w.M = rows; w.N = 96; w.K = 32;
-    SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[0], s.work, st));
+    SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[0], st));
     w.a = op_ident(s.dgh, 96); w.b = op_ident(pl.states, 32);
-    SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[1], s.work, st));
-    SPG_TRY(spg_launch_colsum(s.dui, 96, rows, 96, pl.cell_grads[2], s.work, st));
-    SPG_TRY(spg_launch_colsum(s.duh, 96, rows, 96, pl.cell_grads[3], s.work, st));
+    SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[1], st));
+    SPG_TRY(spg_queue_colsum(rq, s.dui, 96, rows, 96, pl.cell_grads[2], st));
+    SPG_TRY(spg_queue_colsum(rq, s.duh, 96, rows, 96, pl.cell_grads[3], st));
     if (pl.cfg.ingate) {
       w.a = op_ident(s.dpre, 32); w.b = op_ident(pl.states, 32); w.N = 32;
-      SPG_TRY(spg_launch_wgrad(w, pl.cell_grads[4], s.work, st));
-      SPG_TRY(spg_launch_colsum(s.dpre, 32, rows, 32, pl.cell_grads[5], s.work, st));
+      SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[4], st));
+      SPG_TRY(spg_queue_colsum(rq, s.dpre, 32, rows, 32, pl.cell_grads[5], st));
     }
   }
   if (E == 0) {   // no edges: the filter network received no gradient
@@ -291,7 +291,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
       SPG_TRY(zero_async(l.dgamma, (size_t)l.cout * 4, st));
       SPG_TRY(zero_async(l.dbeta, (size_t)l.cout * 4, st));
     }
-    return 0;
+    return spg_flush_reduce(rq, st);
   }
   // ---- per-edge filter gradients (sum over the iterations), then the filter network backward ----
   SPG_TRY(spg_launch_ecc_edge_wgrad(gr, pl.cfg.matrix, pl.states, ldS, s.G, ldS, R, s.dWts, st));
@@ -302,10 +302,10 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     FLayer& l = pl.F[i];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = fnet_input(pl, i, edgefeats); w.M = E; w.N = l.cout; w.K = l.cin;
-    SPG_TRY(spg_launch_wgrad(w, l.dW, s.work, st));
+    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
     if (l.db) {
       if (l.bn) SPG_TRY(zero_async(l.db, (size_t)l.cout * 4, st));
-      else SPG_TRY(spg_launch_colsum(cur.X, cur.ld, E, l.cout, l.db, s.work, st));
+      else SPG_TRY(spg_queue_colsum(rq, cur.X, cur.ld, E, l.cout, l.db, st));
     }
     if (i == 0) break;
     FLayer& prod = pl.F[i - 1];
@@ -325,5 +325,5 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
       cur = op_ident(out, l.cin);
     }
   }
-  return 0;
+  return spg_flush_reduce(rq, st);     // ONE launch sums the split partials of all weight / bias gradients
 }

@@ -52,6 +52,24 @@ size_t spg_wgrad_workspace_floats(long M, int N, int K);
 // dW (dense [N,K], ld = K) = reduction; `work` holds the split partials
 int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t stream);
 
+// Deferred reductions: the split partials of many weight gradients / column sums are summed by ONE launch at the end
+// of a backward pass instead of one tiny launch each (the step is launch-bound: ~200 dependent kernels).
+#define SPG_MAX_REDUCE_JOBS 40
+struct SpgReduceJob {
+  const float* partial;   // [nsplit][n]
+  float* out;             // [n]
+  int nsplit, n;
+};
+struct SpgReduceQueue {
+  SpgReduceJob jobs[SPG_MAX_REDUCE_JOBS];
+  int njobs = 0;
+  float* arena = nullptr;    // scratch for all partials of one backward pass
+  size_t arena_floats = 0, used = 0;
+};
+int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream);
+int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, float* out, hipStream_t stream);
+int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream);
+
 // BatchNorm forward statistics: partials [ntile][2][N] -> mean, rstd, scale s = gamma*rstd, shift t = beta - mean*s;
 // running stats updated `update_times` times (run_full_monger re-runs the forward, learning/pointnet.py:167,173)
 int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,

@@ -549,27 +549,100 @@ static int launch_wgrad_b(const SpgWgradParams& p, int it, int jt, int ns, hipSt
   }
 }
 
-int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t stream) {
-  SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty wgrad");
+// launches the split-partial kernel; `part` = dW itself when the plan has a single split
+static int spg_launch_wgrad_partials(SpgWgradParams p, float* part, hipStream_t stream) {
   int it, jt, ns, rps;
   wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
   p.rows_per_split = rps;
-  p.partial = (ns == 1) ? dW : work;
+  p.partial = part;
   // the vector path needs whole channel quads inside the matrices (N, K multiples of 4 are guaranteed by padded
   // leading dimensions: quads past the last channel are masked, but must be addressable)
   const bool b_ok = p.b.mode == SPG_PRO_CLOUD ? (p.K <= 32) : (spg_operand_vec_ok(p.b) && p.b.ld >= ((p.K + 3) & ~3));
   const bool vec = spg_operand_vec_ok(p.a) && p.a.ld >= ((p.N + 3) & ~3) && b_ok;
-  int rc;
-  if (!vec) rc = launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
-  else if (p.a.mode == SPG_PRO_IDENT) rc = launch_wgrad_b<SPG_PRO_IDENT>(p, it, jt, ns, stream);
-  else if (p.a.mode == SPG_PRO_BNBWD) rc = launch_wgrad_b<SPG_PRO_BNBWD>(p, it, jt, ns, stream);
-  else if (p.a.mode == SPG_PRO_POOLBWD) rc = launch_wgrad_b<SPG_PRO_POOLBWD>(p, it, jt, ns, stream);
-  else rc = launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
-  if (rc) return rc;
+  if (!vec) return launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
+  if (p.a.mode == SPG_PRO_IDENT) return launch_wgrad_b<SPG_PRO_IDENT>(p, it, jt, ns, stream);
+  if (p.a.mode == SPG_PRO_BNBWD) return launch_wgrad_b<SPG_PRO_BNBWD>(p, it, jt, ns, stream);
+  if (p.a.mode == SPG_PRO_POOLBWD) return launch_wgrad_b<SPG_PRO_POOLBWD>(p, it, jt, ns, stream);
+  return launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
+}
+
+int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t stream) {
+  SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty wgrad");
+  int it, jt, ns, rps;
+  wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
+  SPG_TRY(spg_launch_wgrad_partials(p, ns == 1 ? dW : work, stream));
   if (ns > 1) {
     const long n = (long)p.N * p.K;
     hipLaunchKernelGGL(spg_reduce_partials_kernel, dim3(spg_cdiv(n, 64)), dim3(1024), 0, stream, work, ns, n, dW);
     SPG_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// deferred (batched) reductions
+// ---------------------------------------------------------------------------------------------
+struct SpgReduceBatch {
+  SpgReduceJob jobs[SPG_MAX_REDUCE_JOBS];
+  int first_block[SPG_MAX_REDUCE_JOBS + 1];
+  int njobs;
+};
+
+__global__ __launch_bounds__(1024) void spg_reduce_batch_kernel(const SpgReduceBatch b) {
+  __shared__ float red[16][64];
+  int j = 0;
+  while (j + 1 < b.njobs && (int)blockIdx.x >= b.first_block[j + 1]) ++j;      // wave-uniform scan (<= 40 entries)
+  const SpgReduceJob job = b.jobs[j];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long i = (long)(blockIdx.x - b.first_block[j]) * 64 + tx;
+  float s = 0.f;
+  if (i < job.n)
+    for (int k = ty; k < job.nsplit; k += 16) s += job.partial[(long)k * job.n + i];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < job.n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][tx];      // fixed order: deterministic
+    job.out[i] = t;
+  }
+}
+
+int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream) {
+  if (q.njobs == 0) return 0;
+  SpgReduceBatch b;
+  int blocks = 0;
+  for (int j = 0; j < q.njobs; ++j) {
+    b.jobs[j] = q.jobs[j];
+    b.first_block[j] = blocks;
+    blocks += spg_cdiv(q.jobs[j].n, 64);
+  }
+  b.first_block[q.njobs] = blocks;
+  b.njobs = q.njobs;
+  hipLaunchKernelGGL(spg_reduce_batch_kernel, dim3(blocks), dim3(1024), 0, stream, b);
+  SPG_LAUNCH_CHECK();
+  q.njobs = 0;
+  return 0;
+}
+
+static int queue_take(SpgReduceQueue& q, size_t floats, float** out, hipStream_t stream) {
+  if (q.njobs == SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(q, stream));
+  SPG_CHECK_ARG(q.arena != nullptr && q.used + floats <= q.arena_floats, "reduction arena too small");
+  *out = q.arena + q.used;
+  q.used += (floats + 63) & ~(size_t)63;
+  return 0;
+}
+
+int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream) {
+  SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty wgrad");
+  int it, jt, ns, rps;
+  wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
+  float* part = dW;
+  if (ns > 1) SPG_TRY(queue_take(q, (size_t)ns * p.N * p.K, &part, stream));
+  SPG_TRY(spg_launch_wgrad_partials(p, part, stream));
+  if (ns > 1) {
+    SpgReduceJob& j = q.jobs[q.njobs++];
+    j.partial = part; j.out = dW; j.nsplit = ns; j.n = p.N * p.K;
   }
   return 0;
 }
@@ -587,7 +660,7 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
                                                                int update_times, float* mean_o, float* rstd_o, float* s_o,
                                                                float* t_o) {
   __shared__ double r0[32][33], r1[32][33], r2[32][33];
-  const int cx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int cx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 channels x 32 tile-groups per workgroup
   const int c = blockIdx.x * 32 + cx;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   if (c < N)
@@ -657,12 +730,12 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, float* consts,
                                                                    float* dgamma, float* dbeta) {
-  __shared__ double r0[32][33], r1[32][33];
-  const int cx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  __shared__ double r0[64][17], r1[64][17];
+  const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
   double a = 0.0, b = 0.0;
   if (c < N)
-    for (int t = ty; t < ntile; t += 32) {
+    for (int t = ty; t < ntile; t += 64) {
       a += (double)stat[((long)t * 2) * ldstat + c];
       b += (double)stat[((long)t * 2 + 1) * ldstat + c];
     }
@@ -670,7 +743,7 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
   __syncthreads();
   if (ty != 0 || c >= N) return;
   a = b = 0.0;
-  for (int k = 0; k < 32; ++k) { a += r0[k][cx]; b += r1[k][cx]; }
+  for (int k = 0; k < 64; ++k) { a += r0[k][cx]; b += r1[k][cx]; }
   if (dbeta) dbeta[c] = (float)a;
   if (dgamma) dgamma[c] = (float)b;
   const double c1 = a / (double)count, c2 = b / (double)count;
@@ -683,7 +756,7 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
 int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long count, int N, const float* s,
                                const float* mean, const float* rstd, float* consts, float* dgamma, float* dbeta,
                                hipStream_t stream) {
-  hipLaunchKernelGGL(spg_bn_bwd_finalize_kernel, dim3(spg_cdiv(N, 32)), dim3(1024), 0, stream, stat, ntile, ldstat, count, N, s,
+  hipLaunchKernelGGL(spg_bn_bwd_finalize_kernel, dim3(spg_cdiv(N, 16)), dim3(1024), 0, stream, stat, ntile, ldstat, count, N, s,
                      mean, rstd, consts, dgamma, dbeta);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -742,6 +815,21 @@ __global__ __launch_bounds__(1024) void spg_colsum_kernel(const float* __restric
 }
 
 size_t spg_colsum_workspace_floats(int N) { return (size_t)SPG_COLSUM_SLICES * N; }
+
+int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, float* out, hipStream_t stream) {
+  long rps = (M + SPG_COLSUM_SLICES - 1) / SPG_COLSUM_SLICES;
+  if (rps < 16) rps = 16;
+  const int slices = spg_cdiv(M, rps);
+  float* part = out;
+  if (slices > 1) SPG_TRY(queue_take(q, (size_t)slices * N, &part, stream));
+  hipLaunchKernelGGL(spg_colsum_kernel, dim3(spg_cdiv(N, 64), slices), dim3(1024), 0, stream, X, ld, M, N, rps, part);
+  SPG_LAUNCH_CHECK();
+  if (slices > 1) {
+    SpgReduceJob& j = q.jobs[q.njobs++];
+    j.partial = part; j.out = out; j.nsplit = slices; j.n = N;
+  }
+  return 0;
+}
 
 int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, float* work, hipStream_t stream) {
   long rps = (M + SPG_COLSUM_SLICES - 1) / SPG_COLSUM_SLICES;

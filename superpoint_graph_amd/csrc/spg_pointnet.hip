@@ -219,7 +219,8 @@ struct BwdScratch {
   float *dzA = nullptr, *dzB = nullptr;     // [M, cmax_conv] ping-pong for the dense conv gradients
   float *fzA = nullptr, *fzB = nullptr;     // [B, cmax_fc]
   float* consts = nullptr;                  // [4][cmax]
-  float* work = nullptr;                    // wgrad split partials
+  float* work = nullptr;                    // reduction arena: split partials of all weight / bias gradients
+  size_t work_floats = 0;
   float* stat = nullptr;                    // [ntile][2][cmax]
   float* dxy = nullptr;                     // [M, 2]
   float* dT = nullptr;                      // [B, 4]
@@ -235,13 +236,13 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
     else { cfc = l.cin + 4 > cfc ? l.cin + 4 : cfc; }
     cmax = l.cout > cmax ? l.cout : cmax; cmax = l.cin > cmax ? l.cin : cmax;
     wmax = (size_t)l.cin * l.cout > wmax ? (size_t)l.cin * l.cout : wmax;
-    const size_t w = spg_wgrad_workspace_floats(l.conv ? pl.M : pl.B, l.cout, l.cin);
-    workmax = w > workmax ? w : workmax;
+    // every layer gets its own slice of the reduction arena (partials stay alive until the single batched reduce)
+    workmax += ((spg_wgrad_workspace_floats(l.conv ? pl.M : pl.B, l.cout, l.cin) + 63) & ~(size_t)63) + 64 * (size_t)l.cout + 128;
   }
   s.dzA = cv.take<float>((size_t)pl.M * cconv); s.dzB = cv.take<float>((size_t)pl.M * cconv);
   s.fzA = cv.take<float>((size_t)pl.B * cfc); s.fzB = cv.take<float>((size_t)pl.B * cfc);
   s.consts = cv.take<float>((size_t)4 * cmax);
-  s.work = cv.take<float>(workmax);
+  s.work = cv.take<float>(workmax); s.work_floats = workmax;
   s.stat = cv.take<float>((size_t)pl.B * 2 * cmax);
   s.dxy = cv.take<float>((size_t)pl.M * 2);
   s.dT = cv.take<float>((size_t)pl.B * 4);
@@ -264,8 +265,8 @@ int zero_async(float* p, size_t n, hipStream_t st) {
 
 // Backward of one segment.  `cur` is the gradient wrt the raw output of the segment's last fc layer
 // (IDENT operand).  If want_dxy, the gradient wrt the first two input channels of conv 0 is left in s.dxy.
-int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgOperand cur, const float* clouds, const float* stnT,
-                     bool want_dxy, hipStream_t st) {
+int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, SpgOperand cur, const float* clouds,
+                     const float* stnT, bool want_dxy, hipStream_t st) {
   const int B = pl.B;
   // ---- fc head ----
   float* fz[2] = {s.fzA, s.fzB};
@@ -274,10 +275,10 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgOperand cur, const
     Layer& l = pl.L[sg.fcs[k]];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, true, k, clouds, stnT); w.M = B; w.N = l.cout; w.K = l.cin;
-    SPG_TRY(spg_launch_wgrad(w, l.dW, s.work, st));
+    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
     if (l.db) {
       if (l.bn) SPG_TRY(zero_async(l.db, l.cout, st));   // a bias in front of train-mode BatchNorm has zero gradient
-      else SPG_TRY(spg_launch_colsum(cur.X, cur.ld, B, l.cout, l.db, s.work, st));
+      else SPG_TRY(spg_queue_colsum(rq, cur.X, cur.ld, B, l.cout, l.db, st));
     }
     // data gradient -> producer of this layer's input
     const bool first = k == 0;
@@ -311,7 +312,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgOperand cur, const
     Layer& l = pl.L[sg.convs[k]];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, false, k, clouds, stnT); w.M = (int)pl.M; w.N = l.cout; w.K = l.cin;
-    SPG_TRY(spg_launch_wgrad(w, l.dW, s.work, st));
+    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
     if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
     if (k > 0) {
       Layer& prod = pl.L[sg.convs[k - 1]];
@@ -414,10 +415,12 @@ extern "C" int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const f
   carve_bwd(pl, bwd_workspace, s);
   const float* stnT = pl.has_stn ? pl.L[pl.stn.fcs.back()].y : nullptr;
   const int cout = pl.L[pl.main.fcs.back()].cout;
-  SPG_TRY(backward_segment(pl, pl.main, s, op_ident(grad_emb, cout), clouds, stnT, pl.has_stn, st));
+  SpgReduceQueue rq;
+  rq.arena = s.work; rq.arena_floats = s.work_floats;
+  SPG_TRY(backward_segment(pl, pl.main, s, rq, op_ident(grad_emb, cout), clouds, stnT, pl.has_stn, st));
   if (pl.has_stn) {
     SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, s.dT, st));
-    SPG_TRY(backward_segment(pl, pl.stn, s, op_ident(s.dT, 4), clouds, nullptr, false, st));
+    SPG_TRY(backward_segment(pl, pl.stn, s, rq, op_ident(s.dT, 4), clouds, nullptr, false, st));
   }
-  return 0;
+  return spg_flush_reduce(rq, st);      // ONE launch sums the split partials of all weight / bias gradients
 }
