@@ -119,7 +119,6 @@ def main():
     embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
     from superpoint_graph_amd.flat import FlatParameters
     arena = FlatParameters(model)                    # parameters / gradients as views of one flat buffer each
-    optimizer = torch.optim.Adam([arena.flat], lr=1e-2, weight_decay=0.0, capturable=bool(args.hipgraph))
     w_local = spd.loss_weight(label_mode)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     n_sp_step = int(flag.numel())
@@ -133,8 +132,7 @@ def main():
         embedder.bw_hook()
 
     def update():
-        arena.clamp_grad_(1.0)                                           # p.grad.clamp_(-clip, clip), learning/main.py:210-212
-        optimizer.step()
+        arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)        # clamp (main.py:210-212) + Adam (main.py:213), one launch
 
     def eager_step():
         fwd_bwd()

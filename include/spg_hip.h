@@ -148,6 +148,14 @@ int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* gra
                         void* workspace, void* bwd_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Element-wise gradient clamp + Adam step on one flat parameter buffer: replaces the per-parameter loop
+ * `p.grad.data.clamp_(-clip, clip)` (learning/main.py:210-212) and `optimizer.step()` of torch.optim.Adam
+ * (learning/main.py:213, :433-437) by ONE launch.  `step` counts from 1.  grad_clip <= 0 disables the clamp.
+ * ---------------------------------------------------------------------------------------------- */
+int spg_adam_clamp_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_clip, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Instrumentation for bench.py: when enabled, every launch of the row-GEMM kernels is bracketed by
  * hipEvents on its own stream; spg_prof_read synchronises and returns the accumulated milliseconds,
  * launch count and algorithmic FLOPs since the last reset.

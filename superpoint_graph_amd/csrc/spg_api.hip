@@ -276,3 +276,36 @@ extern "C" int spg_linear_wgrad(const float* dY, long lddy, const float* X, long
   w.M = M; w.N = N; w.K = K;
   return spg_launch_wgrad(w, dW, work, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// element-wise gradient clamp + Adam on one flat buffer (learning/main.py:210-213, torch.optim.Adam semantics:
+// weight decay added to the clamped gradient, bias-corrected moments, denom = sqrt(v)/sqrt(1-b2^t) + eps)
+// ---------------------------------------------------------------------------------------------
+__global__ void spg_adam_clamp_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                      float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                      float clip, float bc1, float bc2_sqrt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+  g[i] = gi;                                   // the clamp is observable in p.grad, as in the reference loop
+  if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+  const float mi = m[i] + (1.f - b1) * (gi - m[i]);          // exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+extern "C" int spg_adam_clamp_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, float grad_clip, int step,
+                                   void* stream) {
+  SPG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad argument");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(spg_adam_clamp_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, bc1, bc2_sqrt);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}

@@ -41,6 +41,20 @@ class FlatParameters:
         for m in model.modules():
             m._spg_direct_grads = True                   # the HIP autograd Functions then write into p.grad directly
 
+    def adam_step(self, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip=0.0):
+        """Element-wise gradient clamp (learning/main.py:210-212) + torch.optim.Adam update (learning/main.py:433-437)
+        of the whole arena in ONE HIP launch (spg_adam_clamp_step).  The moments live in this object."""
+        from . import _lib
+        if not hasattr(self, '_m'):
+            self._m = torch.zeros_like(self.flat.data)
+            self._v = torch.zeros_like(self.flat.data)
+            self._t = 0
+        self._t += 1
+        _lib.check(_lib.lib().spg_adam_clamp_step(self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self._m.data_ptr(),
+                                                  self._v.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
+                                                  grad_clip, self._t, torch.cuda.current_stream().cuda_stream),
+                   'spg_adam_clamp_step')
+
     def zero_grad(self):
         self._gbuf.zero_()
 

@@ -76,7 +76,7 @@ class _EccRnnFunction(torch.autograd.Function):
     def forward(ctx, module, hx, edgefeats, graph, training, *flat_params):
         cfg, groups = module._cfg_and_groups()
         out, state = ops.eccrnn_forward(cfg, graph, hx.contiguous(), edgefeats, groups, training, 1)
-        ctx.module, ctx.state, ctx.groups = module, state, groups
+        ctx.module, ctx.state, ctx.groups, ctx.nflat = module, state, groups, len(flat_params)
         return out
 
     @staticmethod
@@ -87,7 +87,7 @@ class _EccRnnFunction(torch.autograd.Function):
         d_c = _direct_grad_targets(ctx.module, ctx.groups[nf:], 6)
         if d_f is not None and d_c is not None:
             grad_h0, _ = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out, d_f + d_c)
-            return (None, grad_h0, None, None, None) + (None,) * len(ctx.module._flat_params())
+            return (None, grad_h0, None, None, None) + (None,) * ctx.nflat
         grad_h0, gg = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out)
         flat = []
         for li, g in enumerate(gg):
@@ -122,6 +122,19 @@ class RNNGraphConvModule(nn.Module):
         self._gci = gc_info
 
     def _cfg_and_groups(self):
+        cached = self.__dict__.get('_cg_cache')
+        if cached is None:
+            cached = self._build_cfg_and_modules()
+            self.__dict__['_cg_cache'] = cached
+        cfg, fg = cached
+        groups = []
+        for lin, b in fg:
+            groups.append((lin.weight, lin.bias, None if b is None else b.weight, None if b is None else b.bias,
+                           None if b is None else b.running_mean, None if b is None else b.running_var))
+        groups.append(self._cell.param_tensors())
+        return cfg, groups
+
+    def _build_cfg_and_modules(self):
         fg, bnidx = _fnet_groups(self._fnet)
         widths = [fg[0][0].in_features] + [lin.out_features for lin, _ in fg]
         nc = self._cell.hidden_size
@@ -130,12 +143,7 @@ class RNNGraphConvModule(nn.Module):
         cfg = ops.make_eccrnn_cfg(nc, self._nrepeats, matrix, self._cell._layernorm, self._cell._ingate, self._cat_all,
                                   widths, bnidx, fg[-1][0].bias is not None,
                                   1e-5 if bn is None else bn.eps, 0.1 if bn is None or bn.momentum is None else bn.momentum)
-        groups = []
-        for lin, b in fg:
-            groups.append((lin.weight, lin.bias, None if b is None else b.weight, None if b is None else b.bias,
-                           None if b is None else b.running_mean, None if b is None else b.running_var))
-        groups.append(self._cell.param_tensors())
-        return cfg, groups
+        return cfg, fg
 
     def _flat_params(self):
         flat = []
@@ -154,5 +162,9 @@ class RNNGraphConvModule(nn.Module):
             for m in self._fnet:
                 if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None:
                     m.num_batches_tracked += 1
-        return _EccRnnFunction.apply(self, hx, edgefeats.contiguous().float(), self._gci.device_graph(), self.training,
-                                     *self._flat_params())
+        if getattr(self, '_spg_direct_grads', False) and torch.is_grad_enabled():
+            from .pointnet import _grad_anchor
+            extra = (_grad_anchor(hx.device),)      # FlatParameters mode: one differentiable anchor instead of all parameters
+        else:
+            extra = tuple(self._flat_params())
+        return _EccRnnFunction.apply(self, hx, edgefeats.contiguous().float(), self._gci.device_graph(), self.training, *extra)

@@ -64,6 +64,19 @@ class STNkD(nn.Module):
         return _seq_groups(self.convs) + _seq_groups(self.fcs) + [(self.proj, None)]
 
 
+_anchors = {}
+
+
+def _grad_anchor(device):
+    """A 1-element tensor that requires grad: the single differentiable input of the HIP autograd nodes in
+    FlatParameters mode."""
+    a = _anchors.get(device)
+    if a is None:
+        a = torch.zeros(1, device=device, requires_grad=True)
+        _anchors[device] = a
+    return a
+
+
 def _direct_grad_targets(module, groups, nparam):
     """When the module was wrapped by superpoint_graph_amd.flat.FlatParameters every parameter owns a .grad view
     into one flat, pre-zeroed gradient buffer: return those views (structure of `groups`; `None` for the bias in
@@ -94,7 +107,7 @@ class _PointNetFunction(torch.autograd.Function):
     def forward(ctx, module, clouds, clouds_global, training, bn_update_times, *flat_params):
         groups = module._groups_tensors()
         emb, state = ops.pointnet_forward(module._cfg(clouds.shape[2]), clouds, clouds_global, groups, training, bn_update_times)
-        ctx.module, ctx.state, ctx.groups = module, state, groups
+        ctx.module, ctx.state, ctx.groups, ctx.nflat = module, state, groups, len(flat_params)
         return emb
 
     @staticmethod
@@ -102,7 +115,7 @@ class _PointNetFunction(torch.autograd.Function):
         direct = _direct_grad_targets(ctx.module, ctx.groups, 4)
         if direct is not None:      # gradients are written straight into the pre-assigned .grad views (FlatParameters)
             ops.pointnet_backward(ctx.state, ctx.groups, grad_emb, direct)
-            return (None,) * (5 + len(ctx.module._flat_params()))
+            return (None,) * (5 + ctx.nflat)
         gg = ops.pointnet_backward(ctx.state, ctx.groups, grad_emb)
         flat = []
         for (gw, gb, ggam, gbet) in gg:
@@ -147,8 +160,12 @@ class PointNet(nn.Module):
 
     # ---- parameter plumbing ----
     def layer_groups(self):
-        g = self.stn.layer_groups() if self.nfeat_stn > 0 else []
-        return g + _seq_groups(self.convs) + _seq_groups(self.fcs)
+        lg = self.__dict__.get('_lg_cache')
+        if lg is None:                # the module structure is fixed after construction
+            g = self.stn.layer_groups() if self.nfeat_stn > 0 else []
+            lg = g + _seq_groups(self.convs) + _seq_groups(self.fcs)
+            self.__dict__['_lg_cache'] = lg
+        return lg
 
     def _groups_tensors(self):
         return [_tensors(lin, bn) for lin, bn in self.layer_groups()]
@@ -160,18 +177,23 @@ class PointNet(nn.Module):
         return [p for p in flat if p is not None]
 
     def _cfg(self, npts):
-        stn_conv = self.stn._nf_conv if self.nfeat_stn > 0 else []
-        stn_fc = self.stn._nf_fc if self.nfeat_stn > 0 else []
-        bn0 = self.convs[1]
-        return ops.make_pointnet_cfg(self._nfeat, self.nfeat_stn, self._nfeat_global, npts, stn_conv, stn_fc,
-                                     self._nf_conv, self._nf_fc, self._last_ac, bn0.eps,
-                                     0.1 if bn0.momentum is None else bn0.momentum)
+        cache = self.__dict__.setdefault('_cfg_cache', {})
+        if npts not in cache:
+            stn_conv = self.stn._nf_conv if self.nfeat_stn > 0 else []
+            stn_fc = self.stn._nf_fc if self.nfeat_stn > 0 else []
+            bn0 = self.convs[1]
+            cache[npts] = ops.make_pointnet_cfg(self._nfeat, self.nfeat_stn, self._nfeat_global, npts, stn_conv, stn_fc,
+                                                self._nf_conv, self._nf_fc, self._last_ac, bn0.eps,
+                                                0.1 if bn0.momentum is None else bn0.momentum)
+        return cache[npts]
 
     def _bump_batches_tracked(self, times):
-        nbt = [m.num_batches_tracked for m in self.modules()
-               if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None]
+        nbt = self.__dict__.get('_nbt_cache')
+        if nbt is None:
+            nbt = [m for m in self.modules() if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None]
+            self.__dict__['_nbt_cache'] = nbt
         if nbt:
-            torch._foreach_add_(nbt, times)          # one launch for all BatchNorm layers
+            torch._foreach_add_([m.num_batches_tracked for m in nbt], times)   # one launch for all BatchNorm layers
 
     def forward(self, input, input_global, bn_update_times=1):
         if not input.is_cuda:
@@ -183,6 +205,10 @@ class PointNet(nn.Module):
         input = input.contiguous().float()
         if self.training:
             self._bump_batches_tracked(bn_update_times)
+        if getattr(self, '_spg_direct_grads', False) and torch.is_grad_enabled():
+            # FlatParameters mode: gradients are written into the arena by the kernels, so autograd only needs ONE
+            # differentiable input to create the node (instead of tracking ~60 parameter tensors)
+            return _PointNetFunction.apply(self, input, input_global, self.training, bn_update_times, _grad_anchor(input.device))
         return _PointNetFunction.apply(self, input, input_global, self.training, bn_update_times, *self._flat_params())
 
 

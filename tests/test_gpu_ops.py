@@ -146,3 +146,28 @@ def test_linear_forward_and_wgrad(hip, M, K, N):
     assert maxrel(dw, dy.double().t() @ x.double()) < 2e-6
     dw2 = ops.linear_wgrad(DY, X, SC, SH, True)
     assert maxrel(dw2, dy.double().t() @ a) < 2e-6
+
+
+def test_fused_clamp_adam_matches_torch(hip):
+    """spg_adam_clamp_step == per-parameter clamp_ + torch.optim.Adam (learning/main.py:210-213, :433-437)."""
+    from superpoint_graph_amd.flat import FlatParameters
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.Tanh(), torch.nn.Linear(64, 7)).to(DEV)
+    ref, mod = make(), make()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-3)
+    arena = FlatParameters(mod)
+    x = torch.randn(50, 20, device=DEV)
+    y = torch.randint(0, 7, (50,), device=DEV)
+    for step in range(4):
+        opt.zero_grad()
+        (torch.nn.functional.cross_entropy(ref(x), y) * 30).backward()
+        for p in ref.parameters():
+            p.grad.data.clamp_(-0.5, 0.5)
+        opt.step()
+        arena.zero_grad()
+        (torch.nn.functional.cross_entropy(mod(x), y) * 30).backward()
+        arena.adam_step(lr=1e-2, weight_decay=1e-3, grad_clip=0.5)
+        for a, b in zip(mod.parameters(), ref.parameters()):
+            assert maxrel(a.grad, b.grad) < 2e-5 and maxrel(a, b) < 2e-5, step   # fp32 trajectories drift by rounding
