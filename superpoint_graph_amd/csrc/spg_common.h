@@ -267,20 +267,28 @@ template <int TI, int TJ>
 __device__ __forceinline__ void spg_mfma_chunk(const f32x4* __restrict__ As, const f32x4* __restrict__ Bs,
                                                int strideA, int strideB, int rowA, int rowB, int h,
                                                f32x16 (&acc)[TI][TJ]) {
+  // register double-buffering of the LDS fragments: the reads of group g+1 are issued before the MFMAs of group g
+  f32x4 a[2][TI], b[2][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) a[0][i] = As[h * strideA + rowA + 32 * i];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) b[0][j] = Bs[h * strideB + rowB + 32 * j];
 #pragma unroll
   for (int g = 0; g < SPG_KC / 8; ++g) {
-    f32x4 a[TI], b[TJ];
+    const int cur = g & 1, nxt = cur ^ 1;
+    if (g + 1 < SPG_KC / 8) {
 #pragma unroll
-    for (int i = 0; i < TI; ++i) a[i] = As[(2 * g + h) * strideA + rowA + 32 * i];
+      for (int i = 0; i < TI; ++i) a[nxt][i] = As[(2 * (g + 1) + h) * strideA + rowA + 32 * i];
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) b[j] = Bs[(2 * g + h) * strideB + rowB + 32 * j];
+      for (int j = 0; j < TJ; ++j) b[nxt][j] = Bs[(2 * (g + 1) + h) * strideB + rowB + 32 * j];
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][s], b[cur][j][s], acc[i][j], 0, 0, 0);
   }
 }
 

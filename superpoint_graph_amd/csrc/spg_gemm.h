@@ -92,6 +92,8 @@ int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax
 size_t spg_colsum_workspace_floats(int N);
 int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, float* work, hipStream_t stream);
 int spg_launch_transpose(const float* W, int N, int K, float* Wt, hipStream_t stream);
+// dst [rows, ldd] = src [rows, cols] with zero padding (ldd >= cols): 16-byte aligned weight rows for the vector path
+int spg_launch_pad_rows(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream);
 // dT[g, 2a+b] = sum_p clouds[g, a, p] * dxy[g*P + p, b]   (gradient of the 2x2 STN transform, pointnet.py:123)
 int spg_launch_stn_dT(const float* clouds, int Ctot, int P, int G, const float* dxy, long ldd, float* dT,
                       hipStream_t stream);

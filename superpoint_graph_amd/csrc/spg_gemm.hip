@@ -88,13 +88,15 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] += bv;
     if (p.Y != nullptr) {      // uniform
-      float* yb = p.Y + (m0 + roww) * p.ldy + col;
+      float* yb = p.Y + m0 * p.ldy + n0;                       // wave-uniform base (SGPRs) + 32-bit lane offsets
+      const unsigned ldy = (unsigned)p.ldy;
+      const unsigned o0 = (unsigned)(roww + 4 * h) * ldy + (unsigned)(colw + 32 * j + r);
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int row = 32 * i + spg_acc_row(q, h);
-          if (FULL || (colok && roww + row < mvalid)) yb[(long)row * p.ldy] = acc[i][j][q];
+          if (FULL || (colok && roww + row < mvalid)) yb[o0 + (unsigned)(32 * i + (q & 3) + 8 * (q >> 2)) * ldy] = acc[i][j][q];
         }
     }
   }
@@ -218,8 +220,13 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
     float sc = 1.f, sh = 0.f, mean = 0.f, rstd = 0.f;
     if (p.ms != nullptr) { sc = p.ms[cc]; sh = p.mt[cc]; }
     if (do_stats) { mean = p.mmean[cc]; rstd = p.mrstd[cc]; }
-    const float* yp = p.Yp + (m0 + roww) * p.ldyp + (colok ? col : 0);
-    float* yo = p.Y + (m0 + roww) * p.ldy + col;
+    // wave-uniform bases (SGPRs) + 32-bit lane offsets: one VGPR per address instead of a 64-bit pair
+    const float* yp = p.Yp + m0 * p.ldyp + n0;
+    float* yo = p.Y + m0 * p.ldy + n0;
+    const unsigned ldyp = (unsigned)p.ldyp, ldyo = (unsigned)p.ldy;
+    const unsigned cl = (unsigned)(colw + 32 * j + r);
+    const unsigned op0 = (unsigned)(roww + 4 * h) * ldyp + (colok ? cl : 0u);
+    const unsigned oo0 = (unsigned)(roww + 4 * h) * ldyo + cl;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -229,7 +236,7 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
         for (int q = 0; q < 16; ++q) {
           const int row = 32 * i + spg_acc_row(q, h);
           const bool ok = FULL || (colok && roww + row < mvalid);
-          yv[q] = yp[ok ? (long)row * p.ldyp : 0];                         // unconditional (clamped) load
+          yv[q] = yp[ok ? op0 + (unsigned)(32 * i + (q & 3) + 8 * (q >> 2)) * ldyp : 0u];   // unconditional (clamped) load
         }
       }
 #pragma unroll
@@ -239,13 +246,14 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
         float v = acc[i][j][q];
         const float y = use_y ? yv[q] : 0.f;
         if (do_mask && inm && !(fmaf(y, sc, sh) > 0.f)) v = 0.f;
-        if (FULL || ok) yo[(long)row * p.ldy] = v;
+        if (FULL || ok) yo[oo0 + (unsigned)(32 * i + (q & 3) + 8 * (q >> 2)) * ldyo] = v;
         if (do_stats) {
           const float w = (ok && inm) ? v : 0.f;
           s1 += w;
           s2 = fmaf(w, (y - mean) * rstd, s2);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the 16-load batches of different sub-tiles apart (register pressure)
     }
     if (p.stat != nullptr) {
       s1 += __shfl_xor(s1, 32, 64);
@@ -274,7 +282,7 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
 // AMODE >= 0: operand mode of A known at compile time, vector + software-pipelined main loop (host guarantees the
 // alignment conditions); AMODE < 0: generic scalar staging (channel-major clouds, unaligned leading dimensions).
 template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE>
-__global__ __launch_bounds__(SPG_THREADS) void spg_rowgemm_kernel(const SpgGemmParams p) {
+__global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGemmParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
   extern __shared__ f32x4 smem[];
@@ -383,8 +391,10 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream) {
   SPG_CHECK_ARG(p.rows_per_tile >= 1 && p.rows_per_tile <= 128, "rows_per_tile must be in [1,128]");
   SPG_CHECK_ARG(p.epi == SPG_EPI_FWD || p.Y != nullptr, "backward epilogue needs an output");
   SPG_CHECK_ARG((p.epi == SPG_EPI_BWD) == (p.w_red != 0), "forward epilogue <-> [N,K] weights, backward epilogue <-> [K,N] weights");
-  const bool walign = (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0;
-  const bool vec = spg_operand_vec_ok(p.a) && walign && ((p.w_red ? p.N : p.K) & 3) == 0;
+  // vector path: 16-byte aligned rows, and every row addressable up to the next multiple of 4 of its logical width
+  // (padded leading dimensions; partial quads are masked through the A operand / the store mask)
+  const bool walign = (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0 && p.ldw >= (((p.w_red ? p.N : p.K) + 3) & ~3);
+  const bool vec = spg_operand_vec_ok(p.a) && walign && p.a.ld >= ((p.K + 3) & ~3);
   const int mode = vec ? p.a.mode : -1;
   if (!p.w_red) {
     switch (mode) {
@@ -843,6 +853,23 @@ int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, float*
                        (long)N, out);
     SPG_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// dst[r, c] = c < cols ? src[r, c] : 0   (copy with a zero-padded leading dimension)
+__global__ void spg_pad_rows_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, long rows,
+                                    int cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ldd) return;
+  const long r = i / ldd;
+  const int c = (int)(i - r * ldd);
+  dst[i] = c < cols ? src[r * lds_ + c] : 0.f;
+}
+
+int spg_launch_pad_rows(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream) {
+  const long n = rows * ldd;
+  hipLaunchKernelGGL(spg_pad_rows_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
+  SPG_LAUNCH_CHECK();
   return 0;
 }
 

@@ -27,6 +27,8 @@ struct Layer {
   float *rm = nullptr, *rv = nullptr;
   float* y = nullptr;           // raw output (workspace or external)
   long ldy = 0;
+  float* Wpad = nullptr;        // FC layers whose input width is not a multiple of 4: zero-padded copy of W
+  long ldw = 0;                 // leading dimension of the weight actually fed to the kernels
   float *mean = nullptr, *rstd = nullptr, *s = nullptr, *t = nullptr;   // BN batch constants
   float *dW = nullptr, *db = nullptr, *dgamma = nullptr, *dbeta = nullptr;
 };
@@ -118,6 +120,11 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
       l.mean = cv.take<float>(l.cout); l.rstd = cv.take<float>(l.cout);
       l.s = cv.take<float>(l.cout); l.t = cv.take<float>(l.cout);
     }
+    l.ldw = l.cin;
+    if (!l.conv && (l.cin & 3) != 0) {     // e.g. 256 pooled channels + 1 diameter = 257
+      l.ldw = (l.cin + 3) & ~3;
+      l.Wpad = cv.take<float>((size_t)l.cout * l.ldw);
+    }
   }
   auto carve_segment = [&](Segment& sg, float* final_out) {
     for (size_t k = 0; k < sg.convs.size(); ++k) {
@@ -205,7 +212,8 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     Layer& l = pl.L[sg.fcs[k]];
     SpgGemmParams g; memset(&g, 0, sizeof(g));
     g.a = input_operand(pl, sg, true, k, clouds, stnT);
-    g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = pl.B; g.N = l.cout; g.K = l.cin;
+    if (l.Wpad) SPG_TRY(spg_launch_pad_rows(l.W, l.cin, l.Wpad, l.ldw, l.cout, l.cin, st));
+    g.W = l.Wpad ? l.Wpad : l.W; g.ldw = l.ldw; g.bias = l.b; g.M = pl.B; g.N = l.cout; g.K = l.cin;
     g.rows_per_tile = SPG_FC_ROWS; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
     g.stat = (pl.training && l.bn) ? pl.stat : nullptr;
     SPG_TRY(spg_launch_gemm(g, st));
@@ -285,7 +293,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     Layer& prod = first ? pl.L[sg.convs.back()] : pl.L[sg.fcs[k - 1]];
     float* out = fz[flip]; flip ^= 1;
     SpgGemmParams g; memset(&g, 0, sizeof(g));
-    g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;   // dz_prev = dy @ W, W read untransposed
+    g.a = cur; g.W = l.Wpad ? l.Wpad : l.W; g.ldw = l.ldw; g.w_red = 1;   // dz_prev = dy @ W, W read untransposed
     g.M = B; g.N = l.cin; g.K = l.cout; g.rows_per_tile = SPG_FC_ROWS;
     g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = first ? sg.ldpool : l.cin;
     g.Yp = first ? sg.pooled : prod.y; g.ldyp = first ? sg.ldpool : prod.ldy;
