@@ -318,7 +318,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     if (prod.bn) { g.ms = prod.s; g.mt = prod.t; g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat; }
     SPG_TRY(spg_launch_gemm(g, st));
     if (prod.bn) {
-      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(E, SPG_FC_ROWS), l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
+      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(E, SPG_FC_ROWS) * spg_gemm_row_waves(SPG_FC_ROWS, l.cin), l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
                                          s.consts, prod.dgamma, prod.dbeta, st));
       cur = op_bnbwd(out, prod.y, prod.cout, s.consts, prod.cout);
     } else {

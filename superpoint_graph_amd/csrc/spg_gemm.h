@@ -19,8 +19,8 @@ struct SpgGemmParams {
   float* Y;           // [M, ldy] or null (pool-only forward)
   long ldy;
   // SPG_EPI_FWD: per-tile BatchNorm partials (mean, M2) and per-tile max/min pooling of the raw output
-  float* stat;        // [ntile][2][N] or null
-  float* pmax;        // [ntile][N] or null
+  float* stat;        // [ntile * row_waves][2][N] or null (one partial per wave, see spg_gemm_row_waves)
+  float* pmax;        // [ntile * row_waves][N] or null
   float* pmin;
   int* imax;
   int* imin;
@@ -45,6 +45,8 @@ struct SpgWgradParams {
 };
 
 int spg_gemm_ntiles(const SpgGemmParams& p);
+// number of statistics / pooling partials per row tile (= waves along the rows of the tile shape used for this problem)
+int spg_gemm_row_waves(int rows_per_tile, int N);
 int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream);
 
 // workspace (floats) needed by spg_launch_wgrad for a problem of this size
@@ -86,7 +88,7 @@ int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long co
 // max-pool selection after the BN statistics are known: out[g, c] = s[c] >= 0 ? pmax : pmin  (+ argidx),
 // out[g, N + e] = extra[g, e]; aidx uses the same leading dimension ldo as out
 int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,
-                           int G, int N, const float* extra, int nextra, float* out, long ldo, int* aidx,
+                           int G, int N, int rows_per_tile, const float* extra, int nextra, float* out, long ldo, int* aidx,
                            hipStream_t stream);
 // work: >= spg_colsum_workspace_floats(N) floats (spg_wgrad_workspace_floats(., N, .) is always large enough)
 size_t spg_colsum_workspace_floats(int N);

@@ -100,10 +100,15 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
         }
     }
   }
-  // ---- BatchNorm partials of this tile: column mean and M2 = sum (y - mean)^2 over the valid rows ----
+  // ---- BatchNorm partials: every WAVE writes (mean, M2 = sum (y - mean)^2) of its own rows -- no LDS, no barrier;
+  //      spg_bn_finalize_kernel combines the ntile*WI partials with Chan's formula ----
+  const int nvw = min(max(mvalid - roww, 0), IT / WI);      // valid rows of this wave
+  const long part = (long)tile * WI + wi;
   if (p.stat != nullptr) {
+    const float inv = nvw > 0 ? 1.f / (float)nvw : 0.f;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + colw + 32 * j + r;
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < TI; ++i)
@@ -111,90 +116,53 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
         for (int q = 0; q < 16; ++q)
           if (FULL || roww + 32 * i + spg_acc_row(q, h) < mvalid) s += acc[i][j][q];
       s += __shfl_xor(s, 32, 64);
-      if (h == 0) red[wi * JT + colw + 32 * j + r] = s;
-    }
-    __syncthreads();
-    if (tid < JT) {
-      float tot = 0.f;
-#pragma unroll
-      for (int w = 0; w < WI; ++w) tot += red[w * JT + tid];
-      red[WI * JT + tid] = tot / (float)mvalid;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const float mean = red[WI * JT + colw + 32 * j + r];
-      float s = 0.f;
+      const float mean = s * inv;
+      float m2 = 0.f;
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int q = 0; q < 16; ++q)
           if (FULL || roww + 32 * i + spg_acc_row(q, h) < mvalid) {
             const float d = acc[i][j][q] - mean;
-            s = fmaf(d, d, s);
+            m2 = fmaf(d, d, m2);
           }
-      s += __shfl_xor(s, 32, 64);
-      if (h == 0) red[wi * JT + colw + 32 * j + r] = s;
+      m2 += __shfl_xor(m2, 32, 64);
+      if (h == 0 && (FULL || col < p.N)) {
+        p.stat[(part * 2 + 0) * p.N + col] = mean;
+        p.stat[(part * 2 + 1) * p.N + col] = m2;
+      }
     }
-    __syncthreads();
-    if (tid < JT && n0 + tid < p.N) {
-      float m2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WI; ++w) m2 += red[w * JT + tid];
-      p.stat[((long)tile * 2 + 0) * p.N + n0 + tid] = red[WI * JT + tid];
-      p.stat[((long)tile * 2 + 1) * p.N + n0 + tid] = m2;
-    }
-    __syncthreads();
   }
-  // ---- max / min over the rows of the tile (= the points of one superpoint), first index wins ties ----
+  // ---- per-wave max / min over its rows (first index wins ties); spg_pool_select combines the WI partials ----
   if (p.pmax != nullptr) {
-    float* rmx = red;
-    float* rmn = red + WI * JT;
-    int* rix = reinterpret_cast<int*>(red + 2 * WI * JT);
-    int* rin = reinterpret_cast<int*>(red + 3 * WI * JT);
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + colw + 32 * j + r;
       float vmx = -FLT_MAX, vmn = FLT_MAX;
       int imx = INT_MAX, imn = INT_MAX;
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+          // rows are visited in increasing order, so a strict comparison keeps the FIRST extremum (torch's max_pool1d
+          // tie rule); written as selects: branch-free v_cmp + v_cndmask
           const int row = roww + 32 * i + spg_acc_row(q, h);
           const float v = acc[i][j][q];
-          if (FULL || row < mvalid) {
-            if (v > vmx || (v == vmx && row < imx)) { vmx = v; imx = row; }
-            if (v < vmn || (v == vmn && row < imn)) { vmn = v; imn = row; }
-          }
+          const bool ok = FULL || row < mvalid;
+          const bool gt = ok && v > vmx, lt = ok && v < vmn;
+          vmx = gt ? v : vmx; imx = gt ? row : imx;
+          vmn = lt ? v : vmn; imn = lt ? row : imn;
         }
-      {
-        const float ov = __shfl_xor(vmx, 32, 64);
-        const int oi = __shfl_xor(imx, 32, 64);
-        if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
-        const float pv = __shfl_xor(vmn, 32, 64);
-        const int pi = __shfl_xor(imn, 32, 64);
-        if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
+      const float ov = __shfl_xor(vmx, 32, 64);
+      const int oi = __shfl_xor(imx, 32, 64);
+      if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
+      const float pv = __shfl_xor(vmn, 32, 64);
+      const int pi = __shfl_xor(imn, 32, 64);
+      if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
+      if (h == 0 && (FULL || col < p.N)) {
+        const long o = part * p.N + col;
+        p.pmax[o] = vmx; p.imax[o] = imx; p.pmin[o] = vmn; p.imin[o] = imn;
       }
-      if (h == 0) {
-        const int c = wi * JT + colw + 32 * j + r;
-        rmx[c] = vmx; rix[c] = imx; rmn[c] = vmn; rin[c] = imn;
-      }
-    }
-    __syncthreads();
-    if (tid < JT && n0 + tid < p.N) {
-      float vmx = rmx[tid], vmn = rmn[tid];
-      int imx = rix[tid], imn = rin[tid];
-#pragma unroll
-      for (int w = 1; w < WI; ++w) {
-        const float ov = rmx[w * JT + tid];
-        const int oi = rix[w * JT + tid];
-        if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
-        const float pv = rmn[w * JT + tid];
-        const int pi = rin[w * JT + tid];
-        if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
-      }
-      const long o = (long)tile * p.N + n0 + tid;
-      p.pmax[o] = vmx; p.imax[o] = imx; p.pmin[o] = vmn; p.imin[o] = imn;
     }
   }
 }
@@ -255,26 +223,14 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the 16-load batches of different sub-tiles apart (register pressure)
     }
-    if (p.stat != nullptr) {
+    if (p.stat != nullptr) {     // per-wave partial sums, no LDS / barrier; spg_bn_bwd_finalize_kernel adds them up
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      if (h == 0) {
-        red[wi * JT + colw + 32 * j + r] = s1;
-        red[(WI + wi) * JT + colw + 32 * j + r] = s2;
+      if (h == 0 && (FULL || col < p.N)) {
+        const long part = (long)tile * WI + wi;
+        p.stat[(part * 2 + 0) * p.N + col] = s1;
+        p.stat[(part * 2 + 1) * p.N + col] = s2;
       }
-    }
-  }
-  if (p.stat != nullptr) {
-    __syncthreads();
-    if (tid < JT && n0 + tid < p.N) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int w = 0; w < WI; ++w) {
-        a += red[w * JT + tid];
-        b += red[(WI + w) * JT + tid];
-      }
-      p.stat[((long)tile * 2 + 0) * p.N + n0 + tid] = a;
-      p.stat[((long)tile * 2 + 1) * p.N + n0 + tid] = b;
     }
   }
 }
@@ -361,6 +317,13 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
 }
 
 int spg_gemm_ntiles(const SpgGemmParams& p) { return spg_cdiv(p.M, p.rows_per_tile); }
+
+// waves along the rows (WI) of the tile shape launch_gemm_shape picks: number of statistics / pooling partials per tile
+int spg_gemm_row_waves(int rows_per_tile, int N) {
+  if (rows_per_tile <= 32) return 1;
+  if (N <= 32) return 4;
+  return 2;
+}
 
 template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE>
 static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
@@ -475,15 +438,21 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
       __syncthreads();
     }
   }
+  // partial tile of this split: wave-uniform base + 32-bit lane offsets; unconditional stores when the tile is full
+  float* pb = p.partial + ((long)split * p.N + i0) * p.K + j0;
+  const unsigned ldk = (unsigned)p.K;
+  const bool full = i0 + IT <= p.N && j0 + JT <= p.K;
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
-    const int k = j0 + wj * (JT / WJ) + 32 * j + r;
+    const int kl = wj * (JT / WJ) + 32 * j + r;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int n = i0 + wi * (IT / WI) + 32 * i + spg_acc_row(q, h);
-        if (n < p.N && k < p.K) p.partial[((long)split * p.N + n) * p.K + k] = acc[i][j][q];
+        const int nl = wi * (IT / WI) + 32 * i + spg_acc_row(q, h);
+        const unsigned off = (unsigned)nl * ldk + (unsigned)kl;
+        if (full) pb[off] = acc[i][j][q];
+        else if (i0 + nl < p.N && j0 + kl < p.K) pb[off] = acc[i][j][q];
       }
   }
 }
@@ -664,28 +633,35 @@ int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t 
 //   mean = sum n_b m_b / M ;  M2 = sum M2_b + sum n_b m_b^2 - M mean^2   (Chan et al.; torch CPU BatchNorm also
 //   accumulates float statistics in double)
 __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __restrict__ stat, int ntile, int rows_per_tile,
-                                                               long M, int N, const float* __restrict__ gamma,
+                                                               int wi, long M, int N, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* running_mean,
                                                                float* running_var, float momentum, float eps,
                                                                int update_times, float* mean_o, float* rstd_o, float* s_o,
                                                                float* t_o) {
-  __shared__ double r0[32][33], r1[32][33], r2[32][33];
-  const int cx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 channels x 32 tile-groups per workgroup
-  const int c = blockIdx.x * 32 + cx;
+  // 16 channels x 64 partial-groups per workgroup (N/16 workgroups); tree reduction: wave shuffles, then 16 waves via LDS
+  __shared__ double r0[16][17], r1[16][17], r2[16][17];
+  const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  const int tile_rows = rows_per_tile <= 32 ? 32 : 128, rpw = tile_rows / wi;     // rows per wave of the GEMM tile
   if (c < N)
-    for (int b = ty; b < ntile; b += 32) {
-      const double nb = (double)min((long)rows_per_tile, M - (long)b * rows_per_tile);
+    for (int b = ty; b < ntile * wi; b += 64) {
+      const int tile = b / wi, w = b - tile * wi;
+      const long tv = min((long)rows_per_tile, M - (long)tile * rows_per_tile);    // valid rows of the tile
+      const double nb = (double)min(max(tv - (long)w * rpw, 0L), (long)rpw);
       const double mb = (double)stat[((long)b * 2) * N + c];
       a0 += nb * mb;
       a1 += nb * mb * mb;
       a2 += (double)stat[((long)b * 2 + 1) * N + c];
     }
-  r0[ty][cx] = a0; r1[ty][cx] = a1; r2[ty][cx] = a2;
+  a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+  a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 16) { r0[wave][cx] = a0; r1[wave][cx] = a1; r2[wave][cx] = a2; }
   __syncthreads();
-  if (ty != 0 || c >= N) return;
+  if (threadIdx.x >= 16 || c >= N) return;
   a0 = a1 = a2 = 0.0;
-  for (int k = 0; k < 32; ++k) { a0 += r0[k][cx]; a1 += r1[k][cx]; a2 += r2[k][cx]; }
+  for (int k = 0; k < 16; ++k) { a0 += r0[k][cx]; a1 += r1[k][cx]; a2 += r2[k][cx]; }
   const double mean = a0 / (double)M;
   double m2 = a2 + a1 - (double)M * mean * mean;
   if (m2 < 0.0) m2 = 0.0;
@@ -711,7 +687,8 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
 int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                            int update_times, float* mean, float* rstd, float* s, float* t, hipStream_t stream) {
-  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(spg_cdiv(N, 32)), dim3(1024), 0, stream, stat, ntile, rows_per_tile, M,
+  const int wi = spg_gemm_row_waves(rows_per_tile, N);
+  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(spg_cdiv(N, 16)), dim3(1024), 0, stream, stat, ntile, rows_per_tile, wi, M,
                      N, gamma, beta, running_mean, running_var, momentum, eps, update_times, mean, rstd, s, t);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -740,8 +717,8 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, float* consts,
                                                                    float* dgamma, float* dbeta) {
-  __shared__ double r0[64][17], r1[64][17];
-  const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  __shared__ double r0[16][17], r1[16][17];
+  const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 channels x 64 partial-groups per workgroup
   const int c = blockIdx.x * 16 + cx;
   double a = 0.0, b = 0.0;
   if (c < N)
@@ -749,11 +726,14 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
       a += (double)stat[((long)t * 2) * ldstat + c];
       b += (double)stat[((long)t * 2 + 1) * ldstat + c];
     }
-  r0[ty][cx] = a; r1[ty][cx] = b;
+  a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+  a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 16) { r0[wave][cx] = a; r1[wave][cx] = b; }
   __syncthreads();
-  if (ty != 0 || c >= N) return;
+  if (threadIdx.x >= 16 || c >= N) return;
   a = b = 0.0;
-  for (int k = 0; k < 64; ++k) { a += r0[k][cx]; b += r1[k][cx]; }
+  for (int k = 0; k < 16; ++k) { a += r0[k][cx]; b += r1[k][cx]; }
   if (dbeta) dbeta[c] = (float)a;
   if (dgamma) dgamma[c] = (float)b;
   const double c1 = a / (double)count, c2 = b / (double)count;
@@ -776,7 +756,7 @@ int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long co
 // small helpers
 // ---------------------------------------------------------------------------------------------
 __global__ void spg_pool_select_kernel(const float* pmax, const float* pmin, const int* imax, const int* imin,
-                                       const float* s, int G, int N, const float* extra, int nextra, float* out,
+                                       const float* s, int G, int N, int wi, const float* extra, int nextra, float* out,
                                        long ldo, int* aidx) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int W = N + nextra;
@@ -784,20 +764,30 @@ __global__ void spg_pool_select_kernel(const float* pmax, const float* pmin, con
   const long g = i / W;
   const int c = (int)(i - g * W);
   if (c < N) {
+    // combine the per-wave partials of the tile (first index wins ties), then pick max or min by the sign of the BN scale
+    float vmx = -FLT_MAX, vmn = FLT_MAX;
+    int imx = INT_MAX, imn = INT_MAX;
+    for (int w = 0; w < wi; ++w) {
+      const long o = (g * wi + w) * N + c;
+      const float ov = pmax[o], pv = pmin[o];
+      const int oi = imax[o], pi = imin[o];
+      if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
+      if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
+    }
     const bool up = s[c] >= 0.f;
-    out[g * ldo + c] = up ? pmax[g * N + c] : pmin[g * N + c];
-    aidx[g * ldo + c] = up ? imax[g * N + c] : imin[g * N + c];   // aidx shares the leading dimension of `out`
+    out[g * ldo + c] = up ? vmx : vmn;
+    aidx[g * ldo + c] = up ? imx : imn;   // aidx shares the leading dimension of `out`
   } else {
     out[g * ldo + c] = extra[g * nextra + (c - N)];
   }
 }
 
 int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,
-                           int G, int N, const float* extra, int nextra, float* out, long ldo, int* aidx,
+                           int G, int N, int rows_per_tile, const float* extra, int nextra, float* out, long ldo, int* aidx,
                            hipStream_t stream) {
   const long n = (long)G * (N + nextra);
   hipLaunchKernelGGL(spg_pool_select_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, pmax, pmin, imax, imin, s,
-                     G, N, extra, nextra, out, ldo, aidx);
+                     G, N, spg_gemm_row_waves(rows_per_tile, N), extra, nextra, out, ldo, aidx);
   SPG_LAUNCH_CHECK();
   return 0;
 }

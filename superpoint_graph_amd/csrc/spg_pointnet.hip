@@ -147,9 +147,9 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
   };
   if (pl.has_stn) carve_segment(pl.stn, nullptr);
   carve_segment(pl.main, emb);
-  pl.stat = cv.take<float>((size_t)B * 2 * cmax);
-  pl.pmax = cv.take<float>((size_t)B * cmax); pl.pmin = cv.take<float>((size_t)B * cmax);
-  pl.imax = cv.take<int>((size_t)B * cmax); pl.imin = cv.take<int>((size_t)B * cmax);
+  pl.stat = cv.take<float>((size_t)B * 4 * 2 * cmax);      // up to 4 per-wave partials per tile
+  pl.pmax = cv.take<float>((size_t)B * 4 * cmax); pl.pmin = cv.take<float>((size_t)B * 4 * cmax);
+  pl.imax = cv.take<int>((size_t)B * 4 * cmax); pl.imin = cv.take<int>((size_t)B * 4 * cmax);
   pl.bytes = cv.off + 256;
   return 0;
 }
@@ -205,7 +205,7 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     SPG_TRY(spg_launch_gemm(g, st));
     SPG_TRY(bn_stats(pl, l, pl.B, pl.P, pl.M, update_times, st));
     if (last)
-      SPG_TRY(spg_launch_pool_select(pl.pmax, pl.pmin, pl.imax, pl.imin, l.s, pl.B, l.cout, sg.extra, sg.nextra,
+      SPG_TRY(spg_launch_pool_select(pl.pmax, pl.pmin, pl.imax, pl.imin, l.s, pl.B, l.cout, pl.P, sg.extra, sg.nextra,
                                      sg.pooled, sg.ldpool, sg.aidx, st));
   }
   for (size_t k = 0; k < sg.fcs.size(); ++k) {
@@ -251,7 +251,7 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   s.fzA = cv.take<float>((size_t)pl.B * cfc); s.fzB = cv.take<float>((size_t)pl.B * cfc);
   s.consts = cv.take<float>((size_t)4 * cmax);
   s.work = cv.take<float>(workmax); s.work_floats = workmax;
-  s.stat = cv.take<float>((size_t)pl.B * 2 * cmax);
+  s.stat = cv.take<float>((size_t)pl.B * 4 * 2 * cmax);
   s.dxy = cv.take<float>((size_t)pl.M * 2);
   s.dT = cv.take<float>((size_t)pl.B * 4);
   s.bytes = cv.off + 256;
@@ -302,7 +302,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     SPG_TRY(spg_launch_gemm(g, st));
     // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
     const int C = prod.cout;
-    SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(B, SPG_FC_ROWS), l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
+    SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(B, SPG_FC_ROWS) * spg_gemm_row_waves(SPG_FC_ROWS, l.cin), l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
                                        prod.rstd, s.consts, prod.dgamma, prod.dbeta, st));
     if (!first) {
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, C);
@@ -332,7 +332,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
       g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
       SPG_TRY(spg_launch_gemm(g, st));
-      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, B, l.cin, pl.M, prod.cout, prod.s, prod.mean, prod.rstd, s.consts,
+      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, B * spg_gemm_row_waves(pl.P, l.cin), l.cin, pl.M, prod.cout, prod.s, prod.mean, prod.rstd, s.consts,
                                          prod.dgamma, prod.dbeta, st));
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, prod.cout);
     } else if (want_dxy) {
