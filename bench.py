@@ -28,30 +28,31 @@ import torch.nn.functional as F  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
 
-def build_model(model_config, device):
-    """create_model of learning/main.py:414-431 with the S3DIS production flags (S3DIS.md:26-28)."""
+def build_model(model_config, device, n_feat=14):
+    """create_model of learning/main.py:414-431 with the S3DIS production flags (S3DIS.md:26-28); n_feat = 11 with
+    --ptn_nfeat_stn 11 is the Semantic3D configuration (Semantic3D.md:20-22)."""
     from superpoint_graph_amd.learning import graphnet, pointnet
     torch.manual_seed(1)
     model = torch.nn.Module()
     model.ecc = graphnet.GraphNetwork(model_config, 32, [13, 32, 128, 64], 1, 0, 2, 30000, use_pyg=0, cuda=1)
-    model.ptn = pointnet.PointNet([64, 64, 128, 128, 256], [256, 64, 32], [64, 64, 128], [128, 64], 14, 14, prelast_do=0)
+    model.ptn = pointnet.PointNet([64, 64, 128, 128, 256], [256, 64, 32], [64, 64, 128], [128, 64], n_feat, n_feat, prelast_do=0)
     return model.to(device)
 
 
-def make_batch(seeds, n_sp, n_edges):
+def make_batch(seeds, n_sp, n_edges, n_feat=14, n_classes=13):
     from superpoint_graph_amd import synth
     from superpoint_graph_amd.learning import spg
-    scenes = [synth.scene(s, n_sp=n_sp, n_edges=n_edges) for s in seeds]
+    scenes = [synth.scene(s, n_sp=n_sp, n_edges=n_edges, n_feat=n_feat, n_classes=n_classes) for s in seeds]
     targets, GIs, (meta, flag, clouds, diam) = spg.eccpc_collate([spg.sample_from_scene(s, f'scene{i}') for i, s in enumerate(scenes)])
     return targets, GIs, flag, clouds, diam, scenes
 
 
-def cpu_baseline(model_config, scenes, state, max_seconds=25.0):
+def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
     """The oracle (CPU restatement of the reference, kind "port") timed on this host's cores on the same scene.
     This is the only place bench.py touches oracle/ -- as the reported CPU baseline, never as the measured path."""
     from oracle import spg_oracle as O
     from superpoint_graph_amd import synth
-    spec = O.ModelSpec(model_config=model_config)
+    spec = O.ModelSpec(model_config=model_config, node_feats=n_feat, ptn_nfeat_stn=n_feat)
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -86,6 +87,7 @@ def main():
     ap.add_argument('--n-sp', type=int, default=1000)
     ap.add_argument('--n-edges', type=int, default=5000)
     ap.add_argument('--model-config', default='gru_10_0,f_13')
+    ap.add_argument('--n-feat', type=int, default=14, help='point features (14: S3DIS xyzrgbelpsvXYZ, 11: Semantic3D)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
@@ -108,10 +110,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    model = build_model(args.model_config, dev)
+    model = build_model(args.model_config, dev, args.n_feat)
+    n_classes = int(args.model_config.split('f_')[-1].split(',')[0])
     model.train()
     seeds = [rank * args.scenes + i for i in range(args.scenes)]          # every rank its own scenes (weak scaling)
-    targets, GIs, flag, clouds, diam, scenes = make_batch(seeds, args.n_sp, args.n_edges)
+    targets, GIs, flag, clouds, diam, scenes = make_batch(seeds, args.n_sp, args.n_edges, args.n_feat, n_classes)
     # inputs resident in HBM before the timed region
     clouds_d, diam_d = clouds.to(dev), diam.to(dev)
     label_mode = targets[:, 0].to(dev)
@@ -192,9 +195,8 @@ def main():
         'metric': 'superpoints/sec (embed+ECC fwd+bwd), S3DIS-shaped SPG', 'value': value, 'unit': 'superpoints/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x 14 feats, '
-                               f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config} (S3DIS production model, '
-                               'matrix filters, 10 GRU iterations), train step fwd+bwd+Adam',
+        'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x {args.n_feat} feats, '
+                               f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config}' + (' (S3DIS production model, matrix filters, 10 GRU iterations)' if args.model_config == 'gru_10_0,f_13' else '') + ', train step fwd+bwd+Adam',
                    'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'parallelism': f'dp{world} (one scene shard per GPU, one flat-bucket '
                                                                               'RCCL all-reduce)' if world > 1 else 'single GPU'},
     }
@@ -225,7 +227,7 @@ def main():
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(args.model_config, scenes, state0)
+            result['cpu_baseline'] = cpu_baseline(args.model_config, scenes, state0, n_feat=args.n_feat)
         print(json.dumps(result), flush=True)
     faulthandler.cancel_dump_traceback_later()
     if world > 1:

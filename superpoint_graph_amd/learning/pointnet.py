@@ -63,6 +63,34 @@ class STNkD(nn.Module):
     def layer_groups(self):
         return _seq_groups(self.convs) + _seq_groups(self.fcs) + [(self.proj, None)]
 
+    # ---- stand-alone evaluation (inside PointNet the STN is part of the fused pipeline) ----
+    # An STN is structurally a PointNet segment without its own STN and without global features:
+    # convs -> max-pool -> fcs -> plain last layer (proj); the same C entry points run it.
+    def _groups_tensors(self):
+        return [_tensors(lin, bn) for lin, bn in self.layer_groups()]
+
+    def _flat_params(self):
+        flat = []
+        for lin, bn in self.layer_groups():
+            flat += [lin.weight, lin.bias] + ([bn.weight, bn.bias] if bn is not None else [])
+        return [p for p in flat if p is not None]
+
+    def _cfg(self, npts):
+        bn0 = self.convs[1]
+        return ops.make_pointnet_cfg(self._nfeat, 0, 0, npts, [], [], self._nf_conv, self._nf_fc + [self._K * self._K], False,
+                                     bn0.eps, 0.1 if bn0.momentum is None else bn0.momentum)
+
+    def forward(self, input):
+        """[B, nfeat, P] -> [B, K, K] transformation matrices (reference learning/pointnet.py:55-61)."""
+        if not input.is_cuda:
+            raise RuntimeError('superpoint_graph_amd.STNkD has no CPU path; move the module and inputs to the GPU')
+        self.eye = self.eye.to(input.device)
+        if self.training:
+            nbt = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm1d)]
+            torch._foreach_add_(nbt, 1)
+        out = _PointNetFunction.apply(self, input.contiguous().float(), None, self.training, 1, *self._flat_params())
+        return out.view(-1, self.eye.size(1), self.eye.size(2)) + self.eye
+
 
 _anchors = {}
 

@@ -75,6 +75,34 @@ def test_train_step_matches_reference(hip, tag, monger):
             assert maxrel(sd[k].double(), torch.from_numpy(g['state1/' + k]).double()) < 1e-5, k
 
 
+def test_stn_standalone_matches_oracle(hip):
+    """STNkD.forward on its own (reference learning/pointnet.py:55-61), eval and train mode, forward and backward."""
+    from superpoint_graph_amd.learning import pointnet
+    spec, batch, state0, g = load_golden('s3dis_gru10_matrix')
+    stn = pointnet.STNkD(14, [64, 64, 128], [128, 64])
+    stn.load_state_dict({k[len('ptn.stn.'):]: v for k, v in state0.items() if k.startswith('ptn.stn.')})
+    stn = stn.to(DEV)
+    clouds = batch['clouds'][:, :14, :]
+    P = {k: (v.double() if v.is_floating_point() else v) for k, v in state0.items()}
+    for training in (False, True):
+        stn.train(training)
+        T = stn(clouds.to(DEV))
+        T_ref = O.stn_forward(clouds.double(), spec, P, training)
+        assert T.shape == (clouds.shape[0], 2, 2)
+        assert maxrel(T, T_ref) < 1e-5
+    # gradient of sum(T * R) wrt the projection layer
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items() if v.is_floating_point() and 'running' not in k and k.startswith('ptn.stn.')}
+    P2 = dict(P); P2.update(leaves)
+    R = torch.randn(clouds.shape[0], 2, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    (O.stn_forward(clouds.double(), spec, P2, True) * R).sum().backward()
+    stn.zero_grad()
+    (stn(clouds.to(DEV)) * R.float().to(DEV)).sum().backward()
+    for k, p in stn.named_parameters():
+        ref = leaves['ptn.stn.' + k].grad
+        if float(ref.abs().max()) > 1e-6:
+            assert maxrel(p.grad, ref) < 5e-4, k
+
+
 def test_flat_parameters_direct_gradients(hip):
     """FlatParameters: the HIP backward writes into the flat gradient arena; same gradients as the reference."""
     from superpoint_graph_amd.flat import FlatParameters
