@@ -193,7 +193,7 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
       if (l.bn) {
         if (pl.training)
           SPG_TRY(spg_launch_bn_finalize(pl.stat, spg_cdiv(E, SPG_FC_ROWS), SPG_FC_ROWS, E, l.cout, l.gamma, l.beta, l.rm, l.rv,
-                                         pl.cfg.bn_momentum, pl.cfg.bn_eps, bn_update_times, l.mean, l.rstd, l.s, l.t, st));
+                                         pl.cfg.bn_momentum, pl.cfg.bn_eps, bn_update_times, l.mean, l.rstd, l.s, l.t, nullptr, st));
         else
           SPG_TRY(spg_launch_bn_eval(l.cout, l.gamma, l.beta, l.rm, l.rv, pl.cfg.bn_eps, l.s, l.t, st));
       }
@@ -319,7 +319,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     SPG_TRY(spg_launch_gemm(g, st));
     if (prod.bn) {
       SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(E, SPG_FC_ROWS) * spg_gemm_row_waves(SPG_FC_ROWS, l.cin), l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
-                                         s.consts, prod.dgamma, prod.dbeta, st));
+                                         s.consts, prod.dgamma, prod.dbeta, nullptr, st));
       cur = op_bnbwd(out, prod.y, prod.cout, s.consts, prod.cout);
     } else {
       cur = op_ident(out, l.cin);

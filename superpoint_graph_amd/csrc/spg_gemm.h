@@ -74,9 +74,12 @@ int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream);
 
 // BatchNorm forward statistics: partials [ntile][2][N] -> mean, rstd, scale s = gamma*rstd, shift t = beta - mean*s;
 // running stats updated `update_times` times (run_full_monger re-runs the forward, learning/pointnet.py:167,173)
+// scratch: >= spg_bn_finalize_scratch_doubles(N) doubles (or null: single-slice reduction)
+size_t spg_bn_finalize_scratch_doubles(int N);
 int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                           int update_times, float* mean, float* rstd, float* s, float* t, hipStream_t stream);
+                           int update_times, float* mean, float* rstd, float* s, float* t, double* scratch,
+                           hipStream_t stream);
 // eval mode: s, t from the running statistics
 int spg_launch_bn_eval(int N, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* s, float* t, hipStream_t stream);
@@ -84,7 +87,7 @@ int spg_launch_bn_eval(int N, const float* gamma, const float* beta, const float
 // dgamma, dbeta
 int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long count, int N, const float* s,
                                const float* mean, const float* rstd, float* consts, float* dgamma, float* dbeta,
-                               hipStream_t stream);
+                               double* scratch, hipStream_t stream);
 // max-pool selection after the BN statistics are known: out[g, c] = s[c] >= 0 ? pmax : pmin  (+ argidx),
 // out[g, N + e] = extra[g, e]; aidx uses the same leading dimension ldo as out
 int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,

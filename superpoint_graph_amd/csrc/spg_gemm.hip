@@ -629,23 +629,47 @@ int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm statistics
 // ---------------------------------------------------------------------------------------------
-// 32 channels x 32 tile-groups per workgroup; single pass in fp64:
+// ---- BatchNorm forward statistics ------------------------------------------------------------------------------
+// Partials (mean, M2) of ntile*wi row groups -> batch mean / rstd / scale / shift.  Single pass in fp64:
 //   mean = sum n_b m_b / M ;  M2 = sum M2_b + sum n_b m_b^2 - M mean^2   (Chan et al.; torch CPU BatchNorm also
-//   accumulates float statistics in double)
+//   accumulates float statistics in double).
+// Geometry: 16 channels x 64 partial-groups per workgroup, grid (N/16, SPG_FIN_SLICES): every slice reduces its share
+// of the partials (tree: wave shuffles, then 16 waves via LDS) and publishes an fp64 triple; the LAST slice to arrive
+// (agent-scope release / acquire around one relaxed ticket, cdna guide G16) combines the slices in fixed order, so the
+// result is deterministic, and resets the ticket for the next launch.
+#define SPG_FIN_SLICES 8
+
+static int* g_fin_counters = nullptr;    // 4096 self-resetting tickets (the only device memory the library owns)
+static unsigned g_fin_next = 0;
+
+static int* spg_fin_counter_window(int n) {
+  if (g_fin_counters == nullptr) {
+    if (hipMalloc((void**)&g_fin_counters, 4096 * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(g_fin_counters, 0, 4096 * sizeof(int)) != hipSuccess) return nullptr;
+  }
+  if (g_fin_next + n > 4096) g_fin_next = 0;
+  int* w = g_fin_counters + g_fin_next;     // rotating windows: concurrent launches on other streams do not collide
+  g_fin_next += n;
+  return w;
+}
+
 __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __restrict__ stat, int ntile, int rows_per_tile,
                                                                int wi, long M, int N, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* running_mean,
                                                                float* running_var, float momentum, float eps,
                                                                int update_times, float* mean_o, float* rstd_o, float* s_o,
-                                                               float* t_o) {
-  // 16 channels x 64 partial-groups per workgroup (N/16 workgroups); tree reduction: wave shuffles, then 16 waves via LDS
+                                                               float* t_o, double* __restrict__ scratch, int* counters) {
   __shared__ double r0[16][17], r1[16][17], r2[16][17];
+  __shared__ int s_last;
   const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cx;
+  const int nslices = gridDim.y, slice = blockIdx.y;
+  const int nparts = ntile * wi, per = (nparts + nslices - 1) / nslices;
+  const int b0 = slice * per, b1 = min(nparts, b0 + per);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   const int tile_rows = rows_per_tile <= 32 ? 32 : 128, rpw = tile_rows / wi;     // rows per wave of the GEMM tile
   if (c < N)
-    for (int b = ty; b < ntile * wi; b += 64) {
+    for (int b = b0 + ty; b < b1; b += 64) {
       const int tile = b / wi, w = b - tile * wi;
       const long tv = min((long)rows_per_tile, M - (long)tile * rows_per_tile);    // valid rows of the tile
       const double nb = (double)min(max(tv - (long)w * rpw, 0L), (long)rpw);
@@ -659,9 +683,41 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) < 16) { r0[wave][cx] = a0; r1[wave][cx] = a1; r2[wave][cx] = a2; }
   __syncthreads();
+  if (threadIdx.x < 16) {
+    a0 = a1 = a2 = 0.0;
+    for (int k = 0; k < 16; ++k) { a0 += r0[k][cx]; a1 += r1[k][cx]; a2 += r2[k][cx]; }
+  }
+  if (nslices > 1) {
+    if (threadIdx.x < 16 && c < N) {
+      scratch[((long)slice * 3 + 0) * N + c] = a0;
+      scratch[((long)slice * 3 + 1) * N + c] = a1;
+      scratch[((long)slice * 3 + 2) * N + c] = a2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == nslices - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-reset
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 16 && c < N) {
+      a0 = a1 = a2 = 0.0;
+      for (int k = 0; k < nslices; ++k) {      // fixed order: deterministic
+        a0 += scratch[((long)k * 3 + 0) * N + c];
+        a1 += scratch[((long)k * 3 + 1) * N + c];
+        a2 += scratch[((long)k * 3 + 2) * N + c];
+      }
+    }
+  }
   if (threadIdx.x >= 16 || c >= N) return;
-  a0 = a1 = a2 = 0.0;
-  for (int k = 0; k < 16; ++k) { a0 += r0[k][cx]; a1 += r1[k][cx]; a2 += r2[k][cx]; }
   const double mean = a0 / (double)M;
   double m2 = a2 + a1 - (double)M * mean * mean;
   if (m2 < 0.0) m2 = 0.0;
@@ -684,12 +740,23 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
   }
 }
 
+size_t spg_bn_finalize_scratch_doubles(int N) { return (size_t)SPG_FIN_SLICES * 3 * N; }
+
 int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                           int update_times, float* mean, float* rstd, float* s, float* t, hipStream_t stream) {
+                           int update_times, float* mean, float* rstd, float* s, float* t, double* scratch,
+                           hipStream_t stream) {
   const int wi = spg_gemm_row_waves(rows_per_tile, N);
-  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(spg_cdiv(N, 16)), dim3(1024), 0, stream, stat, ntile, rows_per_tile, wi, M,
-                     N, gamma, beta, running_mean, running_var, momentum, eps, update_times, mean, rstd, s, t);
+  const int gx = spg_cdiv(N, 16);
+  // many partials: slice the reduction over more workgroups (one CU cannot pull megabytes of partials quickly)
+  int slices = (scratch != nullptr && (long)ntile * wi >= 512) ? SPG_FIN_SLICES : 1;
+  int* counters = nullptr;
+  if (slices > 1) {
+    counters = spg_fin_counter_window(gx);
+    if (counters == nullptr) slices = 1;
+  }
+  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(gx, slices), dim3(1024), 0, stream, stat, ntile, rows_per_tile, wi, M, N,
+                     gamma, beta, running_mean, running_var, momentum, eps, update_times, mean, rstd, s, t, scratch, counters);
   SPG_LAUNCH_CHECK();
   return 0;
 }
@@ -716,13 +783,18 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
                                                                    long count, int N, const float* __restrict__ s,
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, float* consts,
-                                                                   float* dgamma, float* dbeta) {
+                                                                   float* dgamma, float* dbeta,
+                                                                   double* __restrict__ scratch, int* counters) {
   __shared__ double r0[16][17], r1[16][17];
+  __shared__ int s_last;
   const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 channels x 64 partial-groups per workgroup
   const int c = blockIdx.x * 16 + cx;
+  const int nslices = gridDim.y, slice = blockIdx.y;           // sliced like spg_bn_finalize_kernel
+  const int per = (ntile + nslices - 1) / nslices;
+  const int t0 = slice * per, t1 = min(ntile, t0 + per);
   double a = 0.0, b = 0.0;
   if (c < N)
-    for (int t = ty; t < ntile; t += 64) {
+    for (int t = t0 + ty; t < t1; t += 64) {
       a += (double)stat[((long)t * 2) * ldstat + c];
       b += (double)stat[((long)t * 2 + 1) * ldstat + c];
     }
@@ -731,9 +803,39 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) < 16) { r0[wave][cx] = a; r1[wave][cx] = b; }
   __syncthreads();
+  if (threadIdx.x < 16) {
+    a = b = 0.0;
+    for (int k = 0; k < 16; ++k) { a += r0[k][cx]; b += r1[k][cx]; }
+  }
+  if (nslices > 1) {
+    if (threadIdx.x < 16 && c < N) {
+      scratch[((long)slice * 2 + 0) * N + c] = a;
+      scratch[((long)slice * 2 + 1) * N + c] = b;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == nslices - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 16 && c < N) {
+      a = b = 0.0;
+      for (int k = 0; k < nslices; ++k) {
+        a += scratch[((long)k * 2 + 0) * N + c];
+        b += scratch[((long)k * 2 + 1) * N + c];
+      }
+    }
+  }
   if (threadIdx.x >= 16 || c >= N) return;
-  a = b = 0.0;
-  for (int k = 0; k < 16; ++k) { a += r0[k][cx]; b += r1[k][cx]; }
   if (dbeta) dbeta[c] = (float)a;
   if (dgamma) dgamma[c] = (float)b;
   const double c1 = a / (double)count, c2 = b / (double)count;
@@ -745,9 +847,16 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
 
 int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long count, int N, const float* s,
                                const float* mean, const float* rstd, float* consts, float* dgamma, float* dbeta,
-                               hipStream_t stream) {
-  hipLaunchKernelGGL(spg_bn_bwd_finalize_kernel, dim3(spg_cdiv(N, 16)), dim3(1024), 0, stream, stat, ntile, ldstat, count, N, s,
-                     mean, rstd, consts, dgamma, dbeta);
+                               double* scratch, hipStream_t stream) {
+  const int gx = spg_cdiv(N, 16);
+  int slices = (scratch != nullptr && ntile >= 512) ? SPG_FIN_SLICES : 1;
+  int* counters = nullptr;
+  if (slices > 1) {
+    counters = spg_fin_counter_window(gx);
+    if (counters == nullptr) slices = 1;
+  }
+  hipLaunchKernelGGL(spg_bn_bwd_finalize_kernel, dim3(gx, slices), dim3(1024), 0, stream, stat, ntile, ldstat, count, N, s,
+                     mean, rstd, consts, dgamma, dbeta, scratch, counters);
   SPG_LAUNCH_CHECK();
   return 0;
 }

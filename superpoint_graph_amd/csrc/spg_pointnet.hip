@@ -52,6 +52,7 @@ struct Plan {
   bool has_stn = false;
   // shared scratch
   float *stat = nullptr, *pmax = nullptr, *pmin = nullptr;
+  double* fin = nullptr;    // scratch of the sliced BatchNorm finalize
   int *imax = nullptr, *imin = nullptr;
   size_t bytes = 0;
 };
@@ -148,6 +149,7 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
   if (pl.has_stn) carve_segment(pl.stn, nullptr);
   carve_segment(pl.main, emb);
   pl.stat = cv.take<float>((size_t)B * 4 * 2 * cmax);      // up to 4 per-wave partials per tile
+  pl.fin = cv.take<double>(spg_bn_finalize_scratch_doubles(cmax));
   pl.pmax = cv.take<float>((size_t)B * 4 * cmax); pl.pmin = cv.take<float>((size_t)B * 4 * cmax);
   pl.imax = cv.take<int>((size_t)B * 4 * cmax); pl.imin = cv.take<int>((size_t)B * 4 * cmax);
   pl.bytes = cv.off + 256;
@@ -188,7 +190,7 @@ SpgOperand input_operand(const Plan& pl, const Segment& sg, bool is_fc, size_t k
 int bn_stats(const Plan& pl, Layer& l, int ntile, int rows_per_tile, long M, int update_times, hipStream_t st) {
   if (pl.training)
     return spg_launch_bn_finalize(pl.stat, ntile, rows_per_tile, M, l.cout, l.gamma, l.beta, l.rm, l.rv,
-                                  pl.cfg.bn_momentum, pl.cfg.bn_eps, update_times, l.mean, l.rstd, l.s, l.t, st);
+                                  pl.cfg.bn_momentum, pl.cfg.bn_eps, update_times, l.mean, l.rstd, l.s, l.t, pl.fin, st);
   return spg_launch_bn_eval(l.cout, l.gamma, l.beta, l.rm, l.rv, pl.cfg.bn_eps, l.s, l.t, st);
 }
 
@@ -227,6 +229,7 @@ struct BwdScratch {
   float *dzA = nullptr, *dzB = nullptr;     // [M, cmax_conv] ping-pong for the dense conv gradients
   float *fzA = nullptr, *fzB = nullptr;     // [B, cmax_fc]
   float* consts = nullptr;                  // [4][cmax]
+  double* fin = nullptr;                    // scratch of the sliced finalize
   float* work = nullptr;                    // reduction arena: split partials of all weight / bias gradients
   size_t work_floats = 0;
   float* stat = nullptr;                    // [ntile][2][cmax]
@@ -250,6 +253,7 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   s.dzA = cv.take<float>((size_t)pl.M * cconv); s.dzB = cv.take<float>((size_t)pl.M * cconv);
   s.fzA = cv.take<float>((size_t)pl.B * cfc); s.fzB = cv.take<float>((size_t)pl.B * cfc);
   s.consts = cv.take<float>((size_t)4 * cmax);
+  s.fin = cv.take<double>(spg_bn_finalize_scratch_doubles(cmax));
   s.work = cv.take<float>(workmax); s.work_floats = workmax;
   s.stat = cv.take<float>((size_t)pl.B * 4 * 2 * cmax);
   s.dxy = cv.take<float>((size_t)pl.M * 2);
@@ -303,7 +307,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
     const int C = prod.cout;
     SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(B, SPG_FC_ROWS) * spg_gemm_row_waves(SPG_FC_ROWS, l.cin), l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
-                                       prod.rstd, s.consts, prod.dgamma, prod.dbeta, st));
+                                       prod.rstd, s.consts, prod.dgamma, prod.dbeta, s.fin, st));
     if (!first) {
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, C);
     } else {
@@ -333,7 +337,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
       SPG_TRY(spg_launch_gemm(g, st));
       SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, B * spg_gemm_row_waves(pl.P, l.cin), l.cin, pl.M, prod.cout, prod.s, prod.mean, prod.rstd, s.consts,
-                                         prod.dgamma, prod.dbeta, st));
+                                         prod.dgamma, prod.dbeta, s.fin, st));
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, prod.cout);
     } else if (want_dxy) {
       // gradient wrt the transformed xy only (learning/pointnet.py:123-124): 2 output columns
