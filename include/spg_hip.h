@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define SPG_MAX_LAYERS 8
-#define SPG_VERSION 100
+#define SPG_VERSION 101
 
 const char* spg_last_error(void);
 int spg_version(void);
@@ -73,6 +73,19 @@ int spg_gru_cell_fwd(const float* input, const float* hidden, int n_rows, const 
 int spg_gru_cell_bwd(const float* input, const float* hidden, const float* grad_out, int n_rows,
                      const float* const* params, int layernorm, int ingate, float* grad_input, float* grad_hidden,
                      float* const* grads, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LSTMCellEx.forward / backward (learning/modules.py:280-309), hidden = input = 32 channels.
+ * params: 6 pointers {weight_ih [128,32], weight_hh [128,32], bias_ih [128], bias_hh [128], ig.weight [32,32],
+ * ig.bias [32]}.  hidden = (h, c); outputs hy, cy.  Backward takes the gradients wrt hy and cy (either may be NULL =
+ * zero) and returns the gradients wrt input, h and c.  scratch: >= spg_lstm_scratch_floats(n) floats.
+ * ---------------------------------------------------------------------------------------------- */
+size_t spg_lstm_scratch_floats(int n_rows);
+int spg_lstm_cell_fwd(const float* input, const float* h, const float* c, int n_rows, const float* const* params,
+                      int layernorm, int ingate, float* hy, float* cy, float* scratch, void* stream);
+int spg_lstm_cell_bwd(const float* input, const float* h, const float* c, const float* grad_hy, const float* grad_cy,
+                      int n_rows, const float* const* params, int layernorm, int ingate, float* grad_input,
+                      float* grad_h, float* grad_c, float* const* grads, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused dense layer on the MFMA row-GEMM core (replaces nn.Linear / nn.Conv1d(k=1) + the preceding
@@ -122,7 +135,7 @@ int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const float* cloud
                           void* bwd_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * RNN-ECC module = RNNGraphConvModule.forward (learning/modules.py:152-183) with a GRUCellEx cell:
+ * RNN-ECC module = RNNGraphConvModule.forward (learning/modules.py:152-183) with a GRUCellEx or LSTMCellEx cell:
  * filter-generating MLP on the edge features (learning/graphnet.py:17-34, once per forward), then
  * nrepeats x { ECC aggregate (GraphConvFunction) ; GRU }, states concatenated when cat_all.
  * params / grads groups (6 pointers each, as above): fnet linear layers [0..n_fnet) (the BatchNorm
@@ -136,6 +149,8 @@ typedef struct spg_eccrnn_cfg {
   int fnet_widths[SPG_MAX_LAYERS + 1];  /* n_fnet + 1 entries: input width ... output width */
   int bnidx, llbias;
   float bn_eps, bn_momentum;
+  int cell;                             /* 0: GRUCellEx (gru_*), 1: LSTMCellEx (lstm_*; weights [128,32], cx starts at 0,
+                                           learning/modules.py:168-169) */
 } spg_eccrnn_cfg;
 
 size_t spg_eccrnn_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E, int training);

@@ -324,19 +324,30 @@ def check_ops(refmods, write):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--write', action='store_true', help='write tests/golden/*.npz')
+    ap.add_argument('--only', default='', help='run (and write) only this model fixture tag')
     a = ap.parse_args()
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     refmods = import_reference()
-    check_ops(refmods, a.write)
+    if not a.only:
+        check_ops(refmods, a.write)
     cw = torch.linspace(0.5, 1.5, 13)
     # S3DIS production config (S3DIS.md:26-28): matrix filters, 10 GRU iterations, state concat
-    run_config('s3dis_gru10_matrix', O.ModelSpec(), refmods, seeds=(11, 12), n_sp=(30, 19), n_edges=(96, 50),
-               class_weights=cw, write=a.write)
+    if a.only in ('', 's3dis_gru10_matrix'):
+        run_config('s3dis_gru10_matrix', O.ModelSpec(), refmods, seeds=(11, 12), n_sp=(30, 19), n_edges=(96, 50),
+                   class_weights=cw, write=a.write)
     # vector filters, small PointNet, no concat (vKITTI-style widths, vKITTI3D.md:47-51; 11 features as Semantic3D)
     spec_v = O.ModelSpec(model_config='gru_4_1_1_1_0,f_8', node_feats=11, ptn_nfeat_stn=11,
                          ptn_widths=((64, 64, 128), (64, 32, 32)), ptn_widths_stn=((32, 64), (32, 16)))
-    run_config('vector_gru4_small', spec_v, refmods, seeds=(21,), n_sp=(40,), n_edges=(130,),
-               class_weights=torch.ones(8), write=a.write)
+    if a.only in ('', 'vector_gru4_small'):
+        run_config('vector_gru4_small', spec_v, refmods, seeds=(21,), n_sp=(40,), n_edges=(130,),
+                   class_weights=torch.ones(8), write=a.write)
+    # LSTMCellEx variant of the recurrent module (modules.py:262-316, `lstm_R` token of graphnet.py:52-70):
+    # matrix filters, 3 iterations, state concat
+    spec_l = O.ModelSpec(model_config='lstm_3_0,f_8', node_feats=11, ptn_nfeat_stn=11,
+                         ptn_widths=((64, 64, 128), (64, 32, 32)), ptn_widths_stn=((32, 64), (32, 16)))
+    if a.only in ('', 'lstm3_matrix_small'):
+        run_config('lstm3_matrix_small', spec_l, refmods, seeds=(36,), n_sp=(36,), n_edges=(120,),
+                   class_weights=torch.ones(8), write=a.write)
     print('ALL ORACLE CHECKS PASSED')
 
 

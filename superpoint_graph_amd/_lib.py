@@ -32,7 +32,7 @@ class EccRnnCfg(ctypes.Structure):
     _fields_ = [('nc', ctypes.c_int), ('nrepeats', ctypes.c_int), ('matrix', ctypes.c_int), ('layernorm', ctypes.c_int),
                 ('ingate', ctypes.c_int), ('cat_all', ctypes.c_int), ('n_fnet', ctypes.c_int),
                 ('fnet_widths', ctypes.c_int * (SPG_MAX_LAYERS + 1)), ('bnidx', ctypes.c_int), ('llbias', ctypes.c_int),
-                ('bn_eps', ctypes.c_float), ('bn_momentum', ctypes.c_float)]
+                ('bn_eps', ctypes.c_float), ('bn_momentum', ctypes.c_float), ('cell', ctypes.c_int)]
 
 
 _i, _l, _p, _sz = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_size_t
@@ -49,6 +49,9 @@ SIGNATURES = {
     'spg_gru_scratch_floats': (_sz, [_i]),
     'spg_gru_cell_fwd': (_i, [_p, _p, _i, c_void_pp, _i, _i, _p, _p, _p]),
     'spg_gru_cell_bwd': (_i, [_p, _p, _p, _i, c_void_pp, _i, _i, _p, _p, c_void_pp, _p, _p]),
+    'spg_lstm_scratch_floats': (_sz, [_i]),
+    'spg_lstm_cell_fwd': (_i, [_p, _p, _p, _i, c_void_pp, _i, _i, _p, _p, _p, _p]),
+    'spg_lstm_cell_bwd': (_i, [_p, _p, _p, _p, _p, _i, c_void_pp, _i, _i, _p, _p, _p, c_void_pp, _p, _p]),
     'spg_linear_fwd': (_i, [_p, _l, _i, _i, _p, _p, _i, _p, _p, _i, _p, _l, _p]),
     'spg_linear_wgrad_work_floats': (_sz, [_i, _i, _i]),
     'spg_linear_wgrad': (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p]),

@@ -244,6 +244,66 @@ extern "C" int spg_gru_cell_bwd(const float* input, const float* hidden, const f
 }
 
 // ---------------------------------------------------------------------------------------------
+// stand-alone LSTMCellEx
+// ---------------------------------------------------------------------------------------------
+// scratch layout (floats): dgi n*128 | dgh n*128 | dpre n*32 | xg n*32 | zero n*32 | wgrad work
+extern "C" size_t spg_lstm_scratch_floats(int n) {
+  return (size_t)n * (2 * 128 + 3 * 32) + spg_wgrad_workspace_floats(n, 128, 32) + 256;
+}
+
+extern "C" int spg_lstm_cell_fwd(const float* input, const float* h, const float* c, int n, const float* const* params,
+                                 int layernorm, int ingate, float* hy, float* cy, float* scratch, void* stream) {
+  SPG_CHECK_ARG(input && h && params && hy && cy && n > 0, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SpgEccStepFwd p; memset(&p, 0, sizeof(p));
+  SPG_TRY(gru_pack(params, layernorm, ingate, scratch, p.gru, st));
+  p.g.N = n; p.agg_in = input; p.ldagg = 32; p.hin = h; p.hout = hy; p.ld = 32; p.do_gru = 1;
+  p.cell = SPG_CELL_LSTM; p.cin = c; p.cout = cy;
+  return spg_launch_ecc_step_fwd(p, st);
+}
+
+extern "C" int spg_lstm_cell_bwd(const float* input, const float* h, const float* c, const float* grad_hy,
+                                 const float* grad_cy, int n, const float* const* params, int layernorm, int ingate,
+                                 float* grad_input, float* grad_h, float* grad_c, float* const* grads, float* scratch,
+                                 void* stream) {
+  SPG_CHECK_ARG(input && h && params && grad_input && grad_h && grad_c && grads && scratch && n > 0, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SpgEccStepBwd p; memset(&p, 0, sizeof(p));
+  SPG_TRY(gru_pack(params, layernorm, ingate, scratch, p.gru, st));
+  float* f = scratch;
+  float* dgi = f; f += (size_t)n * 128;
+  float* dgh = f; f += (size_t)n * 128;
+  float* dpre = f; f += (size_t)n * 32;
+  float* xg = f; f += (size_t)n * 32;
+  f += (size_t)n * 32;
+  float* work = f;
+  p.g.N = n;   // invdeg == nullptr: no degree scaling
+  p.dcat = grad_hy; p.ldc = 32; p.dhdir = grad_h; p.use_dhdir = 0;
+  p.hin = h; p.ld = 32; p.agg = input; p.ldagg = 32; p.Gcur = grad_input; p.ldg = 32;
+  p.dgi = dgi; p.dgh = dgh; p.ld96 = 128; p.dpre = dpre; p.xg = xg; p.ld32 = 32;
+  p.cell = SPG_CELL_LSTM; p.cin = c; p.dcdir = grad_c; p.use_dcdir = 0;
+  if (grad_cy != nullptr) {     // the incoming cell-state gradient enters through the in/out buffer
+    hipError_t e = hipMemcpyAsync(grad_c, grad_cy, (size_t)n * 32 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { spg_set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return (int)e; }
+    p.use_dcdir = 1;
+  }
+  SPG_TRY(spg_launch_ecc_step_bwd(p, st));
+  auto ident = [](const float* X, long ld) { SpgOperand o; memset(&o, 0, sizeof(o)); o.mode = SPG_PRO_IDENT; o.X = X; o.ld = ld; return o; };
+  SpgWgradParams w; memset(&w, 0, sizeof(w));
+  w.M = n; w.N = 128; w.K = 32;
+  if (grads[0]) { w.a = ident(dgi, 128); w.b = ident(xg, 32); SPG_TRY(spg_launch_wgrad(w, grads[0], work, st)); }
+  if (grads[1]) { w.a = ident(dgh, 128); w.b = ident(h, 32); SPG_TRY(spg_launch_wgrad(w, grads[1], work, st)); }
+  if (grads[2]) SPG_TRY(spg_launch_colsum(dgi, 128, n, 128, grads[2], work, st));
+  if (grads[3]) SPG_TRY(spg_launch_colsum(dgh, 128, n, 128, grads[3], work, st));
+  if (ingate) {
+    w.N = 32;
+    if (grads[4]) { w.a = ident(dpre, 32); w.b = ident(h, 32); SPG_TRY(spg_launch_wgrad(w, grads[4], work, st)); }
+    if (grads[5]) SPG_TRY(spg_launch_colsum(dpre, 32, n, 32, grads[5], work, st));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused dense layer
 // ---------------------------------------------------------------------------------------------
 static SpgOperand affine_operand(const float* X, long ld, int K, const float* sc, const float* sh, int relu) {

@@ -20,11 +20,15 @@ size_t spg_graph_bytes(int N, int Ns, int E);
 SpgGraph spg_graph_view(const void* workspace, int N, int E);
 int spg_graph_build_impl(const int64_t* idxn, const int64_t* degs, int N, int Ns, int E, void* workspace, hipStream_t stream);
 
-struct SpgGruParams {   // GRUCellEx (learning/modules.py:205-259), hidden = input = 32
-  const float* w_ih;    // [96,32]
-  const float* w_hh;    // [96,32]
-  const float* b_ih;    // [96]
-  const float* b_hh;    // [96]
+#define SPG_CELL_GRU 0
+#define SPG_CELL_LSTM 1
+
+// GRUCellEx (learning/modules.py:205-259) / LSTMCellEx (:262-316), hidden = input = 32; G = 96 (GRU) or 128 (LSTM)
+struct SpgGruParams {
+  const float* w_ih;    // [G,32]
+  const float* w_hh;    // [G,32]
+  const float* b_ih;    // [G]
+  const float* b_hh;    // [G]
   const float* w_ig;    // [32,32]
   const float* b_ig;    // [32]
   int layernorm, ingate;
@@ -43,6 +47,9 @@ struct SpgEccStepFwd {
   long ldagg;
   int do_gru;           // 0: aggregation only (result in agg_save)
   SpgGruParams gru;
+  int cell;             // SPG_CELL_GRU / SPG_CELL_LSTM
+  const float* cin;     // LSTM: cell state c^r (rows of ld floats) or null (= zeros)
+  float* cout;          // LSTM: c^r+1
 };
 int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream);
 
@@ -74,6 +81,12 @@ struct SpgEccStepBwd {
   float* xg;            // [N, ld32]
   long ld32;
   SpgGruParams gru;
+  // LSTM only (dui / duh unused: the biases sit in front of the row normalisation, their gradients are the column
+  // sums of dgi / dgh; ld96 is then the leading dimension of the 128-wide gate gradients)
+  int cell;
+  const float* cin;     // c^r (rows of ld floats) or null (= zeros)
+  float* dcdir;         // [N,32] in/out: gradient wrt the cell state
+  int use_dcdir;
 };
 int spg_launch_ecc_step_bwd(const SpgEccStepBwd& p, hipStream_t stream);
 

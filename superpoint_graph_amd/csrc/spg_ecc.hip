@@ -244,10 +244,12 @@ struct GruRows {
   f32x4 ih1[8], hh1[8], ih2[8], hh2[8], ig[8];
 };
 
+template <int CELL = SPG_CELL_GRU>
 __device__ __forceinline__ void spg_gru_load_rows(const SpgGruParams& G, int lane, GruRows& w) {
   const f32x4* pih = reinterpret_cast<const f32x4*>(G.w_ih);
   const f32x4* phh = reinterpret_cast<const f32x4*>(G.w_hh);
-  const int r1 = lane, r2 = 64 + (lane & 31);
+  // LSTM: 128 gate rows, every lane owns two of them (lane, 64 + lane)
+  const int r1 = lane, r2 = CELL == SPG_CELL_LSTM ? 64 + lane : 64 + (lane & 31);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     w.ih1[q] = pih[r1 * 8 + q]; w.hh1[q] = phh[r1 * 8 + q];
@@ -306,16 +308,68 @@ __device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, cons
   if (lane < 32) st.n = tanhf((gi2 + G.b_ih[64 + lane]) + g1 * (gh2 + G.b_hh[64 + lane]));
 }
 
+
+// LSTMCellEx forward internals for one node (learning/modules.py:280-309).  The 128 gate pre-activations
+// (chunks i | f | g | o of 32) are two values per lane: index `lane` (i on lanes 0..31, f on 32..63) and index
+// 64 + lane (g on lanes 0..31, o on 32..63).  Unlike the GRU, the biases are added BEFORE the row normalisation
+// (nnf.linear(input, weight_ih, bias_ih), :297-299).
+struct LstmFwdState {
+  float gin, x;          // input gate and gated input (lanes 0..31)
+  float ui1, ui2;        // normalised W_ih x + b_ih
+  float uh1, uh2;        // normalised W_hh h + b_hh
+  float rstd_i, rstd_h;
+  float i, f, g, o;      // gates, channel = lane (lanes 0..31)
+  float c_prev, tc, cy, hy;
+};
+
+__device__ __forceinline__ void spg_lstm_forward_node(const SpgGruParams& G, const GruRows& w, const float* __restrict__ sa,
+                                                      const float* __restrict__ sh, float* __restrict__ sx, float c_prev,
+                                                      int lane, LstmFwdState& st) {
+  float gin = 1.f, x = 0.f;
+  if (lane < 32) {
+    if (G.ingate) gin = spg_sigmoid(spg_dot32(w.ig, sh) + G.b_ig[lane]);      // :285-286, hidden[0]
+    x = gin * sa[lane];
+    sx[lane] = x;
+  }
+  st.gin = gin; st.x = x;
+  __syncthreads();
+  float gi1 = spg_dot32(w.ih1, sx) + G.b_ih[lane], gi2 = spg_dot32(w.ih2, sx) + G.b_ih[64 + lane];
+  float gh1 = spg_dot32(w.hh1, sh) + G.b_hh[lane], gh2 = spg_dot32(w.hh2, sh) + G.b_hh[64 + lane];
+  st.rstd_i = 1.f; st.rstd_h = 1.f;
+  if (G.layernorm) {   // InstanceNorm1d over the 128 values of the row, biased variance (:275-279)
+    const float mi = spg_wave_sum(gi1 + gi2) * (1.f / 128.f);
+    const float mh = spg_wave_sum(gh1 + gh2) * (1.f / 128.f);
+    const float di1 = gi1 - mi, di2 = gi2 - mi, dh1 = gh1 - mh, dh2 = gh2 - mh;
+    const float vi = spg_wave_sum(di1 * di1 + di2 * di2) * (1.f / 128.f);
+    const float vh = spg_wave_sum(dh1 * dh1 + dh2 * dh2) * (1.f / 128.f);
+    st.rstd_i = 1.0f / sqrtf(vi + SPG_IN_EPS);
+    st.rstd_h = 1.0f / sqrtf(vh + SPG_IN_EPS);
+    gi1 = di1 * st.rstd_i; gi2 = di2 * st.rstd_i; gh1 = dh1 * st.rstd_h; gh2 = dh2 * st.rstd_h;
+  }
+  st.ui1 = gi1; st.ui2 = gi2; st.uh1 = gh1; st.uh2 = gh2;
+  const float p1 = gi1 + gh1, p2 = gi2 + gh2;
+  const float v1 = spg_sigmoid(p1);                         // i (lanes 0..31) / f (lanes 32..63)
+  const float v2 = lane < 32 ? tanhf(p2) : spg_sigmoid(p2); // g (lanes 0..31) / o (lanes 32..63)
+  st.i = v1; st.g = v2;
+  st.f = __shfl(v1, (lane & 31) + 32, 64);
+  st.o = __shfl(v2, (lane & 31) + 32, 64);
+  st.c_prev = c_prev;
+  st.cy = st.f * c_prev + st.i * st.g;                      // :306
+  st.tc = tanhf(st.cy);
+  st.hy = st.o * st.tc;                                     // :307
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward step
 // ---------------------------------------------------------------------------------------------
+template <int CELL>
 __global__ __launch_bounds__(256) void spg_ecc_step_fwd_kernel(const SpgEccStepFwd p) {
   __shared__ __attribute__((aligned(16))) float lds[4][3][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
   const bool active = i < p.g.N;
   GruRows wr;
-  if (p.do_gru) spg_gru_load_rows(p.gru, lane, wr);
+  if (p.do_gru) spg_gru_load_rows<CELL>(p.gru, lane, wr);
   float* sa = lds[wave][0];
   float* sh = lds[wave][1];
   float* sx = lds[wave][2];
@@ -340,16 +394,29 @@ __global__ __launch_bounds__(256) void spg_ecc_step_fwd_kernel(const SpgEccStepF
   __syncthreads();
   if (active && p.agg_save != nullptr && lane < 32) p.agg_save[(long)i * p.ldagg + lane] = sa[lane];
   if (!p.do_gru) return;
-  GruFwdState st;
-  spg_gru_forward_node(p.gru, wr, sa, sh, sx, lane, st);
-  if (active && lane < 32) {
-    const float h = sh[lane];
-    p.hout[(long)i * p.ld + lane] = st.n + st.z * (h - st.n);   // hy = newgate + inputgate*(hidden - newgate)
+  if constexpr (CELL == SPG_CELL_GRU) {
+    GruFwdState st;
+    spg_gru_forward_node(p.gru, wr, sa, sh, sx, lane, st);
+    if (active && lane < 32) {
+      const float h = sh[lane];
+      p.hout[(long)i * p.ld + lane] = st.n + st.z * (h - st.n);   // hy = newgate + inputgate*(hidden - newgate)
+    }
+  } else {
+    LstmFwdState st;
+    const float c = (active && lane < 32 && p.cin != nullptr) ? p.cin[(long)i * p.ld + lane] : 0.f;
+    spg_lstm_forward_node(p.gru, wr, sa, sh, sx, c, lane, st);
+    if (active && lane < 32) {
+      p.hout[(long)i * p.ld + lane] = st.hy;
+      p.cout[(long)i * p.ld + lane] = st.cy;
+    }
   }
 }
 
 int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
-  hipLaunchKernelGGL(spg_ecc_step_fwd_kernel, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
+  if (p.cell == SPG_CELL_LSTM)
+    hipLaunchKernelGGL(spg_ecc_step_fwd_kernel<SPG_CELL_LSTM>, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(spg_ecc_step_fwd_kernel<SPG_CELL_GRU>, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
 }
@@ -357,8 +424,9 @@ int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // backward step
 // ---------------------------------------------------------------------------------------------
+template <int CELL>
 __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepBwd p) {
-  __shared__ __attribute__((aligned(16))) float lds[4][5][96];
+  __shared__ __attribute__((aligned(16))) float lds[4][5][CELL == SPG_CELL_LSTM ? 128 : 96];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 4 + wave;
   const bool active = j < p.g.N;
@@ -436,93 +504,167 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
   }
   __syncthreads();
   const SpgGruParams& G = p.gru;
-  GruFwdState st;
-  {
-    GruRows wr;
-    spg_gru_load_rows(G, lane, wr);
-    spg_gru_forward_node(G, wr, sa, sh, sx, lane, st);
-  }
-  const float a_in = lane < 32 ? sa[lane] : 0.f;
-  const float h_in = lane < 32 ? sh[lane] : 0.f;
-  // gate backward on lanes 0..31 (channel = lane)
-  float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dh_acc = 0.f;
-  if (lane < 32) {
-    const float dn = dH * (1.f - st.z);
-    const float dzg = dH * (h_in - st.n);
-    dh_acc = dH * st.z;
-    dn_pre = dn * (1.f - st.n * st.n);
-    const float dr = dn_pre * (st.uh2 + G.b_hh[64 + lane]);
-    dz_pre = dzg * st.z * (1.f - st.z);
-    dr_pre = dr * st.r * (1.f - st.r);
-  }
-  // gradients wrt the normalised pre-activations, in the first/second-value lane layout
-  const float zsh = __shfl(dz_pre, lane & 31, 64);
-  float dui1 = lane < 32 ? dr_pre : zsh;        // index lane
-  float dui2 = lane < 32 ? dn_pre : 0.f;        // index 64 + lane
-  float duh1 = dui1;
-  float duh2 = lane < 32 ? dn_pre * st.r : 0.f;
-  if (active) {
-    p.dui[(long)j * p.ld96 + lane] = dui1;
-    p.duh[(long)j * p.ld96 + lane] = duh1;
+  if constexpr (CELL == SPG_CELL_LSTM) {
+    // ---- LSTMCellEx backward (learning/modules.py:280-309) ----
+    LstmFwdState st;
+    {
+      GruRows wr;
+      spg_gru_load_rows<SPG_CELL_LSTM>(G, lane, wr);
+      const float c = (active && lane < 32 && p.cin != nullptr) ? p.cin[(long)j * p.ld + lane] : 0.f;
+      spg_lstm_forward_node(G, wr, sa, sh, sx, c, lane, st);
+    }
+    const float a_in = lane < 32 ? sa[lane] : 0.f;
+    // gate backward on lanes 0..31 (channel = lane):  hy = o tanh(cy),  cy = f c + i g
+    float di_pre = 0.f, df_pre = 0.f, dg_pre = 0.f, do_pre = 0.f, dc_prev = 0.f;
     if (lane < 32) {
-      p.dui[(long)j * p.ld96 + 64 + lane] = dui2;
-      p.duh[(long)j * p.ld96 + 64 + lane] = duh2;
+      float dC = dH * st.o * (1.f - st.tc * st.tc);
+      if (p.use_dcdir && active) dC += p.dcdir[(long)j * 32 + lane];
+      do_pre = dH * st.tc * st.o * (1.f - st.o);
+      di_pre = dC * st.g * st.i * (1.f - st.i);
+      df_pre = dC * st.c_prev * st.f * (1.f - st.f);
+      dg_pre = dC * st.i * (1.f - st.g * st.g);
+      dc_prev = dC * st.f;
     }
-  }
-  // through the row normalisation: dg = rstd * (du - mean(du) - u * mean(du*u))
-  float dgi1 = dui1, dgi2 = dui2, dgh1 = duh1, dgh2 = duh2;
-  if (G.layernorm) {
-    const float m1i = spg_wave_sum(dui1 + dui2) * (1.f / 96.f);
-    const float m2i = spg_wave_sum(dui1 * st.ui1 + dui2 * st.ui2) * (1.f / 96.f);
-    const float m1h = spg_wave_sum(duh1 + duh2) * (1.f / 96.f);
-    const float m2h = spg_wave_sum(duh1 * st.uh1 + duh2 * st.uh2) * (1.f / 96.f);
-    dgi1 = st.rstd_i * (dui1 - m1i - st.ui1 * m2i);
-    dgi2 = st.rstd_i * (dui2 - m1i - st.ui2 * m2i);
-    dgh1 = st.rstd_h * (duh1 - m1h - st.uh1 * m2h);
-    dgh2 = st.rstd_h * (duh2 - m1h - st.uh2 * m2h);
-  }
-  __syncthreads();   // sa/sh (as inputs) are no longer needed by any lane of this wave
-  sa[lane] = dgi1;
-  sh[lane] = dgh1;
-  if (lane < 32) { sa[64 + lane] = dgi2; sh[64 + lane] = dgh2; }
-  if (active) {
-    p.dgi[(long)j * p.ld96 + lane] = dgi1;
-    p.dgh[(long)j * p.ld96 + lane] = dgh1;
+    // gradient wrt the sum of the two normalised pre-activations, in the two-values-per-lane layout
+    const float fsh = __shfl(df_pre, lane & 31, 64), osh = __shfl(do_pre, lane & 31, 64);
+    const float du1 = lane < 32 ? di_pre : fsh;      // index lane
+    const float du2 = lane < 32 ? dg_pre : osh;      // index 64 + lane
+    float dgi1 = du1, dgi2 = du2, dgh1 = du1, dgh2 = du2;
+    if (G.layernorm) {
+      const float m1 = spg_wave_sum(du1 + du2) * (1.f / 128.f);
+      const float m2i = spg_wave_sum(du1 * st.ui1 + du2 * st.ui2) * (1.f / 128.f);
+      const float m2h = spg_wave_sum(du1 * st.uh1 + du2 * st.uh2) * (1.f / 128.f);
+      dgi1 = st.rstd_i * (du1 - m1 - st.ui1 * m2i);
+      dgi2 = st.rstd_i * (du2 - m1 - st.ui2 * m2i);
+      dgh1 = st.rstd_h * (du1 - m1 - st.uh1 * m2h);
+      dgh2 = st.rstd_h * (du2 - m1 - st.uh2 * m2h);
+    }
+    __syncthreads();   // sa/sh (as inputs) are no longer needed by any lane of this wave
+    sa[lane] = dgi1; sa[64 + lane] = dgi2;
+    sh[lane] = dgh1; sh[64 + lane] = dgh2;
+    if (active) {
+      p.dgi[(long)j * p.ld96 + lane] = dgi1; p.dgi[(long)j * p.ld96 + 64 + lane] = dgi2;
+      p.dgh[(long)j * p.ld96 + lane] = dgh1; p.dgh[(long)j * p.ld96 + 64 + lane] = dgh2;
+    }
+    __syncthreads();
+    float dx = 0.f, dh_acc = 0.f;
     if (lane < 32) {
-      p.dgi[(long)j * p.ld96 + 64 + lane] = dgi2;
-      p.dgh[(long)j * p.ld96 + 64 + lane] = dgh2;
-    }
-  }
-  __syncthreads();
-  float dx = 0.f;
-  if (lane < 32) {
 #pragma unroll 8
-    for (int o = 0; o < 96; ++o) {
-      dx = fmaf(G.w_ih[o * 32 + lane], sa[o], dx);
-      dh_acc = fmaf(G.w_hh[o * 32 + lane], sh[o], dh_acc);
+      for (int o = 0; o < 128; ++o) {
+        dx = fmaf(G.w_ih[o * 32 + lane], sa[o], dx);
+        dh_acc = fmaf(G.w_hh[o * 32 + lane], sh[o], dh_acc);
+      }
     }
-  }
-  float da = dx, dpre = 0.f;
-  if (G.ingate) {
-    da = dx * st.gin;
-    dpre = dx * a_in * st.gin * (1.f - st.gin);
-    if (lane < 32) sd[lane] = dpre;
-  }
-  __syncthreads();
-  if (G.ingate && lane < 32) {
+    float da = dx, dpre = 0.f;
+    if (G.ingate) {
+      da = dx * st.gin;
+      dpre = dx * a_in * st.gin * (1.f - st.gin);
+      if (lane < 32) sd[lane] = dpre;
+    }
+    __syncthreads();
+    if (G.ingate && lane < 32) {
 #pragma unroll 8
-    for (int o = 0; o < 32; ++o) dh_acc = fmaf(G.w_ig[o * 32 + lane], sd[o], dh_acc);
-  }
-  if (active && lane < 32) {
-    p.dpre[(long)j * p.ld32 + lane] = dpre;
-    p.xg[(long)j * p.ld32 + lane] = st.x;
-    p.dhdir[(long)j * 32 + lane] = dh_acc;
-    p.Gcur[(long)j * p.ldg + lane] = p.g.invdeg != nullptr ? da * p.g.invdeg[j] : da;
+      for (int o = 0; o < 32; ++o) dh_acc = fmaf(G.w_ig[o * 32 + lane], sd[o], dh_acc);
+    }
+    if (active && lane < 32) {
+      p.dpre[(long)j * p.ld32 + lane] = dpre;
+      p.xg[(long)j * p.ld32 + lane] = st.x;
+      p.dhdir[(long)j * 32 + lane] = dh_acc;
+      p.dcdir[(long)j * 32 + lane] = dc_prev;
+      p.Gcur[(long)j * p.ldg + lane] = p.g.invdeg != nullptr ? da * p.g.invdeg[j] : da;
+    }
+  } else {
+    GruFwdState st;
+    {
+      GruRows wr;
+      spg_gru_load_rows(G, lane, wr);
+      spg_gru_forward_node(G, wr, sa, sh, sx, lane, st);
+    }
+    const float a_in = lane < 32 ? sa[lane] : 0.f;
+    const float h_in = lane < 32 ? sh[lane] : 0.f;
+    // gate backward on lanes 0..31 (channel = lane)
+    float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dh_acc = 0.f;
+    if (lane < 32) {
+      const float dn = dH * (1.f - st.z);
+      const float dzg = dH * (h_in - st.n);
+      dh_acc = dH * st.z;
+      dn_pre = dn * (1.f - st.n * st.n);
+      const float dr = dn_pre * (st.uh2 + G.b_hh[64 + lane]);
+      dz_pre = dzg * st.z * (1.f - st.z);
+      dr_pre = dr * st.r * (1.f - st.r);
+    }
+    // gradients wrt the normalised pre-activations, in the first/second-value lane layout
+    const float zsh = __shfl(dz_pre, lane & 31, 64);
+    float dui1 = lane < 32 ? dr_pre : zsh;        // index lane
+    float dui2 = lane < 32 ? dn_pre : 0.f;        // index 64 + lane
+    float duh1 = dui1;
+    float duh2 = lane < 32 ? dn_pre * st.r : 0.f;
+    if (active) {
+      p.dui[(long)j * p.ld96 + lane] = dui1;
+      p.duh[(long)j * p.ld96 + lane] = duh1;
+      if (lane < 32) {
+        p.dui[(long)j * p.ld96 + 64 + lane] = dui2;
+        p.duh[(long)j * p.ld96 + 64 + lane] = duh2;
+      }
+    }
+    // through the row normalisation: dg = rstd * (du - mean(du) - u * mean(du*u))
+    float dgi1 = dui1, dgi2 = dui2, dgh1 = duh1, dgh2 = duh2;
+    if (G.layernorm) {
+      const float m1i = spg_wave_sum(dui1 + dui2) * (1.f / 96.f);
+      const float m2i = spg_wave_sum(dui1 * st.ui1 + dui2 * st.ui2) * (1.f / 96.f);
+      const float m1h = spg_wave_sum(duh1 + duh2) * (1.f / 96.f);
+      const float m2h = spg_wave_sum(duh1 * st.uh1 + duh2 * st.uh2) * (1.f / 96.f);
+      dgi1 = st.rstd_i * (dui1 - m1i - st.ui1 * m2i);
+      dgi2 = st.rstd_i * (dui2 - m1i - st.ui2 * m2i);
+      dgh1 = st.rstd_h * (duh1 - m1h - st.uh1 * m2h);
+      dgh2 = st.rstd_h * (duh2 - m1h - st.uh2 * m2h);
+    }
+    __syncthreads();   // sa/sh (as inputs) are no longer needed by any lane of this wave
+    sa[lane] = dgi1;
+    sh[lane] = dgh1;
+    if (lane < 32) { sa[64 + lane] = dgi2; sh[64 + lane] = dgh2; }
+    if (active) {
+      p.dgi[(long)j * p.ld96 + lane] = dgi1;
+      p.dgh[(long)j * p.ld96 + lane] = dgh1;
+      if (lane < 32) {
+        p.dgi[(long)j * p.ld96 + 64 + lane] = dgi2;
+        p.dgh[(long)j * p.ld96 + 64 + lane] = dgh2;
+      }
+    }
+    __syncthreads();
+    float dx = 0.f;
+    if (lane < 32) {
+  #pragma unroll 8
+      for (int o = 0; o < 96; ++o) {
+        dx = fmaf(G.w_ih[o * 32 + lane], sa[o], dx);
+        dh_acc = fmaf(G.w_hh[o * 32 + lane], sh[o], dh_acc);
+      }
+    }
+    float da = dx, dpre = 0.f;
+    if (G.ingate) {
+      da = dx * st.gin;
+      dpre = dx * a_in * st.gin * (1.f - st.gin);
+      if (lane < 32) sd[lane] = dpre;
+    }
+    __syncthreads();
+    if (G.ingate && lane < 32) {
+  #pragma unroll 8
+      for (int o = 0; o < 32; ++o) dh_acc = fmaf(G.w_ig[o * 32 + lane], sd[o], dh_acc);
+    }
+    if (active && lane < 32) {
+      p.dpre[(long)j * p.ld32 + lane] = dpre;
+      p.xg[(long)j * p.ld32 + lane] = st.x;
+      p.dhdir[(long)j * 32 + lane] = dh_acc;
+      p.Gcur[(long)j * p.ldg + lane] = p.g.invdeg != nullptr ? da * p.g.invdeg[j] : da;
+    }
   }
 }
 
 int spg_launch_ecc_step_bwd(const SpgEccStepBwd& p, hipStream_t stream) {
-  hipLaunchKernelGGL(spg_ecc_step_bwd_kernel, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
+  if (p.cell == SPG_CELL_LSTM)
+    hipLaunchKernelGGL(spg_ecc_step_bwd_kernel<SPG_CELL_LSTM>, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(spg_ecc_step_bwd_kernel<SPG_CELL_GRU>, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
 }

@@ -40,10 +40,13 @@ struct Plan {
   spg_eccrnn_cfg cfg;
   int N = 0, E = 0, R = 0, nout = 0;
   long ldS = 0;                 // (R+1)*32
+  int GW = 96;                  // gate rows of the cell: 96 (GRU) / 128 (LSTM)
+  bool lstm = false;
   bool training = false;
   std::vector<FLayer> F;
   SpgGruParams gru;
   float *states = nullptr, *agg = nullptr, *stat = nullptr;
+  float* cells = nullptr;       // LSTM cell states c^r, laid out like `states`
   float* cell_grads[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t bytes = 0;
 };
@@ -55,7 +58,9 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
   SPG_CHECK_ARG(c.nrepeats >= 1, "nrepeats >= 1");
   SPG_CHECK_ARG(c.n_fnet >= 1 && c.n_fnet <= SPG_MAX_LAYERS, "n_fnet");
   SPG_CHECK_ARG(c.bnidx < c.n_fnet - 1 || c.bnidx < 0, "BatchNorm after the last filter layer is not supported");
+  SPG_CHECK_ARG(c.cell == SPG_CELL_GRU || c.cell == SPG_CELL_LSTM, "cell must be 0 (GRU) or 1 (LSTM)");
   pl.cfg = c; pl.N = N; pl.E = E; pl.R = c.nrepeats; pl.training = training != 0;
+  pl.lstm = c.cell == SPG_CELL_LSTM; pl.GW = pl.lstm ? 128 : 96;
   pl.ldS = (long)(pl.R + 1) * 32;
   pl.nout = c.matrix ? 1024 : 32;
   SPG_CHECK_ARG(c.fnet_widths[c.n_fnet] == pl.nout, "filter network output width must be nc*nc (matrix) or nc (vector)");
@@ -86,12 +91,13 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
     pl.gru.w_ih = (const float*)g[0]; pl.gru.w_hh = (const float*)g[1];
     pl.gru.b_ih = (const float*)g[2]; pl.gru.b_hh = (const float*)g[3];
     pl.gru.w_ig = (const float*)g[4]; pl.gru.b_ig = (const float*)g[5];
-    SPG_CHECK_ARG(pl.gru.w_ih && pl.gru.w_hh && pl.gru.b_ih && pl.gru.b_hh, "missing GRU parameters");
+    SPG_CHECK_ARG(pl.gru.w_ih && pl.gru.w_hh && pl.gru.b_ih && pl.gru.b_hh, "missing RNN cell parameters");
     SPG_CHECK_ARG(!c.ingate || (pl.gru.w_ig && pl.gru.b_ig), "missing input-gate parameters");
   }
   pl.gru.layernorm = c.layernorm; pl.gru.ingate = c.ingate;
   pl.states = cv.take<float>((size_t)N * pl.ldS);
   pl.agg = cv.take<float>((size_t)N * pl.ldS);
+  if (pl.lstm) pl.cells = cv.take<float>((size_t)N * pl.ldS);
   pl.stat = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, SPG_FC_ROWS) * 2 * cmax);
   pl.bytes = cv.off + 256;
   return 0;
@@ -128,6 +134,7 @@ int zero_async(void* p, size_t bytes, hipStream_t st) {
 
 struct BwdScratch {
   float *G = nullptr, *dgi = nullptr, *dgh = nullptr, *dui = nullptr, *duh = nullptr, *dpre = nullptr, *xg = nullptr;
+  float *dcdir = nullptr;
   float *dhdir = nullptr, *dWts = nullptr, *dzA = nullptr, *dzB = nullptr, *Wt = nullptr, *consts = nullptr;
   float *work = nullptr, *stat = nullptr;
   size_t work_floats = 0;
@@ -139,11 +146,12 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   Carver cv(ws);
   const size_t rows = (size_t)pl.N * (pl.R + 1);
   s.G = cv.take<float>(rows * 32);
-  s.dgi = cv.take<float>(rows * 96); s.dgh = cv.take<float>(rows * 96);
-  s.dui = cv.take<float>(rows * 96); s.duh = cv.take<float>(rows * 96);
+  s.dgi = cv.take<float>(rows * pl.GW); s.dgh = cv.take<float>(rows * pl.GW);
+  if (!pl.lstm) { s.dui = cv.take<float>(rows * 96); s.duh = cv.take<float>(rows * 96); }
   s.dpre = cv.take<float>(rows * 32); s.xg = cv.take<float>(rows * 32);
   s.zero_bytes = cv.off;
   s.dhdir = cv.take<float>((size_t)pl.N * 32);
+  if (pl.lstm) s.dcdir = cv.take<float>((size_t)pl.N * 32);
   const size_t Er = pl.E > 0 ? pl.E : 1;
   s.dWts = cv.take<float>(Er * pl.nout);
   int cmax = 4;
@@ -154,7 +162,7 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
     workmax += ((spg_wgrad_workspace_floats(Er, l.cout, l.cin) + 63) & ~(size_t)63) + 64 * (size_t)l.cout + 128;
   }
   // GRU: three weight gradients + three bias column sums over all (node, iteration) rows
-  workmax += 3 * (((spg_wgrad_workspace_floats((long)rows, 96, 32) + 63) & ~(size_t)63) + 64 * 96 + 128);
+  workmax += 3 * (((spg_wgrad_workspace_floats((long)rows, pl.GW, 32) + 63) & ~(size_t)63) + 64 * (size_t)pl.GW + 128);
   int hmax = 4;   // widest hidden activation
   for (int i = 0; i + 1 < (int)pl.F.size(); ++i) hmax = pl.F[i].cout > hmax ? pl.F[i].cout : hmax;
   s.dzA = cv.take<float>(Er * hmax); s.dzB = cv.take<float>(Er * hmax);
@@ -207,7 +215,8 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
     p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;
     p.hin = pl.states + (size_t)r * 32; p.hout = pl.states + (size_t)(r + 1) * 32; p.ld = pl.ldS;
     p.agg_save = pl.training ? pl.agg + (size_t)r * 32 : nullptr; p.ldagg = pl.ldS;
-    p.do_gru = 1; p.gru = pl.gru;
+    p.do_gru = 1; p.gru = pl.gru; p.cell = pl.cfg.cell;
+    if (pl.lstm) { p.cin = r > 0 ? pl.cells + (size_t)r * 32 : nullptr; p.cout = pl.cells + (size_t)(r + 1) * 32; }
     SPG_TRY(spg_launch_ecc_step_fwd(p, st));
   }
   if (pl.cfg.cat_all) SPG_TRY(spg_launch_copy2d(pl.states, pl.ldS, out, pl.ldS, N, (int)pl.ldS, st));
@@ -242,7 +251,8 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
   rq.arena = s.work; rq.arena_floats = s.work_floats;
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
   const int R = pl.R;
-  const long ldS = pl.ldS, ld96 = (long)(R + 1) * 96;
+  const int GW = pl.GW;
+  const long ldS = pl.ldS, ld96 = (long)(R + 1) * GW;
   // ---- back-propagation through the R iterations ----
   for (int r = R - 1; r >= 0; --r) {
     SpgEccStepBwd p; memset(&p, 0, sizeof(p));
@@ -254,10 +264,11 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     p.hin = pl.states + (size_t)r * 32; p.ld = ldS;
     p.agg = pl.agg + (size_t)r * 32; p.ldagg = ldS;
     p.Gcur = s.G + (size_t)r * 32;
-    p.dgi = s.dgi + (size_t)r * 96; p.dgh = s.dgh + (size_t)r * 96;
-    p.dui = s.dui + (size_t)r * 96; p.duh = s.duh + (size_t)r * 96; p.ld96 = ld96;
+    p.dgi = s.dgi + (size_t)r * GW; p.dgh = s.dgh + (size_t)r * GW; p.ld96 = ld96;
+    if (!pl.lstm) { p.dui = s.dui + (size_t)r * 96; p.duh = s.duh + (size_t)r * 96; }
     p.dpre = s.dpre + (size_t)r * 32; p.xg = s.xg + (size_t)r * 32; p.ld32 = ldS;
-    p.gru = pl.gru;
+    p.gru = pl.gru; p.cell = pl.cfg.cell;
+    if (pl.lstm) { p.cin = r > 0 ? pl.cells + (size_t)r * 32 : nullptr; p.dcdir = s.dcdir; p.use_dcdir = r < R - 1; }
     SPG_TRY(spg_launch_ecc_step_bwd(p, st));
   }
   {
@@ -265,19 +276,20 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;
     if (pl.cfg.cat_all) { p.dcat = grad_out; p.ldc = ldS; }
     p.Gnext = s.G; p.ldg = ldS; p.dhdir = s.dhdir; p.use_dhdir = 1; p.gx = grad_h0; p.final_only = 1;
-    p.gru = pl.gru;
+    p.gru = pl.gru; p.cell = pl.cfg.cell;
     SPG_TRY(spg_launch_ecc_step_bwd(p, st));
   }
   // ---- GRU parameter gradients: three weight-gradient GEMMs over all (node, iteration) rows ----
   const int rows = N * (R + 1);
   {
     SpgWgradParams w; memset(&w, 0, sizeof(w));
-    w.a = op_ident(s.dgi, 96); w.b = op_ident(s.xg, 32); w.M = rows; w.N = 96; w.K = 32;
+    w.a = op_ident(s.dgi, GW); w.b = op_ident(s.xg, 32); w.M = rows; w.N = GW; w.K = 32;
     SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[0], st));
-    w.a = op_ident(s.dgh, 96); w.b = op_ident(pl.states, 32);
+    w.a = op_ident(s.dgh, GW); w.b = op_ident(pl.states, 32);
     SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[1], st));
-    SPG_TRY(spg_queue_colsum(rq, s.dui, 96, rows, 96, pl.cell_grads[2], st));
-    SPG_TRY(spg_queue_colsum(rq, s.duh, 96, rows, 96, pl.cell_grads[3], st));
+    // GRU: the biases are added behind the row normalisation; LSTM: in front of it
+    SPG_TRY(spg_queue_colsum(rq, pl.lstm ? s.dgi : s.dui, GW, rows, GW, pl.cell_grads[2], st));
+    SPG_TRY(spg_queue_colsum(rq, pl.lstm ? s.dgh : s.duh, GW, rows, GW, pl.cell_grads[3], st));
     if (pl.cfg.ingate) {
       w.a = op_ident(s.dpre, 32); w.b = op_ident(pl.states, 32); w.N = 32;
       SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[4], st));

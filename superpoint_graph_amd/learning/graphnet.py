@@ -5,7 +5,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from . import ecc  # noqa: F401  (kept for API parity: `learning.graphnet.ecc`)
-from .modules import GRUCellEx, RNNGraphConvModule
+from .modules import GRUCellEx, LSTMCellEx, RNNGraphConvModule
 
 
 def create_fnet(widths, orthoinit, llbias, bnidx=-1):
@@ -59,7 +59,7 @@ class GraphNetwork(nn.Module):
                 if conf[0] == 'gru':
                     cell = GRUCellEx(nfeat, nfeat, bias=True, layernorm=layernorm, ingate=ingate)
                 else:
-                    raise NotImplementedError('lstm_* model configs are not implemented on the HIP path yet')
+                    cell = LSTMCellEx(nfeat, nfeat, bias=True, layernorm=layernorm, ingate=ingate)
                 gconv = RNNGraphConvModule(cell, fnet, nfeat, vv=vv, nrepeats=nrepeats, cat_all=cat_all,
                                            edge_mem_limit=edge_mem_limit, use_pyg=use_pyg, cuda=cuda)
                 self.add_module(str(d), gconv)

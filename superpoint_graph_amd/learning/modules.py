@@ -1,4 +1,4 @@
-"""RNN-ECC module and GRU cell with the reference's module API (learning/modules.py:128-259)."""
+"""RNN-ECC module and GRU / LSTM cells with the reference's module API (learning/modules.py:128-316)."""
 import torch
 import torch.nn as nn
 
@@ -57,6 +57,55 @@ class _GRUCellFunction(torch.autograd.Function):
         return (None, gi, gh) + tuple(g for g in grads if g is not None)
 
 
+class LSTMCellEx(nn.LSTMCell):
+    """LSTM cell extended with row normalisation of the gate pre-activations and an input gate (reference
+    learning/modules.py:262-316; same parameters).  forward(input, (h, c)) -> (hy, cy), one fused HIP kernel each way."""
+
+    def __init__(self, input_size, hidden_size, bias=True, layernorm=True, ingate=True):
+        super(LSTMCellEx, self).__init__(input_size, hidden_size, bias)
+        self._layernorm = layernorm
+        self._ingate = ingate
+        if layernorm:
+            self.add_module('ini', nn.InstanceNorm1d(1, eps=1e-5, affine=False, track_running_stats=False))
+            self.add_module('inh', nn.InstanceNorm1d(1, eps=1e-5, affine=False, track_running_stats=False))
+        if ingate:
+            self.add_module('ig', nn.Linear(hidden_size, input_size, bias=True))
+
+    param_tensors = GRUCellEx.param_tensors
+
+    def forward(self, input, hidden):
+        if not input.is_cuda:
+            raise RuntimeError('superpoint_graph_amd.LSTMCellEx has no CPU path')
+        if self.input_size != 32 or self.hidden_size != 32 or self.bias_ih is None:
+            raise NotImplementedError('the HIP LSTM cell is specialised for 32 channels with bias')
+        params = [p for p in self.param_tensors() if p is not None]
+        return _LSTMCellFunction.apply(self, input.contiguous(), hidden[0].contiguous(), hidden[1].contiguous(), *params)
+
+    def __repr__(self):
+        s = super(LSTMCellEx, self).__repr__() + '('
+        if self._ingate:
+            s += 'ingate'
+        if self._layernorm:
+            s += ' layernorm'
+        return s + ')'
+
+
+class _LSTMCellFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cell, input, h, c, *params):
+        ctx.cell = cell
+        ctx.save_for_backward(input, h, c)
+        return ops.lstm_cell_fwd(input, h, c, cell.param_tensors(), cell._layernorm, cell._ingate)
+
+    @staticmethod
+    def backward(ctx, grad_hy, grad_cy):
+        input, h, c = ctx.saved_tensors
+        cell = ctx.cell
+        gi, gh, gc, grads = ops.lstm_cell_bwd(input, h, c, grad_hy, grad_cy, cell.param_tensors(), cell._layernorm,
+                                              cell._ingate)
+        return (None, gi, gh, gc) + tuple(g for g in grads if g is not None)
+
+
 def _fnet_groups(fnet):
     """(Linear, BatchNorm-or-None) pairs of a create_fnet() Sequential, plus its bnidx."""
     groups, bnidx, mods = [], -1, list(fnet)
@@ -99,7 +148,7 @@ class _EccRnnFunction(torch.autograd.Function):
 class RNNGraphConvModule(nn.Module):
     """Recurrent graph convolution: filter-generating network once, then nrepeats x {ECC, RNN cell}
     (reference learning/modules.py:128-183; same constructor signature, `_cell` / `_fnet` attribute names).
-    With a GRUCellEx cell and 32 channels the whole module is one C call (spg_eccrnn_forward)."""
+    With a GRUCellEx / LSTMCellEx cell and 32 channels the whole module is one C call (spg_eccrnn_forward)."""
 
     def __init__(self, cell, filter_net, nfeat=None, vv=True, gc_info=None, nrepeats=1, cat_all=False,
                  edge_mem_limit=1e20, use_pyg=True, cuda=True):
@@ -115,8 +164,6 @@ class RNNGraphConvModule(nn.Module):
         self.use_pyg = use_pyg
         if use_pyg:
             raise NotImplementedError('--use_pyg 1 (torch_geometric NNConv) is out of scope of the HIP path; use --use_pyg 0')
-        if self._isLSTM:
-            raise NotImplementedError('lstm_* model configs are not implemented on the HIP path yet (gru_* are)')
 
     def set_info(self, gc_info):
         self._gci = gc_info
@@ -142,7 +189,8 @@ class RNNGraphConvModule(nn.Module):
         bn = next((b for _, b in fg if b is not None), None)
         cfg = ops.make_eccrnn_cfg(nc, self._nrepeats, matrix, self._cell._layernorm, self._cell._ingate, self._cat_all,
                                   widths, bnidx, fg[-1][0].bias is not None,
-                                  1e-5 if bn is None else bn.eps, 0.1 if bn is None or bn.momentum is None else bn.momentum)
+                                  1e-5 if bn is None else bn.eps, 0.1 if bn is None or bn.momentum is None else bn.momentum,
+                                  cell='lstm' if self._isLSTM else 'gru')
         return cfg, fg
 
     def _flat_params(self):

@@ -125,6 +125,28 @@ def gru_cell_bwd(inp, hidden, grad_out, params, layernorm: bool, ingate: bool):
     return gi, gh, grads
 
 
+def lstm_cell_fwd(inp, h, c, params: Sequence[Optional[torch.Tensor]], layernorm: bool, ingate: bool):
+    _req(inp, torch.float32, 'input'); _req(h, torch.float32, 'hidden[0]'); _req(c, torch.float32, 'hidden[1]')
+    n = inp.shape[0]
+    hy, cy = torch.empty_like(h), torch.empty_like(c)
+    check(lib().spg_lstm_cell_fwd(_ptr(inp), _ptr(h), _ptr(c), n, _ptr_array(params), int(layernorm), int(ingate), _ptr(hy),
+                                  _ptr(cy), None, _stream()), 'spg_lstm_cell_fwd')
+    return hy, cy
+
+
+def lstm_cell_bwd(inp, h, c, grad_hy, grad_cy, params, layernorm: bool, ingate: bool):
+    n = inp.shape[0]
+    grad_hy = None if grad_hy is None else grad_hy.contiguous()
+    grad_cy = None if grad_cy is None else grad_cy.contiguous()
+    gi, gh, gc = torch.empty_like(inp), torch.empty_like(h), torch.empty_like(c)
+    grads = [None if p is None else torch.empty_like(p) for p in params]
+    scratch = torch.empty(lib().spg_lstm_scratch_floats(n), dtype=torch.float32, device=inp.device)
+    check(lib().spg_lstm_cell_bwd(_ptr(inp), _ptr(h), _ptr(c), _ptr(grad_hy), _ptr(grad_cy), n, _ptr_array(params),
+                                  int(layernorm), int(ingate), _ptr(gi), _ptr(gh), _ptr(gc), _ptr_array(grads), _ptr(scratch),
+                                  _stream()), 'spg_lstm_cell_bwd')
+    return gi, gh, gc, grads
+
+
 # --------------------------------------------------------------------------------------------------
 # dense layer
 # --------------------------------------------------------------------------------------------------
@@ -224,7 +246,7 @@ def pointnet_backward(state: PointNetState, groups, grad_emb, out_grads=None):
 # RNN-ECC module
 # --------------------------------------------------------------------------------------------------
 def make_eccrnn_cfg(nc, nrepeats, matrix, layernorm, ingate, cat_all, fnet_widths, bnidx, llbias, bn_eps=1e-5,
-                    bn_momentum=0.1) -> EccRnnCfg:
+                    bn_momentum=0.1, cell='gru') -> EccRnnCfg:
     c = EccRnnCfg()
     c.nc, c.nrepeats, c.matrix, c.layernorm, c.ingate, c.cat_all = nc, nrepeats, int(matrix), int(layernorm), int(ingate), int(cat_all)
     c.n_fnet = len(fnet_widths) - 1
@@ -233,6 +255,7 @@ def make_eccrnn_cfg(nc, nrepeats, matrix, layernorm, ingate, cat_all, fnet_width
     for i, v in enumerate(fnet_widths):
         c.fnet_widths[i] = int(v)
     c.bnidx, c.llbias, c.bn_eps, c.bn_momentum = bnidx, int(llbias), bn_eps, bn_momentum
+    c.cell = {'gru': 0, 'lstm': 1}[cell]
     return c
 
 

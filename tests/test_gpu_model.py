@@ -33,7 +33,7 @@ def _run(model, batch, monger=1):
     return emb, model.ecc(emb), emb_er
 
 
-@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small'])
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small', 'lstm3_matrix_small'])
 def test_eval_forward_matches_reference(hip, tag):
     spec, batch, state0, g = load_golden(tag)
     model = build_model(spec, state0).to(DEV).eval()
@@ -46,7 +46,7 @@ def test_eval_forward_matches_reference(hip, tag):
 
 
 @pytest.mark.parametrize('monger', [1, 0])
-@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small'])
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small', 'lstm3_matrix_small'])
 def test_train_step_matches_reference(hip, tag, monger):
     spec, batch, state0, g = load_golden(tag)
     model = build_model(spec, state0).to(DEV).train()

@@ -125,6 +125,48 @@ def test_gru_cell(hip, layernorm, ingate):
         assert maxrel(p.grad, P['c.' + k].grad) < 5e-6, k
 
 
+@pytest.mark.parametrize('layernorm,ingate', [(True, True), (False, False), (True, False), (False, True)])
+def test_lstm_cell(hip, layernorm, ingate):
+    """LSTMCellEx.forward (reference learning/modules.py:280-309): the reference's own outputs on the golden inputs, then
+    the fp64 oracle + autograd for every gradient (incl. the one entering through cy)."""
+    from superpoint_graph_amd.learning import modules
+    g = np.load(os.path.join(GOLDEN, 'ops.npz'))
+    torch.manual_seed(6)
+    cell = modules.LSTMCellEx(32, 32, bias=True, layernorm=layernorm, ingate=ingate)
+    if layernorm and ingate:
+        cell.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('lstm_p/')})
+    cell = cell.to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    n = 9 if (layernorm and ingate) else 257
+    inp = torch.from_numpy(g['gru_in']) if n == 9 else torch.randn(n, 32, generator=gen)
+    hid = torch.from_numpy(g['gru_h']) if n == 9 else torch.randn(n, 32, generator=gen)
+    cx = torch.from_numpy(g['lstm_c']) if n == 9 else torch.randn(n, 32, generator=gen)
+    xi, xh, xc = [t.to(DEV).requires_grad_(True) for t in (inp, hid, cx)]
+    hy, cy = cell(xi, (xh, xc))
+    if n == 9:
+        assert maxrel(hy, torch.from_numpy(g['lstm_hy'])) < 2e-6        # the reference's own outputs
+        assert maxrel(cy, torch.from_numpy(g['lstm_cy'])) < 2e-6
+    P = {'c.' + k: v.detach().cpu().double().requires_grad_(True) for k, v in cell.state_dict().items()}
+    oi, oh, oc = [t.double().requires_grad_(True) for t in (inp, hid, cx)]
+    rhy, rcy = O.lstm_cell_ex(oi, (oh, oc), P, 'c', layernorm, ingate)
+    assert maxrel(hy, rhy) < 2e-6 and maxrel(cy, rcy) < 2e-6
+    gh, gc = torch.randn(n, 32, generator=gen), torch.randn(n, 32, generator=gen)
+    torch.autograd.backward([hy, cy], [gh.to(DEV), gc.to(DEV)])
+    torch.autograd.backward([rhy, rcy], [gh.double(), gc.double()])
+    for a, b in ((xi, oi), (xh, oh), (xc, oc)):
+        assert maxrel(a.grad, b.grad) < 5e-6
+    for k, p in cell.named_parameters():
+        assert maxrel(p.grad, P['c.' + k].grad) < 5e-6, k
+    # only hy used downstream: the cy gradient is absent
+    cell.zero_grad()
+    hy2, _ = cell(xi.detach().requires_grad_(True), (xh.detach(), xc.detach()))
+    hy2.sum().backward()
+    P2 = {k: v.detach().requires_grad_(True) for k, v in P.items()}
+    r2, _ = O.lstm_cell_ex(inp.double(), (hid.double(), cx.double()), P2, 'c', layernorm, ingate)
+    r2.sum().backward()
+    assert maxrel(cell.weight_hh.grad, P2['c.weight_hh'].grad) < 5e-6
+
+
 @pytest.mark.parametrize('M,K,N', [(300, 14, 64), (129, 13, 32), (1000, 64, 64), (517, 64, 128), (256, 128, 256),
                                    (300, 257, 256), (100, 64, 4), (640, 64, 1024), (77, 352, 13), (128, 32, 96)])
 def test_linear_forward_and_wgrad(hip, M, K, N):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(hip, name), f'{name} declared in include/spg_hip.h but not exported'
         assert name in _lib.SIGNATURES, f'{name} has no ctypes signature'
-    assert hip.spg_version() == 100
+    assert hip.spg_version() == 101
 
 
 def test_size_queries(hip):
@@ -62,7 +62,7 @@ def test_golden_index_buffers_from_graphs():
 
 
 def test_state_dict_keys_and_init_match_reference():
-    for tag in ('s3dis_gru10_matrix', 'vector_gru4_small'):
+    for tag in ('s3dis_gru10_matrix', 'vector_gru4_small', 'lstm3_matrix_small'):
         spec, batch, state0, g = load_golden(tag)
         torch.manual_seed(1)
         model = build_model(spec)
@@ -100,6 +100,8 @@ def test_model_config_dsl():
     assert sum(p.numel() for p in net.parameters()) == 90573
     net = graphnet.GraphNetwork('gru_10,f_8', 32, [13, 32, 128, 64], 1, 0, 2, 30000, use_pyg=0, cuda=0)
     assert net.gconvs[0]._fnet[-1].weight.shape == (32, 64)
+    net = graphnet.GraphNetwork('lstm_3_0,f_8', 32, [13, 32, 128, 64], 1, 0, 2, 30000, use_pyg=0, cuda=0)
+    assert net.gconvs[0]._isLSTM and net.gconvs[0]._cell.weight_ih.shape == (128, 32) and net._modules['1'].in_features == 128
     with pytest.raises(NotImplementedError):
         graphnet.GraphNetwork('crf_3', 32, [13, 32], use_pyg=0)
     with pytest.raises(NotImplementedError):

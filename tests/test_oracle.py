@@ -9,7 +9,7 @@ from conftest import load_golden, maxrel
 from oracle import spg_oracle as O
 
 
-@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small'])
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small', 'lstm3_matrix_small'])
 def test_oracle_eval_forward_matches_reference(tag):
     spec, batch, state0, g = load_golden(tag)
     emb, logits = O.model_forward(batch, spec, {k: v.clone() for k, v in state0.items()}, False)
@@ -17,7 +17,7 @@ def test_oracle_eval_forward_matches_reference(tag):
     assert maxrel(logits, torch.from_numpy(g['eval/logits'])) < 5e-6
 
 
-@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small'])
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small', 'lstm3_matrix_small'])
 def test_oracle_train_step_matches_reference(tag):
     spec, batch, state0, g = load_golden(tag)
     st = {k: v.clone() for k, v in state0.items()}
@@ -36,7 +36,7 @@ def test_oracle_train_step_matches_reference(tag):
 
 
 def test_index_contract_bit_exact():
-    for tag in ('s3dis_gru10_matrix', 'vector_gru4_small'):
+    for tag in ('s3dis_gru10_matrix', 'vector_gru4_small', 'lstm3_matrix_small'):
         spec, batch, state0, g = load_golden(tag)
         n_graphs = len([k for k in g.files if k.startswith('graph/') and k.endswith('/n')])
         el = [g[f'graph/{i}/edges'] for i in range(n_graphs)]
