@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--n-feat', type=int, default=14, help='point features (14: S3DIS xyzrgbelpsvXYZ, 11: Semantic3D)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--sync-bn', type=int, default=0, help='1: BatchNorm statistics all-reduced over the ranks (exact single-process batch semantics); 0: per-rank statistics')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
     args = ap.parse_args()
 
@@ -126,11 +127,15 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     n_sp_step = int(flag.numel())
 
+    if args.sync_bn:       # BatchNorm statistics over the scenes of ALL ranks (exact single-process-batch semantics)
+        spd.enable_sync_bn(dev)
+
     def fwd_bwd():
         arena.zero_grad()
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
-        loss = F.cross_entropy(out, label_mode)
+        # sync-BN couples the ranks in the backward: the loss normaliser is applied before it (dist.py)
+        loss = F.cross_entropy(out, label_mode, reduction='sum' if args.sync_bn else 'mean')
         loss.backward()
         embedder.bw_hook()
 
@@ -139,8 +144,8 @@ def main():
 
     def eager_step():
         fwd_bwd()
-        if world > 1:
-            arena.allreduce(w_local)
+        if world > 1 or args.sync_bn:
+            arena.allreduce(w_local, prescaled=bool(args.sync_bn))
         update()
 
     step = eager_step
@@ -162,8 +167,8 @@ def main():
 
         def graph_step():
             g_fb.replay()
-            if world > 1:
-                arena.allreduce(w_local)
+            if world > 1 or args.sync_bn:
+                arena.allreduce(w_local, prescaled=bool(args.sync_bn))
             g_up.replay()
         step = graph_step
         log('hipGraph captured')
@@ -198,7 +203,8 @@ def main():
         'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x {args.n_feat} feats, '
                                f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config}' + (' (S3DIS production model, matrix filters, 10 GRU iterations)' if args.model_config == 'gru_10_0,f_13' else '') + ', train step fwd+bwd+Adam',
                    'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'parallelism': f'dp{world} (one scene shard per GPU, one flat-bucket '
-                                                                              'RCCL all-reduce)' if world > 1 else 'single GPU'},
+                                                                              'RCCL all-reduce)' if world > 1 else 'single GPU',
+                   'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics'},
     }
 
     if rank == 0 and not args.no_roofline:

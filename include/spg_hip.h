@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define SPG_MAX_LAYERS 8
-#define SPG_VERSION 101
+#define SPG_VERSION 102
 
 const char* spg_last_error(void);
 int spg_version(void);
@@ -161,6 +161,19 @@ size_t spg_eccrnn_bwd_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E);
 int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
                         const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
                         void* workspace, void* bwd_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synchronised BatchNorm for the data-parallel mode (the reference's single process normalises over
+ * ALL scenes of the batch, learning/pointnet.py:34-47,93-108, graphnet.py:26-27).  The library owns no communicator:
+ * the host registers an all-reduce(SUM) callback over a caller-owned fp64 DEVICE buffer.  While registered, every
+ * train-mode BatchNorm of spg_pointnet_* / spg_eccrnn_* (forward statistics and the two backward sums) runs as
+ *   local reduction into buf -> fn(ctx, buf, n, stream) -> finish from the global sums,
+ * n <= 3*C+1 doubles for a C-channel layer.  fn must enqueue the collective so that it is ordered after the work
+ * already on `stream` and before later work on it (torch.distributed semantics), and return 0.  All ranks must
+ * run the same layer sequence.  fn == NULL restores per-rank statistics (the default).
+ * ---------------------------------------------------------------------------------------------- */
+typedef int (*spg_allreduce_fn)(void* ctx, double* buf, long n, void* stream);
+int spg_set_bn_allreduce(spg_allreduce_fn fn, void* ctx, double* buf, long buf_doubles);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise gradient clamp + Adam step on one flat parameter buffer: replaces the per-parameter loop

@@ -9,6 +9,7 @@
 //     epilogue.
 // One workgroup = 4 wavefronts (one per SIMD); tile = 128 rows x JT columns, reduction staged through
 // LDS in chunks of 32 in the [k/4][row][4] layout of spg_common.h.
+#include "../../include/spg_hip.h"
 #include "spg_gemm.h"
 #include <float.h>
 #include <limits.h>
@@ -653,12 +654,64 @@ static int* spg_fin_counter_window(int n) {
   return w;
 }
 
+// (sum n_b m_b, sum n_b m_b^2, sum M2_b, count) of one channel -> the BatchNorm constants + running statistics
+__device__ __forceinline__ void spg_bn_finish(double a0, double a1, double a2, double M, int c,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              float* running_mean, float* running_var, float momentum, float eps,
+                                              int update_times, float* mean_o, float* rstd_o, float* s_o, float* t_o) {
+  const double mean = a0 / M;
+  double m2 = a2 + a1 - M * mean * mean;
+  if (m2 < 0.0) m2 = 0.0;
+  const double var = m2 / M;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+  mean_o[c] = (float)mean;
+  rstd_o[c] = (float)rstd;
+  s_o[c] = (float)(g * rstd);
+  t_o[c] = (float)(be - mean * g * rstd);
+  if (running_mean != nullptr && update_times > 0) {
+    const double uvar = M > 1.0 ? m2 / (M - 1.0) : var;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int u = 0; u < update_times; ++u) {
+      rm = (1.f - momentum) * rm + momentum * (float)mean;
+      rv = (1.f - momentum) * rv + momentum * (float)uvar;
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+}
+
+// ---- synchronised BatchNorm (data-parallel ranks normalise over the union of their batches) --------------------
+// The library has no communicator of its own: the host registers an all-reduce(sum) over a caller-owned fp64 device
+// buffer (spg_set_bn_allreduce, include/spg_hip.h).  Every train-mode BatchNorm then runs as
+//   reduce the local partials into the buffer -> all-reduce on the same stream -> finish from the global sums.
+struct SpgSyncBn {
+  spg_allreduce_fn fn = nullptr;
+  void* ctx = nullptr;
+  double* buf = nullptr;
+  long ndoubles = 0;
+};
+static SpgSyncBn g_sync;
+
+extern "C" int spg_set_bn_allreduce(spg_allreduce_fn fn, void* ctx, double* buf, long buf_doubles) {
+  if (fn != nullptr) SPG_CHECK_ARG(buf != nullptr && buf_doubles >= 4, "synchronised BatchNorm needs a device buffer");
+  g_sync.fn = fn; g_sync.ctx = ctx; g_sync.buf = fn ? buf : nullptr; g_sync.ndoubles = fn ? buf_doubles : 0;
+  return 0;
+}
+
+static int spg_sync_allreduce(long n, hipStream_t stream) {
+  const int rc = g_sync.fn(g_sync.ctx, g_sync.buf, n, (void*)stream);
+  if (rc != 0) { spg_set_error("the registered BatchNorm all-reduce failed (rc %d)", rc); return -1; }
+  return 0;
+}
+
 __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __restrict__ stat, int ntile, int rows_per_tile,
                                                                int wi, long M, int N, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* running_mean,
                                                                float* running_var, float momentum, float eps,
                                                                int update_times, float* mean_o, float* rstd_o, float* s_o,
-                                                               float* t_o, double* __restrict__ scratch, int* counters) {
+                                                               float* t_o, double* __restrict__ scratch, int* counters,
+                                                               double* __restrict__ sync_out) {
   __shared__ double r0[16][17], r1[16][17], r2[16][17];
   __shared__ int s_last;
   const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -718,26 +771,26 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
     }
   }
   if (threadIdx.x >= 16 || c >= N) return;
-  const double mean = a0 / (double)M;
-  double m2 = a2 + a1 - (double)M * mean * mean;
-  if (m2 < 0.0) m2 = 0.0;
-  const double var = m2 / (double)M;
-  const double rstd = 1.0 / sqrt(var + (double)eps);
-  const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
-  mean_o[c] = (float)mean;
-  rstd_o[c] = (float)rstd;
-  s_o[c] = (float)(g * rstd);
-  t_o[c] = (float)(be - mean * g * rstd);
-  if (running_mean != nullptr && update_times > 0) {
-    const double uvar = M > 1 ? m2 / (double)(M - 1) : var;
-    float rm = running_mean[c], rv = running_var[c];
-    for (int u = 0; u < update_times; ++u) {
-      rm = (1.f - momentum) * rm + momentum * (float)mean;
-      rv = (1.f - momentum) * rv + momentum * (float)uvar;
-    }
-    running_mean[c] = rm;
-    running_var[c] = rv;
+  if (sync_out != nullptr) {     // synchronised BatchNorm: publish the local sums, the host all-reduces them
+    sync_out[0 * (long)N + c] = a0;
+    sync_out[1 * (long)N + c] = a1;
+    sync_out[2 * (long)N + c] = a2;
+    if (c == 0) sync_out[3 * (long)N] = (double)M;
+    return;
   }
+  spg_bn_finish(a0, a1, a2, (double)M, c, gamma, beta, running_mean, running_var, momentum, eps, update_times, mean_o,
+                rstd_o, s_o, t_o);
+}
+
+// second half of the synchronised mode: sums over all ranks -> mean / rstd / scale / shift
+__global__ void spg_bn_finish_kernel(const double* __restrict__ sync, int N, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* running_mean, float* running_var,
+                                     float momentum, float eps, int update_times, float* mean_o, float* rstd_o,
+                                     float* s_o, float* t_o) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  spg_bn_finish(sync[c], sync[(long)N + c], sync[2 * (long)N + c], sync[3 * (long)N], c, gamma, beta, running_mean,
+                running_var, momentum, eps, update_times, mean_o, rstd_o, s_o, t_o);
 }
 
 size_t spg_bn_finalize_scratch_doubles(int N) { return (size_t)SPG_FIN_SLICES * 3 * N; }
@@ -755,9 +808,21 @@ int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long
     counters = spg_fin_counter_window(gx);
     if (counters == nullptr) slices = 1;
   }
+  double* sync = nullptr;
+  if (g_sync.fn != nullptr) {
+    SPG_CHECK_ARG(3L * N + 1 <= g_sync.ndoubles, "synchronised BatchNorm buffer too small for this layer");
+    sync = g_sync.buf;
+  }
   hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(gx, slices), dim3(1024), 0, stream, stat, ntile, rows_per_tile, wi, M, N,
-                     gamma, beta, running_mean, running_var, momentum, eps, update_times, mean, rstd, s, t, scratch, counters);
+                     gamma, beta, running_mean, running_var, momentum, eps, update_times, mean, rstd, s, t, scratch, counters,
+                     sync);
   SPG_LAUNCH_CHECK();
+  if (sync != nullptr) {
+    SPG_TRY(spg_sync_allreduce(3L * N + 1, stream));
+    hipLaunchKernelGGL(spg_bn_finish_kernel, dim3(spg_cdiv(N, 256)), dim3(256), 0, stream, sync, N, gamma, beta, running_mean,
+                       running_var, momentum, eps, update_times, mean, rstd, s, t);
+    SPG_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -784,7 +849,8 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, float* consts,
                                                                    float* dgamma, float* dbeta,
-                                                                   double* __restrict__ scratch, int* counters) {
+                                                                   double* __restrict__ scratch, int* counters,
+                                                                   double* __restrict__ sync_out) {
   __shared__ double r0[16][17], r1[16][17];
   __shared__ int s_last;
   const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 channels x 64 partial-groups per workgroup
@@ -836,9 +902,27 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
     }
   }
   if (threadIdx.x >= 16 || c >= N) return;
-  if (dbeta) dbeta[c] = (float)a;
+  if (dbeta) dbeta[c] = (float)a;      // parameter gradients stay local sums (the gradient all-reduce adds the ranks)
   if (dgamma) dgamma[c] = (float)b;
+  if (sync_out != nullptr) {
+    sync_out[c] = a;
+    sync_out[(long)N + c] = b;
+    if (c == 0) sync_out[2 * (long)N] = (double)count;
+    return;
+  }
   const double c1 = a / (double)count, c2 = b / (double)count;
+  consts[0 * N + c] = s[c];
+  consts[1 * N + c] = (float)c1;
+  consts[2 * N + c] = mean[c];
+  consts[3 * N + c] = (float)((double)s[c] * c2 * (double)rstd[c]);
+}
+
+__global__ void spg_bn_bwd_finish_kernel(const double* __restrict__ sync, int N, const float* __restrict__ s,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd, float* consts) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const double count = sync[2 * (long)N];
+  const double c1 = sync[c] / count, c2 = sync[(long)N + c] / count;
   consts[0 * N + c] = s[c];
   consts[1 * N + c] = (float)c1;
   consts[2 * N + c] = mean[c];
@@ -855,9 +939,19 @@ int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long co
     counters = spg_fin_counter_window(gx);
     if (counters == nullptr) slices = 1;
   }
+  double* sync = nullptr;
+  if (g_sync.fn != nullptr) {
+    SPG_CHECK_ARG(2L * N + 1 <= g_sync.ndoubles, "synchronised BatchNorm buffer too small for this layer");
+    sync = g_sync.buf;
+  }
   hipLaunchKernelGGL(spg_bn_bwd_finalize_kernel, dim3(gx, slices), dim3(1024), 0, stream, stat, ntile, ldstat, count, N, s,
-                     mean, rstd, consts, dgamma, dbeta, scratch, counters);
+                     mean, rstd, consts, dgamma, dbeta, scratch, counters, sync);
   SPG_LAUNCH_CHECK();
+  if (sync != nullptr) {
+    SPG_TRY(spg_sync_allreduce(2L * N + 1, stream));
+    hipLaunchKernelGGL(spg_bn_bwd_finish_kernel, dim3(spg_cdiv(N, 256)), dim3(256), 0, stream, sync, N, s, mean, rstd, consts);
+    SPG_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -8,8 +8,13 @@ Semantics: the reference's loss is a (class-weighted) mean over the labelled sup
 so every rank scales its local gradients by w_r, the bucket (gradients + w_r in one extra slot) is summed by
 ONE all-reduce, and the result is divided by w_tot.  The bucket is ~1.1 MB (279 409 floats for S3DIS): the
 collective is latency-bound on xGMI, so a single bucket and no overlap machinery is the right shape.
-BatchNorm statistics stay per-rank (local BN): each rank normalises over its own scenes.
-The all-reduce happens after CloudEmbedder.bw_hook() and before the element-wise gradient clamp
+BatchNorm: two modes.  Default = per-rank statistics (each rank normalises over its own scenes; what plain data
+parallelism gives).  `enable_sync_bn()` = statistics over the union of all ranks' scenes, which reproduces the
+reference's single-process batch exactly: the 13 train-mode BatchNorm layers all-reduce their
+per-channel fp64 sums (forward: 3C+1 doubles, backward: 2C+1) through the callback the C library exposes
+(include/spg_hip.h: spg_set_bn_allreduce).  In that mode the backward couples the ranks, so the loss has to be
+scaled BEFORE the backward: loss_r = w_r * CE_r, then `allreduce(w_r, prescaled=True)` sums and divides by w_tot.
+The gradient all-reduce happens after CloudEmbedder.bw_hook() and before the element-wise gradient clamp
 (learning/main.py:208-212 order)."""
 from __future__ import annotations
 
@@ -54,9 +59,10 @@ class GradBucket:
         dev = self.params[0].device
         self.flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=dev)
 
-    def allreduce(self, local_weight: float = 1.0, group=None):
+    def allreduce(self, local_weight: float = 1.0, group=None, prescaled: bool = False):
         """Weighted data-parallel mean of the gradients, in place.  No-op maths at world_size 1 but the same code
-        path (flatten -> [all-reduce] -> unflatten)."""
+        path (flatten -> [all-reduce] -> unflatten).  prescaled: the loss was already multiplied by local_weight
+        (synchronised-BatchNorm mode)."""
         off = 0
         for p in self.params:
             n = p.numel()
@@ -65,7 +71,8 @@ class GradBucket:
             else:
                 self.flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        self.flat[:self.numel].mul_(float(local_weight))
+        if not prescaled:
+            self.flat[:self.numel].mul_(float(local_weight))
         self.flat[self.numel] = float(local_weight)
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -78,6 +85,46 @@ class GradBucket:
             p.grad.copy_(self.flat[off:off + n].view_as(p))
             off += n
         return self.flat[self.numel]
+
+
+_SYNC_BN = {}
+
+
+def enable_sync_bn(device, group=None, max_channels: int = 1024):
+    """Synchronise the BatchNorm statistics of the HIP path over `group` (all ranks must run the same layers)."""
+    import ctypes
+    from ._lib import check, lib
+    buf = torch.zeros(3 * max_channels + 16, dtype=torch.float64, device=device)
+    staged = dist.is_initialized() and dist.get_backend(group) == 'gloo' and buf.is_cuda
+    state = {'calls': 0, 'error': None}
+
+    def _allreduce(ctx, ptr, n, stream):
+        try:
+            state['calls'] += 1
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
+                view = buf[:n]
+                if staged:                         # CPU-side test backend: through the host (synchronises)
+                    host = view.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                    view.copy_(host)
+                else:                              # RCCL: enqueued in stream order w.r.t. torch's current stream
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:                     # never let an exception cross the C boundary
+            state['error'] = e
+            return 1
+
+    cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p)(_allreduce)
+    check(lib().spg_set_bn_allreduce(ctypes.cast(cb, ctypes.c_void_p), None, buf.data_ptr(), buf.numel()),
+          'spg_set_bn_allreduce')
+    _SYNC_BN.update(cb=cb, buf=buf, state=state)
+    return state
+
+
+def disable_sync_bn():
+    from ._lib import check, lib
+    check(lib().spg_set_bn_allreduce(None, None, None, 0), 'spg_set_bn_allreduce')
+    _SYNC_BN.clear()
 
 
 def loss_weight(label_mode: torch.Tensor, class_weights: Optional[torch.Tensor] = None) -> float:

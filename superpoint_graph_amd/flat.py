@@ -62,11 +62,15 @@ class FlatParameters:
         if clip > 0:
             self.flat.grad.clamp_(-clip, clip)
 
-    def allreduce(self, local_weight: float = 1.0, group=None):
-        """Weighted data-parallel mean of the gradients (see superpoint_graph_amd/dist.py), in place on the arena."""
+    def allreduce(self, local_weight: float = 1.0, group=None, prescaled: bool = False):
+        """Weighted data-parallel mean of the gradients (see superpoint_graph_amd/dist.py), in place on the arena.
+        prescaled: the loss was already multiplied by local_weight (synchronised-BatchNorm mode)."""
         if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+            if prescaled:
+                self.flat.grad.div_(float(local_weight))
             return
-        self.flat.grad.mul_(float(local_weight))
+        if not prescaled:
+            self.flat.grad.mul_(float(local_weight))
         self._gbuf[self.numel] = float(local_weight)
         dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
         self.flat.grad.div_(self._gbuf[self.numel])

@@ -103,6 +103,43 @@ def test_flat_parameters_world2_matches_single_process():
             assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
 
 
+def _prescaled_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from superpoint_graph_amd import dist as spd
+    from superpoint_graph_amd.flat import FlatParameters
+    spd.init_from_env('gloo')
+    model, x, y, cw = _make()
+    arena = FlatParameters(model)
+    cut = 9
+    xs, ys = (x[:cut], y[:cut]) if rank == 0 else (x[cut:], y[cut:])
+    arena.zero_grad()
+    F.cross_entropy(model(xs), ys, weight=cw, reduction='sum').backward()       # = w_r * mean loss of the rank
+    arena.allreduce(spd.loss_weight(ys, cw), prescaled=True)
+    g_arena = [p.grad.clone() for p in model.parameters()]
+    bucket = spd.GradBucket(model.parameters())
+    model.zero_grad()
+    arena.zero_grad()
+    F.cross_entropy(model(xs), ys, weight=cw, reduction='sum').backward()
+    bucket.allreduce(spd.loss_weight(ys, cw), prescaled=True)
+    ret[rank] = (g_arena, [p.grad.clone() for p in model.parameters()])
+    torch.distributed.destroy_process_group()
+
+
+def test_prescaled_loss_allreduce_world2():
+    """synchronised-BatchNorm mode: loss scaled by w_r before the backward, all-reduce = plain sum / w_tot"""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_prescaled_worker, args=(2, port, ret), nprocs=2, join=True)
+    model, x, y, cw = _make()
+    F.cross_entropy(model(x), y, weight=cw).backward()
+    ref = [p.grad for p in model.parameters()]
+    for r in (0, 1):
+        for k in (0, 1):
+            for a, b in zip(ret[r][k], ref):
+                assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+
+
 def test_flat_parameters_keeps_state_dict():
     from superpoint_graph_amd.flat import FlatParameters
     model, x, y, cw = _make(3)
