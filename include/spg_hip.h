@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define SPG_MAX_LAYERS 8
-#define SPG_VERSION 102
+#define SPG_VERSION 103
 
 const char* spg_last_error(void);
 int spg_version(void);
@@ -161,6 +161,22 @@ size_t spg_eccrnn_bwd_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E);
 int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
                         const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
                         void* workspace, void* bwd_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-side superpoint loader: the body of load_superpoint (learning/spg.py:198-236: resample to npts rows,
+ * centre / normalise xyz, select the feature columns, transpose) and the geometric part of augment_cloud
+ * (:239-258) for ALL superpoints of a ragged point buffer in one launch.
+ *   points [Ntot, ncols] raw rows (xyz first), offsets i64 [S+1] first row of each superpoint,
+ *   slot i32 [S]: output row of the superpoint, or -1 when it has fewer than ptn_minpts points (spg.py:203),
+ *   sample_idx i32 [S, npts]: row indices inside the superpoint = the reference's `rs.choice` stream (:207-214),
+ *   colmap i32 [nfeat]: raw column of each output feature (the pc_attribs selection, :224-232; 0..2 = normalised xyz),
+ *   M f64 [S, 3, 3] or NULL: augmentation matrix, applied as P[:, :3] @ M^T (:252), noise [Nv, npts, nfeat] or NULL: jitter,
+ *   clouds [Nv, nfeat, npts] (the layout spg_pointnet_forward consumes), diam [Nv] (0 when xyznormalize == 0).
+ * ---------------------------------------------------------------------------------------------- */
+#define SPG_LOADER_MAX_FEATS 16
+int spg_load_superpoints(const float* points, int ncols, const int64_t* offsets, int n_superpoints, const int32_t* slot,
+                         const int32_t* sample_idx, int npts, int xyznormalize, const int32_t* colmap, int nfeat,
+                         const double* M, const float* noise, float* clouds, float* diam, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Synchronised BatchNorm for the data-parallel mode (the reference's single process normalises over

@@ -321,6 +321,86 @@ def check_ops(refmods, write):
         print(f'  wrote {out}')
 
 
+def check_loader(write):
+    """load_superpoint / augment_cloud (learning/spg.py:198-258) imported from the reference; h5py -> in-memory stub,
+    transforms3d (absent) -> its closed forms, see oracle/spg_loader_oracle.py."""
+    import random as pyrandom
+    from oracle import spg_loader_oracle as L
+    print('== loader: load_superpoint / augment_cloud')
+    store = {}
+
+    class _DS:
+        def __init__(self, a):
+            self._a = a
+            self.shape = a.shape
+
+        def __getitem__(self, k):
+            return self._a[k]
+
+    h5 = types.ModuleType('h5py')
+    h5.File = lambda fname, mode='r': {k: _DS(v) for k, v in store[fname].items()}
+    t3 = types.ModuleType('transforms3d')
+    t3.zooms = types.SimpleNamespace(zfdir2mat=lambda s, d=None: L.zoom(s) if d is None else (
+        np.eye(3) + (s - 1) * np.outer(d, d) / np.dot(d, d)))
+    t3.axangles = types.SimpleNamespace(axangle2mat=lambda ax, a: L.rot_z(a) if list(ax) == [0, 0, 1] else None)
+    sk = sys.modules.get('sklearn')
+    sys.modules['h5py'], sys.modules['transforms3d'] = h5, t3
+    from learning import spg as refspg
+
+    rng = np.random.default_rng(77)
+    counts = [5, 39, 40, 127, 128, 129, 400, 1, 3000, 64]
+    pts = [np.concatenate([rng.normal(size=(n, 3)) * rng.uniform(0.2, 5) + rng.normal(size=3) * 10,
+                           rng.uniform(-0.5, 0.5, size=(n, 8)), rng.uniform(0, 1, size=(n, 3))], 1).astype(np.float32)
+           for n in counts]
+    pts[4][:, :3] = pts[4][0, :3]                       # a degenerate superpoint: all points identical (diameter 0)
+    store['scene.h5'] = {str(i): p for i, p in enumerate(pts)}
+    points = np.concatenate(pts, 0)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ids = np.arange(len(counts))
+    out = {}
+    for tag, attribs, norm in (('s3dis', 'xyzrgbelpsvXYZ', 1), ('sema3d', 'xyzrgbelpsv', 1), ('nonorm', 'xyzelpsv', 0)):
+        args = types.SimpleNamespace(ptn_minpts=40, ptn_npts=128, pc_xyznormalize=norm, pc_attribs=attribs,
+                                     pc_augm_scale=0, pc_augm_rot=0, pc_augm_mirror_prob=0, pc_augm_jitter=0)
+        mine = L.load_batch(points, offsets, ids, 40, 128, norm, attribs, train=False, test_seed_offset=3)
+        k = 0
+        for i in range(len(counts)):
+            P, d = refspg.load_superpoint(args, 'scene.h5', i, False, 3)
+            if P is None:
+                assert mine['flag'][i] == -1 and d == counts[i]
+                continue
+            assert mine['flag'][i] == 0 and mine['slot'][i] == k
+            assert np.array_equal(P.T, mine['clouds'][k]) and np.array_equal(d, mine['diam'][k:k + 1]), (tag, i)
+            k += 1
+        print(f'  test-mode {tag:7s}: {k} clouds bit-equal to the reference (flags, diameters, resampling stream)')
+        out[tag] = mine
+    # training mode: global numpy / python random streams, full augmentation
+    args = types.SimpleNamespace(ptn_minpts=40, ptn_npts=128, pc_xyznormalize=1, pc_attribs='xyzrgbelpsvXYZ',
+                                 pc_augm_scale=1.1, pc_augm_rot=1, pc_augm_mirror_prob=1.0, pc_augm_jitter=1)
+    np.random.seed(5); pyrandom.seed(6)
+    ref = [refspg.load_superpoint(args, 'scene.h5', i, True, 0) for i in range(len(counts))]
+    np.random.seed(5); pyrandom.seed(6)
+    mine = L.load_batch(points, offsets, ids, 40, 128, 1, 'xyzrgbelpsvXYZ', train=True,
+                        augm=dict(scale=1.1, rot=1, mirror_prob=1.0, jitter=1), nprandom=np.random, pyrandom=pyrandom)
+    k = 0
+    for i, (P, d) in enumerate(ref):
+        if P is None:
+            continue
+        assert np.array_equal(P.T, mine['clouds'][k]) and np.array_equal(d, mine['diam'][k:k + 1]), i
+        k += 1
+    print(f'  train-mode (scale+rot+mirror+jitter): {k} clouds bit-equal to the reference')
+    out['train'] = mine
+    if write:
+        path = os.path.join(ROOT, 'tests', 'golden', 'loader.npz')
+        arrs = dict(points=points, offsets=offsets, ids=ids)
+        for tag, m in out.items():
+            for key in ('flag', 'slot', 'sample_idx', 'clouds', 'diam', 'M'):
+                arrs[f'{tag}/{key}'] = m[key]
+        arrs['train/noise'] = out['train']['noise']
+        np.savez_compressed(path, **arrs)
+        print(f'  wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
+    del sys.modules['h5py'], sys.modules['transforms3d']
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--write', action='store_true', help='write tests/golden/*.npz')
@@ -330,6 +410,8 @@ def main():
     refmods = import_reference()
     if not a.only:
         check_ops(refmods, a.write)
+    if a.only in ('', 'loader'):
+        check_loader(a.write)
     cw = torch.linspace(0.5, 1.5, 13)
     # S3DIS production config (S3DIS.md:26-28): matrix filters, 10 GRU iterations, state concat
     if a.only in ('', 's3dis_gru10_matrix'):

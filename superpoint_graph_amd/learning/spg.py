@@ -1,7 +1,8 @@
 """Batching contract of the reference's learning/spg.py for the hot path: `eccpc_collate` turns a list of
 loader samples `(targets, graph, clouds_meta, clouds_flag, clouds, clouds_global)` (reference
 learning/spg.py:130-171) into `(targets, [GraphConvInfo], (clouds_meta, clouds_flag, clouds,
-clouds_global))` (reference learning/spg.py:178-193).  File readers / augmentation are out of scope;
+clouds_global))` (reference learning/spg.py:178-193), and `load_superpoints_device` is the device-side form of the
+per-superpoint loader (`load_superpoint` + `augment_cloud`, :198-258) over a ragged point buffer.  File readers are out of scope;
 `SuperpointGraph` is a minimal stand-in for the igraph.Graph API that GraphConvInfo.set_batch touches, so
 synthetic scenes (and tests) need no igraph install.  Real igraph graphs work unchanged (duck typing)."""
 import numpy as np
@@ -73,3 +74,85 @@ def sample_from_scene(scene, name='synthetic'):
     G = SuperpointGraph(scene['n_sp'], scene['edges'], {'f': list(scene['edge_feats'])})
     meta = ['{}.{:d}'.format(name, i) for i in range(scene['n_sp'])]
     return scene['targets'], G, meta, scene['flag'], scene['clouds'], scene['diam']
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# device-side load_superpoint / augment_cloud
+# --------------------------------------------------------------------------------------------------------------------
+_RAW_COLUMNS = {'xyz': (0, 1, 2), 'rgb': (3, 4, 5), 'e': (6,), 'lpsv': (7, 8, 9, 10), 'XYZ': (11, 12, 13)}
+
+
+def pc_attribs_columns(pc_attribs):
+    """Raw column of each output feature, in the reference's order (substring tests, learning/spg.py:224-232)."""
+    if 'd' in pc_attribs:
+        raise NotImplementedError("pc_attribs 'd' does not work in the reference either (1-D column, spg.py:231)")
+    cols = []
+    for key in ('xyz', 'rgb', 'e', 'lpsv', 'XYZ'):
+        if key in pc_attribs:
+            cols += _RAW_COLUMNS[key]
+    return cols
+
+
+def load_superpoints_device(args, points, offsets, ids, train, test_seed_offset=0, counts=None):
+    """All superpoints of a scene in ONE kernel launch: what `loader` does with one `load_superpoint` call per
+    superpoint (reference learning/spg.py:150-167, 198-236) plus `augment_cloud` (:239-258) when `train`.
+
+    points: device f32 [Ntot, ncols] raw rows of every superpoint back to back (the content of parsed/<scene>.h5),
+    offsets: i64 [S+1] (host or device), ids: the superpoint ids (seed of the evaluation stream, :205).
+    The random streams stay on the host and are consumed in the reference's order -- per superpoint: resampling
+    (`rs.choice`, numpy), then the augmentation matrix (python `random`), then the jitter (numpy `randn`) -- so a seeded
+    run yields the reference's clouds.  -> (clouds_flag i64[S] host, clouds f32[Nv, F, npts] device, clouds_global f32[Nv] device)
+    """
+    import math
+    import random
+    from .. import ops
+    if not points.is_cuda:
+        raise RuntimeError('superpoint_graph_amd.load_superpoints_device has no CPU path')
+    off_h = offsets.cpu().numpy() if torch.is_tensor(offsets) else np.asarray(offsets, dtype=np.int64)
+    S, npts = len(off_h) - 1, int(args.ptn_npts)
+    counts = np.diff(off_h)
+    cols = pc_attribs_columns(args.pc_attribs) if args.pc_attribs != '' else list(range(points.shape[1]))
+    F = len(cols)
+    flag = np.where(counts < args.ptn_minpts, -1, 0).astype(np.int64)           # :203
+    slot = np.full(S, -1, dtype=np.int32)
+    slot[flag == 0] = np.arange(int((flag == 0).sum()), dtype=np.int32)
+    nv = int((flag == 0).sum())
+    sidx = np.zeros((S, npts), dtype=np.int32)
+    augment = bool(train)
+    Ms = np.tile(np.eye(3), (S, 1, 1)) if augment else None
+    jitter = augment and bool(getattr(args, 'pc_augm_jitter', 0))
+    noise = np.zeros((nv, npts, F), dtype=np.float32) if jitter else None
+    for s in range(S):
+        n = int(counts[s])
+        if flag[s] != 0:
+            continue
+        rs = np.random if train else np.random.RandomState(seed=int(ids[s]) + test_seed_offset)     # :205
+        if n > npts:                                                                              # :207-214
+            sidx[s] = rs.choice(n, npts)
+        elif n < npts:
+            sidx[s, :n] = np.arange(n)
+            sidx[s, n:] = rs.choice(n, npts - n)
+        else:
+            sidx[s] = np.arange(n)
+        if augment:                                                                               # :241-251
+            M = np.eye(3)
+            if args.pc_augm_scale > 1:
+                M = np.dot(np.eye(3) * random.uniform(1 / args.pc_augm_scale, args.pc_augm_scale), M)
+            if args.pc_augm_rot == 1:
+                a = random.uniform(0, 2 * math.pi)
+                c, sn = math.cos(a), math.sin(a)
+                M = np.dot(np.array([[c, -sn, 0.0], [sn, c, 0.0], [0.0, 0.0, 1.0]]), M)           # z = upright
+            if args.pc_augm_mirror_prob > 0:
+                if random.random() < args.pc_augm_mirror_prob / 2:
+                    M = np.dot(np.diag([-1.0, 1.0, 1.0]), M)
+                if random.random() < args.pc_augm_mirror_prob / 2:
+                    M = np.dot(np.diag([1.0, -1.0, 1.0]), M)
+            Ms[s] = M
+            if jitter:                                                                            # :255-257
+                noise[slot[s]] = np.clip(0.01 * np.random.randn(npts, F), -0.05, 0.05).astype(np.float32)
+    dev = points.device
+    clouds, diam = ops.load_superpoints(
+        points, torch.from_numpy(off_h.astype(np.int64)).to(dev), torch.from_numpy(slot).to(dev),
+        torch.from_numpy(sidx).to(dev), cols, bool(args.pc_xyznormalize), nv,
+        None if Ms is None else torch.from_numpy(Ms).to(dev), None if noise is None else torch.from_numpy(noise).to(dev))
+    return torch.from_numpy(flag), clouds, diam

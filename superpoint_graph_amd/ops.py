@@ -304,3 +304,28 @@ def eccrnn_backward(state: EccRnnState, groups, grad_out, out_grads=None):
                                     _ptr(grad_out), _ptr(grad_h0), _ptr_array(flatg), _ptr(state.ws), _ptr(bws), _stream()),
           'spg_eccrnn_backward')
     return grad_h0, gg
+
+
+# --------------------------------------------------------------------------------------------------
+# superpoint loader
+# --------------------------------------------------------------------------------------------------
+def load_superpoints(points, offsets, slot, sample_idx, colmap, xyznormalize: bool, n_valid: int, M=None, noise=None):
+    """points f32 [Ntot, ncols], offsets i64 [S+1], slot i32 [S], sample_idx i32 [S, npts] (on the device), colmap:
+    sequence of raw column indices (host) -> clouds f32 [n_valid, F, npts], diam f32 [n_valid].
+    M: f64 [S, 3, 3] or None, noise: f32 [n_valid, npts, F] or None (device)."""
+    _req(points, torch.float32, 'points'); _req(offsets, torch.int64, 'offsets'); _req(slot, torch.int32, 'slot')
+    _req(sample_idx, torch.int32, 'sample_idx')
+    colmap_h = (ctypes.c_int32 * len(colmap))(*[int(c) for c in colmap])
+    S, npts, F = slot.numel(), sample_idx.shape[1], len(colmap)
+    if offsets.numel() != S + 1 or sample_idx.shape[0] != S:
+        raise ValueError('offsets / slot / sample_idx disagree on the number of superpoints')
+    if M is not None:
+        _req(M, torch.float64, 'M')
+    if noise is not None:
+        _req(noise, torch.float32, 'noise')
+    clouds = torch.empty(n_valid, F, npts, dtype=torch.float32, device=points.device)
+    diam = torch.empty(n_valid, dtype=torch.float32, device=points.device)
+    check(lib().spg_load_superpoints(_ptr(points), points.shape[1], _ptr(offsets), S, _ptr(slot), _ptr(sample_idx), npts,
+                                     int(bool(xyznormalize)), ctypes.cast(colmap_h, ctypes.c_void_p), F, _ptr(M), _ptr(noise), _ptr(clouds),
+                                     _ptr(diam), _stream()), 'spg_load_superpoints')
+    return clouds, diam

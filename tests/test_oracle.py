@@ -80,3 +80,31 @@ def test_gradcheck_and_shard_invariance():
     for lim in (1, 30, 1e10):
         sh = O.get_edge_shards(degs.numpy(), lim)
         assert sum(a for a, _ in sh) == 5 and sum(b for _, b in sh) == 50
+
+
+def test_loader_oracle_matches_reference_golden():
+    """oracle/spg_loader_oracle.py against the clouds the imported reference's load_superpoint / augment_cloud produced
+    (tests/golden/loader.npz, written by oracle/validate_against_reference.py::check_loader)."""
+    import os
+    import random as pyrandom
+    from conftest import GOLDEN
+    from oracle import spg_loader_oracle as L
+    g = np.load(os.path.join(GOLDEN, 'loader.npz'))
+    points, offsets, ids = g['points'], g['offsets'], g['ids']
+    for tag, attribs, norm in (('s3dis', 'xyzrgbelpsvXYZ', 1), ('sema3d', 'xyzrgbelpsv', 1), ('nonorm', 'xyzelpsv', 0)):
+        m = L.load_batch(points, offsets, ids, 40, 128, norm, attribs, train=False, test_seed_offset=3)
+        for key in ('flag', 'slot', 'sample_idx', 'clouds', 'diam'):
+            assert np.array_equal(m[key], g[f'{tag}/{key}']), (tag, key)
+    assert list(g['s3dis/flag']) == [-1, -1, 0, 0, 0, 0, 0, -1, 0, 0]            # < ptn_minpts points: no cloud
+    assert g['s3dis/diam'][2] == 0.0      # degenerate superpoint (all points equal): (x - mean) / 1e-10, rounding noise blown up
+    np.random.seed(5); pyrandom.seed(6)
+    m = L.load_batch(points, offsets, ids, 40, 128, 1, 'xyzrgbelpsvXYZ', train=True,
+                     augm=dict(scale=1.1, rot=1, mirror_prob=1.0, jitter=1), nprandom=np.random, pyrandom=pyrandom)
+    for key in ('sample_idx', 'clouds', 'diam', 'M', 'noise'):
+        assert np.array_equal(m[key], g[f'train/{key}']), key
+    # the summation order the device kernel relies on: numpy's float32 mean over axis 0 adds the rows one by one
+    rows = points[offsets[8]:offsets[9]][g['s3dis/sample_idx'][8]][:, :3]
+    acc = np.zeros(3, np.float32)
+    for r in rows:
+        acc = acc + r
+    assert np.array_equal(acc / np.float32(128), np.mean(rows, axis=0))
