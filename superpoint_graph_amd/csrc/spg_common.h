@@ -126,6 +126,7 @@ struct SpgQuad {
   int nvalid;    // number of valid channels in this quad (0..4); the others are forced to zero
   int naff;      // AFFINE: number of leading channels of the quad that get scale/shift(/ReLU); the rest pass through
   int relu;
+  int has;       // AFFINE: scale / shift arrays present (otherwise ReLU only)
 };
 
 __host__ __device__ inline bool spg_operand_vec_ok(const SpgOperand& d) {
@@ -133,6 +134,11 @@ __host__ __device__ inline bool spg_operand_vec_ok(const SpgOperand& d) {
   if ((d.ld & 3) != 0 || (((uintptr_t)d.X) & 15) != 0) return false;
   if ((d.mode == SPG_PRO_BNBWD || d.mode == SPG_PRO_POOLBWD) && (((uintptr_t)d.X2) & 15) != 0) return false;
   if (d.mode == SPG_PRO_POOLBWD && ((d.ldg & 3) != 0 || (((uintptr_t)d.aidx) & 15) != 0)) return false;
+  // per-channel constants are fetched as aligned quads
+  if (d.mode == SPG_PRO_AFFINE &&
+      ((d.n_affine & 3) != 0 || (d.c0 != nullptr && ((((uintptr_t)d.c0) | ((uintptr_t)d.c1)) & 15) != 0))) return false;
+  if ((d.mode == SPG_PRO_BNBWD || d.mode == SPG_PRO_POOLBWD) &&
+      ((((uintptr_t)d.c0) | ((uintptr_t)d.c1) | ((uintptr_t)d.c2) | ((uintptr_t)d.c3)) & 15) != 0) return false;
   return true;
 }
 
@@ -143,28 +149,26 @@ template <int MODE>
 __device__ __forceinline__ SpgQuad spg_quad_consts(const SpgOperand& d, int c, int nch) {
   SpgQuad q;
   q.nvalid = nch - c < 0 ? 0 : (nch - c > 4 ? 4 : nch - c);
-  q.naff = 0; q.relu = 0;
+  q.naff = 0; q.relu = 0; q.has = 0;
   if (MODE == SPG_PRO_AFFINE) {
+    // n_affine is a multiple of 4 (spg_operand_vec_ok): a quad is either fully affine or passes through
     const int lim = d.n_affine < nch ? d.n_affine : nch;
-    q.naff = lim - c < 0 ? 0 : (lim - c > 4 ? 4 : lim - c);
+    q.naff = c + 4 <= lim ? 4 : 0;
     q.relu = d.relu;
-    if (d.c0 != nullptr) {                                  // wave-uniform
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ci = c + i < lim ? c + i : 0;
-        q.a[i] = d.c0[ci];
-        q.b[i] = d.c1[ci];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { q.a[i] = 1.f; q.b[i] = 0.f; }
-    }
+    q.has = d.c0 != nullptr;
+    // no branch: without scale / shift the loads read the (always readable) operand itself and are ignored
+    const float* p0 = q.has ? d.c0 : d.X;
+    const float* p1 = q.has ? d.c1 : d.X;
+    const int cb = (q.has && q.naff) ? c : 0;
+    q.a = *reinterpret_cast<const f32x4*>(p0 + cb);
+    q.b = *reinterpret_cast<const f32x4*>(p1 + cb);
   } else if (MODE == SPG_PRO_BNBWD || MODE == SPG_PRO_POOLBWD) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ci = c + i < nch ? c + i : 0;
-      q.a[i] = d.c0[ci]; q.b[i] = d.c1[ci]; q.c[i] = d.c2[ci]; q.d[i] = d.c3[ci];
-    }
+    // a partial last quad reads up to 3 floats past nch inside the [4][C] constant block; its lanes are masked
+    const int cb = c < nch ? c : 0;
+    q.a = *reinterpret_cast<const f32x4*>(d.c0 + cb);
+    q.b = *reinterpret_cast<const f32x4*>(d.c1 + cb);
+    q.c = *reinterpret_cast<const f32x4*>(d.c2 + cb);
+    q.d = *reinterpret_cast<const f32x4*>(d.c3 + cb);
   } else if (MODE == SPG_PRO_CLOUD) {
     q.naff = (d.stnT != nullptr && c == 0) ? 1 : 0;         // this quad holds x, y: apply the 2x2 STN transform
   }
@@ -175,12 +179,14 @@ __device__ __forceinline__ SpgQuad spg_quad_consts(const SpgOperand& d, int c, i
 // while the MFMAs of the previous chunk run) and finished -- prologue arithmetic -- right before the LDS write.
 struct SpgRaw {
   f32x4 x, y;
+  int4 ai;     // POOLBWD: arg-max point of the (group, channel)s of the quad
+  int pp;      // POOLBWD: point index of this row inside its group
 };
 
 // rows m[i] (already clamped into the matrix), channels c..c+3 (clamped; each row segment must be readable as one
 // aligned 16-byte load: ld % 4 == 0).  All loads are unconditional.  Load order: primary loads (and, for the
-// max-pool backward, the tiny per-group arg-max rows), then the secondary loads; the arg-max mask is resolved
-// while the secondary loads are still in flight.
+// max-pool backward, the tiny per-group arg-max rows), then the secondary loads.  NOTHING loaded here is consumed
+// here: every use (masks included) sits in spg_finish_raw, behind the MFMAs of the previous chunk.
 template <int MODE, int NI>
 __device__ __forceinline__ void spg_load_raw(const SpgOperand& d, const long (&m)[NI], int c, int nvalid, SpgRaw (&r)[NI]) {
   if (MODE == SPG_PRO_CLOUD) {
@@ -195,23 +201,16 @@ __device__ __forceinline__ void spg_load_raw(const SpgOperand& d, const long (&m
       if (d.stnT != nullptr) r[i].y = *reinterpret_cast<const f32x4*>(d.stnT + (long)g * 4);   // wave-uniform branch
     }
   } else if (MODE == SPG_PRO_POOLBWD) {
-    int4 ai[NI];
-    int pp[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const unsigned mu = (unsigned)m[i], P = (unsigned)d.P;
       const unsigned g = mu / P;
-      pp[i] = (int)(mu - g * P);
+      r[i].pp = (int)(mu - g * P);
       r[i].x = *reinterpret_cast<const f32x4*>(d.X + (long)g * d.ldg + c);
-      ai[i] = *reinterpret_cast<const int4*>(d.aidx + (long)g * d.ldg + c);
+      r[i].ai = *reinterpret_cast<const int4*>(d.aidx + (long)g * d.ldg + c);
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) r[i].y = *reinterpret_cast<const f32x4*>(d.X2 + m[i] * d.ld + c);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {   // gradient of the max-pool goes to the winning row of each (group, channel)
-      r[i].x[0] = ai[i].x == pp[i] ? r[i].x[0] : 0.f; r[i].x[1] = ai[i].y == pp[i] ? r[i].x[1] : 0.f;
-      r[i].x[2] = ai[i].z == pp[i] ? r[i].x[2] : 0.f; r[i].x[3] = ai[i].w == pp[i] ? r[i].x[3] : 0.f;
-    }
   } else {
 #pragma unroll
     for (int i = 0; i < NI; ++i) r[i].x = *reinterpret_cast<const f32x4*>(d.X + m[i] * d.ld + c);
@@ -237,9 +236,17 @@ __device__ __forceinline__ f32x4 spg_finish_raw(const SpgQuad& q, const SpgRaw& 
   } else if (MODE == SPG_PRO_AFFINE) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float t = fmaf(r.x[i], q.a[i], q.b[i]);
-      v[i] = i < q.naff ? (q.relu ? fmaxf(t, 0.f) : t) : r.x[i];
+      const float t = q.has ? fmaf(r.x[i], q.a[i], q.b[i]) : r.x[i];
+      v[i] = q.naff ? (q.relu ? fmaxf(t, 0.f) : t) : r.x[i];
     }
+  } else if (MODE == SPG_PRO_POOLBWD) {
+    // the gradient of the max-pool goes to the winning row of each (group, channel)
+    const float g0 = r.ai.x == r.pp ? r.x[0] : 0.f, g1 = r.ai.y == r.pp ? r.x[1] : 0.f;
+    const float g2 = r.ai.z == r.pp ? r.x[2] : 0.f, g3 = r.ai.w == r.pp ? r.x[3] : 0.f;
+    v[0] = q.a[0] * (g0 - q.b[0]) - (r.y[0] - q.c[0]) * q.d[0];
+    v[1] = q.a[1] * (g1 - q.b[1]) - (r.y[1] - q.c[1]) * q.d[1];
+    v[2] = q.a[2] * (g2 - q.b[2]) - (r.y[2] - q.c[2]) * q.d[2];
+    v[3] = q.a[3] * (g3 - q.b[3]) - (r.y[3] - q.c[3]) * q.d[3];
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = q.a[i] * (r.x[i] - q.b[i]) - (r.y[i] - q.c[i]) * q.d[i];
@@ -488,21 +495,28 @@ template <int JT>
 struct SpgWeightPipe {        // out-major [JT x 32] weight tile: W [nout, kred]
   static constexpr int NI = JT / 32;
   f32x4 raw[NI];
+  unsigned vmask;
   __device__ __forceinline__ void load(const float* __restrict__ W, long ld, int n0, int nout, int k0, int kred) {
     const int tid = threadIdx.x, k = k0 + 4 * (tid & 7);
+    vmask = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int j = (tid >> 3) + 32 * i;
       const bool ok = n0 + j < nout && k < kred;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(W + (ok ? (long)(n0 + j) * ld + k : 0));   // unconditional, clamped
-#pragma unroll
-      for (int e = 0; e < 4; ++e) raw[i][e] = ok ? v[e] : 0.f;
+      raw[i] = *reinterpret_cast<const f32x4*>(W + (ok ? (long)(n0 + j) * ld + k : 0));   // unconditional, clamped
+      vmask |= ok ? (1u << i) : 0u;       // applied in store(): nothing consumes the loads before the MFMAs
     }
   }
   __device__ __forceinline__ void store(f32x4* __restrict__ lds) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) lds[(tid & 7) * (JT + 1) + (tid >> 3) + 32 * i] = raw[i];
+    for (int i = 0; i < NI; ++i) {
+      f32x4 v = raw[i];
+      const bool ok = (vmask >> i) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+      lds[(tid & 7) * (JT + 1) + (tid >> 3) + 32 * i] = v;
+    }
   }
 };
 
@@ -510,22 +524,28 @@ template <int JT>
 struct SpgWeightRedPipe {     // red-major [32 x JT] weight tile: W [kred, nout] read untransposed
   static constexpr int QUADS = JT / 4, RPP = SPG_THREADS / QUADS, NI = SPG_KC / RPP;
   f32x4 raw[NI];
+  unsigned vmask;
   __device__ __forceinline__ void load(const float* __restrict__ W, long ld, int n0, int nout, int k0, int kred) {
     const int tid = threadIdx.x, c = n0 + 4 * (tid % QUADS);
+    vmask = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = tid / QUADS + RPP * i;
       const bool ok = k0 + r < kred && c < nout;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(W + (ok ? (long)(k0 + r) * ld + c : 0));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) raw[i][e] = ok ? v[e] : 0.f;
+      raw[i] = *reinterpret_cast<const f32x4*>(W + (ok ? (long)(k0 + r) * ld + c : 0));
+      vmask |= ok ? (1u << i) : 0u;
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ lds) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      *reinterpret_cast<f32x4*>(lds + (tid / QUADS + RPP * i) * (JT + 4) + 4 * (tid % QUADS)) = raw[i];
+    for (int i = 0; i < NI; ++i) {
+      f32x4 v = raw[i];
+      const bool ok = (vmask >> i) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+      *reinterpret_cast<f32x4*>(lds + (tid / QUADS + RPP * i) * (JT + 4) + 4 * (tid % QUADS)) = v;
+    }
   }
 };
 

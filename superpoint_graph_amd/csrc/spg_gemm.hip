@@ -281,10 +281,12 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
         pa.load(p.a, m0, mvalid, k0 + SPG_KC, p.K);
         if (WRED) pwr.load(p.W, p.ldw, n0, p.N, k0 + SPG_KC, p.K); else pw.load(p.W, p.ldw, n0, p.N, k0 + SPG_KC, p.K);
       }
+      __builtin_amdgcn_sched_barrier(0);     // the loads stay in front of the MFMAs, their consumers behind them
       const f32x4* Ac = As + buf * (A_F4 + B_F4);
       const f32x4* Bc = Bs + buf * (A_F4 + B_F4);
       if (WRED) spg_mfma_chunk_or<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
       else spg_mfma_chunk<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      __builtin_amdgcn_sched_barrier(0);
       if (more) {
         f32x4* An = As + (buf ^ 1) * (A_F4 + B_F4);
         f32x4* Bn = Bs + (buf ^ 1) * (A_F4 + B_F4);
@@ -421,7 +423,9 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
         pa.load(p.a, qa, m + SPG_KC, me, i0);
         pb.load(p.b, qb, m + SPG_KC, me, j0);
       }
+      __builtin_amdgcn_sched_barrier(0);     // the loads stay in front of the MFMAs, their consumers behind them
       spg_mfma_chunk_rr<TI, TJ>(As + buf * BUF, Bs + buf * BUF, IT + 4, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      __builtin_amdgcn_sched_barrier(0);
       if (more) {
         pa.store(qa, As + (buf ^ 1) * BUF);
         pb.store(qb, Bs + (buf ^ 1) * BUF);
