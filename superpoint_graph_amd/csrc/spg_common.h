@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the superpoint-graph hot path.
 // Written for wave64 / MFMA f32 (v_mfma_f32_32x32x2_f32) only -- no other target is supported.
 #pragma once
+#include <float.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -221,6 +222,15 @@ __device__ __forceinline__ void spg_load_raw(const SpgOperand& d, const long (&m
   }
 }
 
+// one row quad (same contract as spg_load_raw)
+template <int MODE>
+__device__ __forceinline__ void spg_load_raw1(const SpgOperand& d, long m, int c, int nvalid, SpgRaw& r) {
+  const long mm[1] = {m};
+  SpgRaw rr[1];
+  spg_load_raw<MODE, 1>(d, mm, c, nvalid, rr);
+  r = rr[0];
+}
+
 template <int MODE>
 __device__ __forceinline__ f32x4 spg_finish_raw(const SpgQuad& q, const SpgRaw& r, bool valid) {
   f32x4 v;
@@ -296,6 +306,105 @@ __device__ __forceinline__ void spg_mfma_chunk(const f32x4* __restrict__ As, con
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][s], b[cur][j][s], acc[i][j], 0, 0, 0);
+  }
+}
+
+// ---- software-pipelined variants --------------------------------------------------------------------------
+// A wave issues in order: while it sits in a run of back-to-back MFMAs (64 cycles each) it can do nothing else, and
+// while it stages the next chunk its MFMA pipe idles.  The *_il variants take a functor `piece(slot)` and call it after
+// every MFMA k-step (16 slots per chunk), fenced by scheduling barriers, so the staging work of the NEXT chunks (global
+// loads, prologue arithmetic, LDS writes) is issued in the shadow of the matrix pipe instead of between two chunks.
+template <int TI, int TJ, class Piece>
+__device__ __forceinline__ void spg_mfma_chunk_il(const f32x4* __restrict__ As, const f32x4* __restrict__ Bs,
+                                                  int strideA, int strideB, int rowA, int rowB, int h,
+                                                  f32x16 (&acc)[TI][TJ], Piece&& piece) {
+  f32x4 a[2][TI], b[2][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) a[0][i] = As[h * strideA + rowA + 32 * i];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) b[0][j] = Bs[h * strideB + rowB + 32 * j];
+#pragma unroll
+  for (int g = 0; g < SPG_KC / 8; ++g) {
+    const int cur = g & 1, nxt = cur ^ 1;
+    if (g + 1 < SPG_KC / 8) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a[nxt][i] = As[(2 * (g + 1) + h) * strideA + rowA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b[nxt][j] = Bs[(2 * (g + 1) + h) * strideB + rowB + 32 * j];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][s], b[cur][j][s], acc[i][j], 0, 0, 0);
+      piece(4 * g + s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int TI, int TJ, class Piece>
+__device__ __forceinline__ void spg_mfma_chunk_or_il(const f32x4* __restrict__ As, const float* __restrict__ Bs,
+                                                     int strideA, int strideB, int rowA, int colB, int h,
+                                                     f32x16 (&acc)[TI][TJ], Piece&& piece) {
+  f32x4 a[2][TI];
+  float b[2][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) a[0][i] = As[h * strideA + rowA + 32 * i];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) b[0][j] = Bs[(4 * h) * strideB + colB + 32 * j];
+#pragma unroll
+  for (int g = 0; g < SPG_KC / 8; ++g) {
+    if (g + 1 < SPG_KC / 8) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a[(g + 1) & 1][i] = As[(2 * (g + 1) + h) * strideA + rowA + 32 * i];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int t = 4 * g + s;          // k-step inside the chunk
+      if (t + 1 < SPG_KC / 2) {
+        const int g1 = (t + 1) >> 2, s1 = (t + 1) & 3;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) b[(t + 1) & 1][j] = Bs[(8 * g1 + 4 * h + s1) * strideB + colB + 32 * j];
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][s], b[t & 1][j], acc[i][j], 0, 0, 0);
+      piece(t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int TI, int TJ, class Piece>
+__device__ __forceinline__ void spg_mfma_chunk_rr_il(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                     int strideA, int strideB, int colA, int colB, int h,
+                                                     f32x16 (&acc)[TI][TJ], Piece&& piece) {
+  float a[2][TI], b[2][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) a[0][i] = As[h * strideA + colA + 32 * i];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) b[0][j] = Bs[h * strideB + colB + 32 * j];
+#pragma unroll
+  for (int kk = 0; kk < SPG_KC / 2; ++kk) {
+    const int cur = kk & 1, nxt = cur ^ 1;
+    if (kk + 1 < SPG_KC / 2) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a[nxt][i] = As[(2 * (kk + 1) + h) * strideA + colA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b[nxt][j] = Bs[(2 * (kk + 1) + h) * strideB + colB + 32 * j];
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    piece(kk);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -453,6 +562,24 @@ struct SpgRowsPipe {          // out-major [ROWS x 32] tile of an operand
     for (int i = 0; i < NI; ++i)
       lds[kq * (ROWS + 1) + (tid >> 3) + 32 * i] = spg_finish_raw<MODE>(q, raw[i], (vmask >> i) & 1u);
   }
+  // the same in parts, for the interleaved main loop: prepare(k0) once per chunk, then load_part(i) for every i;
+  // later store_part(i) for every i
+  int cq;
+  __device__ __forceinline__ void prepare(const SpgOperand& d, int k0, int nch) {
+    cq = k0 + 4 * (threadIdx.x & 7);
+    q = spg_quad_consts<MODE>(d, cq, nch);
+    vmask = 0;
+  }
+  __device__ __forceinline__ void load_part(const SpgOperand& d, long m0, int mvalid, int i) {
+    const int row = (threadIdx.x >> 3) + 32 * i;
+    const bool ok = row < mvalid;
+    vmask |= ok ? (1u << i) : 0u;
+    spg_load_raw1<MODE>(d, m0 + (ok ? row : 0), q.nvalid > 0 ? cq : 0, q.nvalid, raw[i]);
+  }
+  __device__ __forceinline__ void store_part(f32x4* __restrict__ lds, int i) const {
+    const int tid = threadIdx.x;
+    lds[(tid & 7) * (ROWS + 1) + (tid >> 3) + 32 * i] = spg_finish_raw<MODE>(q, raw[i], (vmask >> i) & 1u);
+  }
 };
 
 template <int MODE, int CH>
@@ -489,6 +616,24 @@ struct SpgRedPipe {           // red-major [32 x CH] tile of an operand (the thr
           spg_finish_raw<MODE>(q, raw[i], (vmask >> i) & 1u);
     }
   }
+  // part-wise form for the interleaved main loop: rows outside [mchunk, mend) are read from
+  // `mclamp` (any valid row) and written as zeros
+  __device__ __forceinline__ void load_part(const SpgOperand& d, const SpgQuad& q, long mchunk, long mend, long mclamp,
+                                            int c0, int i) {
+    const int tid = threadIdx.x;
+    if (i == 0) vmask = 0;
+    const long mm = mchunk + row_of(tid, i);
+    const bool ok = mm < mend && (MODE != SPG_PRO_CLOUD || (i == 0 && quad_of(tid) < QUADS));
+    vmask |= ok ? (1u << i) : 0u;
+    const int c = c0 + 4 * quad_of(tid);
+    spg_load_raw1<MODE>(d, ok ? mm : mclamp, q.nvalid > 0 ? c : 0, q.nvalid, raw[i]);
+  }
+  __device__ __forceinline__ void store_part(const SpgQuad& q, float* __restrict__ lds, int i) const {
+    const int tid = threadIdx.x;
+    if (MODE == SPG_PRO_CLOUD && (i > 0 || quad_of(tid) >= QUADS)) return;
+    *reinterpret_cast<f32x4*>(lds + row_of(tid, i) * (CH + 4) + 4 * quad_of(tid)) =
+        spg_finish_raw<MODE>(q, raw[i], (vmask >> i) & 1u);
+  }
 };
 
 template <int JT>
@@ -518,6 +663,21 @@ struct SpgWeightPipe {        // out-major [JT x 32] weight tile: W [nout, kred]
       lds[(tid & 7) * (JT + 1) + (tid >> 3) + 32 * i] = v;
     }
   }
+  __device__ __forceinline__ void load_part(const float* __restrict__ W, long ld, int n0, int nout, int k0, int kred, int i) {
+    const int tid = threadIdx.x, k = k0 + 4 * (tid & 7), j = (tid >> 3) + 32 * i;
+    if (i == 0) vmask = 0;
+    const bool ok = n0 + j < nout && k < kred;
+    raw[i] = *reinterpret_cast<const f32x4*>(W + (ok ? (long)(n0 + j) * ld + k : 0));
+    vmask |= ok ? (1u << i) : 0u;
+  }
+  __device__ __forceinline__ void store_part(f32x4* __restrict__ lds, int i) const {
+    const int tid = threadIdx.x;
+    f32x4 v = raw[i];
+    const bool ok = (vmask >> i) & 1u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+    lds[(tid & 7) * (JT + 1) + (tid >> 3) + 32 * i] = v;
+  }
 };
 
 template <int JT>
@@ -546,6 +706,185 @@ struct SpgWeightRedPipe {     // red-major [32 x JT] weight tile: W [kred, nout]
       for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
       *reinterpret_cast<f32x4*>(lds + (tid / QUADS + RPP * i) * (JT + 4) + 4 * (tid % QUADS)) = v;
     }
+  }
+  __device__ __forceinline__ void load_part(const float* __restrict__ W, long ld, int n0, int nout, int k0, int kred, int i) {
+    const int tid = threadIdx.x, c = n0 + 4 * (tid % QUADS), r = tid / QUADS + RPP * i;
+    if (i == 0) vmask = 0;
+    const bool ok = k0 + r < kred && c < nout;
+    raw[i] = *reinterpret_cast<const f32x4*>(W + (ok ? (long)(k0 + r) * ld + c : 0));
+    vmask |= ok ? (1u << i) : 0u;
+  }
+  __device__ __forceinline__ void store_part(float* __restrict__ lds, int i) const {
+    const int tid = threadIdx.x;
+    f32x4 v = raw[i];
+    const bool ok = (vmask >> i) & 1u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+    *reinterpret_cast<f32x4*>(lds + (tid / QUADS + RPP * i) * (JT + 4) + 4 * (tid % QUADS)) = v;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// Full-tile fast path.  VALU instructions are NOT free next to MFMAs on gfx950 -- they take issue cycles from the same
+// SIMD (measured, tools/probe/mfma_probe.hip: 4 VALU per fp32 MFMA cost 25 % of the MFMA rate) -- and in the masked
+// pipes above most of the VALU work of a chunk is 64-bit address arithmetic, clamps and validity selects.  When every
+// tile of the launch is full (host-side check: no partial rows / channels / reduction chunks), all of that is loop
+// invariant: each thread keeps 32-bit byte offsets, the per-chunk base is wave-uniform (scalar unit), loads are
+// `global_load_dwordx4 v, v_off, s[base]`, and the prologue arithmetic is the only VALU work left in the loop.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 spg_ld16(const float* __restrict__ ubase, unsigned voff) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+__device__ __forceinline__ int4 spg_ld16i(const int* __restrict__ ubase, unsigned voff) {
+  return *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+
+// shared finish arithmetic of the fast pipes (no masks)
+template <int MODE>
+__device__ __forceinline__ f32x4 spg_finish_fast(const SpgQuad& q, const SpgRaw& r, float lo, const f32x4& px,
+                                                 const int4& pai, int pp) {
+  f32x4 v;
+  if (MODE == SPG_PRO_IDENT) {
+    v = r.x;
+  } else if (MODE == SPG_PRO_AFFINE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(r.x[e], q.a[e], q.b[e]), lo);
+  } else if (MODE == SPG_PRO_BNBWD) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = q.a[e] * (r.x[e] - q.b[e]) - (r.y[e] - q.c[e]) * q.d[e];
+  } else {   // POOLBWD: the pooled gradient goes to the arg-max point of each (group, channel)
+    const float g0 = pai.x == pp ? px[0] : 0.f, g1 = pai.y == pp ? px[1] : 0.f;
+    const float g2 = pai.z == pp ? px[2] : 0.f, g3 = pai.w == pp ? px[3] : 0.f;
+    v[0] = q.a[0] * (g0 - q.b[0]) - (r.y[0] - q.c[0]) * q.d[0];
+    v[1] = q.a[1] * (g1 - q.b[1]) - (r.y[1] - q.c[1]) * q.d[1];
+    v[2] = q.a[2] * (g2 - q.b[2]) - (r.y[2] - q.c[2]) * q.d[2];
+    v[3] = q.a[3] * (g3 - q.b[3]) - (r.y[3] - q.c[3]) * q.d[3];
+  }
+  return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ void spg_consts_fast(const SpgOperand& d, int c, unsigned coff, SpgQuad& q) {
+  if (MODE == SPG_PRO_AFFINE) {
+    q.a = spg_ld16(d.c0 + c, coff);
+    q.b = spg_ld16(d.c1 + c, coff);
+  } else if (MODE == SPG_PRO_BNBWD || MODE == SPG_PRO_POOLBWD) {
+    q.a = spg_ld16(d.c0 + c, coff); q.b = spg_ld16(d.c1 + c, coff);
+    q.c = spg_ld16(d.c2 + c, coff); q.d = spg_ld16(d.c3 + c, coff);
+  }
+}
+
+template <int MODE, int ROWS>
+struct SpgRowsFast {           // out-major [ROWS x 32] tile, every row and channel valid; POOLBWD: the tile is one group
+  static constexpr int NI = ROWS / 32;
+  SpgRaw raw[NI];
+  SpgQuad q;
+  f32x4 px;                    // POOLBWD: pooled gradient / arg-max of the group, channels of this thread's quad
+  int4 pai;
+  unsigned voff[NI], coff;
+  float lo;
+  __device__ __forceinline__ void init(const SpgOperand& d) {
+    const unsigned tid = threadIdx.x, kq = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) voff[i] = ((r0 + 32u * i) * (unsigned)d.ld + 4u * kq) * 4u;
+    coff = 16u * kq;
+    lo = d.relu ? 0.f : -FLT_MAX;
+  }
+  __device__ __forceinline__ void prepare(const SpgOperand& d, long group, int k0) {
+    spg_consts_fast<MODE>(d, k0, coff, q);
+    if (MODE == SPG_PRO_POOLBWD) {
+      px = spg_ld16(d.X + group * d.ldg + k0, coff);
+      pai = spg_ld16i(d.aidx + group * d.ldg + k0, coff);
+    }
+  }
+  __device__ __forceinline__ void load_part(const SpgOperand& d, long m0, int k0, int i) {
+    if (MODE == SPG_PRO_POOLBWD) {
+      raw[i].y = spg_ld16(d.X2 + m0 * d.ld + k0, voff[i]);
+    } else {
+      raw[i].x = spg_ld16(d.X + m0 * d.ld + k0, voff[i]);
+      if (MODE == SPG_PRO_BNBWD) raw[i].y = spg_ld16(d.X2 + m0 * d.ld + k0, voff[i]);
+    }
+  }
+  __device__ __forceinline__ void store_part(f32x4* __restrict__ lds, int i) const {
+    const int tid = threadIdx.x;
+    lds[(tid & 7) * (ROWS + 1) + (tid >> 3) + 32 * i] = spg_finish_fast<MODE>(q, raw[i], lo, px, pai, (tid >> 3) + 32 * i);
+  }
+};
+
+template <int JT>
+struct SpgWeightFast {         // out-major [JT x 32] weight tile, W [nout, kred], all valid
+  static constexpr int NI = JT / 32;
+  f32x4 raw[NI];
+  unsigned voff[NI];
+  __device__ __forceinline__ void init(long ld) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) voff[i] = (((tid >> 3) + 32u * i) * (unsigned)ld + 4u * (tid & 7)) * 4u;
+  }
+  __device__ __forceinline__ void load_part(const float* __restrict__ W, long ld, int n0, int k0, int i) {
+    raw[i] = spg_ld16(W + (long)n0 * ld + k0, voff[i]);
+  }
+  __device__ __forceinline__ void store_part(f32x4* __restrict__ lds, int i) const {
+    const int tid = threadIdx.x;
+    lds[(tid & 7) * (JT + 1) + (tid >> 3) + 32 * i] = raw[i];
+  }
+};
+
+template <int JT>
+struct SpgWeightRedFast {      // red-major [32 x JT] weight tile, W [kred, nout] read untransposed, all valid
+  static constexpr int QUADS = JT / 4, RPP = SPG_THREADS / QUADS, NI = SPG_KC / RPP;
+  f32x4 raw[NI];
+  unsigned voff[NI];
+  __device__ __forceinline__ void init(long ld) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) voff[i] = ((tid / QUADS + RPP * i) * (unsigned)ld + 4u * (tid % QUADS)) * 4u;
+  }
+  __device__ __forceinline__ void load_part(const float* __restrict__ W, long ld, int n0, int k0, int i) {
+    raw[i] = spg_ld16(W + (long)k0 * ld + n0, voff[i]);
+  }
+  __device__ __forceinline__ void store_part(float* __restrict__ lds, int i) const {
+    const int tid = threadIdx.x;
+    *reinterpret_cast<f32x4*>(lds + (tid / QUADS + RPP * i) * (JT + 4) + 4 * (tid % QUADS)) = raw[i];
+  }
+};
+
+template <int MODE, int CH>
+struct SpgRedFast {            // red-major [32 x CH] operand tile of the weight gradient, all rows / channels valid
+  static constexpr int QUADS = CH / 4, RPP = SPG_THREADS / QUADS, NI = SPG_KC / RPP;
+  SpgRaw raw[NI];
+  f32x4 px;
+  int4 pai;
+  unsigned voff[NI], coff;
+  int pbase;                   // POOLBWD: point index of this thread's first row relative to the chunk start
+  float lo;
+  __device__ __forceinline__ void init(const SpgOperand& d, int c0, SpgQuad& q) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) voff[i] = ((tid / QUADS + RPP * i) * (unsigned)d.ld + 4u * (tid % QUADS)) * 4u;
+    coff = 16u * (tid % QUADS);
+    lo = d.relu ? 0.f : -FLT_MAX;
+    spg_consts_fast<MODE>(d, c0, coff, q);
+  }
+  // the 32 rows of a chunk belong to ONE pooling group (P % 32 == 0, chunk starts are multiples of 32)
+  __device__ __forceinline__ void load_part(const SpgOperand& d, long mchunk, int c0, int i) {
+    if (MODE == SPG_PRO_POOLBWD) {
+      if (i == 0) {
+        const unsigned g = (unsigned)mchunk / (unsigned)d.P;      // M < 2^32 rows
+        pbase = (int)((unsigned)mchunk - g * (unsigned)d.P);
+        px = spg_ld16(d.X + g * d.ldg + c0, coff);
+        pai = spg_ld16i(d.aidx + g * d.ldg + c0, coff);
+      }
+      raw[i].y = spg_ld16(d.X2 + mchunk * d.ld + c0, voff[i]);
+    } else {
+      raw[i].x = spg_ld16(d.X + mchunk * d.ld + c0, voff[i]);
+      if (MODE == SPG_PRO_BNBWD) raw[i].y = spg_ld16(d.X2 + mchunk * d.ld + c0, voff[i]);
+    }
+  }
+  __device__ __forceinline__ void store_part(const SpgQuad& q, float* __restrict__ lds, int i) const {
+    const int tid = threadIdx.x, row = tid / QUADS + RPP * i;
+    *reinterpret_cast<f32x4*>(lds + row * (CH + 4) + 4 * (tid % QUADS)) =
+        spg_finish_fast<MODE>(q, raw[i], lo, px, pai, pbase + row);
   }
 };
 

@@ -238,7 +238,9 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
 
 // AMODE >= 0: operand mode of A known at compile time, vector + software-pipelined main loop (host guarantees the
 // alignment conditions); AMODE < 0: generic scalar staging (channel-major clouds, unaligned leading dimensions).
-template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE>
+// FULL: every tile of the launch is complete (rows, output channels, reduction chunks): the masked staging pipes are
+// replaced by the loop-invariant-address fast pipes (spg_common.h).
+template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false>
 __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGemmParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
@@ -264,37 +266,120 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
 
   constexpr int A_F4 = (SPG_KC / 4) * (IT + 1);                                  // float4 slots of one A buffer
   constexpr int B_F4 = WRED ? SPG_KC * (JT + 4) / 4 : (SPG_KC / 4) * (JT + 1);   // float4 slots of one weight buffer
-  if constexpr (AMODE >= 0) {
-    // software-pipelined main loop, two LDS buffers, ONE barrier per chunk
+  if constexpr (AMODE >= 0 && FULL) {
+    // same pipeline as below on the fast pipes
+    SpgRowsFast<AMODE, IT> pa;
+    SpgWeightFast<JT> pw;
+    SpgWeightRedFast<JT> pwr;
+    constexpr int NIA = SpgRowsFast<AMODE, IT>::NI;
+    constexpr int NIW = WRED ? SpgWeightRedFast<JT>::NI : SpgWeightFast<JT>::NI;
+    static_assert(NIA + NIW + 4 <= SPG_KC / 2, "staging pieces must fit the MFMA slots of a chunk");
+    const int nchunk = p.K / SPG_KC;
+    pa.init(p.a);
+    if (WRED) pwr.init(p.ldw); else pw.init(p.ldw);
+    pa.prepare(p.a, tile, 0);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) pa.load_part(p.a, m0, 0, i);
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) { if (WRED) pwr.load_part(p.W, p.ldw, n0, 0, i); else pw.load_part(p.W, p.ldw, n0, 0, i); }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) pa.store_part(As, i);
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) { if (WRED) pwr.store_part(Bsr, i); else pw.store_part(Bs, i); }
+    {
+      const int k1 = nchunk > 1 ? SPG_KC : 0;
+      pa.prepare(p.a, tile, k1);
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) pa.load_part(p.a, m0, k1, i);
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) { if (WRED) pwr.load_part(p.W, p.ldw, n0, k1, i); else pw.load_part(p.W, p.ldw, n0, k1, i); }
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+      const int k2 = (c + 2 < nchunk ? c + 2 : nchunk - 1) * SPG_KC;
+      const int buf = c & 1;
+      const f32x4* Ac = As + buf * (A_F4 + B_F4);
+      const f32x4* Bc = Bs + buf * (A_F4 + B_F4);
+      f32x4* An = As + (buf ^ 1) * (A_F4 + B_F4);
+      f32x4* Bn = Bs + (buf ^ 1) * (A_F4 + B_F4);
+      auto piece = [&](int slot) __attribute__((always_inline)) {
+        if (slot < NIA) {
+          pa.store_part(An, slot);
+        } else if (slot < NIA + NIW) {
+          if (WRED) pwr.store_part(reinterpret_cast<float*>(Bn), slot - NIA); else pw.store_part(Bn, slot - NIA);
+        } else if (slot == NIA + NIW) {
+          pa.prepare(p.a, tile, k2);
+#pragma unroll
+          for (int i = 0; i < (NIA + 1) / 2; ++i) pa.load_part(p.a, m0, k2, i);
+        } else if (slot == NIA + NIW + 1) {
+#pragma unroll
+          for (int i = (NIA + 1) / 2; i < NIA; ++i) pa.load_part(p.a, m0, k2, i);
+        } else if (slot == NIA + NIW + 2) {
+#pragma unroll
+          for (int i = 0; i < NIW; ++i) { if (WRED) pwr.load_part(p.W, p.ldw, n0, k2, i); else pw.load_part(p.W, p.ldw, n0, k2, i); }
+        }
+      };
+      if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+      else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+      __syncthreads();
+    }
+  } else if constexpr (AMODE >= 0) {
+    // software-pipelined main loop, two LDS buffers, ONE barrier per chunk.  Iteration c runs the MFMAs of chunk c and,
+    // in their shadow (spg_mfma_chunk_il), finishes chunk c+1 (prologue arithmetic + LDS write into the other buffer;
+    // its global loads were issued one iteration earlier) and then issues the global loads of chunk c+2.  The loop is
+    // branch-free: past the end, the chunk index is clamped (a redundant, harmless re-load / re-write of the last chunk
+    // into the buffer nobody reads any more).
     SpgRowsPipe<AMODE, IT> pa;
     SpgWeightPipe<JT> pw;
     SpgWeightRedPipe<JT> pwr;
+    constexpr int NIA = SpgRowsPipe<AMODE, IT>::NI;
+    constexpr int NIW = WRED ? SpgWeightRedPipe<JT>::NI : SpgWeightPipe<JT>::NI;
+    static_assert(NIA + NIW + 4 <= SPG_KC / 2, "staging pieces must fit the MFMA slots of a chunk");
+    const int nchunk = (p.K + SPG_KC - 1) / SPG_KC;
     pa.load(p.a, m0, mvalid, 0, p.K);
     if (WRED) pwr.load(p.W, p.ldw, n0, p.N, 0, p.K); else pw.load(p.W, p.ldw, n0, p.N, 0, p.K);
     pa.store(As);
     if (WRED) pwr.store(Bsr); else pw.store(Bs);
+    {
+      const int k1 = nchunk > 1 ? SPG_KC : 0;
+      pa.load(p.a, m0, mvalid, k1, p.K);
+      if (WRED) pwr.load(p.W, p.ldw, n0, p.N, k1, p.K); else pw.load(p.W, p.ldw, n0, p.N, k1, p.K);
+    }
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
-      const bool more = k0 + SPG_KC < p.K;
-      if (more) {
-        pa.load(p.a, m0, mvalid, k0 + SPG_KC, p.K);
-        if (WRED) pwr.load(p.W, p.ldw, n0, p.N, k0 + SPG_KC, p.K); else pw.load(p.W, p.ldw, n0, p.N, k0 + SPG_KC, p.K);
-      }
-      __builtin_amdgcn_sched_barrier(0);     // the loads stay in front of the MFMAs, their consumers behind them
+    for (int c = 0; c < nchunk; ++c) {
+      const int k2 = (c + 2 < nchunk ? c + 2 : nchunk - 1) * SPG_KC;
+      const int buf = c & 1;
       const f32x4* Ac = As + buf * (A_F4 + B_F4);
       const f32x4* Bc = Bs + buf * (A_F4 + B_F4);
-      if (WRED) spg_mfma_chunk_or<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
-      else spg_mfma_chunk<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        f32x4* An = As + (buf ^ 1) * (A_F4 + B_F4);
-        f32x4* Bn = Bs + (buf ^ 1) * (A_F4 + B_F4);
-        pa.store(An);
-        if (WRED) pwr.store(reinterpret_cast<float*>(Bn)); else pw.store(Bn);
-      }
+      f32x4* An = As + (buf ^ 1) * (A_F4 + B_F4);
+      f32x4* Bn = Bs + (buf ^ 1) * (A_F4 + B_F4);
+      auto piece = [&](int slot) __attribute__((always_inline)) {
+        if (slot < NIA) {
+          pa.store_part(An, slot);
+        } else if (slot < NIA + NIW) {
+          if (WRED) pwr.store_part(reinterpret_cast<float*>(Bn), slot - NIA); else pw.store_part(Bn, slot - NIA);
+        } else if (slot == NIA + NIW) {
+          pa.prepare(p.a, k2, p.K);
+#pragma unroll
+          for (int i = 0; i < (NIA + 1) / 2; ++i) pa.load_part(p.a, m0, mvalid, i);
+        } else if (slot == NIA + NIW + 1) {
+#pragma unroll
+          for (int i = (NIA + 1) / 2; i < NIA; ++i) pa.load_part(p.a, m0, mvalid, i);
+        } else if (slot == NIA + NIW + 2) {
+#pragma unroll
+          for (int i = 0; i < (NIW + 1) / 2; ++i) {
+            if (WRED) pwr.load_part(p.W, p.ldw, n0, p.N, k2, p.K, i); else pw.load_part(p.W, p.ldw, n0, p.N, k2, p.K, i);
+          }
+        } else if (slot == NIA + NIW + 3) {
+#pragma unroll
+          for (int i = (NIW + 1) / 2; i < NIW; ++i) {
+            if (WRED) pwr.load_part(p.W, p.ldw, n0, p.N, k2, p.K, i); else pw.load_part(p.W, p.ldw, n0, p.N, k2, p.K, i);
+          }
+        }
+      };
+      if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+      else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
       __syncthreads();
-      buf ^= 1;
     }
   } else {
     for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
@@ -339,6 +424,19 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
   if (lds < epi) lds = epi;
   dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
+  if constexpr (AMODE >= 0 && IT == 128) {
+    // every tile complete and every offset inside 32 bits: fast pipes
+    const bool mode_ok = AMODE == SPG_PRO_IDENT || AMODE == SPG_PRO_BNBWD ||
+                         (AMODE == SPG_PRO_AFFINE && p.a.c0 != nullptr && p.a.n_affine >= p.K) ||
+                         (AMODE == SPG_PRO_POOLBWD && p.a.P == IT);
+    const bool full = mode_ok && p.rows_per_tile == IT && p.M % IT == 0 && p.K % SPG_KC == 0 && p.N % JT == 0 &&
+                      (long)IT * p.a.ld < (1L << 29) && (long)(WRED ? SPG_KC : JT) * p.ldw < (1L << 29);
+    if (full) {
+      hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true>), grid, dim3(SPG_THREADS), lds, stream, p);
+      SPG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -381,7 +479,7 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream) {
 // weight-gradient kernel: reduction over the rows (points / superpoints / edges / nodes)
 // ---------------------------------------------------------------------------------------------
 // AMODE / BMODE >= 0: compile-time operand modes, vector + software-pipelined loop; < 0: generic scalar staging.
-template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE>
+template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE, bool FULL = false>
 __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
@@ -403,33 +501,104 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  if constexpr (AMODE >= 0 && BMODE >= 0) {
-    // software-pipelined: global loads of chunk c+1 fly during the MFMAs of chunk c; two LDS buffers, one barrier.
+  if constexpr (AMODE >= 0 && BMODE >= 0 && FULL) {
+    // full tiles: the fast pipes (loop-invariant offsets, no masks), same pipeline as below
+    constexpr int BUF = SPG_KC * (IT + 4 + JT + 4);
+    SpgRedFast<AMODE, IT> pa;
+    SpgRedFast<BMODE, JT> pb;
+    constexpr int NIA = SpgRedFast<AMODE, IT>::NI, NIB = SpgRedFast<BMODE, JT>::NI;
+    static_assert(NIA + NIB + 4 <= SPG_KC / 2, "staging pieces must fit the MFMA slots of a chunk");
+    SpgQuad qa, qb;
+    pa.init(p.a, i0, qa);
+    pb.init(p.b, j0, qb);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) pa.load_part(p.a, ms, i0, i);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) pb.load_part(p.b, ms, j0, i);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) pa.store_part(qa, As, i);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) pb.store_part(qb, Bs, i);
+    const long mlast = me - SPG_KC;                 // first row of the last chunk of this split
+    {
+      const long m1 = ms + SPG_KC <= mlast ? ms + SPG_KC : mlast;
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) pa.load_part(p.a, m1, i0, i);
+#pragma unroll
+      for (int i = 0; i < NIB; ++i) pb.load_part(p.b, m1, j0, i);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (long m = ms; m < me; m += SPG_KC) {
+      float* An = As + (buf ^ 1) * BUF;
+      float* Bn = Bs + (buf ^ 1) * BUF;
+      const long m2 = m + 2 * SPG_KC <= mlast ? m + 2 * SPG_KC : mlast;      // clamped: a harmless re-load past the end
+      auto piece = [&](int slot) __attribute__((always_inline)) {
+        if (slot < NIA) {
+          pa.store_part(qa, An, slot);
+        } else if (slot < NIA + NIB) {
+          pb.store_part(qb, Bn, slot - NIA);
+        } else if (slot == NIA + NIB) {
+#pragma unroll
+          for (int i = 0; i < (NIA + 1) / 2; ++i) pa.load_part(p.a, m2, i0, i);
+        } else if (slot == NIA + NIB + 1) {
+#pragma unroll
+          for (int i = (NIA + 1) / 2; i < NIA; ++i) pa.load_part(p.a, m2, i0, i);
+        } else if (slot == NIA + NIB + 2) {
+#pragma unroll
+          for (int i = 0; i < NIB; ++i) pb.load_part(p.b, m2, j0, i);
+        }
+      };
+      spg_mfma_chunk_rr_il<TI, TJ>(As + buf * BUF, Bs + buf * BUF, IT + 4, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else if constexpr (AMODE >= 0 && BMODE >= 0) {
+    // software-pipelined like spg_rowgemm_kernel: iteration c = MFMAs of chunk c, in their shadow the finish + LDS write
+    // of chunk c+1 and then the global loads of chunk c+2; two LDS buffers, one barrier; branch-free (rows past the end
+    // of the split are read from its first row and written as zeros).
     // A thread keeps the same channel quad for every row: the per-channel constants are loaded once.
     constexpr int BUF = SPG_KC * (IT + 4 + JT + 4);
     SpgRedPipe<AMODE, IT> pa;
     SpgRedPipe<BMODE, JT> pb;
+    constexpr int NIA = SpgRedPipe<AMODE, IT>::NI, NIB = SpgRedPipe<BMODE, JT>::NI;
+    static_assert(NIA + NIB + 4 <= SPG_KC / 2, "staging pieces must fit the MFMA slots of a chunk");
     const SpgQuad qa = spg_quad_consts<AMODE>(p.a, i0 + 4 * pa.quad_of(tid), p.N);
     const SpgQuad qb = spg_quad_consts<BMODE>(p.b, j0 + 4 * pb.quad_of(tid), p.K);
     pa.load(p.a, qa, ms, me, i0);
     pb.load(p.b, qb, ms, me, j0);
     pa.store(qa, As);
     pb.store(qb, Bs);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) pa.load_part(p.a, qa, ms + SPG_KC, me, ms, i0, i);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) pb.load_part(p.b, qb, ms + SPG_KC, me, ms, j0, i);
     __syncthreads();
     int buf = 0;
     for (long m = ms; m < me; m += SPG_KC) {
-      const bool more = m + SPG_KC < me;
-      if (more) {
-        pa.load(p.a, qa, m + SPG_KC, me, i0);
-        pb.load(p.b, qb, m + SPG_KC, me, j0);
-      }
-      __builtin_amdgcn_sched_barrier(0);     // the loads stay in front of the MFMAs, their consumers behind them
-      spg_mfma_chunk_rr<TI, TJ>(As + buf * BUF, Bs + buf * BUF, IT + 4, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        pa.store(qa, As + (buf ^ 1) * BUF);
-        pb.store(qb, Bs + (buf ^ 1) * BUF);
-      }
+      float* An = As + (buf ^ 1) * BUF;
+      float* Bn = Bs + (buf ^ 1) * BUF;
+      const long m2 = m + 2 * SPG_KC;
+      auto piece = [&](int slot) __attribute__((always_inline)) {
+        if (slot < NIA) {
+          pa.store_part(qa, An, slot);
+        } else if (slot < NIA + NIB) {
+          pb.store_part(qb, Bn, slot - NIA);
+        } else if (slot == NIA + NIB) {
+#pragma unroll
+          for (int i = 0; i < (NIA + 1) / 2; ++i) pa.load_part(p.a, qa, m2, me, ms, i0, i);
+        } else if (slot == NIA + NIB + 1) {
+#pragma unroll
+          for (int i = (NIA + 1) / 2; i < NIA; ++i) pa.load_part(p.a, qa, m2, me, ms, i0, i);
+        } else if (slot == NIA + NIB + 2) {
+#pragma unroll
+          for (int i = 0; i < (NIB + 1) / 2; ++i) pb.load_part(p.b, qb, m2, me, ms, j0, i);
+        } else if (slot == NIA + NIB + 3) {
+#pragma unroll
+          for (int i = (NIB + 1) / 2; i < NIB; ++i) pb.load_part(p.b, qb, m2, me, ms, j0, i);
+        }
+      };
+      spg_mfma_chunk_rr_il<TI, TJ>(As + buf * BUF, Bs + buf * BUF, IT + 4, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
       __syncthreads();
       buf ^= 1;
     }
@@ -508,6 +677,21 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
   const size_t lds = (size_t)((AMODE >= 0 && BMODE >= 0) ? 2 : 1) * SPG_KC * (IT + 4 + JT + 4) * sizeof(float);
   dim3 grid(nsplit, spg_cdiv(p.N, IT), spg_cdiv(p.K, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
+  if constexpr (AMODE >= 0 && BMODE >= 0 && AMODE != SPG_PRO_CLOUD && BMODE != SPG_PRO_CLOUD) {
+    auto mode_ok = [](int mode, const SpgOperand& d, int nch) {
+      if (mode == SPG_PRO_AFFINE) return d.c0 != nullptr && d.n_affine >= nch;
+      if (mode == SPG_PRO_POOLBWD) return d.P % SPG_KC == 0;
+      return true;
+    };
+    const bool full = mode_ok(AMODE, p.a, p.N) && mode_ok(BMODE, p.b, p.K) && p.M % SPG_KC == 0 &&
+                      p.rows_per_split % SPG_KC == 0 && p.N % IT == 0 && p.K % JT == 0 &&
+                      (long)SPG_KC * p.a.ld < (1L << 29) && (long)SPG_KC * p.b.ld < (1L << 29);
+    if (full) {
+      hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true>), grid, dim3(SPG_THREADS), lds, stream, p);
+      SPG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
