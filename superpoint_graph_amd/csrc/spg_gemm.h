@@ -29,6 +29,7 @@ struct SpgGemmParams {
   long ldyp;
   const float* ms;    // producer BN scale / shift (null: 1 / 0)
   const float* mt;
+  int vec_store;     // set by the launcher (full tiles, aligned output rows): dwordx4 stores through LDS
   int mask_relu;
   int n_mask;         // columns >= n_mask are passed through (concatenated global features)
   const float* mmean; // producer BN batch mean / rstd (null: no stats)

@@ -66,6 +66,37 @@ extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int rese
 // Epilogues.  FULL: the tile is completely inside the matrix (and, for the backward, inside the masked channel
 // range), so every load / store is unconditional: straight-line code without per-element exec-mask branches and the
 // conservative s_waitcnt the compiler puts at their joins.
+// LDS floats of one wave's staging region for the vector store: rows x (cols + 8) (the +8 keeps the two lane halves of an
+// accumulator register on disjoint banks)
+#define SPG_EPI_WAVE_FLOATS(RW, CW) ((RW) * ((CW) + 8))
+
+// accumulators of one wave (RW x CW sub-tile in the MFMA C layout) -> LDS (wave-private, no barrier) -> rows of float4
+template <int RW, int CW, int TI, int TJ>
+__device__ __forceinline__ void spg_store_tile_vec_impl(const f32x16 (&acc)[TI][TJ], float* __restrict__ st,
+                                                        float* __restrict__ ybase, unsigned ldy, int lane) {
+  constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR;      // lanes per row, rows per store instruction
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) st[(32 * i + spg_acc_row(q, h)) * LD + 32 * j + r] = acc[i][j][q];
+  const int lr = lane / LPR, lc = 4 * (lane % LPR);
+  const unsigned o0 = (unsigned)lr * ldy + (unsigned)lc;
+#pragma unroll
+  for (int it = 0; it < RW / RPI; ++it) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * it) * LD + lc);
+    *reinterpret_cast<f32x4*>(ybase + o0 + (unsigned)(RPI * it) * ldy) = v;
+  }
+}
+template <int RW, int CW, int TI, int TJ>
+__device__ __forceinline__ void spg_store_tile_vec(const f32x16 (&acc)[TI][TJ], float* __restrict__ st,
+                                                   float* __restrict__ ybase, unsigned ldy, int lane) {
+  static_assert(TI * 32 == RW && TJ * 32 == CW, "wave sub-tile");
+  spg_store_tile_vec_impl<RW, CW, TI, TJ>(acc, st, ybase, ldy, lane);
+}
+
 template <int IT, int JT, int WI, int WJ, bool FULL>
 __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
                                                  float* __restrict__ red, int tile, long m0, int mvalid, int n0) {
@@ -88,7 +119,7 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
     for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] += bv;
-    if (p.Y != nullptr) {      // uniform
+    if (p.Y != nullptr && !(FULL && p.vec_store)) {      // uniform
       float* yb = p.Y + m0 * p.ldy + n0;                       // wave-uniform base (SGPRs) + 32-bit lane offsets
       const unsigned ldy = (unsigned)p.ldy;
       const unsigned o0 = (unsigned)(roww + 4 * h) * ldy + (unsigned)(colw + 32 * j + r);
@@ -100,6 +131,12 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
           if (FULL || (colok && roww + row < mvalid)) yb[o0 + (unsigned)(32 * i + (q & 3) + 8 * (q >> 2)) * ldy] = acc[i][j][q];
         }
     }
+  }
+  if (FULL && p.vec_store && p.Y != nullptr) {
+    // full tiles, 16-byte aligned rows: the wave's sub-tile goes through its private LDS region and leaves as whole
+    // row segments with dwordx4 stores -- 4x fewer store instructions (the epilogue is store-issue bound)
+    spg_store_tile_vec<IT / WI, JT / WJ>(acc, red + wave * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ),
+                                         p.Y + (m0 + roww) * p.ldy + n0 + colw, (unsigned)p.ldy, lane);
   }
   // ---- BatchNorm partials: every WAVE writes (mean, M2 = sum (y - mean)^2) of its own rows -- no LDS, no barrier;
   //      spg_bn_finalize_kernel combines the ntile*WI partials with Chan's formula ----
@@ -164,6 +201,76 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
         const long o = part * p.N + col;
         p.pmax[o] = vmx; p.imax[o] = imx; p.pmin[o] = vmn; p.imin[o] = imn;
       }
+    }
+  }
+}
+
+// Vector form of the backward epilogue for full tiles with 16-byte aligned rows: the wave's accumulators go through its
+// private LDS region; every lane then owns 4 consecutive channels of a few rows -- one dwordx4 load of the producer's
+// output, the ReLU mask, one dwordx4 store, and the two BatchNorm-backward sums in registers (reduced over the 4 lane
+// groups that share a channel quad).  16 + 16 memory instructions per lane instead of 64 + 64.
+template <int IT, int JT, int WI, int WJ>
+__device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
+                                                     float* __restrict__ red, int tile, long m0, int n0) {
+  constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32, RW = IT / WI, CW = JT / WJ;
+  constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int colw = wj * CW, roww = wi * RW;
+  float* st = red + wave * SPG_EPI_WAVE_FLOATS(RW, CW);
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) st[(32 * i + spg_acc_row(q, h)) * LD + 32 * j + r] = acc[i][j][q];
+  const bool do_stats = p.stat != nullptr && p.mmean != nullptr;           // uniform
+  const bool do_mask = p.mask_relu != 0 && p.Yp != nullptr;                // uniform
+  const bool use_y = p.Yp != nullptr && (do_stats || do_mask);
+  const int lr = lane / LPR, lc = 4 * (lane % LPR);
+  const int col = n0 + colw + lc;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, mean = sh, rstd = sh;
+  if (p.ms != nullptr) { sc = *reinterpret_cast<const f32x4*>(p.ms + col); sh = *reinterpret_cast<const f32x4*>(p.mt + col); }
+  if (do_stats) { mean = *reinterpret_cast<const f32x4*>(p.mmean + col); rstd = *reinterpret_cast<const f32x4*>(p.mrstd + col); }
+  const float* yp = p.Yp + (m0 + roww) * p.ldyp + n0 + colw;
+  float* yo = p.Y + (m0 + roww) * p.ldy + n0 + colw;
+  const unsigned op0 = (unsigned)lr * (unsigned)p.ldyp + (unsigned)lc, oo0 = (unsigned)lr * (unsigned)p.ldy + (unsigned)lc;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  constexpr int NIT = RW / RPI, BATCH = NIT < 8 ? NIT : 8;
+#pragma unroll
+  for (int b = 0; b < NIT; b += BATCH) {
+    f32x4 yv[BATCH];
+    if (use_y) {
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) yv[u] = *reinterpret_cast<const f32x4*>(yp + op0 + (unsigned)(RPI * (b + u)) * (unsigned)p.ldyp);
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * (b + u)) * LD + lc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = use_y ? yv[u][e] : 0.f;
+        if (do_mask && !(fmaf(y, sc[e], sh[e]) > 0.f)) v[e] = 0.f;
+        if (do_stats) {
+          s1[e] += v[e];
+          s2[e] = fmaf(v[e], (y - mean[e]) * rstd[e], s2[e]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(yo + oo0 + (unsigned)(RPI * (b + u)) * (unsigned)p.ldy) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (p.stat != nullptr) {
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+    }
+    if (lane < LPR) {
+      const long part = (long)tile * WI + wi;
+      *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 0) * p.N + col) = s1;
+      *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 1) * p.N + col) = s2;
     }
   }
 }
@@ -399,7 +506,8 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
     else spg_epilogue_fwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
   } else {
     const bool full = mvalid == IT && n0 + JT <= p.N && (n0 + JT <= p.n_mask || (p.stat == nullptr && !p.mask_relu));
-    if (full) spg_epilogue_bwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
+    if (FULL && full && p.vec_store) spg_epilogue_bwd_vec<IT, JT, WI, WJ>(p, acc, red, tile, m0, n0);
+    else if (full) spg_epilogue_bwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
     else spg_epilogue_bwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
   }
 }
@@ -420,7 +528,9 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
   size_t lds = (size_t)(SPG_KC / 4) * (IT + 1) * sizeof(f32x4) +
                (WRED ? (size_t)SPG_KC * (JT + 4) * sizeof(float) : (size_t)(SPG_KC / 4) * (JT + 1) * sizeof(f32x4));
   if (AMODE >= 0) lds *= 2;
-  const size_t epi = (size_t)4 * WI * JT * sizeof(float);
+  size_t epi = (size_t)4 * WI * JT * sizeof(float);
+  const size_t epi_vec = (size_t)4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) * sizeof(float);
+  if (epi < epi_vec) epi = epi_vec;
   if (lds < epi) lds = epi;
   dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
@@ -432,7 +542,12 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
     const bool full = mode_ok && p.rows_per_tile == IT && p.M % IT == 0 && p.K % SPG_KC == 0 && p.N % JT == 0 &&
                       (long)IT * p.a.ld < (1L << 29) && (long)(WRED ? SPG_KC : JT) * p.ldw < (1L << 29);
     if (full) {
-      hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true>), grid, dim3(SPG_THREADS), lds, stream, p);
+      SpgGemmParams q = p;
+      q.vec_store = p.Y != nullptr && (p.ldy & 3) == 0 && (((uintptr_t)p.Y) & 15) == 0;
+      if (WRED)    // the backward epilogue also reads the producer's output and the per-channel constants as quads
+        q.vec_store = q.vec_store && (p.N & 3) == 0 && (p.Yp == nullptr || ((p.ldyp & 3) == 0 && (((uintptr_t)p.Yp) & 15) == 0)) &&
+                      ((((uintptr_t)p.ms) | ((uintptr_t)p.mt) | ((uintptr_t)p.mmean) | ((uintptr_t)p.mrstd) | ((uintptr_t)p.stat)) & 15) == 0;
+      hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true>), grid, dim3(SPG_THREADS), lds, stream, q);
       SPG_LAUNCH_CHECK();
       return 0;
     }
