@@ -78,6 +78,20 @@ def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
                       'oracle/spg_oracle.py train_step on torch-CPU'}
 
 
+def gemm_traffic(args):
+    """HBM bytes per row-GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    runs, gfx950 correction applied; profiles/*_gemm_traffic.json) -- only for the workload they were collected on."""
+    import glob
+    default = (args.scenes == 1 and args.n_sp == 1000 and args.n_edges == 5000 and args.model_config == 'gru_10_0,f_13'
+               and args.n_feat == 14)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_gemm_traffic.json')))
+    if not default or not files:
+        return None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    return t['hbm_mb_per_launch'] * 1e6        # bytes per launch, like `achieved` (which is FLOP per launch / duration)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -225,7 +239,7 @@ def main():
         log('instrumented pass done')
         ach = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': gemm_traffic(args), 'traffic_unit': 'HBM bytes per launch (PMC, profiles/*_gemm_traffic.json)',
                               'kernel': 'spg_rowgemm_kernel + spg_wgrad_kernel (fp32 MFMA 32x32x2)',
                               'launches_per_step': launches.value / nprof, 'gemm_ms_per_step': ms.value / nprof,
                               'algorithmic_gflop_per_step': flops.value / nprof / 1e9}
