@@ -426,7 +426,25 @@ int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 template <int CELL>
 __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepBwd p) {
-  __shared__ __attribute__((aligned(16))) float lds[4][5][CELL == SPG_CELL_LSTM ? 128 : 96];
+  constexpr int GW = CELL == SPG_CELL_LSTM ? 128 : 96;
+  __shared__ __attribute__((aligned(16))) float lds[4][5][GW];
+  // the backward needs COLUMNS of the weight matrices (dx[c] = sum_o W[o][c] dg[o]): the block stages them in LDS once
+  // (loads issued here, in flight during the reverse gather) instead of 2*GW+32 global loads per lane
+  constexpr int WQ = (2 * GW * 32 + 1024) / 4;                   // float4 slots: w_ih | w_hh | w_ig
+  __shared__ f32x4 sw4[WQ];
+  constexpr int WPT = (WQ + SPG_THREADS - 1) / SPG_THREADS;
+  f32x4 wreg[WPT];
+  if (!p.final_only) {
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      const int idx = threadIdx.x + SPG_THREADS * u;
+      const int ii = idx < WQ ? idx : 0;
+      const f32x4* src = ii < GW * 8 ? reinterpret_cast<const f32x4*>(p.gru.w_ih) + ii
+                       : (ii < 2 * GW * 8 ? reinterpret_cast<const f32x4*>(p.gru.w_hh) + (ii - GW * 8)
+                                          : reinterpret_cast<const f32x4*>(p.gru.ingate ? p.gru.w_ig : p.gru.w_ih) + (ii - 2 * GW * 8));
+      wreg[u] = *src;
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 4 + wave;
   const bool active = j < p.g.N;
@@ -502,6 +520,14 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     sa[lane] = active ? p.agg[(long)j * p.ldagg + lane] : 0.f;
     sh[lane] = active ? p.hin[(long)j * p.ld + lane] : 0.f;
   }
+#pragma unroll
+  for (int u = 0; u < WPT; ++u) {
+    const int idx = threadIdx.x + SPG_THREADS * u;
+    if (idx < WQ) sw4[idx] = wreg[u];
+  }
+  const float* sw_ih = reinterpret_cast<const float*>(sw4);
+  const float* sw_hh = sw_ih + GW * 32;
+  const float* sw_ig = sw_hh + GW * 32;
   __syncthreads();
   const SpgGruParams& G = p.gru;
   if constexpr (CELL == SPG_CELL_LSTM) {
@@ -551,8 +577,8 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     if (lane < 32) {
 #pragma unroll 8
       for (int o = 0; o < 128; ++o) {
-        dx = fmaf(G.w_ih[o * 32 + lane], sa[o], dx);
-        dh_acc = fmaf(G.w_hh[o * 32 + lane], sh[o], dh_acc);
+        dx = fmaf(sw_ih[o * 32 + lane], sa[o], dx);
+        dh_acc = fmaf(sw_hh[o * 32 + lane], sh[o], dh_acc);
       }
     }
     float da = dx, dpre = 0.f;
@@ -564,7 +590,7 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     __syncthreads();
     if (G.ingate && lane < 32) {
 #pragma unroll 8
-      for (int o = 0; o < 32; ++o) dh_acc = fmaf(G.w_ig[o * 32 + lane], sd[o], dh_acc);
+      for (int o = 0; o < 32; ++o) dh_acc = fmaf(sw_ig[o * 32 + lane], sd[o], dh_acc);
     }
     if (active && lane < 32) {
       p.dpre[(long)j * p.ld32 + lane] = dpre;
@@ -636,8 +662,8 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     if (lane < 32) {
   #pragma unroll 8
       for (int o = 0; o < 96; ++o) {
-        dx = fmaf(G.w_ih[o * 32 + lane], sa[o], dx);
-        dh_acc = fmaf(G.w_hh[o * 32 + lane], sh[o], dh_acc);
+        dx = fmaf(sw_ih[o * 32 + lane], sa[o], dx);
+        dh_acc = fmaf(sw_hh[o * 32 + lane], sh[o], dh_acc);
       }
     }
     float da = dx, dpre = 0.f;
@@ -649,7 +675,7 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     __syncthreads();
     if (G.ingate && lane < 32) {
   #pragma unroll 8
-      for (int o = 0; o < 32; ++o) dh_acc = fmaf(G.w_ig[o * 32 + lane], sd[o], dh_acc);
+      for (int o = 0; o < 32; ++o) dh_acc = fmaf(sw_ig[o * 32 + lane], sd[o], dh_acc);
     }
     if (active && lane < 32) {
       p.dpre[(long)j * p.ld32 + lane] = dpre;
