@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define SPG_MAX_LAYERS 8
-#define SPG_VERSION 103
+#define SPG_VERSION 104
 
 const char* spg_last_error(void);
 int spg_version(void);
@@ -177,6 +177,16 @@ int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* gra
 int spg_load_superpoints(const float* points, int ncols, const int64_t* offsets, int n_superpoints, const int32_t* slot,
                          const int32_t* sample_idx, int npts, int xyznormalize, const int32_t* colmap, int nfeat,
                          const double* M, const float* noise, float* clouds, float* diam, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Evaluation accounting on the device (learning/main.py:246-263, eval_final :267-311, metrics.py:16-18):
+ * logits [n_samples][N][C] (sample_stride floats between samples; the mean over the test-time samples is taken in
+ * float32 in sample order like np.mean), pred i64 [N] = first arg-max per superpoint, and for superpoints with
+ * label_mode != -100: confusion i64 [C][C] (ground truth x predicted) += label_vec[i, :] in column pred_i,
+ * counters[0] += (pred == label_mode), counters[1] += 1.  Exact integer atomics; confusion / counters accumulate.
+ * ---------------------------------------------------------------------------------------------- */
+int spg_eval_accumulate(const float* logits, int n_samples, long sample_stride, int N, int C, const int64_t* label_mode,
+                        const int64_t* label_vec, int64_t* pred, int64_t* confusion, int64_t* counters, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Synchronised BatchNorm for the data-parallel mode (the reference's single process normalises over

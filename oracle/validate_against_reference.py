@@ -401,6 +401,43 @@ def check_loader(write):
     del sys.modules['h5py'], sys.modules['transforms3d']
 
 
+def check_metrics(write):
+    """metrics.ConfusionMatrix (learning/metrics.py) imported from the reference, driven like eval_final does."""
+    from oracle import spg_metrics_oracle as MO
+    from learning import metrics as refmetrics
+    print('== metrics: ConfusionMatrix / eval accounting')
+    rng = np.random.default_rng(5)
+    N, C, S = 300, 13, 3
+    samples = [rng.normal(size=(N, C)).astype(np.float32) for _ in range(S)]
+    samples[1][7] = samples[0][7] = samples[2][7] = 0.25          # an exact tie: the first arg-max wins
+    label_vec = rng.integers(0, 4000, size=(N, C)).astype(np.int64) * (rng.random((N, C)) < 0.3)
+    label_mode = np.where(label_vec.sum(1) == 0, -100, label_vec.argmax(1)).astype(np.int64)
+    label_vec[:, 11] = 0                                          # a class that never occurs as ground truth
+    out = {}
+    for tag, smp in (('multi', samples), ('single', samples[:1])):
+        ref = refmetrics.ConfusionMatrix(C)
+        o = np.mean(np.stack(smp, 0), 0) if len(smp) > 1 else smp[0]
+        idx = label_mode != -100
+        ref.count_predicted_batch(label_vec[idx], np.argmax(o[idx], 1))
+        pred, cm, correct, counted = MO.aggregate(smp, label_mode, label_vec, C)
+        assert np.array_equal(cm, ref.confusion_matrix) and np.array_equal(pred, np.argmax(o, 1))
+        iou, oa, miou, mca = MO.scores(cm)
+        assert iou == ref.get_intersection_union_per_class() and oa == ref.get_overall_accuracy()
+        assert miou == ref.get_average_intersection_union() and mca == ref.get_mean_class_accuracy()
+        print(f'  {tag}: confusion matrix, predictions and all four scores equal the reference bit for bit '
+              f'(OA {oa:.4f}, mIoU {miou:.4f}, {counted} counted superpoints)')
+        out[tag] = dict(pred=pred, cm=cm, correct=np.int64(correct), counted=np.int64(counted),
+                        iou=np.array(iou), oa=np.float64(oa), miou=np.float64(miou), mca=np.float64(mca))
+    if write:
+        path = os.path.join(ROOT, 'tests', 'golden', 'metrics.npz')
+        arrs = dict(samples=np.stack(samples), label_vec=label_vec, label_mode=label_mode)
+        for tag, d in out.items():
+            for k, v in d.items():
+                arrs[f'{tag}/{k}'] = v
+        np.savez_compressed(path, **arrs)
+        print(f'  wrote {path}')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--write', action='store_true', help='write tests/golden/*.npz')
@@ -412,6 +449,8 @@ def main():
         check_ops(refmods, a.write)
     if a.only in ('', 'loader'):
         check_loader(a.write)
+    if a.only in ('', 'metrics'):
+        check_metrics(a.write)
     cw = torch.linspace(0.5, 1.5, 13)
     # S3DIS production config (S3DIS.md:26-28): matrix filters, 10 GRU iterations, state concat
     if a.only in ('', 's3dis_gru10_matrix'):

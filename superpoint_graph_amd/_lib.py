@@ -68,6 +68,7 @@ SIGNATURES = {
     'spg_adam_clamp_step': (_i, [_p, _p, _p, _p, _l, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_float, _i, _p]),
     'spg_load_superpoints': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
+    'spg_eval_accumulate': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
     'spg_set_bn_allreduce': (_i, [_p, _p, _p, _l]),
     'spg_prof_enable': (None, [_i]),
     'spg_prof_read': (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double), _i]),

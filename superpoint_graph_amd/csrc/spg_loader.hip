@@ -144,3 +144,51 @@ extern "C" int spg_load_superpoints(const float* points, int ncols, const int64_
   SPG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation accounting on the device (reference learning/main.py:246-263 and eval_final :267-311 with
+// learning/metrics.py:16-18): mean of the logits over the test-time samples, arg-max prediction of every superpoint,
+// and for the superpoints with ground truth (label_mode != -100, main.py:447-452) the confusion-matrix update
+// confusion[:, pred_i] += label_vec[i, :] plus the top-1 accuracy counters.  Integer accumulation with 64-bit atomics:
+// exact, hence order-independent.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void spg_eval_accumulate_kernel(const float* __restrict__ logits, int S, long sstride, int N, int C,
+                                           const int64_t* __restrict__ label_mode, const int64_t* __restrict__ label_vec,
+                                           int64_t* __restrict__ pred, unsigned long long* __restrict__ confusion,
+                                           unsigned long long* __restrict__ counters) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int best = 0;
+  float bv = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float v = logits[(long)i * C + c];
+    // np.mean(np.stack(o, 0), 0): float32 sum over the samples in order, then one division (main.py:296-297)
+    for (int s = 1; s < S; ++s) v += logits[s * sstride + (long)i * C + c];
+    if (S > 1) v = v / (float)S;
+    if (c == 0 || v > bv) { bv = v; best = c; }      // np.argmax: the first maximum
+  }
+  pred[i] = best;
+  const int64_t t = label_mode[i];
+  if (t == -100) return;                              // no ground truth: not counted (filter_valid)
+  for (int c = 0; c < C; ++c) {
+    const int64_t n = label_vec[(long)i * C + c];
+    if (n != 0) atomicAdd(&confusion[(long)c * C + best], (unsigned long long)n);
+  }
+  atomicAdd(&counters[1], 1ull);
+  if ((int64_t)best == t) atomicAdd(&counters[0], 1ull);
+}
+}  // namespace
+
+extern "C" int spg_eval_accumulate(const float* logits, int n_samples, long sample_stride, int N, int C,
+                                   const int64_t* label_mode, const int64_t* label_vec, int64_t* pred,
+                                   int64_t* confusion, int64_t* counters, void* stream) {
+  SPG_CHECK_ARG(logits && label_mode && label_vec && pred && confusion && counters, "null pointer");
+  SPG_CHECK_ARG(n_samples >= 1 && N >= 0 && C >= 1, "n_samples >= 1, C >= 1");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(spg_eval_accumulate_kernel, dim3(spg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, logits, n_samples,
+                     sample_stride, N, C, label_mode, label_vec, pred, reinterpret_cast<unsigned long long*>(confusion),
+                     reinterpret_cast<unsigned long long*>(counters));
+  SPG_LAUNCH_CHECK();
+  return 0;
+}

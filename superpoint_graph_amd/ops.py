@@ -329,3 +329,21 @@ def load_superpoints(points, offsets, slot, sample_idx, colmap, xyznormalize: bo
                                      int(bool(xyznormalize)), ctypes.cast(colmap_h, ctypes.c_void_p), F, _ptr(M), _ptr(noise), _ptr(clouds),
                                      _ptr(diam), _stream()), 'spg_load_superpoints')
     return clouds, diam
+
+
+# --------------------------------------------------------------------------------------------------
+# evaluation accounting
+# --------------------------------------------------------------------------------------------------
+def eval_accumulate(logits, label_mode, label_vec, confusion, counters):
+    """logits f32 [N, C] or [S, N, C]; label_mode i64 [N]; label_vec i64 [N, C]; confusion i64 [C, C] and counters i64 [2]
+    are accumulated in place.  Returns pred i64 [N]."""
+    _req(logits, torch.float32, 'logits'); _req(label_mode, torch.int64, 'label_mode'); _req(label_vec, torch.int64, 'label_vec')
+    _req(confusion, torch.int64, 'confusion'); _req(counters, torch.int64, 'counters')
+    S = 1 if logits.dim() == 2 else logits.shape[0]
+    N, C = logits.shape[-2], logits.shape[-1]
+    if label_vec.shape != (N, C) or label_mode.shape != (N,) or confusion.shape != (C, C):
+        raise ValueError('shapes: logits [S,]N,C; label_vec N,C; label_mode N; confusion C,C')
+    pred = torch.empty(N, dtype=torch.int64, device=logits.device)
+    check(lib().spg_eval_accumulate(_ptr(logits), S, N * C, N, C, _ptr(label_mode), _ptr(label_vec), _ptr(pred),
+                                    _ptr(confusion), _ptr(counters), _stream()), 'spg_eval_accumulate')
+    return pred

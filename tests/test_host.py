@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(hip, name), f'{name} declared in include/spg_hip.h but not exported'
         assert name in _lib.SIGNATURES, f'{name} has no ctypes signature'
-    assert hip.spg_version() == 103
+    assert hip.spg_version() == 104
 
 
 def test_size_queries(hip):

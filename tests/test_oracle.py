@@ -108,3 +108,29 @@ def test_loader_oracle_matches_reference_golden():
     for r in rows:
         acc = acc + r
     assert np.array_equal(acc / np.float32(128), np.mean(rows, axis=0))
+
+
+def test_metrics_oracle_and_host_mirror_match_reference_golden():
+    """Evaluation accounting (reference learning/metrics.py + main.py eval loops): the oracle and the host interface of the
+    product's ConfusionMatrix against the values the imported reference produced (tests/golden/metrics.npz)."""
+    import os
+    from conftest import GOLDEN
+    from oracle import spg_metrics_oracle as MO
+    from superpoint_graph_amd.learning import metrics
+    g = np.load(os.path.join(GOLDEN, 'metrics.npz'))
+    samples, lv, lm = list(g['samples']), g['label_vec'], g['label_mode']
+    for tag, smp in (('multi', samples), ('single', samples[:1])):
+        pred, cm, correct, counted = MO.aggregate(smp, lm, lv, 13)
+        assert np.array_equal(pred, g[f'{tag}/pred']) and np.array_equal(cm, g[f'{tag}/cm'])
+        assert (correct, counted) == (int(g[f'{tag}/correct']), int(g[f'{tag}/counted']))
+        iou, oa, miou, mca = MO.scores(cm)
+        assert np.array_equal(np.array(iou), g[f'{tag}/iou']) and oa == float(g[f'{tag}/oa'])
+        assert miou == float(g[f'{tag}/miou']) and mca == float(g[f'{tag}/mca'])
+        # the product class, host interface (same method names as the reference)
+        m = metrics.ConfusionMatrix(13)
+        idx = lm != -100
+        m.count_predicted_batch(lv[idx], pred[idx])
+        assert np.array_equal(m.confusion_matrix, cm)
+        assert m.get_intersection_union_per_class() == iou and m.get_overall_accuracy() == oa
+        assert m.get_average_intersection_union() == miou and m.get_mean_class_accuracy() == mca
+    assert g['multi/pred'][7] == 0          # exact tie: the first arg-max
