@@ -49,3 +49,11 @@ def test_two_ranks_sync_bn_reproduce_single_process_reference(hip):
 
 def test_two_ranks_local_bn_is_a_different_model(hip):
     _run_world2(0)
+
+
+def test_rccl_collectives_single_rank_smoke(hip):
+    """every collective of the data-parallel mode on the RCCL backend (one rank: the test box has one GPU)"""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), 'tools', 'rccl_smoke.py')], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and 'rccl smoke ok' in out.stdout, (out.stdout + out.stderr)[-3000:]
