@@ -28,6 +28,7 @@ void spg_set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // optional instrumentation (bench.py): hipEvents around every MFMA GEMM launch, on the launch stream
 // ---------------------------------------------------------------------------------------------
+#include <mutex>
 #include <vector>
 namespace {
 struct ProfRec { hipEvent_t a, b; double flops; };
@@ -945,8 +946,10 @@ int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t 
 
 static int* g_fin_counters = nullptr;    // 4096 self-resetting tickets (the only device memory the library owns)
 static unsigned g_fin_next = 0;
+static std::mutex g_fin_mutex;           // host threads may drive different streams of the (single) device
 
 static int* spg_fin_counter_window(int n) {
+  std::lock_guard<std::mutex> lock(g_fin_mutex);
   if (g_fin_counters == nullptr) {
     if (hipMalloc((void**)&g_fin_counters, 4096 * sizeof(int)) != hipSuccess) return nullptr;
     if (hipMemset(g_fin_counters, 0, 4096 * sizeof(int)) != hipSuccess) return nullptr;
