@@ -205,3 +205,66 @@ def test_baseline_size_properties(hip):
     # layers in front of a max-pool: one flipped near-tie moves a gradient by ~1e-3 relative
     assert max(err_hip.values()) < 1e-2, err_hip
     assert sorted(err_hip.values())[len(err_hip) // 2] < 3 * sorted(err_o32.values())[len(err_o32) // 2] + 1e-4
+
+
+_ODD_SPECS = {
+    # 64 points, widths that are no multiples of 32, vector filters, 6 classes
+    'p64_odd_widths': dict(spec=dict(model_config='gru_3_1,f_6', node_feats=9, ptn_nfeat_stn=9, ptn_npts=64,
+                                     ptn_widths=((48, 80, 96), (96, 40, 32)), ptn_widths_stn=((24, 40), (40, 20))),
+                           n_sp=37, n_edges=140, n_classes=6),
+    # 100 points per superpoint (partial row tiles everywhere), matrix filters, no state concatenation
+    'p100_matrix': dict(spec=dict(model_config='gru_2_0_1_1_0,f_5', node_feats=11, ptn_nfeat_stn=11, ptn_npts=100,
+                                  ptn_widths=((64, 64, 128), (128, 64, 32)), ptn_widths_stn=((32, 64), (64, 16))),
+                        n_sp=45, n_edges=200, n_classes=5),
+    # 50 points (not even a multiple of 4), 2-feature spatial transformer (the reference's default nfeat_stn), LSTM cell
+    'p50_stn2_lstm': dict(spec=dict(model_config='lstm_2_1,f_4', node_feats=6, ptn_nfeat_stn=2, ptn_npts=50,
+                                    ptn_widths=((32, 64), (64, 32)), ptn_widths_stn=((16, 32), (32, 16))),
+                          n_sp=29, n_edges=90, n_classes=4),
+}
+
+
+@pytest.mark.parametrize('name', sorted(_ODD_SPECS))
+def test_odd_shapes_train_step_vs_oracle(hip, name):
+    """Shapes off the production path (partial tiles, widths that are not multiples of the tile sizes, odd point counts):
+    a whole training step against the fp32 CPU oracle on the same seeded scene."""
+    cfg = _ODD_SPECS[name]
+    spec = O.ModelSpec(**cfg['spec'])
+    sc = synth.scene(5, n_sp=cfg['n_sp'], n_edges=cfg['n_edges'], n_feat=spec.node_feats, n_pts=spec.ptn_npts,
+                     n_classes=cfg['n_classes'], small_frac=0.15)
+    col = synth.collate_numpy([sc])
+    idxn, degs, ef, ei = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    torch.manual_seed(3)
+    model = build_model(spec)
+    with torch.no_grad():                       # non-trivial BatchNorm parameters / spatial transformer
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.normal_(1, 0.3); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.8, 1.2)
+        model.ptn.stn.proj.weight.normal_(0, 0.05)
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cw = torch.linspace(0.5, 1.5, cfg['n_classes'])
+    st = {k: v.clone() for k, v in state0.items()}
+    loss_o, logits_o, emb_o, grads_o = O.train_step(batch, spec, st, cw)
+    model = model.to(DEV).train()
+    emb, logits, embedder = _run(model, batch, 1)
+    loss = F.cross_entropy(logits, batch['label_mode'].to(DEV), weight=cw.to(DEV))
+    model.zero_grad()
+    loss.backward()
+    embedder.bw_hook()
+    assert maxrel(emb, emb_o) < TOL and maxrel(logits, logits_o) < TOL and maxrel(loss, loss_o) < TOL
+    bad = {}
+    for k, p in model.named_parameters():
+        ref = grads_o[k]
+        if float(ref.abs().max()) < 1e-6:
+            assert float(p.grad.abs().max()) < 1e-5, k
+            continue
+        e = maxrel(p.grad, ref)
+        if e > 1e-3:
+            bad[k] = e
+    assert not bad, bad
+    sd = model.state_dict()
+    for k, v in st.items():
+        if 'running' in k:
+            assert maxrel(sd[k].double(), v.double()) < 1e-5, k
