@@ -57,3 +57,47 @@ def test_rccl_collectives_single_rank_smoke(hip):
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), 'tools', 'rccl_smoke.py')], env=env,
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and 'rccl smoke ok' in out.stdout, (out.stdout + out.stderr)[-3000:]
+
+
+def test_sync_bn_world1_equals_local_bn_at_full_size(hip):
+    """At world size 1 the synchronised mode (reduce -> callback -> finish, here on top of the sliced reduction of the
+    large layers) must reproduce the fused finalize bit for bit: same fp64 sums, same finishing arithmetic."""
+    import types
+
+    import torch
+    import torch.nn.functional as F
+
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from superpoint_graph_amd import dist as spd
+    from superpoint_graph_amd.learning import pointnet
+    dev = torch.device('cuda')
+    model = bench.build_model('gru_10_0,f_13', dev).train()
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    targets, GIs, flag, clouds, diam, _ = bench.make_batch([0], 1000, 5000)
+    clouds_d, diam_d, label = clouds.to(dev), diam.to(dev), targets[:, 0].to(dev)
+    model.ecc.set_info(GIs, 1)
+
+    def run():
+        model.load_state_dict(state0)
+        model.zero_grad()
+        emb_er = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
+        emb = emb_er.run(model, None, flag, clouds_d, diam_d)
+        out = model.ecc(emb)
+        F.cross_entropy(out, label).backward()
+        emb_er.bw_hook()
+        return out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, \
+            {k: v.detach().clone() for k, v in model.state_dict().items() if 'running' in k}
+
+    out0, g0, r0 = run()
+    st = spd.enable_sync_bn(dev)
+    try:
+        out1, g1, r1 = run()
+    finally:
+        spd.disable_sync_bn()
+    assert st['error'] is None and st['calls'] >= 26
+    assert torch.equal(out0, out1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
