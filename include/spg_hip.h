@@ -216,6 +216,11 @@ int spg_adam_clamp_step(float* param, float* grad, float* exp_avg, float* exp_av
  * ---------------------------------------------------------------------------------------------- */
 void spg_prof_enable(int on);
 int spg_prof_read(double* ms, long* launches, double* flops, int reset);
+/* the same, restricted to one kernel instantiation: tag = spg_prof_tag(kind, IT, JT, x, y, full) with kind 1 = row-GEMM
+ * (x = 1 for the data-gradient form, y = operand mode of A) or 2 = weight gradient (x, y = operand modes of A and B);
+ * call before spg_prof_read(..., reset = 1) */
+int spg_prof_tag(int kind, int it, int jt, int x, int y, int full);
+int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,8 @@ SIGNATURES = {
     'spg_eval_accumulate': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
     'spg_set_bn_allreduce': (_i, [_p, _p, _p, _l]),
     'spg_prof_enable': (None, [_i]),
+    'spg_prof_tag': (_i, [_i, _i, _i, _i, _i, _i]),
+    'spg_prof_read_tag': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double)]),
     'spg_prof_read': (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double), _i]),
 }
 

@@ -31,18 +31,36 @@ void spg_set_error(const char* fmt, ...) {
 #include <mutex>
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int tag; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 struct ProfScope {
   hipStream_t st; bool on; ProfRec r;
-  ProfScope(hipStream_t s, double flops) : st(s), on(g_prof_on) {
-    if (on) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.flops = flops; (void)hipEventRecord(r.a, st); }
+  ProfScope(hipStream_t s, double flops, int tag = 0) : st(s), on(g_prof_on) {
+    if (on) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.flops = flops; r.tag = tag; (void)hipEventRecord(r.a, st); }
   }
   ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); } }
 };
 }  // namespace
 extern "C" void spg_prof_enable(int on) { g_prof_on = on != 0; }
+// kernel tag of an instrumented launch: kind (1 row-GEMM, 2 weight gradient), tile, weight layout / operand modes, fast path
+#define SPG_PROF_TAG(kind, IT, JT, X, Y, FULL) ((kind) * 1000000 + ((IT) / 32) * 100000 + ((JT) / 32) * 10000 + ((X) + 1) * 100 + ((Y) + 1) * 10 + (FULL))
+extern "C" int spg_prof_tag(int kind, int it, int jt, int x, int y, int full) { return SPG_PROF_TAG(kind, it, jt, x, y, full ? 1 : 0); }
+extern "C" int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops) {
+  double t = 0.0, f = 0.0;
+  long n = 0;
+  for (ProfRec& r : g_prof) {
+    if (r.tag != tag) continue;
+    (void)hipEventSynchronize(r.b);
+    float dt = 0.f;
+    (void)hipEventElapsedTime(&dt, r.a, r.b);
+    t += dt; f += r.flops; ++n;
+  }
+  if (ms) *ms = t;
+  if (launches) *launches = n;
+  if (flops) *flops = f;
+  return 0;
+}
 extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int reset) {
   double t = 0.0, f = 0.0;
   for (ProfRec& r : g_prof) {
@@ -548,11 +566,13 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
       if (WRED)    // the backward epilogue also reads the producer's output and the per-channel constants as quads
         q.vec_store = q.vec_store && (p.N & 3) == 0 && (p.Yp == nullptr || ((p.ldyp & 3) == 0 && (((uintptr_t)p.Yp) & 15) == 0)) &&
                       ((((uintptr_t)p.ms) | ((uintptr_t)p.mt) | ((uintptr_t)p.mmean) | ((uintptr_t)p.mrstd) | ((uintptr_t)p.stat)) & 15) == 0;
+      prof.r.tag = SPG_PROF_TAG(1, IT, JT, WRED ? 1 : 0, AMODE, 1);
       hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true>), grid, dim3(SPG_THREADS), lds, stream, q);
       SPG_LAUNCH_CHECK();
       return 0;
     }
   }
+  prof.r.tag = SPG_PROF_TAG(1, IT, JT, WRED ? 1 : 0, AMODE, 0);
   hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -803,11 +823,13 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
                       p.rows_per_split % SPG_KC == 0 && p.N % IT == 0 && p.K % JT == 0 &&
                       (long)SPG_KC * p.a.ld < (1L << 29) && (long)SPG_KC * p.b.ld < (1L << 29);
     if (full) {
+      prof.r.tag = SPG_PROF_TAG(2, IT, JT, AMODE, BMODE, 1);
       hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true>), grid, dim3(SPG_THREADS), lds, stream, p);
       SPG_LAUNCH_CHECK();
       return 0;
     }
   }
+  prof.r.tag = SPG_PROF_TAG(2, IT, JT, AMODE, BMODE, 0);
   hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
