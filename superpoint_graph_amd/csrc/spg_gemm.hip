@@ -894,23 +894,47 @@ struct SpgReduceBatch {
   int njobs;
 };
 
+// 256 output elements x 16 split-groups per workgroup: a wave reads 1 KiB of one partial per instruction (float4 per
+// lane, 4 loads in flight); fixed summation order (group-local sequence, then the 16 groups in order): deterministic
+#define SPG_REDUCE_ELEMS 256
 __global__ __launch_bounds__(1024) void spg_reduce_batch_kernel(const SpgReduceBatch b) {
-  __shared__ float red[16][64];
+  __shared__ f32x4 red[16][64];
   int j = 0;
   while (j + 1 < b.njobs && (int)blockIdx.x >= b.first_block[j + 1]) ++j;      // wave-uniform scan (<= 40 entries)
   const SpgReduceJob job = b.jobs[j];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long i = (long)(blockIdx.x - b.first_block[j]) * 64 + tx;
-  float s = 0.f;
-  if (i < job.n)
-    for (int k = ty; k < job.nsplit; k += 16) s += job.partial[(long)k * job.n + i];
+  const long i = ((long)(blockIdx.x - b.first_block[j]) * 64 + tx) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = (job.n & 3) == 0 && ((((uintptr_t)job.out) | ((uintptr_t)job.partial)) & 15) == 0;   // wave-uniform
+  if (vec) {                         // whole, aligned quads
+    if (i < job.n) {
+      int k = ty;
+      for (; k + 48 < job.nsplit; k += 64) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(job.partial + (long)k * job.n + i);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(job.partial + (long)(k + 16) * job.n + i);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(job.partial + (long)(k + 32) * job.n + i);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(job.partial + (long)(k + 48) * job.n + i);
+        s += v0; s += v1; s += v2; s += v3;
+      }
+      for (; k < job.nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(job.partial + (long)k * job.n + i);
+    }
+  } else {
+    for (int e = 0; e < 4; ++e)
+      if (i + e < job.n)
+        for (int k = ty; k < job.nsplit; k += 16) s[e] += job.partial[(long)k * job.n + i + e];
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && i < job.n) {
-    float t = 0.f;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][tx];      // fixed order: deterministic
-    job.out[i] = t;
+    if (vec) {
+      *reinterpret_cast<f32x4*>(job.out + i) = t;
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (i + e < job.n) job.out[i + e] = t[e];
+    }
   }
 }
 
@@ -921,7 +945,7 @@ int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream) {
   for (int j = 0; j < q.njobs; ++j) {
     b.jobs[j] = q.jobs[j];
     b.first_block[j] = blocks;
-    blocks += spg_cdiv(q.jobs[j].n, 64);
+    blocks += spg_cdiv(q.jobs[j].n, SPG_REDUCE_ELEMS);
   }
   b.first_block[q.njobs] = blocks;
   b.njobs = q.njobs;
