@@ -97,7 +97,6 @@ int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax
 // work: >= spg_colsum_workspace_floats(N) floats (spg_wgrad_workspace_floats(., N, .) is always large enough)
 size_t spg_colsum_workspace_floats(int N);
 int spg_launch_colsum(const float* X, long ld, long M, int N, float* out, float* work, hipStream_t stream);
-int spg_launch_transpose(const float* W, int N, int K, float* Wt, hipStream_t stream);
 // dst [rows, ldd] = src [rows, cols] with zero padding (ldd >= cols): 16-byte aligned weight rows for the vector path
 int spg_launch_pad_rows(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream);
 // dT[g, 2a+b] = sum_p clouds[g, a, p] * dxy[g*P + p, b]   (gradient of the 2x2 STN transform, pointnet.py:123)

@@ -1418,20 +1418,6 @@ int spg_launch_pad_rows(const float* src, long lds, float* dst, long ldd, long r
   return 0;
 }
 
-__global__ void spg_transpose_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ Wt) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)N * K) return;
-  const int k = (int)(i / N), n = (int)(i - (long)k * N);   // consecutive threads -> consecutive Wt elements
-  Wt[i] = W[(long)n * K + k];
-}
-
-int spg_launch_transpose(const float* W, int N, int K, float* Wt, hipStream_t stream) {
-  const long n = (long)N * K;
-  hipLaunchKernelGGL(spg_transpose_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, W, N, K, Wt);
-  SPG_LAUNCH_CHECK();
-  return 0;
-}
-
 __global__ void spg_stn_dT_kernel(const float* __restrict__ clouds, int Ctot, int P, int G, const float* __restrict__ dxy,
                                   long ldd, float* __restrict__ dT) {
   // one wavefront per superpoint
