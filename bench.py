@@ -92,6 +92,33 @@ def gemm_traffic(args):
     return t['hbm_mb_per_launch'] * 1e6        # bytes per launch, like `achieved` (which is FLOP per launch / duration)
 
 
+def forward_only(dev, flag, clouds_d, diam_d, GIs, n_feat, iters=40):
+    """BASELINE.json configs[1]: PointNet + 1 x ECC, FORWARD only, on the same scene (model `gru_1_0,f_13`), eval-mode
+    BatchNorm (inference) and train-mode BatchNorm (batch statistics), no autograd."""
+    import types
+    from superpoint_graph_amd.learning import pointnet
+    model = build_model('gru_1_0,f_13', dev, n_feat)
+    model.ecc.set_info(GIs, 1)
+    embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
+    out = {'workload': 'same scene, PointNet + gru_1_0,f_13 (one ECC iteration), forward only, no_grad'}
+    for mode in ('eval', 'train'):
+        model.train(mode == 'train')
+
+        def fwd():
+            with torch.no_grad():
+                return model.ecc(embedder.run(model, None, flag, clouds_d, diam_d))
+        for _ in range(5):
+            fwd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fwd()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[mode + '_bn'] = {'ms': dt * 1e3, 'superpoints_per_s': int(flag.numel()) / dt}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -104,6 +131,7 @@ def main():
     ap.add_argument('--n-feat', type=int, default=14, help='point features (14: S3DIS xyzrgbelpsvXYZ, 11: Semantic3D)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-forward-only', action='store_true', help='skip the forward-only side measurement (BASELINE configs[1])')
     ap.add_argument('--sync-bn', type=int, default=0, help='1: BatchNorm statistics all-reduced over the ranks (exact single-process batch semantics); 0: per-rank statistics')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
     args = ap.parse_args()
@@ -257,6 +285,9 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
+        if world == 1 and not args.no_forward_only:
+            model.ecc.set_info(GIs, 1)
+            result['forward_only'] = forward_only(dev, flag, clouds_d, diam_d, GIs, args.n_feat)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.model_config, scenes, state0, n_feat=args.n_feat)
         print(json.dumps(result), flush=True)
