@@ -81,7 +81,11 @@ int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                            int update_times, float* mean, float* rstd, float* s, float* t, double* scratch,
                            hipStream_t stream);
-// eval mode: s, t from the running statistics
+// eval mode: s, t from the running statistics; the batch form handles every BatchNorm layer of a network in one launch
+struct SpgBnEvalJob { int N; const float *gamma, *beta, *rm, *rv; float *s, *t; };
+#define SPG_BN_EVAL_MAX_JOBS 40
+struct SpgBnEvalBatch { SpgBnEvalJob jobs[SPG_BN_EVAL_MAX_JOBS]; int njobs = 0; };
+int spg_launch_bn_eval_batch(const SpgBnEvalBatch& b, float eps, hipStream_t stream);
 int spg_launch_bn_eval(int N, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* s, float* t, hipStream_t stream);
 // BatchNorm backward: partials [ntile][2][N] (sum dz, sum dz*xhat) -> consts[4][N] = {s, c1, mean, s*c2*rstd},

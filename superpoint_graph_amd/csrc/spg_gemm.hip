@@ -1188,6 +1188,26 @@ __global__ void spg_bn_eval_kernel(int N, const float* gamma, const float* beta,
   t[c] = (float)(be - (double)rm[c] * g * rstd);
 }
 
+// all BatchNorm layers of a network in ONE launch (eval mode: the constants depend on the parameters only)
+__global__ void spg_bn_eval_batch_kernel(const SpgBnEvalBatch b, float eps) {
+  const SpgBnEvalJob j = b.jobs[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= j.N) return;
+  const double rstd = 1.0 / sqrt((double)j.rv[c] + (double)eps);
+  const double g = j.gamma ? (double)j.gamma[c] : 1.0, be = j.beta ? (double)j.beta[c] : 0.0;
+  j.s[c] = (float)(g * rstd);
+  j.t[c] = (float)(be - (double)j.rm[c] * g * rstd);
+}
+
+int spg_launch_bn_eval_batch(const SpgBnEvalBatch& b, float eps, hipStream_t stream) {
+  if (b.njobs == 0) return 0;
+  int nmax = 1;
+  for (int i = 0; i < b.njobs; ++i) nmax = b.jobs[i].N > nmax ? b.jobs[i].N : nmax;
+  hipLaunchKernelGGL(spg_bn_eval_batch_kernel, dim3(spg_cdiv(nmax, 64), b.njobs), dim3(64), 0, stream, b, eps);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
 int spg_launch_bn_eval(int N, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* s, float* t, hipStream_t stream) {
   hipLaunchKernelGGL(spg_bn_eval_kernel, dim3(spg_cdiv(N, 64)), dim3(64), 0, stream, N, gamma, beta, running_mean,

@@ -191,7 +191,7 @@ int bn_stats(const Plan& pl, Layer& l, int ntile, int rows_per_tile, long M, int
   if (pl.training)
     return spg_launch_bn_finalize(pl.stat, ntile, rows_per_tile, M, l.cout, l.gamma, l.beta, l.rm, l.rv,
                                   pl.cfg.bn_momentum, pl.cfg.bn_eps, update_times, l.mean, l.rstd, l.s, l.t, pl.fin, st);
-  return spg_launch_bn_eval(l.cout, l.gamma, l.beta, l.rm, l.rv, pl.cfg.bn_eps, l.s, l.t, st);
+  return 0;     // eval mode: all layers were handled by one spg_launch_bn_eval_batch at the start of the forward
 }
 
 int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stnT, int update_times, hipStream_t st) {
@@ -202,6 +202,7 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     g.a = input_operand(pl, sg, false, k, clouds, stnT);
     g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = (int)pl.M; g.N = l.cout; g.K = l.cin;
     g.rows_per_tile = pl.P; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
+    if (last && !pl.training) g.Y = nullptr;     // inference: only the pooled values of the last conv are consumed
     g.stat = pl.training ? pl.stat : nullptr;
     if (last) { g.pmax = pl.pmax; g.pmin = pl.pmin; g.imax = pl.imax; g.imin = pl.imin; }
     SPG_TRY(spg_launch_gemm(g, st));
@@ -377,6 +378,15 @@ extern "C" int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const fl
   SPG_TRY(make_plan(cfg, B, training, workspace, params, emb, pl));
   SPG_CHECK_ARG(pl.cfg.nfeat_global == 0 || clouds_global != nullptr, "clouds_global is required");
   pl.main.extra = clouds_global;
+  if (!pl.training) {        // eval mode: the BatchNorm constants of every layer in one launch
+    SpgBnEvalBatch eb;
+    for (Layer& l : pl.L)
+      if (l.bn) {
+        SPG_CHECK_ARG(eb.njobs < SPG_BN_EVAL_MAX_JOBS, "too many BatchNorm layers");
+        eb.jobs[eb.njobs++] = SpgBnEvalJob{l.cout, l.gamma, l.beta, l.rm, l.rv, l.s, l.t};
+      }
+    SPG_TRY(spg_launch_bn_eval_batch(eb, pl.cfg.bn_eps, st));
+  }
   const float* stnT = nullptr;
   if (pl.has_stn) {
     SPG_TRY(forward_segment(pl, pl.stn, clouds, nullptr, bn_update_times, st));
