@@ -16,13 +16,18 @@ from superpoint_graph_amd.learning import pointnet  # noqa: E402
 
 def main():
     dev = torch.device('cuda', 0)
+    only = os.environ.get('FWD_ONLY', '')            # e.g. FWD_ONLY='gru_1_0,f_13:eval' (profiling)
     for cfgname in ('gru_10_0,f_13', 'gru_1_0,f_13', 'gru_10,f_13'):
+        if only and only.split(':')[0] != cfgname:
+            continue
         model = bench.build_model(cfgname, dev)
         targets, GIs, flag, clouds, diam, scenes = bench.make_batch([0], 1000, 5000)
         clouds_d, diam_d = clouds.to(dev), diam.to(dev)
         model.ecc.set_info(GIs, 1)
         emb = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
         for mode in ('eval', 'train'):
+            if only and only.split(':')[1] != mode:
+                continue
             model.train(mode == 'train')
             def fwd():
                 with torch.no_grad():
