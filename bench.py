@@ -131,6 +131,8 @@ def main():
     ap.add_argument('--n-feat', type=int, default=14, help='point features (14: S3DIS xyzrgbelpsvXYZ, 11: Semantic3D)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default: nccl = RCCL); gloo is for the control-flow test on a 1-GPU box')
+    ap.add_argument('--device-index', type=int, default=-1, help='GPU of this rank (default: LOCAL_RANK)')
     ap.add_argument('--no-forward-only', action='store_true', help='skip the forward-only side measurement (BASELINE configs[1])')
     ap.add_argument('--sync-bn', type=int, default=0, help='1: BatchNorm statistics all-reduced over the ranks (exact single-process batch semantics); 0: per-rank statistics')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
@@ -146,7 +148,11 @@ def main():
     T0 = time.perf_counter()
     from superpoint_graph_amd import _lib, dist as spd
     from superpoint_graph_amd.learning import pointnet
-    rank, local, world = spd.init_from_env()
+    if args.device_index >= 0:
+        torch.cuda.set_device(args.device_index)
+    rank, local, world = spd.init_from_env(args.backend)
+    if args.device_index >= 0:
+        local = args.device_index
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
@@ -249,10 +255,10 @@ def main():
                    'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics'},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         # dominant kernels = the MFMA row-GEMMs (PointNet convs/FCs + filter net, fwd/dgrad/wgrad): each launch bracketed by
         # hipEvents on its stream in a separate instrumented pass of the SAME step (events inside the timed region would
-        # perturb `value`).
+        # perturb `value`).  EVERY rank runs the pass (the step contains the gradient all-reduce); rank 0 reports.
         L = _lib.lib()
         import ctypes
         torch.cuda.synchronize()

@@ -101,3 +101,22 @@ def test_sync_bn_world1_equals_local_bn_at_full_size(hip):
         assert torch.equal(g0[k], g1[k]), k
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k
+
+
+def test_bench_two_ranks_control_flow(hip):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank); both ranks
+    share the test box's single GPU and talk over gloo, which exercises every rank-dependent branch (sharding, barriers,
+    the collectives of the step and of the instrumented pass, rank-0 reporting)."""
+    import json
+    root = os.path.dirname(HERE)
+    port = _free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+           '--backend', 'gloo', '--device-index', '0', '--n-sp', '200', '--n-edges', '800']
+    out = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                        # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['superpoints_per_step'] == 400
+    assert 'roofline' in d and 'cpu_baseline' not in d
