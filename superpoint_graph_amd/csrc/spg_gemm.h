@@ -106,3 +106,21 @@ int spg_launch_pad_rows(const float* src, long lds, float* dst, long ldd, long r
 // dT[g, 2a+b] = sum_p clouds[g, a, p] * dxy[g*P + p, b]   (gradient of the 2x2 STN transform, pointnet.py:123)
 int spg_launch_stn_dT(const float* clouds, int Ctot, int P, int G, const float* dxy, long ldd, float* dT,
                       hipStream_t stream);
+
+
+// ---- inference-mode convolution stack of one PointNet segment in a single kernel (spg_convstack.hip) ----
+#define SPG_CONVSTACK_MAX_LAYERS 8
+struct SpgConvStackParams {
+  const float* clouds;      // [B, Ctot, P] channel-major
+  const float* stnT;        // [B, 4] or null
+  int B, P, Ctot, nlayers;
+  int cin[SPG_CONVSTACK_MAX_LAYERS], cout[SPG_CONVSTACK_MAX_LAYERS];
+  const float *W[SPG_CONVSTACK_MAX_LAYERS], *bias[SPG_CONVSTACK_MAX_LAYERS];
+  const float *s[SPG_CONVSTACK_MAX_LAYERS], *t[SPG_CONVSTACK_MAX_LAYERS];   // eval-mode BatchNorm scale / shift (spg_launch_bn_eval*)
+  float *pmax, *pmin;       // [B][4][cout_last] per-wave raw max / min of the last layer (spg_launch_pool_select, 4 partials)
+};
+int spg_launch_pool_select_parts(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,
+                                 int G, int N, int nparts, const float* extra, int nextra, float* out, long ldo, int* aidx,
+                                 hipStream_t stream);
+bool spg_conv_stack_eval_supported(const SpgConvStackParams& p);
+int spg_launch_conv_stack_eval(const SpgConvStackParams& p, hipStream_t stream);

@@ -1345,13 +1345,13 @@ __global__ void spg_pool_select_kernel(const float* pmax, const float* pmin, con
     for (int w = 0; w < wi; ++w) {
       const long o = (g * wi + w) * N + c;
       const float ov = pmax[o], pv = pmin[o];
-      const int oi = imax[o], pi = imin[o];
+      const int oi = imax ? imax[o] : 0, pi = imin ? imin[o] : 0;      // no indices in inference
       if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
       if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
     }
     const bool up = s[c] >= 0.f;
     out[g * ldo + c] = up ? vmx : vmn;
-    aidx[g * ldo + c] = up ? imx : imn;   // aidx shares the leading dimension of `out`
+    if (aidx) aidx[g * ldo + c] = up ? imx : imn;   // aidx shares the leading dimension of `out`
   } else {
     out[g * ldo + c] = extra[g * nextra + (c - N)];
   }
@@ -1363,6 +1363,17 @@ int spg_launch_pool_select(const float* pmax, const float* pmin, const int* imax
   const long n = (long)G * (N + nextra);
   hipLaunchKernelGGL(spg_pool_select_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, pmax, pmin, imax, imin, s,
                      G, N, spg_gemm_row_waves(rows_per_tile, N), extra, nextra, out, ldo, aidx);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same with an explicit number of partials per group and optional (null) index arrays
+int spg_launch_pool_select_parts(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,
+                                 int G, int N, int nparts, const float* extra, int nextra, float* out, long ldo, int* aidx,
+                                 hipStream_t stream) {
+  const long n = (long)G * (N + nextra);
+  hipLaunchKernelGGL(spg_pool_select_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, pmax, pmin, imax, imin, s,
+                     G, N, nparts, extra, nextra, out, ldo, aidx);
   SPG_LAUNCH_CHECK();
   return 0;
 }

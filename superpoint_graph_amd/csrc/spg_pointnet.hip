@@ -194,8 +194,30 @@ int bn_stats(const Plan& pl, Layer& l, int ntile, int rows_per_tile, long M, int
   return 0;     // eval mode: all layers were handled by one spg_launch_bn_eval_batch at the start of the forward
 }
 
-int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stnT, int update_times, hipStream_t st) {
+// inference: the whole convolution stack + max-pool of a segment in one kernel (spg_convstack.hip), when its shape allows
+bool fused_eval_convs(Plan& pl, Segment& sg, const float* clouds, const float* stnT, SpgConvStackParams& cp) {
+  if (pl.training || sg.convs.size() > SPG_CONVSTACK_MAX_LAYERS) return false;
+  memset(&cp, 0, sizeof(cp));
+  cp.clouds = clouds; cp.stnT = stnT; cp.B = pl.B; cp.P = pl.P; cp.Ctot = pl.cfg.nfeat; cp.nlayers = (int)sg.convs.size();
   for (size_t k = 0; k < sg.convs.size(); ++k) {
+    const Layer& l = pl.L[sg.convs[k]];
+    if (!l.bn) return false;
+    cp.cin[k] = l.cin; cp.cout[k] = l.cout; cp.W[k] = l.W; cp.bias[k] = l.b; cp.s[k] = l.s; cp.t[k] = l.t;
+  }
+  cp.pmax = pl.pmax; cp.pmin = pl.pmin;
+  return spg_conv_stack_eval_supported(cp);
+}
+
+int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stnT, int update_times, hipStream_t st) {
+  SpgConvStackParams cp;
+  const bool fused = fused_eval_convs(pl, sg, clouds, stnT, cp);
+  if (fused) {
+    const Layer& ll = pl.L[sg.convs.back()];
+    SPG_TRY(spg_launch_conv_stack_eval(cp, st));
+    SPG_TRY(spg_launch_pool_select_parts(pl.pmax, pl.pmin, nullptr, nullptr, ll.s, pl.B, ll.cout, 4, sg.extra, sg.nextra,
+                                         sg.pooled, sg.ldpool, nullptr, st));
+  }
+  for (size_t k = 0; !fused && k < sg.convs.size(); ++k) {
     Layer& l = pl.L[sg.convs[k]];
     const bool last = k + 1 == sg.convs.size();
     SpgGemmParams g; memset(&g, 0, sizeof(g));
