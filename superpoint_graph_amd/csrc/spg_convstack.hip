@@ -20,21 +20,17 @@ constexpr int CS_APLANE = 32 + 1;                 // float4 slots per reduction 
 constexpr int CS_WAVE_F4 = (CS_KMAX / 4) * CS_APLANE;
 
 // one <=128-column pass of a layer for the wave's 32 rows: acc[j] += A[32 x K] * W[n0 + 32 j .. +31][K]^T
+// Weights are pre-packed per launch (spg_pack_w_kernel) in MFMA B-operand order: [K/8 groups][cout/32 tiles][64 lanes]
+// float4, lane (r, h) of tile t and group g holds W[32 t + r][8 g + 4 h .. +3] (zero beyond cin) -- one fully coalesced
+// 1 KiB load per operand instead of 32 strided 32-byte pieces (the per-CU L1 was the limiter with the row-major layout).
 template <int TJ>
-__device__ __forceinline__ void cs_gemm_pass(const f32x4* __restrict__ A, const float* __restrict__ W, int cin, int K, int n0,
-                                             int r, int h, bool vecw, f32x16 (&acc)[4]) {
+__device__ __forceinline__ void cs_gemm_pass(const f32x4* __restrict__ A, const f32x4* __restrict__ Wp, int ntile, int K,
+                                             int n0, int r, int h, f32x16 (&acc)[4]) {
+  const int lane = r + 32 * h, t0 = n0 >> 5;
   auto load_b = [&](int k0, f32x4 (&b)[TJ]) {
-    const int k = k0 + 4 * h;
+    const f32x4* src = Wp + ((long)(k0 >> 3) * ntile + t0) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const float* src = W + (long)(n0 + 32 * j + r) * cin + k;
-      if (vecw) {
-        b[j] = *reinterpret_cast<const f32x4*>(src);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b[j][e] = k + e < cin ? src[e] : 0.f;
-      }
-    }
+    for (int j = 0; j < TJ; ++j) b[j] = src[j * 64];
   };
   // two statically named fragment sets: the loads of the next group of 8 reduction steps fly during the MFMAs of this one
   f32x4 b0[TJ], b1[TJ];
@@ -91,9 +87,10 @@ __global__ __launch_bounds__(256, 2) void spg_conv_stack_eval_kernel(const SpgCo
   for (int l = 0; l < p.nlayers; ++l) {
     const int cin = p.cin[l], cout = p.cout[l];
     const int K = (cin + 7) & ~7;
+    (void)cin;
     const bool last = l + 1 == p.nlayers;
-    const float* __restrict__ W = p.W[l];
-    const bool vecw = (cin & 7) == 0 && ((((uintptr_t)W) & 15) == 0);
+    const f32x4* __restrict__ Wp = p.Wp[l];
+    const int ntile = cout >> 5;
     const float* __restrict__ cs = p.s[l];
     const float* __restrict__ ct = p.t[l];
     const float* __restrict__ bias = p.bias[l];
@@ -104,9 +101,9 @@ __global__ __launch_bounds__(256, 2) void spg_conv_stack_eval_kernel(const SpgCo
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-      if (NP == 128) cs_gemm_pass<4>(A4, W, cin, K, n0, r, h, vecw, acc);
-      else if (NP == 64) cs_gemm_pass<2>(A4, W, cin, K, n0, r, h, vecw, acc);
-      else cs_gemm_pass<1>(A4, W, cin, K, n0, r, h, vecw, acc);
+      if (NP == 128) cs_gemm_pass<4>(A4, Wp, ntile, K, n0, r, h, acc);
+      else if (NP == 64) cs_gemm_pass<2>(A4, Wp, ntile, K, n0, r, h, acc);
+      else cs_gemm_pass<1>(A4, Wp, ntile, K, n0, r, h, acc);
       const int TJ = NP / 32;
       if (!last) {
         // the whole reduction of this layer has been read: overwrite the tile in place with relu(s * y + t)
@@ -146,13 +143,33 @@ __global__ __launch_bounds__(256, 2) void spg_conv_stack_eval_kernel(const SpgCo
   }
 }
 
+// W [cout, cin] row-major -> packed operand order (all layers of the stack in one launch: blockIdx.y = layer)
+__global__ void spg_pack_w_kernel(const SpgConvStackParams p) {
+  const int l = blockIdx.y;
+  if (l >= p.nlayers) return;
+  const int cin = p.cin[l], cout = p.cout[l], ntile = cout >> 5, K = (cin + 7) & ~7;
+  const long n = (long)(K >> 3) * ntile * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long gt = i >> 6;
+    const int t = (int)(gt % ntile), g = (int)(gt / ntile);
+    const int row = 32 * t + (lane & 31), k = 8 * g + 4 * (lane >> 5);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = k + e < cin ? p.W[l][(long)row * cin + k + e] : 0.f;
+    p.Wp[l][i] = v;
+  }
+}
+
 }  // namespace
+
+size_t spg_conv_stack_packed_floats(int cin, int cout) { return (size_t)((cin + 7) & ~7) * cout; }
 
 bool spg_conv_stack_eval_supported(const SpgConvStackParams& p) {
   if (p.nlayers < 1 || p.nlayers > SPG_CONVSTACK_MAX_LAYERS || p.P < 1 || p.P > 128) return false;
   if (p.cin[0] < 1 || p.cin[0] > CS_KMAX) return false;
   for (int l = 0; l < p.nlayers; ++l) {
-    if (p.cout[l] < 32 || p.cout[l] > 256 || p.W[l] == nullptr) return false;
+    if (p.cout[l] < 32 || p.cout[l] > 256 || p.W[l] == nullptr || p.Wp[l] == nullptr) return false;
     for (int n0 = 0; n0 < p.cout[l]; n0 += 128) {
       const int np = p.cout[l] - n0 < 128 ? p.cout[l] - n0 : 128;
       if (np != 32 && np != 64 && np != 128) return false;
@@ -166,6 +183,8 @@ bool spg_conv_stack_eval_supported(const SpgConvStackParams& p) {
 int spg_launch_conv_stack_eval(const SpgConvStackParams& p, hipStream_t stream) {
   SPG_CHECK_ARG(spg_conv_stack_eval_supported(p), "unsupported layer stack for the fused inference kernel");
   const size_t lds = (size_t)4 * CS_WAVE_F4 * sizeof(f32x4);
+  hipLaunchKernelGGL(spg_pack_w_kernel, dim3(16, p.nlayers), dim3(256), 0, stream, p);
+  SPG_LAUNCH_CHECK();
   hipLaunchKernelGGL(spg_conv_stack_eval_kernel, dim3(p.B), dim3(256), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;

@@ -116,11 +116,13 @@ struct SpgConvStackParams {
   int B, P, Ctot, nlayers;
   int cin[SPG_CONVSTACK_MAX_LAYERS], cout[SPG_CONVSTACK_MAX_LAYERS];
   const float *W[SPG_CONVSTACK_MAX_LAYERS], *bias[SPG_CONVSTACK_MAX_LAYERS];
+  f32x4* Wp[SPG_CONVSTACK_MAX_LAYERS];   // scratch for the packed weights: spg_conv_stack_packed_floats(cin, cout) floats each
   const float *s[SPG_CONVSTACK_MAX_LAYERS], *t[SPG_CONVSTACK_MAX_LAYERS];   // eval-mode BatchNorm scale / shift (spg_launch_bn_eval*)
   float *pmax, *pmin;       // [B][4][cout_last] per-wave raw max / min of the last layer (spg_launch_pool_select, 4 partials)
 };
 int spg_launch_pool_select_parts(const float* pmax, const float* pmin, const int* imax, const int* imin, const float* s,
                                  int G, int N, int nparts, const float* extra, int nextra, float* out, long ldo, int* aidx,
                                  hipStream_t stream);
+size_t spg_conv_stack_packed_floats(int cin, int cout);
 bool spg_conv_stack_eval_supported(const SpgConvStackParams& p);
 int spg_launch_conv_stack_eval(const SpgConvStackParams& p, hipStream_t stream);

@@ -27,6 +27,7 @@ struct Layer {
   float *rm = nullptr, *rv = nullptr;
   float* y = nullptr;           // raw output (workspace or external)
   long ldy = 0;
+  float* Wpack = nullptr;       // conv layers, inference: weights in MFMA operand order (spg_convstack.hip)
   float* Wpad = nullptr;        // FC layers whose input width is not a multiple of 4: zero-padded copy of W
   long ldw = 0;                 // leading dimension of the weight actually fed to the kernels
   float *mean = nullptr, *rstd = nullptr, *s = nullptr, *t = nullptr;   // BN batch constants
@@ -126,6 +127,7 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
       l.ldw = (l.cin + 3) & ~3;
       l.Wpad = cv.take<float>((size_t)l.cout * l.ldw);
     }
+    if (l.conv && !pl.training) l.Wpack = cv.take<float>(spg_conv_stack_packed_floats(l.cin, l.cout));
   }
   auto carve_segment = [&](Segment& sg, float* final_out) {
     for (size_t k = 0; k < sg.convs.size(); ++k) {
@@ -203,6 +205,7 @@ bool fused_eval_convs(Plan& pl, Segment& sg, const float* clouds, const float* s
     const Layer& l = pl.L[sg.convs[k]];
     if (!l.bn) return false;
     cp.cin[k] = l.cin; cp.cout[k] = l.cout; cp.W[k] = l.W; cp.bias[k] = l.b; cp.s[k] = l.s; cp.t[k] = l.t;
+    cp.Wp[k] = reinterpret_cast<f32x4*>(l.Wpack);
   }
   cp.pmax = pl.pmax; cp.pmin = pl.pmin;
   return spg_conv_stack_eval_supported(cp);
