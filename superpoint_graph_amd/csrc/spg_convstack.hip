@@ -33,21 +33,22 @@ __device__ __forceinline__ void cs_gemm_pass(const f32x4* __restrict__ A, const 
     for (int j = 0; j < TJ; ++j) b[j] = src[j * 64];
   };
   // two statically named fragment sets: the loads of the next group of 8 reduction steps fly during the MFMAs of this one
-  f32x4 b0[TJ], b1[TJ];
-  auto mfma_group = [&](int k0, const f32x4 (&b)[TJ]) {
-    const f32x4 a = A[((k0 >> 2) + h) * CS_APLANE + r];
+  f32x4 b0[TJ], b1[TJ], a0, a1;
+  auto load_a = [&](int k0) -> f32x4 { return A[((k0 >> 2) + h) * CS_APLANE + r]; };
+  auto mfma_group = [&](const f32x4& a, const f32x4 (&b)[TJ]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int j = 0; j < TJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[j][s], acc[j], 0, 0, 0);
   };
   load_b(0, b0);
+  a0 = load_a(0);
   for (int k0 = 0; k0 < K; k0 += 16) {
-    if (k0 + 8 < K) load_b(k0 + 8, b1);
-    mfma_group(k0, b0);
+    if (k0 + 8 < K) { load_b(k0 + 8, b1); a1 = load_a(k0 + 8); }
+    mfma_group(a0, b0);
     if (k0 + 8 < K) {
-      if (k0 + 16 < K) load_b(k0 + 16, b0);
-      mfma_group(k0 + 8, b1);
+      if (k0 + 16 < K) { load_b(k0 + 16, b0); a0 = load_a(k0 + 16); }
+      mfma_group(a1, b1);
     }
   }
 }
