@@ -24,6 +24,11 @@ def main():
     arena = FlatParameters(model)
 
     def step():
+        if os.environ.get('TRACE_FWD'):
+            model.eval()
+            with torch.no_grad():
+                model.ecc(emb_er.run(model, None, flag, clouds_d, diam_d))
+            return
         arena.zero_grad()
         emb = emb_er.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
