@@ -268,3 +268,45 @@ def test_odd_shapes_train_step_vs_oracle(hip, name):
     for k, v in st.items():
         if 'running' in k:
             assert maxrel(sd[k].double(), v.double()) < 1e-5, k
+
+
+@pytest.mark.parametrize('config', ['gru_3_0,f_7', 'lstm_2_1,f_7'])
+def test_rnn_ecc_module_large_graph_vs_oracle(hip, config):
+    """The recurrent ECC module alone on a 7000-node / 30000-edge graph (several nodes per wavefront in the step kernels),
+    forward and every gradient against the fp32 oracle."""
+    from superpoint_graph_amd.learning import ecc, graphnet
+    n, e = 7000, 30000
+    rng = np.random.default_rng(4)
+    tgt = np.sort(rng.integers(0, n, size=e))
+    tgt[tgt == 5] = 6                                           # an isolated node
+    src = rng.integers(0, n, size=e)
+    idxn = torch.from_numpy(src.astype(np.int64))
+    degs = torch.from_numpy(np.bincount(tgt, minlength=n).astype(np.int64))
+    edgefeats = torch.randn(e, 13, generator=torch.Generator().manual_seed(1))
+    x = torch.randn(n, 32, generator=torch.Generator().manual_seed(2))
+    spec = O.ModelSpec(model_config=config)
+    torch.manual_seed(7)
+    net = graphnet.GraphNetwork(config, 32, [13, 32, 128, 64], 1, 0, 2, 30000, use_pyg=0, cuda=1)
+    P = {'ecc.' + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in net.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    ref = O.graph_network_forward(xo, edgefeats, idxn, degs, spec, P, True)
+    go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+    ref.backward(go)
+    net = net.to(DEV).train()
+    net.set_info([ecc.GraphConvInfo.from_buffers(idxn.clone(), degs.clone(), edgefeats.clone(), None, None)], 1)
+    xg = x.to(DEV).requires_grad_(True)
+    out = net(xg)
+    out.backward(go.to(DEV))
+    assert maxrel(out, ref) < TOL
+    assert maxrel(xg.grad, xo.grad) < 5e-4
+    bad = {}
+    for k, p in net.named_parameters():
+        r = P['ecc.' + k].grad
+        if r is None or float(r.abs().max()) < 1e-6:
+            continue
+        if k.endswith('_fnet.4.bias'):         # bias in front of the train-mode BatchNorm: analytically zero (oracle: rounding noise)
+            assert float(p.grad.abs().max()) < 1e-5 and float(r.abs().max()) < 1e-3
+            continue
+        if maxrel(p.grad, r) > 1e-3:
+            bad[k] = maxrel(p.grad, r)
+    assert not bad, bad

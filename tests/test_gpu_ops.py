@@ -76,7 +76,7 @@ def test_generic_ecc_fp64_golden_and_gradcheck(hip):
 
 
 @pytest.mark.parametrize('matrix', [True, False])
-@pytest.mark.parametrize('n,e', [(40, 150), (1000, 5000)])
+@pytest.mark.parametrize('n,e', [(40, 150), (1000, 5000), (7000, 30000)])
 def test_fused_ecc_32_channels(hip, matrix, n, e):
     """hot-path shape through spg_ecc_aggregate_fwd's fused wave-per-node kernel + the generic backward."""
     from superpoint_graph_amd.learning import ecc
@@ -105,7 +105,7 @@ def test_gru_cell(hip, layernorm, ingate):
         cell.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('gru_p/')})
     cell = cell.to(DEV)
     gen = torch.Generator().manual_seed(3)
-    n = 9 if (layernorm and ingate) else 333
+    n = 9 if (layernorm and ingate) else (3333 if ingate or layernorm else 7001)
     inp = torch.from_numpy(g['gru_in']) if n == 9 else torch.randn(n, 32, generator=gen)
     hid = torch.from_numpy(g['gru_h']) if n == 9 else torch.randn(n, 32, generator=gen)
     xi, xh = inp.to(DEV).requires_grad_(True), hid.to(DEV).requires_grad_(True)
@@ -137,7 +137,7 @@ def test_lstm_cell(hip, layernorm, ingate):
         cell.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('lstm_p/')})
     cell = cell.to(DEV)
     gen = torch.Generator().manual_seed(4)
-    n = 9 if (layernorm and ingate) else 257
+    n = 9 if (layernorm and ingate) else (257 if layernorm else 6500)
     inp = torch.from_numpy(g['gru_in']) if n == 9 else torch.randn(n, 32, generator=gen)
     hid = torch.from_numpy(g['gru_h']) if n == 9 else torch.randn(n, 32, generator=gen)
     cx = torch.from_numpy(g['lstm_c']) if n == 9 else torch.randn(n, 32, generator=gen)
