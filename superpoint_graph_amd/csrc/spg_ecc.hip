@@ -11,6 +11,8 @@
 //   * no atomics anywhere: the backward walks a reverse CSR (by source) built once per batch, so
 //     results are deterministic.
 #include "spg_ecc.h"
+#include <stdlib.h>
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // graph build
@@ -242,7 +244,58 @@ struct GruFwdState {
 // independent of the graph data -- so their latency overlaps the edge gather.
 struct GruRows {
   f32x4 ih1[8], hh1[8], ih2[8], hh2[8], ig[8];
+  __device__ __forceinline__ float dot_ih1(const float* v) const;
+  __device__ __forceinline__ float dot_hh1(const float* v) const;
+  __device__ __forceinline__ float dot_ih2(const float* v) const;
+  __device__ __forceinline__ float dot_hh2(const float* v) const;
+  __device__ __forceinline__ float dot_ig(const float* v) const;
 };
+
+// The same rows read from a workgroup copy of the matrices in LDS, rows padded to 33 floats (conflict-free both along a
+// row and along a column): ~150 VGPRs less, i.e. 3-4 waves per SIMD instead of 1-2.  Used for large graphs, where the
+// step kernels are bound by the number of nodes in flight, not by the latency of one node.
+#define SPG_WLD 33
+struct GruRowsLds {
+  const float *ih1, *hh1, *ih2, *hh2, *ig;     // row pointers of this lane
+  __device__ __forceinline__ float dot(const float* __restrict__ row, const float* __restrict__ v) const {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(v + 4 * q);   // LDS broadcast read
+      a0 = fmaf(row[4 * q + 0], x[0], a0); a1 = fmaf(row[4 * q + 1], x[1], a1);
+      a0 = fmaf(row[4 * q + 2], x[2], a0); a1 = fmaf(row[4 * q + 3], x[3], a1);
+    }
+    return a0 + a1;
+  }
+  __device__ __forceinline__ float dot_ih1(const float* v) const { return dot(ih1, v); }
+  __device__ __forceinline__ float dot_hh1(const float* v) const { return dot(hh1, v); }
+  __device__ __forceinline__ float dot_ih2(const float* v) const { return dot(ih2, v); }
+  __device__ __forceinline__ float dot_hh2(const float* v) const { return dot(hh2, v); }
+  __device__ __forceinline__ float dot_ig(const float* v) const { return dot(ig, v); }
+};
+
+// block-wide: global [GW][32] x2 + [32][32] -> LDS rows of SPG_WLD floats (w_ih | w_hh | w_ig); caller synchronises
+template <int GW>
+__device__ __forceinline__ void spg_stage_cell_weights(const SpgGruParams& G, float* __restrict__ sw) {
+  constexpr int NQ = (2 * GW + 32) * 8;          // float4 pieces
+  for (int idx = threadIdx.x; idx < NQ; idx += SPG_THREADS) {
+    const int row = idx >> 3, q = idx & 7;
+    const f32x4* src = row < GW ? reinterpret_cast<const f32x4*>(G.w_ih) + row * 8
+                     : (row < 2 * GW ? reinterpret_cast<const f32x4*>(G.w_hh) + (row - GW) * 8
+                                     : reinterpret_cast<const f32x4*>(G.ingate ? G.w_ig : G.w_ih) + (row - 2 * GW) * 8);
+    const f32x4 v = src[q];
+    float* d = sw + row * SPG_WLD + 4 * q;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+}
+template <int CELL>
+__device__ __forceinline__ void spg_gru_lds_rows(const float* __restrict__ sw, int lane, GruRowsLds& w) {
+  constexpr int GW = CELL == SPG_CELL_LSTM ? 128 : 96;
+  const int r1 = lane, r2 = CELL == SPG_CELL_LSTM ? 64 + lane : 64 + (lane & 31);
+  w.ih1 = sw + r1 * SPG_WLD; w.ih2 = sw + r2 * SPG_WLD;
+  w.hh1 = sw + (GW + r1) * SPG_WLD; w.hh2 = sw + (GW + r2) * SPG_WLD;
+  w.ig = sw + (2 * GW + (lane & 31)) * SPG_WLD;
+}
 
 template <int CELL = SPG_CELL_GRU>
 __device__ __forceinline__ void spg_gru_load_rows(const SpgGruParams& G, int lane, GruRows& w) {
@@ -262,6 +315,12 @@ __device__ __forceinline__ void spg_gru_load_rows(const SpgGruParams& G, int lan
   }
 }
 
+__device__ __forceinline__ float spg_dot32(const f32x4 (&w)[8], const float* __restrict__ v);
+__device__ __forceinline__ float GruRows::dot_ih1(const float* v) const { return spg_dot32(ih1, v); }
+__device__ __forceinline__ float GruRows::dot_hh1(const float* v) const { return spg_dot32(hh1, v); }
+__device__ __forceinline__ float GruRows::dot_ih2(const float* v) const { return spg_dot32(ih2, v); }
+__device__ __forceinline__ float GruRows::dot_hh2(const float* v) const { return spg_dot32(hh2, v); }
+__device__ __forceinline__ float GruRows::dot_ig(const float* v) const { return spg_dot32(ig, v); }
 __device__ __forceinline__ float spg_dot32(const f32x4 (&w)[8], const float* __restrict__ v) {
   float a0 = 0.f, a1 = 0.f;    // k-order 0..31 split over two chains (exact order is immaterial at 1e-6)
 #pragma unroll
@@ -273,21 +332,22 @@ __device__ __forceinline__ float spg_dot32(const f32x4 (&w)[8], const float* __r
   return a0 + a1;
 }
 
-__device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, const GruRows& w, const float* __restrict__ sa,
+template <class Rows>
+__device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, const Rows& w, const float* __restrict__ sa,
                                                      const float* __restrict__ sh, float* __restrict__ sx, int lane,
                                                      GruFwdState& st) {
   // input gate: x = sigmoid(W_ig h + b_ig) * a      (learning/modules.py:225-226)
   float gin = 1.f, x = 0.f;
   if (lane < 32) {
-    if (G.ingate) gin = spg_sigmoid(spg_dot32(w.ig, sh) + G.b_ig[lane]);
+    if (G.ingate) gin = spg_sigmoid(w.dot_ig(sh) + G.b_ig[lane]);
     x = gin * sa[lane];
     sx[lane] = x;
   }
   st.gin = gin; st.x = x;
   __syncthreads();
-  float gi1 = spg_dot32(w.ih1, sx), gh1 = spg_dot32(w.hh1, sh);
+  float gi1 = w.dot_ih1(sx), gh1 = w.dot_hh1(sh);
   float gi2 = 0.f, gh2 = 0.f;
-  if (lane < 32) { gi2 = spg_dot32(w.ih2, sx); gh2 = spg_dot32(w.hh2, sh); }
+  if (lane < 32) { gi2 = w.dot_ih2(sx); gh2 = w.dot_hh2(sh); }
   st.rstd_i = 1.f; st.rstd_h = 1.f;
   if (G.layernorm) {   // per-row (x - mean)/sqrt(var_biased + eps) over the 96 values (learning/modules.py:218-222)
     const float mi = spg_wave_sum(gi1 + (lane < 32 ? gi2 : 0.f)) * (1.f / 96.f);
@@ -322,19 +382,20 @@ struct LstmFwdState {
   float c_prev, tc, cy, hy;
 };
 
-__device__ __forceinline__ void spg_lstm_forward_node(const SpgGruParams& G, const GruRows& w, const float* __restrict__ sa,
+template <class Rows>
+__device__ __forceinline__ void spg_lstm_forward_node(const SpgGruParams& G, const Rows& w, const float* __restrict__ sa,
                                                       const float* __restrict__ sh, float* __restrict__ sx, float c_prev,
                                                       int lane, LstmFwdState& st) {
   float gin = 1.f, x = 0.f;
   if (lane < 32) {
-    if (G.ingate) gin = spg_sigmoid(spg_dot32(w.ig, sh) + G.b_ig[lane]);      // :285-286, hidden[0]
+    if (G.ingate) gin = spg_sigmoid(w.dot_ig(sh) + G.b_ig[lane]);      // :285-286, hidden[0]
     x = gin * sa[lane];
     sx[lane] = x;
   }
   st.gin = gin; st.x = x;
   __syncthreads();
-  float gi1 = spg_dot32(w.ih1, sx) + G.b_ih[lane], gi2 = spg_dot32(w.ih2, sx) + G.b_ih[64 + lane];
-  float gh1 = spg_dot32(w.hh1, sh) + G.b_hh[lane], gh2 = spg_dot32(w.hh2, sh) + G.b_hh[64 + lane];
+  float gi1 = w.dot_ih1(sx) + G.b_ih[lane], gi2 = w.dot_ih2(sx) + G.b_ih[64 + lane];
+  float gh1 = w.dot_hh1(sh) + G.b_hh[lane], gh2 = w.dot_hh2(sh) + G.b_hh[64 + lane];
   st.rstd_i = 1.f; st.rstd_h = 1.f;
   if (G.layernorm) {   // InstanceNorm1d over the 128 values of the row, biased variance (:275-279)
     const float mi = spg_wave_sum(gi1 + gi2) * (1.f / 128.f);
@@ -362,14 +423,24 @@ __device__ __forceinline__ void spg_lstm_forward_node(const SpgGruParams& G, con
 // ---------------------------------------------------------------------------------------------
 // forward step
 // ---------------------------------------------------------------------------------------------
-template <int CELL>
-__global__ __launch_bounds__(256) void spg_ecc_step_fwd_kernel(const SpgEccStepFwd p) {
+// WLDS = false: the cell's weight rows live in registers (loaded at entry, their latency hidden behind the gather): lowest
+// latency per node, one wave per SIMD -- right for a scene-sized graph (one wave per node fills the chip once).
+// WLDS = true: rows read from a workgroup copy in LDS: 3-4 waves per SIMD -- right when there are several rounds of nodes.
+template <int CELL, bool WLDS>
+__global__ __launch_bounds__(256, WLDS ? 3 : 1) void spg_ecc_step_fwd_kernel(const SpgEccStepFwd p) {
+  constexpr int GW = CELL == SPG_CELL_LSTM ? 128 : 96;
   __shared__ __attribute__((aligned(16))) float lds[4][3][32];
+  __shared__ float sw[WLDS ? (2 * GW + 32) * SPG_WLD : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
   const bool active = i < p.g.N;
-  GruRows wr;
-  if (p.do_gru) spg_gru_load_rows<CELL>(p.gru, lane, wr);
+  typename std::conditional<WLDS, GruRowsLds, GruRows>::type wr;
+  if constexpr (WLDS) {
+    if (p.do_gru) spg_stage_cell_weights<GW>(p.gru, sw);        // visible after the barrier behind the aggregation
+    spg_gru_lds_rows<CELL>(sw, lane, wr);
+  } else {
+    if (p.do_gru) spg_gru_load_rows<CELL>(p.gru, lane, wr);
+  }
   float* sa = lds[wave][0];
   float* sh = lds[wave][1];
   float* sx = lds[wave][2];
@@ -412,11 +483,23 @@ __global__ __launch_bounds__(256) void spg_ecc_step_fwd_kernel(const SpgEccStepF
   }
 }
 
+// graphs beyond this many nodes take the LDS-weights variants (more than one round of one-wave-per-node workgroups)
+static int spg_ecc_lds_threshold() {
+  static int t = -1;
+  if (t < 0) { const char* e = getenv("SPG_ECC_LDS_NODES"); t = e ? atoi(e) : 2048; }
+  return t;
+}
+
 int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
-  if (p.cell == SPG_CELL_LSTM)
-    hipLaunchKernelGGL(spg_ecc_step_fwd_kernel<SPG_CELL_LSTM>, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL(spg_ecc_step_fwd_kernel<SPG_CELL_GRU>, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
+  const dim3 grid(spg_cdiv(p.g.N, 4));
+  const bool wlds = p.do_gru && p.g.N >= spg_ecc_lds_threshold();
+  if (p.cell == SPG_CELL_LSTM) {
+    if (wlds) hipLaunchKernelGGL((spg_ecc_step_fwd_kernel<SPG_CELL_LSTM, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((spg_ecc_step_fwd_kernel<SPG_CELL_LSTM, false>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (wlds) hipLaunchKernelGGL((spg_ecc_step_fwd_kernel<SPG_CELL_GRU, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((spg_ecc_step_fwd_kernel<SPG_CELL_GRU, false>), grid, dim3(256), 0, stream, p);
+  }
   SPG_LAUNCH_CHECK();
   return 0;
 }
@@ -424,14 +507,14 @@ int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // backward step
 // ---------------------------------------------------------------------------------------------
-template <int CELL>
-__global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepBwd p) {
+template <int CELL, bool WLDS>
+__global__ __launch_bounds__(256, WLDS ? 3 : 2) void spg_ecc_step_bwd_kernel(const SpgEccStepBwd p) {
   constexpr int GW = CELL == SPG_CELL_LSTM ? 128 : 96;
   __shared__ __attribute__((aligned(16))) float lds[4][5][GW];
   // the backward needs COLUMNS of the weight matrices (dx[c] = sum_o W[o][c] dg[o]): the block stages them in LDS once
   // (loads issued here, in flight during the reverse gather) instead of 2*GW+32 global loads per lane
-  constexpr int WQ = (2 * GW * 32 + 1024) / 4;                   // float4 slots: w_ih | w_hh | w_ig
-  __shared__ f32x4 sw4[WQ];
+  constexpr int WQ = (2 * GW * 32 + 1024) / 4;                   // float4 pieces: w_ih | w_hh | w_ig
+  __shared__ float sw[(2 * GW + 32) * SPG_WLD];                   // rows padded to SPG_WLD: conflict-free along rows and columns
   constexpr int WPT = (WQ + SPG_THREADS - 1) / SPG_THREADS;
   f32x4 wreg[WPT];
   if (!p.final_only) {
@@ -523,21 +606,30 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
 #pragma unroll
   for (int u = 0; u < WPT; ++u) {
     const int idx = threadIdx.x + SPG_THREADS * u;
-    if (idx < WQ) sw4[idx] = wreg[u];
+    if (idx < WQ) {
+      float* d = sw + (idx >> 3) * SPG_WLD + 4 * (idx & 7);
+      d[0] = wreg[u][0]; d[1] = wreg[u][1]; d[2] = wreg[u][2]; d[3] = wreg[u][3];
+    }
   }
-  const float* sw_ih = reinterpret_cast<const float*>(sw4);
-  const float* sw_hh = sw_ih + GW * 32;
-  const float* sw_ig = sw_hh + GW * 32;
+  const float* sw_ih = sw;
+  const float* sw_hh = sw_ih + GW * SPG_WLD;
+  const float* sw_ig = sw_hh + GW * SPG_WLD;
   __syncthreads();
   const SpgGruParams& G = p.gru;
   if constexpr (CELL == SPG_CELL_LSTM) {
     // ---- LSTMCellEx backward (learning/modules.py:280-309) ----
     LstmFwdState st;
     {
-      GruRows wr;
-      spg_gru_load_rows<SPG_CELL_LSTM>(G, lane, wr);
       const float c = (active && lane < 32 && p.cin != nullptr) ? p.cin[(long)j * p.ld + lane] : 0.f;
-      spg_lstm_forward_node(G, wr, sa, sh, sx, c, lane, st);
+      if constexpr (WLDS) {
+        GruRowsLds wr;
+        spg_gru_lds_rows<SPG_CELL_LSTM>(sw, lane, wr);
+        spg_lstm_forward_node(G, wr, sa, sh, sx, c, lane, st);
+      } else {
+        GruRows wr;
+        spg_gru_load_rows<SPG_CELL_LSTM>(G, lane, wr);
+        spg_lstm_forward_node(G, wr, sa, sh, sx, c, lane, st);
+      }
     }
     const float a_in = lane < 32 ? sa[lane] : 0.f;
     // gate backward on lanes 0..31 (channel = lane):  hy = o tanh(cy),  cy = f c + i g
@@ -577,8 +669,8 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     if (lane < 32) {
 #pragma unroll 8
       for (int o = 0; o < 128; ++o) {
-        dx = fmaf(sw_ih[o * 32 + lane], sa[o], dx);
-        dh_acc = fmaf(sw_hh[o * 32 + lane], sh[o], dh_acc);
+        dx = fmaf(sw_ih[o * SPG_WLD + lane], sa[o], dx);
+        dh_acc = fmaf(sw_hh[o * SPG_WLD + lane], sh[o], dh_acc);
       }
     }
     float da = dx, dpre = 0.f;
@@ -590,7 +682,7 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     __syncthreads();
     if (G.ingate && lane < 32) {
 #pragma unroll 8
-      for (int o = 0; o < 32; ++o) dh_acc = fmaf(sw_ig[o * 32 + lane], sd[o], dh_acc);
+      for (int o = 0; o < 32; ++o) dh_acc = fmaf(sw_ig[o * SPG_WLD + lane], sd[o], dh_acc);
     }
     if (active && lane < 32) {
       p.dpre[(long)j * p.ld32 + lane] = dpre;
@@ -601,7 +693,11 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     }
   } else {
     GruFwdState st;
-    {
+    if constexpr (WLDS) {
+      GruRowsLds wr;
+      spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane, wr);
+      spg_gru_forward_node(G, wr, sa, sh, sx, lane, st);
+    } else {
       GruRows wr;
       spg_gru_load_rows(G, lane, wr);
       spg_gru_forward_node(G, wr, sa, sh, sx, lane, st);
@@ -662,8 +758,8 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     if (lane < 32) {
   #pragma unroll 8
       for (int o = 0; o < 96; ++o) {
-        dx = fmaf(sw_ih[o * 32 + lane], sa[o], dx);
-        dh_acc = fmaf(sw_hh[o * 32 + lane], sh[o], dh_acc);
+        dx = fmaf(sw_ih[o * SPG_WLD + lane], sa[o], dx);
+        dh_acc = fmaf(sw_hh[o * SPG_WLD + lane], sh[o], dh_acc);
       }
     }
     float da = dx, dpre = 0.f;
@@ -675,7 +771,7 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
     __syncthreads();
     if (G.ingate && lane < 32) {
   #pragma unroll 8
-      for (int o = 0; o < 32; ++o) dh_acc = fmaf(sw_ig[o * 32 + lane], sd[o], dh_acc);
+      for (int o = 0; o < 32; ++o) dh_acc = fmaf(sw_ig[o * SPG_WLD + lane], sd[o], dh_acc);
     }
     if (active && lane < 32) {
       p.dpre[(long)j * p.ld32 + lane] = dpre;
@@ -687,10 +783,15 @@ __global__ __launch_bounds__(256) void spg_ecc_step_bwd_kernel(const SpgEccStepB
 }
 
 int spg_launch_ecc_step_bwd(const SpgEccStepBwd& p, hipStream_t stream) {
-  if (p.cell == SPG_CELL_LSTM)
-    hipLaunchKernelGGL(spg_ecc_step_bwd_kernel<SPG_CELL_LSTM>, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL(spg_ecc_step_bwd_kernel<SPG_CELL_GRU>, dim3(spg_cdiv(p.g.N, 4)), dim3(256), 0, stream, p);
+  const dim3 grid(spg_cdiv(p.g.N, 4));
+  const bool wlds = p.g.N >= spg_ecc_lds_threshold();
+  if (p.cell == SPG_CELL_LSTM) {
+    if (wlds) hipLaunchKernelGGL((spg_ecc_step_bwd_kernel<SPG_CELL_LSTM, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((spg_ecc_step_bwd_kernel<SPG_CELL_LSTM, false>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (wlds) hipLaunchKernelGGL((spg_ecc_step_bwd_kernel<SPG_CELL_GRU, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((spg_ecc_step_bwd_kernel<SPG_CELL_GRU, false>), grid, dim3(256), 0, stream, p);
+  }
   SPG_LAUNCH_CHECK();
   return 0;
 }
