@@ -11,8 +11,6 @@
 //   * no atomics anywhere: the backward walks a reverse CSR (by source) built once per batch, so
 //     results are deterministic.
 #include "spg_ecc.h"
-#include <stdlib.h>
-#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // graph build
@@ -239,21 +237,9 @@ struct GruFwdState {
   float r, z, n;         // gates (lanes 0..31; z was shuffled from lanes 32..63)
 };
 
-// Rows of the GRU weight matrices held in registers: lane l owns gate rows l (first value) and 64 + (l & 31)
-// (second value) of W_ih / W_hh and row (l & 31) of the input-gate matrix.  They are loaded at kernel entry --
-// independent of the graph data -- so their latency overlaps the edge gather.
-struct GruRows {
-  f32x4 ih1[8], hh1[8], ih2[8], hh2[8], ig[8];
-  __device__ __forceinline__ float dot_ih1(const float* v) const;
-  __device__ __forceinline__ float dot_hh1(const float* v) const;
-  __device__ __forceinline__ float dot_ih2(const float* v) const;
-  __device__ __forceinline__ float dot_hh2(const float* v) const;
-  __device__ __forceinline__ float dot_ig(const float* v) const;
-};
-
-// The same rows read from a workgroup copy of the matrices in LDS, rows padded to 33 floats (conflict-free both along a
-// row and along a column): ~150 VGPRs less, i.e. 3-4 waves per SIMD instead of 1-2.  Used for large graphs, where the
-// step kernels are bound by the number of nodes in flight, not by the latency of one node.
+// Gate rows of the cell's weight matrices, read from a workgroup copy in LDS, rows padded to 33 floats (conflict-free both
+// along a row -- the forward dot products -- and along a column -- the backward's W^T products): lane l owns gate rows l
+// (first value) and 64 + (l & 31) (GRU) / 64 + l (LSTM) (second value) of W_ih / W_hh and row (l & 31) of the input gate.
 #define SPG_WLD 33
 struct GruRowsLds {
   const float *ih1, *hh1, *ih2, *hh2, *ig;     // row pointers of this lane
@@ -295,41 +281,6 @@ __device__ __forceinline__ void spg_gru_lds_rows(const float* __restrict__ sw, i
   w.ih1 = sw + r1 * SPG_WLD; w.ih2 = sw + r2 * SPG_WLD;
   w.hh1 = sw + (GW + r1) * SPG_WLD; w.hh2 = sw + (GW + r2) * SPG_WLD;
   w.ig = sw + (2 * GW + (lane & 31)) * SPG_WLD;
-}
-
-template <int CELL = SPG_CELL_GRU>
-__device__ __forceinline__ void spg_gru_load_rows(const SpgGruParams& G, int lane, GruRows& w) {
-  const f32x4* pih = reinterpret_cast<const f32x4*>(G.w_ih);
-  const f32x4* phh = reinterpret_cast<const f32x4*>(G.w_hh);
-  // LSTM: 128 gate rows, every lane owns two of them (lane, 64 + lane)
-  const int r1 = lane, r2 = CELL == SPG_CELL_LSTM ? 64 + lane : 64 + (lane & 31);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    w.ih1[q] = pih[r1 * 8 + q]; w.hh1[q] = phh[r1 * 8 + q];
-    w.ih2[q] = pih[r2 * 8 + q]; w.hh2[q] = phh[r2 * 8 + q];
-  }
-  if (G.ingate) {
-    const f32x4* pig = reinterpret_cast<const f32x4*>(G.w_ig);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) w.ig[q] = pig[(lane & 31) * 8 + q];
-  }
-}
-
-__device__ __forceinline__ float spg_dot32(const f32x4 (&w)[8], const float* __restrict__ v);
-__device__ __forceinline__ float GruRows::dot_ih1(const float* v) const { return spg_dot32(ih1, v); }
-__device__ __forceinline__ float GruRows::dot_hh1(const float* v) const { return spg_dot32(hh1, v); }
-__device__ __forceinline__ float GruRows::dot_ih2(const float* v) const { return spg_dot32(ih2, v); }
-__device__ __forceinline__ float GruRows::dot_hh2(const float* v) const { return spg_dot32(hh2, v); }
-__device__ __forceinline__ float GruRows::dot_ig(const float* v) const { return spg_dot32(ig, v); }
-__device__ __forceinline__ float spg_dot32(const f32x4 (&w)[8], const float* __restrict__ v) {
-  float a0 = 0.f, a1 = 0.f;    // k-order 0..31 split over two chains (exact order is immaterial at 1e-6)
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x4 x = *reinterpret_cast<const f32x4*>(v + 4 * q);   // LDS broadcast read
-    a0 = fmaf(w[q][0], x[0], a0); a1 = fmaf(w[q][1], x[1], a1);
-    a0 = fmaf(w[q][2], x[2], a0); a1 = fmaf(w[q][3], x[3], a1);
-  }
-  return a0 + a1;
 }
 
 template <class Rows>
@@ -423,24 +374,20 @@ __device__ __forceinline__ void spg_lstm_forward_node(const SpgGruParams& G, con
 // ---------------------------------------------------------------------------------------------
 // forward step
 // ---------------------------------------------------------------------------------------------
-// WLDS = false: the cell's weight rows live in registers (loaded at entry, their latency hidden behind the gather): lowest
-// latency per node, one wave per SIMD -- right for a scene-sized graph (one wave per node fills the chip once).
-// WLDS = true: rows read from a workgroup copy in LDS: 3-4 waves per SIMD -- right when there are several rounds of nodes.
-template <int CELL, bool WLDS>
-__global__ __launch_bounds__(256, WLDS ? 3 : 1) void spg_ecc_step_fwd_kernel(const SpgEccStepFwd p) {
+// The cell's weight matrices are staged once per workgroup in LDS (rows padded to SPG_WLD floats) and every lane reads its
+// gate rows from there: 103-168 VGPRs, 3-4 waves per SIMD.  (Register-resident rows -- 264 VGPRs, one wave per SIMD -- were
+// measured slower at every graph size: 1 scene 1.83 -> 1.79 ms/step, 8 scenes 811k -> 887k superpoints/s.)
+template <int CELL>
+__global__ __launch_bounds__(256, 3) void spg_ecc_step_fwd_kernel(const SpgEccStepFwd p) {
   constexpr int GW = CELL == SPG_CELL_LSTM ? 128 : 96;
   __shared__ __attribute__((aligned(16))) float lds[4][3][32];
-  __shared__ float sw[WLDS ? (2 * GW + 32) * SPG_WLD : 1];
+  __shared__ float sw[(2 * GW + 32) * SPG_WLD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
   const bool active = i < p.g.N;
-  typename std::conditional<WLDS, GruRowsLds, GruRows>::type wr;
-  if constexpr (WLDS) {
-    if (p.do_gru) spg_stage_cell_weights<GW>(p.gru, sw);        // visible after the barrier behind the aggregation
-    spg_gru_lds_rows<CELL>(sw, lane, wr);
-  } else {
-    if (p.do_gru) spg_gru_load_rows<CELL>(p.gru, lane, wr);
-  }
+  GruRowsLds wr;
+  if (p.do_gru) spg_stage_cell_weights<GW>(p.gru, sw);          // visible after the barrier behind the aggregation
+  spg_gru_lds_rows<CELL>(sw, lane, wr);
   float* sa = lds[wave][0];
   float* sh = lds[wave][1];
   float* sx = lds[wave][2];
@@ -483,23 +430,10 @@ __global__ __launch_bounds__(256, WLDS ? 3 : 1) void spg_ecc_step_fwd_kernel(con
   }
 }
 
-// graphs beyond this many nodes take the LDS-weights variants (more than one round of one-wave-per-node workgroups)
-static int spg_ecc_lds_threshold() {
-  static int t = -1;
-  if (t < 0) { const char* e = getenv("SPG_ECC_LDS_NODES"); t = e ? atoi(e) : 2048; }
-  return t;
-}
-
 int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
   const dim3 grid(spg_cdiv(p.g.N, 4));
-  const bool wlds = p.do_gru && p.g.N >= spg_ecc_lds_threshold();
-  if (p.cell == SPG_CELL_LSTM) {
-    if (wlds) hipLaunchKernelGGL((spg_ecc_step_fwd_kernel<SPG_CELL_LSTM, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((spg_ecc_step_fwd_kernel<SPG_CELL_LSTM, false>), grid, dim3(256), 0, stream, p);
-  } else {
-    if (wlds) hipLaunchKernelGGL((spg_ecc_step_fwd_kernel<SPG_CELL_GRU, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((spg_ecc_step_fwd_kernel<SPG_CELL_GRU, false>), grid, dim3(256), 0, stream, p);
-  }
+  if (p.cell == SPG_CELL_LSTM) hipLaunchKernelGGL(spg_ecc_step_fwd_kernel<SPG_CELL_LSTM>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(spg_ecc_step_fwd_kernel<SPG_CELL_GRU>, grid, dim3(256), 0, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
 }
@@ -507,8 +441,8 @@ int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // backward step
 // ---------------------------------------------------------------------------------------------
-template <int CELL, bool WLDS>
-__global__ __launch_bounds__(256, WLDS ? 3 : 2) void spg_ecc_step_bwd_kernel(const SpgEccStepBwd p) {
+template <int CELL>
+__global__ __launch_bounds__(256, 3) void spg_ecc_step_bwd_kernel(const SpgEccStepBwd p) {
   constexpr int GW = CELL == SPG_CELL_LSTM ? 128 : 96;
   __shared__ __attribute__((aligned(16))) float lds[4][5][GW];
   // the backward needs COLUMNS of the weight matrices (dx[c] = sum_o W[o][c] dg[o]): the block stages them in LDS once
@@ -621,15 +555,9 @@ __global__ __launch_bounds__(256, WLDS ? 3 : 2) void spg_ecc_step_bwd_kernel(con
     LstmFwdState st;
     {
       const float c = (active && lane < 32 && p.cin != nullptr) ? p.cin[(long)j * p.ld + lane] : 0.f;
-      if constexpr (WLDS) {
-        GruRowsLds wr;
-        spg_gru_lds_rows<SPG_CELL_LSTM>(sw, lane, wr);
-        spg_lstm_forward_node(G, wr, sa, sh, sx, c, lane, st);
-      } else {
-        GruRows wr;
-        spg_gru_load_rows<SPG_CELL_LSTM>(G, lane, wr);
-        spg_lstm_forward_node(G, wr, sa, sh, sx, c, lane, st);
-      }
+      GruRowsLds wr;
+      spg_gru_lds_rows<SPG_CELL_LSTM>(sw, lane, wr);
+      spg_lstm_forward_node(G, wr, sa, sh, sx, c, lane, st);
     }
     const float a_in = lane < 32 ? sa[lane] : 0.f;
     // gate backward on lanes 0..31 (channel = lane):  hy = o tanh(cy),  cy = f c + i g
@@ -693,13 +621,9 @@ __global__ __launch_bounds__(256, WLDS ? 3 : 2) void spg_ecc_step_bwd_kernel(con
     }
   } else {
     GruFwdState st;
-    if constexpr (WLDS) {
+    {
       GruRowsLds wr;
       spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane, wr);
-      spg_gru_forward_node(G, wr, sa, sh, sx, lane, st);
-    } else {
-      GruRows wr;
-      spg_gru_load_rows(G, lane, wr);
       spg_gru_forward_node(G, wr, sa, sh, sx, lane, st);
     }
     const float a_in = lane < 32 ? sa[lane] : 0.f;
@@ -784,14 +708,8 @@ __global__ __launch_bounds__(256, WLDS ? 3 : 2) void spg_ecc_step_bwd_kernel(con
 
 int spg_launch_ecc_step_bwd(const SpgEccStepBwd& p, hipStream_t stream) {
   const dim3 grid(spg_cdiv(p.g.N, 4));
-  const bool wlds = p.g.N >= spg_ecc_lds_threshold();
-  if (p.cell == SPG_CELL_LSTM) {
-    if (wlds) hipLaunchKernelGGL((spg_ecc_step_bwd_kernel<SPG_CELL_LSTM, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((spg_ecc_step_bwd_kernel<SPG_CELL_LSTM, false>), grid, dim3(256), 0, stream, p);
-  } else {
-    if (wlds) hipLaunchKernelGGL((spg_ecc_step_bwd_kernel<SPG_CELL_GRU, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((spg_ecc_step_bwd_kernel<SPG_CELL_GRU, false>), grid, dim3(256), 0, stream, p);
-  }
+  if (p.cell == SPG_CELL_LSTM) hipLaunchKernelGGL(spg_ecc_step_bwd_kernel<SPG_CELL_LSTM>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(spg_ecc_step_bwd_kernel<SPG_CELL_GRU>, grid, dim3(256), 0, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
 }
