@@ -393,35 +393,36 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
   constexpr int A_F4 = (SPG_KC / 4) * (IT + 1);                                  // float4 slots of one A buffer
   constexpr int B_F4 = WRED ? SPG_KC * (JT + 4) / 4 : (SPG_KC / 4) * (JT + 1);   // float4 slots of one weight buffer
   if constexpr (AMODE >= 0 && FULL) {
-    // same pipeline as below on the fast pipes
-    SpgRowsFast<AMODE, IT> pa;
-    SpgWeightFast<JT> pw;
-    SpgWeightRedFast<JT> pwr;
+    // Same pipeline as the masked path below on the fast pipes, with a LONGER prefetch distance: two register sets.
+    // Iteration c first issues the global loads of chunk c+2 into one set (slots 0-2), then finishes chunk c+1 from the
+    // other set (loaded during iteration c-1, i.e. a full chunk of MFMAs ago) into the idle LDS buffer.
+    SpgRowsFast<AMODE, IT> pa0, pa1;
+    SpgWeightFast<JT> pw0, pw1;
+    SpgWeightRedFast<JT> pwr0, pwr1;
     constexpr int NIA = SpgRowsFast<AMODE, IT>::NI;
     constexpr int NIW = WRED ? SpgWeightRedFast<JT>::NI : SpgWeightFast<JT>::NI;
     static_assert(NIA + NIW + 4 <= SPG_KC / 2, "staging pieces must fit the MFMA slots of a chunk");
     const int nchunk = p.K / SPG_KC;
-    pa.init(p.a);
-    if (WRED) pwr.init(p.ldw); else pw.init(p.ldw);
-    pa.prepare(p.a, tile, 0);
+    pa0.init(p.a); pa1.init(p.a);
+    if (WRED) { pwr0.init(p.ldw); pwr1.init(p.ldw); } else { pw0.init(p.ldw); pw1.init(p.ldw); }
+    auto issue = [&](SpgRowsFast<AMODE, IT>& pa, SpgWeightFast<JT>& pw, SpgWeightRedFast<JT>& pwr, int k) __attribute__((always_inline)) {
+      pa.prepare(p.a, tile, k);
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) pa.load_part(p.a, m0, 0, i);
+      for (int i = 0; i < NIA; ++i) pa.load_part(p.a, m0, k, i);
 #pragma unroll
-    for (int i = 0; i < NIW; ++i) { if (WRED) pwr.load_part(p.W, p.ldw, n0, 0, i); else pw.load_part(p.W, p.ldw, n0, 0, i); }
+      for (int i = 0; i < NIW; ++i) { if (WRED) pwr.load_part(p.W, p.ldw, n0, k, i); else pw.load_part(p.W, p.ldw, n0, k, i); }
+    };
+    // chunk 0 -> LDS buffer 0; chunk 1 in flight in set 1
+    issue(pa0, pw0, pwr0, 0);
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) pa.store_part(As, i);
+    for (int i = 0; i < NIA; ++i) pa0.store_part(As, i);
 #pragma unroll
-    for (int i = 0; i < NIW; ++i) { if (WRED) pwr.store_part(Bsr, i); else pw.store_part(Bs, i); }
-    {
-      const int k1 = nchunk > 1 ? SPG_KC : 0;
-      pa.prepare(p.a, tile, k1);
-#pragma unroll
-      for (int i = 0; i < NIA; ++i) pa.load_part(p.a, m0, k1, i);
-#pragma unroll
-      for (int i = 0; i < NIW; ++i) { if (WRED) pwr.load_part(p.W, p.ldw, n0, k1, i); else pw.load_part(p.W, p.ldw, n0, k1, i); }
-    }
+    for (int i = 0; i < NIW; ++i) { if (WRED) pwr0.store_part(Bsr, i); else pw0.store_part(Bs, i); }
+    issue(pa1, pw1, pwr1, nchunk > 1 ? SPG_KC : 0);
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
+    // body(c, F, L): MFMAs of chunk c; finish chunk c+1 from set F; load chunk c+2 into set L (the one finished last time)
+    auto body = [&](int c, SpgRowsFast<AMODE, IT>& paF, SpgWeightFast<JT>& pwF, SpgWeightRedFast<JT>& pwrF,
+                    SpgRowsFast<AMODE, IT>& paL, SpgWeightFast<JT>& pwL, SpgWeightRedFast<JT>& pwrL) __attribute__((always_inline)) {
       const int k2 = (c + 2 < nchunk ? c + 2 : nchunk - 1) * SPG_KC;
       const int buf = c & 1;
       const f32x4* Ac = As + buf * (A_F4 + B_F4);
@@ -429,25 +430,29 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
       f32x4* An = As + (buf ^ 1) * (A_F4 + B_F4);
       f32x4* Bn = Bs + (buf ^ 1) * (A_F4 + B_F4);
       auto piece = [&](int slot) __attribute__((always_inline)) {
-        if (slot < NIA) {
-          pa.store_part(An, slot);
-        } else if (slot < NIA + NIW) {
-          if (WRED) pwr.store_part(reinterpret_cast<float*>(Bn), slot - NIA); else pw.store_part(Bn, slot - NIA);
-        } else if (slot == NIA + NIW) {
-          pa.prepare(p.a, tile, k2);
+        if (slot == 0) {
+          paL.prepare(p.a, tile, k2);
 #pragma unroll
-          for (int i = 0; i < (NIA + 1) / 2; ++i) pa.load_part(p.a, m0, k2, i);
-        } else if (slot == NIA + NIW + 1) {
+          for (int i = 0; i < (NIA + 1) / 2; ++i) paL.load_part(p.a, m0, k2, i);
+        } else if (slot == 1) {
 #pragma unroll
-          for (int i = (NIA + 1) / 2; i < NIA; ++i) pa.load_part(p.a, m0, k2, i);
-        } else if (slot == NIA + NIW + 2) {
+          for (int i = (NIA + 1) / 2; i < NIA; ++i) paL.load_part(p.a, m0, k2, i);
+        } else if (slot == 2) {
 #pragma unroll
-          for (int i = 0; i < NIW; ++i) { if (WRED) pwr.load_part(p.W, p.ldw, n0, k2, i); else pw.load_part(p.W, p.ldw, n0, k2, i); }
+          for (int i = 0; i < NIW; ++i) { if (WRED) pwrL.load_part(p.W, p.ldw, n0, k2, i); else pwL.load_part(p.W, p.ldw, n0, k2, i); }
+        } else if (slot < 3 + NIA) {
+          paF.store_part(An, slot - 3);
+        } else if (slot < 3 + NIA + NIW) {
+          if (WRED) pwrF.store_part(reinterpret_cast<float*>(Bn), slot - 3 - NIA); else pwF.store_part(Bn, slot - 3 - NIA);
         }
       };
       if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
       else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
       __syncthreads();
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+      body(c, pa1, pw1, pwr1, pa0, pw0, pwr0);          // set 1 holds chunk c+1; set 0 is free for chunk c+2
+      if (c + 1 < nchunk) body(c + 1, pa0, pw0, pwr0, pa1, pw1, pwr1);
     }
   } else if constexpr (AMODE >= 0) {
     // software-pipelined main loop, two LDS buffers, ONE barrier per chunk.  Iteration c runs the MFMAs of chunk c and,
