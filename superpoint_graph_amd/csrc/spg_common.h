@@ -783,10 +783,14 @@ struct SpgRowsFast {           // out-major [ROWS x 32] tile, every row and chan
   int4 pai;
   unsigned voff[NI], coff;
   float lo;
-  __device__ __forceinline__ void init(const SpgOperand& d) {
+  // rows >= mvalid (partial last tile) read row 0 of the tile: harmless garbage, their outputs are never stored
+  __device__ __forceinline__ void init(const SpgOperand& d, int mvalid) {
     const unsigned tid = threadIdx.x, kq = tid & 7, r0 = tid >> 3;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) voff[i] = ((r0 + 32u * i) * (unsigned)d.ld + 4u * kq) * 4u;
+    for (int i = 0; i < NI; ++i) {
+      const unsigned row = r0 + 32u * i;
+      voff[i] = ((row < (unsigned)mvalid ? row : 0u) * (unsigned)d.ld + 4u * kq) * 4u;
+    }
     coff = 16u * kq;
     lo = d.relu ? 0.f : -FLT_MAX;
   }
@@ -816,10 +820,14 @@ struct SpgWeightFast {         // out-major [JT x 32] weight tile, W [nout, kred
   static constexpr int NI = JT / 32;
   f32x4 raw[NI];
   unsigned voff[NI];
-  __device__ __forceinline__ void init(long ld) {
+  // output channels >= nout (partial last column tile) read channel n0: their columns are never stored
+  __device__ __forceinline__ void init(long ld, int n0, int nout) {
     const unsigned tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) voff[i] = (((tid >> 3) + 32u * i) * (unsigned)ld + 4u * (tid & 7)) * 4u;
+    for (int i = 0; i < NI; ++i) {
+      const unsigned j = (tid >> 3) + 32u * i;
+      voff[i] = (((int)(n0 + j) < nout ? j : 0u) * (unsigned)ld + 4u * (tid & 7)) * 4u;
+    }
   }
   __device__ __forceinline__ void load_part(const float* __restrict__ W, long ld, int n0, int k0, int i) {
     raw[i] = spg_ld16(W + (long)n0 * ld + k0, voff[i]);
@@ -835,10 +843,11 @@ struct SpgWeightRedFast {      // red-major [32 x JT] weight tile, W [kred, nout
   static constexpr int QUADS = JT / 4, RPP = SPG_THREADS / QUADS, NI = SPG_KC / RPP;
   f32x4 raw[NI];
   unsigned voff[NI];
-  __device__ __forceinline__ void init(long ld) {
+  __device__ __forceinline__ void init(long ld, int n0, int nout) {
     const unsigned tid = threadIdx.x;
+    const unsigned cq = 4u * (tid % QUADS);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) voff[i] = ((tid / QUADS + RPP * i) * (unsigned)ld + 4u * (tid % QUADS)) * 4u;
+    for (int i = 0; i < NI; ++i) voff[i] = ((tid / QUADS + RPP * i) * (unsigned)ld + ((int)(n0 + cq) < nout ? cq : 0u)) * 4u;
   }
   __device__ __forceinline__ void load_part(const float* __restrict__ W, long ld, int n0, int k0, int i) {
     raw[i] = spg_ld16(W + (long)k0 * ld + n0, voff[i]);

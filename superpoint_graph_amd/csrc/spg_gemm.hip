@@ -403,8 +403,8 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
     constexpr int NIW = WRED ? SpgWeightRedFast<JT>::NI : SpgWeightFast<JT>::NI;
     static_assert(NIA + NIW + 4 <= SPG_KC / 2, "staging pieces must fit the MFMA slots of a chunk");
     const int nchunk = p.K / SPG_KC;
-    pa0.init(p.a); pa1.init(p.a);
-    if (WRED) { pwr0.init(p.ldw); pwr1.init(p.ldw); } else { pw0.init(p.ldw); pw1.init(p.ldw); }
+    pa0.init(p.a, mvalid); pa1.init(p.a, mvalid);
+    if (WRED) { pwr0.init(p.ldw, n0, p.N); pwr1.init(p.ldw, n0, p.N); } else { pw0.init(p.ldw, n0, p.N); pw1.init(p.ldw, n0, p.N); }
     auto issue = [&](SpgRowsFast<AMODE, IT>& pa, SpgWeightFast<JT>& pw, SpgWeightRedFast<JT>& pwr, int k) __attribute__((always_inline)) {
       pa.prepare(p.a, tile, k);
 #pragma unroll
@@ -558,12 +558,13 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
   if (lds < epi) lds = epi;
   dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-  if constexpr (AMODE >= 0 && IT == 128) {
-    // every tile complete and every offset inside 32 bits: fast pipes
+  if constexpr (AMODE >= 0) {
+    // whole reduction chunks, no per-element prologue masks, every offset inside 32 bits: fast pipes (rows / output channels
+    // of a partial last tile are clamped, their results masked by the epilogue)
     const bool mode_ok = AMODE == SPG_PRO_IDENT || AMODE == SPG_PRO_BNBWD ||
                          (AMODE == SPG_PRO_AFFINE && p.a.c0 != nullptr && p.a.n_affine >= p.K) ||
-                         (AMODE == SPG_PRO_POOLBWD && p.a.P == IT);
-    const bool full = mode_ok && p.rows_per_tile == IT && p.M % IT == 0 && p.K % SPG_KC == 0 && p.N % JT == 0 &&
+                         (AMODE == SPG_PRO_POOLBWD && p.a.P == IT && p.rows_per_tile == IT && p.M % IT == 0);
+    const bool full = mode_ok && p.K % SPG_KC == 0 && (!WRED || (p.N & 3) == 0) &&
                       (long)IT * p.a.ld < (1L << 29) && (long)(WRED ? SPG_KC : JT) * p.ldw < (1L << 29);
     if (full) {
       SpgGemmParams q = p;
