@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Sanity: a few hundred optimiser steps on one synthetic scene (random labels) must drive the loss down -- the whole loop
+(HIP forward / backward, flat arena, fused clamp + Adam) learns."""
+import os
+import sys
+import types
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.learning import pointnet
+    dev = torch.device('cuda')
+    model = bench.build_model('gru_10_0,f_13', dev).train()
+    targets, GIs, flag, clouds, diam, _ = bench.make_batch([0], 1000, 5000)
+    clouds_d, diam_d, label = clouds.to(dev), diam.to(dev), targets[:, 0].to(dev)
+    model.ecc.set_info(GIs, 1)
+    emb_er = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
+    arena = FlatParameters(model)
+    losses = []
+    for it in range(301):
+        arena.zero_grad()
+        out = model.ecc(emb_er.run(model, None, flag, clouds_d, diam_d))
+        loss = F.cross_entropy(out, label)
+        loss.backward()
+        emb_er.bw_hook()
+        arena.adam_step(lr=1e-3, weight_decay=0.0, grad_clip=1.0)
+        if it % 50 == 0:
+            acc = float((out.argmax(1) == label)[label >= 0].float().mean())
+            losses.append(float(loss))
+            print(f'step {it:4d}  loss {float(loss):.4f}  train accuracy {acc:.3f}', flush=True)
+    assert losses[-1] < 0.7 * losses[0], losses
+    print('ok: loss decreased')
+
+
+if __name__ == '__main__':
+    main()
