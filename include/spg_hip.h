@@ -220,6 +220,16 @@ int spg_prof_read(double* ms, long* launches, double* flops, int reset);
  * (x = 1 for the data-gradient form, y = operand mode of A) or 2 = weight gradient (x, y = operand modes of A and B);
  * call before spg_prof_read(..., reset = 1) */
 int spg_prof_tag(int kind, int it, int jt, int x, int y, int full);
+/* per-(kernel instantiation, layer shape) totals of the instrumented launches: row j = keys[4j..4j+3] = {tag, N, K,
+ * launches}, vals[2j..2j+1] = {milliseconds, FLOP}; returns the number of rows (<= max); call before
+ * spg_prof_read(..., reset = 1) */
+int spg_prof_read_shapes(int* keys, double* vals, int max);
+/* Tuning knobs of the row-GEMM launches (process-global; the defaults are the production values).  key 0: 1 = launch
+ * one workgroup per tile instead of the persistent chunk stream (A/B timing in tools/); key 3: timing-attribution
+ * switches of the persistent forward launches (bit 0 no output store, 1 no BatchNorm partials, 2 no pooling, 3 no
+ * epilogue at all, 4 A operand from L2, 5 no main-loop barriers, bits 8-11 extra repetitions of the chunk loop) --
+ * results are WRONG while it is non-zero, tools/ only.  Returns the previous value, -1 for an unknown key. */
+int spg_tune(int key, int value);
 int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops);
 
 #ifdef __cplusplus

@@ -73,6 +73,8 @@ SIGNATURES = {
     'spg_prof_enable': (None, [_i]),
     'spg_prof_tag': (_i, [_i, _i, _i, _i, _i, _i]),
     'spg_prof_read_tag': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double)]),
+    'spg_prof_read_shapes': (_i, [ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double), _i]),
+    'spg_tune': (_i, [_i, _i]),
     'spg_prof_read': (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double), _i]),
 }
 

@@ -188,6 +188,9 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
   hipStream_t st = (hipStream_t)stream;
   Plan pl;
   SPG_TRY(make_plan(cfg, N, E, training, workspace, params, pl));
+  if (E == 0 && pl.training && spg_sync_bn_active())
+    for (const FLayer& l : pl.F)      // the other ranks enter the layer's all-reduce: skipping it here would hang the job
+      SPG_CHECK_ARG(!l.bn, "synchronised BatchNorm: a rank with an edge-less batch cannot take part in the filter-network statistics");
   // ---- filter-generating network (once per forward, shared by all iterations) ----
   if (E > 0) {
     for (int i = 0; i < (int)pl.F.size(); ++i) {

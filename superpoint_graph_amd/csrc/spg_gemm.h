@@ -34,7 +34,15 @@ struct SpgGemmParams {
   int n_mask;         // columns >= n_mask are passed through (concatenated global features)
   const float* mmean; // producer BN batch mean / rstd (null: no stats)
   const float* mrstd;
+  // set by the launcher (full-tile fast path): work-item map of the persistent chunk stream -- a workgroup handles row
+  // tiles tile0, tile0 + rstride, ... (< ntile) of one column tile; remap: XCD-aware block -> (row tile, column tile) map
+  int remap, ncol, ntile, rstride;
+  int dbg;            // timing-attribution switches (spg_tune key 3), persistent launches only
 };
+
+// tuning knobs (process-global; defaults are the production values): see spg_tune in include/spg_hip.h
+enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_COUNT = 16 };
+int spg_tune_get(int key);
 
 // dW[N,K] = sum_m prologue_a(dY)[m, n] * prologue_b(A)[m, k]
 struct SpgWgradParams {
@@ -81,6 +89,9 @@ int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                            int update_times, float* mean, float* rstd, float* s, float* t, double* scratch,
                            hipStream_t stream);
+// true while a BatchNorm all-reduce is registered (spg_set_bn_allreduce): every rank must then run the same sequence of
+// train-mode BatchNorm layers
+bool spg_sync_bn_active();
 // eval mode: s, t from the running statistics; the batch form handles every BatchNorm layer of a network in one launch
 struct SpgBnEvalJob { int N; const float *gamma, *beta, *rm, *rv; float *s, *t; };
 #define SPG_BN_EVAL_MAX_JOBS 40

@@ -31,18 +31,58 @@ void spg_set_error(const char* fmt, ...) {
 #include <mutex>
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int tag; };
+struct ProfRec { hipEvent_t a, b; double flops; int tag; int M, N, K; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 struct ProfScope {
   hipStream_t st; bool on; ProfRec r;
   ProfScope(hipStream_t s, double flops, int tag = 0) : st(s), on(g_prof_on) {
-    if (on) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.flops = flops; r.tag = tag; (void)hipEventRecord(r.a, st); }
+    if (on) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.flops = flops; r.tag = tag; r.M = r.N = r.K = 0; (void)hipEventRecord(r.a, st); }
   }
   ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); } }
 };
 }  // namespace
 extern "C" void spg_prof_enable(int on) { g_prof_on = on != 0; }
+
+// tuning knobs (spg_tune): process-global, read by the launchers
+static int g_tune[SPG_TUNE_COUNT] = {0};
+static int spg_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+int spg_tune_get(int key) { return (key >= 0 && key < SPG_TUNE_COUNT) ? g_tune[key] : 0; }
+extern "C" int spg_tune(int key, int value) {
+  if (key < 0 || key >= SPG_TUNE_COUNT) return -1;
+  const int old = g_tune[key];
+  g_tune[key] = value;
+  return old;
+}
+
+// per-(instantiation, shape) totals of the instrumented launches: up to `max` rows {tag, N, K, launches} / {ms, flops}
+extern "C" int spg_prof_read_shapes(int* keys, double* vals, int max) {
+  int n = 0;
+  for (ProfRec& r : g_prof) {
+    (void)hipEventSynchronize(r.b);
+    float dt = 0.f;
+    (void)hipEventElapsedTime(&dt, r.a, r.b);
+    int j = 0;
+    for (; j < n; ++j)
+      if (keys[4 * j] == r.tag && keys[4 * j + 1] == r.N && keys[4 * j + 2] == r.K) break;
+    if (j == n) {
+      if (n == max) continue;
+      keys[4 * n] = r.tag; keys[4 * n + 1] = r.N; keys[4 * n + 2] = r.K; keys[4 * n + 3] = 0;
+      vals[2 * n] = 0.0; vals[2 * n + 1] = 0.0;
+      ++n;
+    }
+    keys[4 * j + 3] += 1; vals[2 * j] += dt; vals[2 * j + 1] += r.flops;
+  }
+  return n;
+}
 // kernel tag of an instrumented launch: kind (1 row-GEMM, 2 weight gradient), tile, weight layout / operand modes, fast path
 #define SPG_PROF_TAG(kind, IT, JT, X, Y, FULL) ((kind) * 1000000 + ((IT) / 32) * 100000 + ((JT) / 32) * 10000 + ((X) + 1) * 100 + ((Y) + 1) * 10 + (FULL))
 extern "C" int spg_prof_tag(int kind, int it, int jt, int x, int y, int full) { return SPG_PROF_TAG(kind, it, jt, x, y, full ? 1 : 0); }
@@ -85,29 +125,40 @@ extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int rese
 // Epilogues.  FULL: the tile is completely inside the matrix (and, for the backward, inside the masked channel
 // range), so every load / store is unconditional: straight-line code without per-element exec-mask branches and the
 // conservative s_waitcnt the compiler puts at their joins.
-// LDS floats of one wave's staging region for the vector store: rows x (cols + 8) (the +8 keeps the two lane halves of an
-// accumulator register on disjoint banks)
-#define SPG_EPI_WAVE_FLOATS(RW, CW) ((RW) * ((CW) + 8))
+// LDS floats of one wave's staging region for the vector store: 16 rows x (cols + 8) (the +8 keeps the two lane halves of
+// an accumulator register on disjoint banks).  The sub-tile goes through it in pieces of 16 rows (= 8 accumulator
+// registers per 32x32 block), so that the staging of all four waves fits into ONE of the two main-loop LDS buffers: the
+// other one already holds the first chunk of the workgroup's next tile (persistent launches).
+// a zero the optimiser cannot see through: added to the thread index inside the epilogues so that their (many) per-lane
+// address computations are NOT hoisted out of the persistent tile loop (they would stay live across the main loop)
+__device__ __forceinline__ int spg_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+#define SPG_EPI_PIECE_ROWS 16
+#define SPG_EPI_WAVE_FLOATS(RW, CW) (SPG_EPI_PIECE_ROWS * ((CW) + 8))
 
 // accumulators of one wave (RW x CW sub-tile in the MFMA C layout) -> LDS (wave-private, no barrier) -> rows of float4
 template <int RW, int CW, int TI, int TJ>
 __device__ __forceinline__ void spg_store_tile_vec_impl(const f32x16 (&acc)[TI][TJ], float* __restrict__ st,
                                                         float* __restrict__ ybase, unsigned ldy, int lane) {
   constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR;      // lanes per row, rows per store instruction
+  static_assert(SPG_EPI_PIECE_ROWS % RPI == 0, "a piece is a whole number of store instructions");
   const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) st[(32 * i + spg_acc_row(q, h)) * LD + 32 * j + r] = acc[i][j][q];
   const int lr = lane / LPR, lc = 4 * (lane % LPR);
   const unsigned o0 = (unsigned)lr * ldy + (unsigned)lc;
 #pragma unroll
-  for (int it = 0; it < RW / RPI; ++it) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * it) * LD + lc);
-    *reinterpret_cast<f32x4*>(ybase + o0 + (unsigned)(RPI * it) * ldy) = v;
-  }
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      // registers 8*half .. 8*half+7 of a 32x32 block are its rows 16*half + (u&3) + 8*(u>>2) + 4h
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) st[((u & 3) + 8 * (u >> 2) + 4 * h) * LD + 32 * j + r] = acc[i][j][8 * half + u];
+#pragma unroll
+      for (int it = 0; it < SPG_EPI_PIECE_ROWS / RPI; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * it) * LD + lc);
+        *reinterpret_cast<f32x4*>(ybase + o0 + (unsigned)(32 * i + 16 * half + RPI * it) * ldy) = v;
+      }
+    }
 }
 template <int RW, int CW, int TI, int TJ>
 __device__ __forceinline__ void spg_store_tile_vec(const f32x16 (&acc)[TI][TJ], float* __restrict__ st,
@@ -116,11 +167,12 @@ __device__ __forceinline__ void spg_store_tile_vec(const f32x16 (&acc)[TI][TJ], 
   spg_store_tile_vec_impl<RW, CW, TI, TJ>(acc, st, ybase, ldy, lane);
 }
 
-template <int IT, int JT, int WI, int WJ, bool FULL>
+// BIAS_DONE: the accumulators were initialised with the bias (persistent fast path), nothing to add here
+template <int IT, int JT, int WI, int WJ, bool FULL, bool BIAS_DONE = false>
 __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
                                                  float* __restrict__ red, int tile, long m0, int mvalid, int n0) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x + spg_opaque_zero(), lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
   const int colw = wj * (JT / WJ), roww = wi * (IT / WI);
@@ -129,15 +181,14 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
   for (int j = 0; j < TJ; ++j) {
     const int col = n0 + colw + 32 * j + r;
     const bool colok = FULL || col < p.N;
-    float bv = 0.f;
-    if (p.bias != nullptr) {   // uniform
+    if (!BIAS_DONE && p.bias != nullptr) {   // uniform
       const float t = p.bias[colok ? col : 0];
-      bv = colok ? t : 0.f;
+      const float bv = colok ? t : 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] += bv;
     }
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] += bv;
     if (p.Y != nullptr && !(FULL && p.vec_store)) {      // uniform
       float* yb = p.Y + m0 * p.ldy + n0;                       // wave-uniform base (SGPRs) + 32-bit lane offsets
       const unsigned ldy = (unsigned)p.ldy;
@@ -232,18 +283,13 @@ template <int IT, int JT, int WI, int WJ>
 __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
                                                      float* __restrict__ red, int tile, long m0, int n0) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32, RW = IT / WI, CW = JT / WJ;
-  constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR, NIT = SPG_EPI_PIECE_ROWS / RPI;
+  static_assert(SPG_EPI_PIECE_ROWS % RPI == 0, "a piece is a whole number of store instructions");
+  const int tid = threadIdx.x + spg_opaque_zero(), lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
   const int colw = wj * CW, roww = wi * RW;
   float* st = red + wave * SPG_EPI_WAVE_FLOATS(RW, CW);
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) st[(32 * i + spg_acc_row(q, h)) * LD + 32 * j + r] = acc[i][j][q];
   const bool do_stats = p.stat != nullptr && p.mmean != nullptr;           // uniform
   const bool do_mask = p.mask_relu != 0 && p.Yp != nullptr;                // uniform
   const bool use_y = p.Yp != nullptr && (do_stats || do_mask);
@@ -256,30 +302,36 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32
   float* yo = p.Y + (m0 + roww) * p.ldy + n0 + colw;
   const unsigned op0 = (unsigned)lr * (unsigned)p.ldyp + (unsigned)lc, oo0 = (unsigned)lr * (unsigned)p.ldy + (unsigned)lc;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
-  constexpr int NIT = RW / RPI, BATCH = NIT < 8 ? NIT : 8;
 #pragma unroll
-  for (int b = 0; b < NIT; b += BATCH) {
-    f32x4 yv[BATCH];
-    if (use_y) {
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) yv[u] = *reinterpret_cast<const f32x4*>(yp + op0 + (unsigned)(RPI * (b + u)) * (unsigned)p.ldyp);
-    }
+    for (int half = 0; half < 2; ++half) {
+      const int rb = 32 * i + 16 * half;       // first row of this piece inside the wave's sub-tile
+      f32x4 yv[NIT];
+      if (use_y) {
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * (b + u)) * LD + lc);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float y = use_y ? yv[u][e] : 0.f;
-        if (do_mask && !(fmaf(y, sc[e], sh[e]) > 0.f)) v[e] = 0.f;
-        if (do_stats) {
-          s1[e] += v[e];
-          s2[e] = fmaf(v[e], (y - mean[e]) * rstd[e], s2[e]);
-        }
+        for (int u = 0; u < NIT; ++u) yv[u] = *reinterpret_cast<const f32x4*>(yp + op0 + (unsigned)(rb + RPI * u) * (unsigned)p.ldyp);
       }
-      *reinterpret_cast<f32x4*>(yo + oo0 + (unsigned)(RPI * (b + u)) * (unsigned)p.ldy) = v;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) st[((u & 3) + 8 * (u >> 2) + 4 * h) * LD + 32 * j + r] = acc[i][j][8 * half + u];
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * u) * LD + lc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = use_y ? yv[u][e] : 0.f;
+          if (do_mask && !(fmaf(y, sc[e], sh[e]) > 0.f)) v[e] = 0.f;
+          if (do_stats) {
+            s1[e] += v[e];
+            s2[e] = fmaf(v[e], (y - mean[e]) * rstd[e], s2[e]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(yo + oo0 + (unsigned)(rb + RPI * u) * (unsigned)p.ldy) = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
   if (p.stat != nullptr) {
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
@@ -299,7 +351,7 @@ template <int IT, int JT, int WI, int WJ, bool FULL>
 __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
                                                  float* __restrict__ red, int tile, long m0, int mvalid, int n0) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x + spg_opaque_zero(), lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
   const int colw = wj * (JT / WJ), roww = wi * (IT / WI);
@@ -362,11 +414,32 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
   }
 }
 
+// epilogue of one finished tile (all variants): `red` = LDS staging region that nobody reads any more
+template <int IT, int JT, int WI, int WJ, bool WRED, bool FULL, bool BIAS_DONE>
+__device__ __forceinline__ void spg_tile_epilogue(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
+                                                  float* __restrict__ red, int tile, long m0, int mvalid, int n0) {
+  if constexpr (!WRED) {      // forward kernels: weights [N,K]; backward (dgrad) kernels: untransposed weights [K,N]
+    if (mvalid == IT && n0 + JT <= p.N) spg_epilogue_fwd<IT, JT, WI, WJ, true, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0);
+    else spg_epilogue_fwd<IT, JT, WI, WJ, false, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0);
+  } else {
+    const bool full = mvalid == IT && n0 + JT <= p.N && (n0 + JT <= p.n_mask || (p.stat == nullptr && !p.mask_relu));
+    if (FULL && full && p.vec_store) spg_epilogue_bwd_vec<IT, JT, WI, WJ>(p, acc, red, tile, m0, n0);
+    else if (full) spg_epilogue_bwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
+    else spg_epilogue_bwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
+  }
+}
+
 // AMODE >= 0: operand mode of A known at compile time, vector + software-pipelined main loop (host guarantees the
 // alignment conditions); AMODE < 0: generic scalar staging (channel-major clouds, unaligned leading dimensions).
 // FULL: every tile of the launch is complete (rows, output channels, reduction chunks): the masked staging pipes are
-// replaced by the loop-invariant-address fast pipes (spg_common.h).
-template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false>
+// replaced by the loop-invariant-address fast pipes (spg_common.h), and the kernel is a PERSISTENT CHUNK STREAM: a
+// workgroup takes row tiles tile, tile + rstride, ... of its column tile and treats their reduction chunks as one
+// stream -- the loads of the next tile's first two chunks are issued under the last two chunks of the current one and
+// its first chunk is already in LDS when the epilogue starts, so neither workgroup launch latency nor first-load
+// latency is paid per tile (measured before: wave slots empty 20 % of the kernel, conv5 at 0.69 of the MFMA peak even
+// without any epilogue).  A launch with one tile per workgroup (rstride >= ntile) is the degenerate case.
+// STREAM: compiled with the multi-tile stream (persistent launches); without it has_next is a compile-time false
+template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false, bool STREAM = false>
 __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGemmParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
@@ -378,24 +451,27 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
-  const int tile = blockIdx.x;
-  const long m0 = (long)tile * p.rows_per_tile;
-  const int mvalid = (int)min((long)p.rows_per_tile, (long)p.M - m0);
-  const int n0 = blockIdx.y * JT;
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-
   constexpr int A_F4 = (SPG_KC / 4) * (IT + 1);                                  // float4 slots of one A buffer
   constexpr int B_F4 = WRED ? SPG_KC * (JT + 4) / 4 : (SPG_KC / 4) * (JT + 1);   // float4 slots of one weight buffer
+  f32x16 acc[TI][TJ];
+
   if constexpr (AMODE >= 0 && FULL) {
-    // Same pipeline as the masked path below on the fast pipes, with a LONGER prefetch distance: two register sets.
-    // Iteration c first issues the global loads of chunk c+2 into one set (slots 0-2), then finishes chunk c+1 from the
-    // other set (loaded during iteration c-1, i.e. a full chunk of MFMAs ago) into the idle LDS buffer.
+    static_assert(4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) <= 4 * (A_F4 + B_F4), "epilogue staging must fit one LDS buffer");
+    int tile = blockIdx.x, ct = blockIdx.y;
+    if (p.remap) {
+      // XCD-aware item map (workgroup b runs on XCD b % 8): the column tiles of one row tile are consecutive workgroups
+      // of ONE XCD (the second reader of an A tile finds it in that XCD's L2); a workgroup keeps its column tile
+      const int lin = blockIdx.x, j = lin >> 3;
+      ct = j % p.ncol;
+      tile = (j / p.ncol) * 8 + (lin & 7);
+    }
+    const int ntile = p.ntile, rstride = p.rstride;
+    if (tile >= ntile) return;
+    const int n0 = ct * JT;
+    long m0 = (long)tile * p.rows_per_tile;
+    int mvalid = (int)min((long)p.rows_per_tile, (long)p.M - m0);     // == IT for every tile of a multi-tile stream (host)
+    // two register sets: iteration c issues the global loads of chunk c+2 into one set (slots 0-2), then finishes chunk
+    // c+1 from the other set (loaded during iteration c-1, i.e. a full chunk of MFMAs ago) into the idle LDS buffer
     SpgRowsFast<AMODE, IT> pa0, pa1;
     SpgWeightFast<JT> pw0, pw1;
     SpgWeightRedFast<JT> pwr0, pwr1;
@@ -405,56 +481,142 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
     const int nchunk = p.K / SPG_KC;
     pa0.init(p.a, mvalid); pa1.init(p.a, mvalid);
     if (WRED) { pwr0.init(p.ldw, n0, p.N); pwr1.init(p.ldw, n0, p.N); } else { pw0.init(p.ldw, n0, p.N); pw1.init(p.ldw, n0, p.N); }
-    auto issue = [&](SpgRowsFast<AMODE, IT>& pa, SpgWeightFast<JT>& pw, SpgWeightRedFast<JT>& pwr, int k) __attribute__((always_inline)) {
-      pa.prepare(p.a, tile, k);
-#pragma unroll
-      for (int i = 0; i < NIA; ++i) pa.load_part(p.a, m0, k, i);
-#pragma unroll
-      for (int i = 0; i < NIW; ++i) { if (WRED) pwr.load_part(p.W, p.ldw, n0, k, i); else pw.load_part(p.W, p.ldw, n0, k, i); }
-    };
     // chunk 0 -> LDS buffer 0; chunk 1 in flight in set 1
-    issue(pa0, pw0, pwr0, 0);
+    {
+      pa0.prepare(p.a, tile, 0);
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) pa0.store_part(As, i);
+      for (int i = 0; i < NIA; ++i) pa0.load_part(p.a, m0, 0, i);
 #pragma unroll
-    for (int i = 0; i < NIW; ++i) { if (WRED) pwr0.store_part(Bsr, i); else pw0.store_part(Bs, i); }
-    issue(pa1, pw1, pwr1, nchunk > 1 ? SPG_KC : 0);
-    __syncthreads();
-    // body(c, F, L): MFMAs of chunk c; finish chunk c+1 from set F; load chunk c+2 into set L (the one finished last time)
-    auto body = [&](int c, SpgRowsFast<AMODE, IT>& paF, SpgWeightFast<JT>& pwF, SpgWeightRedFast<JT>& pwrF,
-                    SpgRowsFast<AMODE, IT>& paL, SpgWeightFast<JT>& pwL, SpgWeightRedFast<JT>& pwrL) __attribute__((always_inline)) {
-      const int k2 = (c + 2 < nchunk ? c + 2 : nchunk - 1) * SPG_KC;
-      const int buf = c & 1;
-      const f32x4* Ac = As + buf * (A_F4 + B_F4);
-      const f32x4* Bc = Bs + buf * (A_F4 + B_F4);
-      f32x4* An = As + (buf ^ 1) * (A_F4 + B_F4);
-      f32x4* Bn = Bs + (buf ^ 1) * (A_F4 + B_F4);
-      auto piece = [&](int slot) __attribute__((always_inline)) {
-        if (slot == 0) {
-          paL.prepare(p.a, tile, k2);
+      for (int i = 0; i < NIW; ++i) { if (WRED) pwr0.load_part(p.W, p.ldw, n0, 0, i); else pw0.load_part(p.W, p.ldw, n0, 0, i); }
 #pragma unroll
-          for (int i = 0; i < (NIA + 1) / 2; ++i) paL.load_part(p.a, m0, k2, i);
-        } else if (slot == 1) {
+      for (int i = 0; i < NIA; ++i) pa0.store_part(As, i);
 #pragma unroll
-          for (int i = (NIA + 1) / 2; i < NIA; ++i) paL.load_part(p.a, m0, k2, i);
-        } else if (slot == 2) {
+      for (int i = 0; i < NIW; ++i) { if (WRED) pwr0.store_part(Bsr, i); else pw0.store_part(Bs, i); }
+      const int k1 = nchunk > 1 ? SPG_KC : 0;
+      pa1.prepare(p.a, tile, k1);
 #pragma unroll
-          for (int i = 0; i < NIW; ++i) { if (WRED) pwrL.load_part(p.W, p.ldw, n0, k2, i); else pwL.load_part(p.W, p.ldw, n0, k2, i); }
-        } else if (slot < 3 + NIA) {
-          paF.store_part(An, slot - 3);
-        } else if (slot < 3 + NIA + NIW) {
-          if (WRED) pwrF.store_part(reinterpret_cast<float*>(Bn), slot - 3 - NIA); else pwF.store_part(Bn, slot - 3 - NIA);
-        }
-      };
-      if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
-      else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
-      __syncthreads();
-    };
-    for (int c = 0; c < nchunk; c += 2) {
-      body(c, pa1, pw1, pwr1, pa0, pw0, pwr0);          // set 1 holds chunk c+1; set 0 is free for chunk c+2
-      if (c + 1 < nchunk) body(c + 1, pa0, pw0, pwr0, pa1, pw1, pwr1);
+      for (int i = 0; i < NIA; ++i) pa1.load_part(p.a, m0, k1, i);
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) { if (WRED) pwr1.load_part(p.W, p.ldw, n0, k1, i); else pw1.load_part(p.W, p.ldw, n0, k1, i); }
     }
-  } else if constexpr (AMODE >= 0) {
+    __syncthreads();
+    constexpr bool BIAS_IN_ACC = !WRED;
+    // backward kernels (two operand streams + four constant arrays per register set): the loads of the next tile's SECOND
+    // chunk are issued after the epilogue instead of under the last chunk -- nothing but the accumulators and the
+    // loop-invariant offsets is then live across the epilogue (no spills)
+    constexpr bool DEFER2 = WRED;
+    for (;;) {
+      tile = __builtin_amdgcn_readfirstlane(tile);             // wave-uniform by construction: keep the tile stream in SGPRs
+      m0 = (long)tile * p.rows_per_tile;
+      const int nxt = tile + rstride;
+      const bool has_next = STREAM && nxt < ntile;               // uniform
+      const long m0n = has_next ? (long)nxt * p.rows_per_tile : m0;
+      const int tilen = has_next ? nxt : tile;
+      // accumulators start from the bias (forward) / zero
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        float bv = 0.f;
+        if (BIAS_IN_ACC && p.bias != nullptr) {                  // uniform
+          const int col = n0 + wj * (JT / WJ) + 32 * j + r;
+          const float t = p.bias[col < p.N ? col : 0];
+          bv = col < p.N ? t : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][j][q] = bv;
+      }
+      // body(c, F, L): MFMAs of chunk c; finish chunk c+1 from set F; load chunk c+2 into set L (the one finished last
+      // time).  Chunks nchunk, nchunk+1 are chunks 0, 1 of the NEXT tile of this workgroup (clamped re-loads of the last
+      // chunk when there is none: harmless).
+      auto body = [&](int c, int k2, long ml, int tl, bool noload, SpgRowsFast<AMODE, IT>& paF, SpgWeightFast<JT>& pwF, SpgWeightRedFast<JT>& pwrF,
+                      SpgRowsFast<AMODE, IT>& paL, SpgWeightFast<JT>& pwL, SpgWeightRedFast<JT>& pwrL) __attribute__((always_inline)) {
+        const int buf = c & 1;
+        const f32x4* Ac = As + buf * (A_F4 + B_F4);
+        const f32x4* Bc = Bs + buf * (A_F4 + B_F4);
+        f32x4* An = As + (buf ^ 1) * (A_F4 + B_F4);
+        f32x4* Bn = Bs + (buf ^ 1) * (A_F4 + B_F4);
+        auto piece = [&](int slot) __attribute__((always_inline)) {
+          if (slot == 0) {
+            if (!(DEFER2 && noload)) {
+              paL.prepare(p.a, tl, k2);
+#pragma unroll
+              for (int i = 0; i < (NIA + 1) / 2; ++i) paL.load_part(p.a, ml, k2, i);
+            }
+          } else if (slot == 1) {
+            if (!(DEFER2 && noload)) {
+#pragma unroll
+              for (int i = (NIA + 1) / 2; i < NIA; ++i) paL.load_part(p.a, ml, k2, i);
+            }
+          } else if (slot == 2) {
+            if (!(DEFER2 && noload)) {
+#pragma unroll
+              for (int i = 0; i < NIW; ++i) { if (WRED) pwrL.load_part(p.W, p.ldw, n0, k2, i); else pwL.load_part(p.W, p.ldw, n0, k2, i); }
+            }
+          } else if (slot < 3 + NIA) {
+            paF.store_part(An, slot - 3);
+          } else if (slot < 3 + NIA + NIW) {
+            if (WRED) pwrF.store_part(reinterpret_cast<float*>(Bn), slot - 3 - NIA); else pwF.store_part(Bn, slot - 3 - NIA);
+          }
+        };
+        if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+        else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+        if (!(STREAM && (p.dbg & 32))) __syncthreads();      // (attribution switch: main loop without barriers)
+      };
+      const int reps = STREAM ? 1 + ((p.dbg >> 8) & 15) : 1;      // (attribution switch: the chunk loop repeated -> steady-state rate)
+      for (int rep = 0; rep < reps; ++rep)
+      for (int c = 0; c < nchunk; c += 2) {
+        // where the loads of chunk c+2 / c+3 come from: this tile, the next tile of the stream, or (at the very end) a
+        // clamped re-load of the last chunk -- plain scalar values, computed outside the lambdas
+        int ka = c + 2, kb = c + 3;
+        long ma = m0, mb = m0;
+        if (STREAM && (p.dbg & 16)) ma = mb = (long)(tile & 15) * p.rows_per_tile;     // (attribution switch: A from L2)
+        int ta = tile, tb = tile;
+        if (ka >= nchunk) { if (has_next) { ka -= nchunk; ma = (STREAM && (p.dbg & 16)) ? ma : m0n; ta = tilen; } else ka = nchunk - 1; }
+        if (kb >= nchunk) { if (has_next) { kb -= nchunk; mb = (STREAM && (p.dbg & 16)) ? mb : m0n; tb = tilen; } else kb = nchunk - 1; }
+        body(c, ka * SPG_KC, ma, ta, false, pa1, pw1, pwr1, pa0, pw0, pwr0);          // set 1 holds chunk c+1; set 0 is free for chunk c+2
+        if (c + 1 < nchunk) body(c + 1, kb * SPG_KC, mb, tb, has_next && c + 2 >= nchunk, pa0, pw0, pwr0, pa1, pw1, pwr1);
+      }
+      // Here (nchunk even when there is a next tile -- host): LDS buffer 0 holds chunk 0 of the next tile, set 1 its chunk
+      // 1 (in flight); buffer 1 was read by the last chunk and is free: the epilogue stages through it.
+      float* red = reinterpret_cast<float*>(smem + (A_F4 + B_F4));
+      if (STREAM && p.dbg) {       // timing attribution only (spg_tune key 3; results are WRONG): parts of the epilogue off
+        if (p.dbg & 8) {
+          if (acc[0][0][0] + acc[TI - 1][TJ - 1][5] == 123.456f) p.Y[0] = 0.f;
+        } else {
+          SpgGemmParams q = p;
+          if (p.dbg & 1) q.Y = nullptr;
+          if (p.dbg & 2) q.stat = nullptr;
+          if (p.dbg & 4) q.pmax = nullptr;
+          spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(q, acc, red, tile, m0, mvalid, n0);
+        }
+      } else
+      spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(p, acc, red, tile, m0, mvalid, n0);
+      if (!has_next) break;
+      tile = nxt; m0 = m0n;
+      if (DEFER2) {
+        pa1.prepare(p.a, tile, SPG_KC);
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) pa1.load_part(p.a, m0, SPG_KC, i);
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) { if (WRED) pwr1.load_part(p.W, p.ldw, n0, SPG_KC, i); else pw1.load_part(p.W, p.ldw, n0, SPG_KC, i); }
+      }
+      __syncthreads();          // the staging region is overwritten by the next chunk's finish stage
+    }
+    return;
+  }
+
+  const int tile = blockIdx.x;
+  const long m0 = (long)tile * p.rows_per_tile;
+  const int mvalid = (int)min((long)p.rows_per_tile, (long)p.M - m0);
+  const int n0 = blockIdx.y * JT;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  if constexpr (AMODE >= 0) {
     // software-pipelined main loop, two LDS buffers, ONE barrier per chunk.  Iteration c runs the MFMAs of chunk c and,
     // in their shadow (spg_mfma_chunk_il), finishes chunk c+1 (prologue arithmetic + LDS write into the other buffer;
     // its global loads were issued one iteration earlier) and then issues the global loads of chunk c+2.  The loop is
@@ -523,18 +685,10 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
       __syncthreads();
     }
   }
-
   float* red = reinterpret_cast<float*>(smem);  // LDS is free again after the last barrier
-  if constexpr (!WRED) {      // forward kernels: weights [N,K]; backward (dgrad) kernels: untransposed weights [K,N]
-    if (mvalid == IT && n0 + JT <= p.N) spg_epilogue_fwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
-    else spg_epilogue_fwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
-  } else {
-    const bool full = mvalid == IT && n0 + JT <= p.N && (n0 + JT <= p.n_mask || (p.stat == nullptr && !p.mask_relu));
-    if (FULL && full && p.vec_store) spg_epilogue_bwd_vec<IT, JT, WI, WJ>(p, acc, red, tile, m0, n0);
-    else if (full) spg_epilogue_bwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
-    else spg_epilogue_bwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
-  }
+  spg_tile_epilogue<IT, JT, WI, WJ, WRED, false, false>(p, acc, red, tile, m0, mvalid, n0);
 }
+
 
 int spg_gemm_ntiles(const SpgGemmParams& p) { return spg_cdiv(p.M, p.rows_per_tile); }
 
@@ -558,6 +712,7 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
   if (lds < epi) lds = epi;
   dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
+  prof.r.M = p.M; prof.r.N = p.N; prof.r.K = p.K;
   if constexpr (AMODE >= 0) {
     // whole reduction chunks, no per-element prologue masks, every offset inside 32 bits: fast pipes (rows / output channels
     // of a partial last tile are clamped, their results masked by the epilogue)
@@ -573,7 +728,26 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
         q.vec_store = q.vec_store && (p.N & 3) == 0 && (p.Yp == nullptr || ((p.ldyp & 3) == 0 && (((uintptr_t)p.Yp) & 15) == 0)) &&
                       ((((uintptr_t)p.ms) | ((uintptr_t)p.mt) | ((uintptr_t)p.mmean) | ((uintptr_t)p.mrstd) | ((uintptr_t)p.stat)) & 15) == 0;
       prof.r.tag = SPG_PROF_TAG(1, IT, JT, WRED ? 1 : 0, AMODE, 1);
-      hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true>), grid, dim3(SPG_THREADS), lds, stream, q);
+      // Persistent chunk stream (see the kernel): as many workgroups as the chip holds at once (2 per CU), each walks
+      // the row tiles of ONE column tile.  Needs whole tiles everywhere, an even number of reduction chunks (the LDS
+      // buffer / register set roles are then the same at every tile start) and a column-tile count dividing the stride.
+      q.ntile = (int)grid.x; q.rstride = 1 << 30; q.remap = 0; q.ncol = (int)grid.y;
+      const int slots = 2 * spg_num_cus();
+      const int ncol = (int)grid.y;
+      // (the 128-column backward kernels -- two operand streams, four constant arrays -- have no registers left for the
+      // stream state: measured slower with it, so they keep one workgroup per tile)
+      if (!g_tune[SPG_TUNE_NO_PERSIST] && IT == 128 && !(WRED && JT == 128) && p.rows_per_tile == IT && p.M % IT == 0 && p.N % JT == 0 &&
+          (p.K / SPG_KC) % 2 == 0 && (long)grid.x * ncol > slots && slots % (8 * ncol) == 0) {
+        q.remap = 1; q.rstride = slots / ncol;
+        q.dbg = WRED ? 0 : g_tune[SPG_TUNE_DBG];      // attribution switches: forward launches only
+        grid = dim3((unsigned)slots, 1);
+        if constexpr (IT == 128 && !(WRED && JT == 128)) {
+          hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true>), grid, dim3(SPG_THREADS), lds, stream, q);
+          SPG_LAUNCH_CHECK();
+          return 0;
+        }
+      }
+      hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false>), grid, dim3(SPG_THREADS), lds, stream, q);
       SPG_LAUNCH_CHECK();
       return 0;
     }
@@ -1056,6 +1230,8 @@ extern "C" int spg_set_bn_allreduce(spg_allreduce_fn fn, void* ctx, double* buf,
   g_sync.fn = fn; g_sync.ctx = ctx; g_sync.buf = fn ? buf : nullptr; g_sync.ndoubles = fn ? buf_doubles : 0;
   return 0;
 }
+
+bool spg_sync_bn_active() { return g_sync.fn != nullptr; }
 
 static int spg_sync_allreduce(long n, hipStream_t stream) {
   const int rc = g_sync.fn(g_sync.ctx, g_sync.buf, n, (void*)stream);

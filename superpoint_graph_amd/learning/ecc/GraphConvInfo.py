@@ -52,8 +52,23 @@ class GraphConvInfo(object):
         gi._idxn, gi._degrees, gi._edgefeats, gi._idxe, gi._edge_indexes = idxn, degs, edgefeats, idxe, edge_indexes
         return gi
 
+    def _validate(self):
+        """Host-side check of the index contract before the device CSR is built from it (the reference's index_select
+        would raise a device assert; the HIP graph build would write out of bounds): sum(degs) == E, 0 <= idxn < N."""
+        idxn, degs = self._idxn, self._degrees
+        if idxn.is_cuda or degs.is_cuda:
+            return            # already-resident buffers (from_buffers with device tensors): checked by the caller
+        N, E = int(degs.numel()), int(idxn.numel())
+        if int(degs.sum()) != E or (N and int(degs.min()) < 0):
+            raise ValueError(f'GraphConvInfo: sum(degs) = {int(degs.sum())} does not match the number of edges {E}')
+        if E and (int(idxn.min()) < 0 or int(idxn.max()) >= N):
+            raise IndexError(f'GraphConvInfo: idxn entries must be in [0, {N}), got [{int(idxn.min())}, {int(idxn.max())}]')
+        if self._edgefeats is not None and self._idxe is None and self._edgefeats.shape[0] != E:
+            raise ValueError(f'GraphConvInfo: {self._edgefeats.shape[0]} edge-feature rows for {E} edges')
+
     def cuda(self):
         from ... import ops
+        self._validate()
         self._idxn = self._idxn.cuda()
         if self._idxe is not None:
             self._idxe = self._idxe.cuda()

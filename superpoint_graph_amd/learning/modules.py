@@ -137,6 +137,9 @@ class _EccRnnFunction(torch.autograd.Function):
         if d_f is not None and d_c is not None:
             grad_h0, _ = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out, d_f + d_c)
             return (None, grad_h0, None, None, None) + (None,) * ctx.nflat
+        if ctx.nflat == 1 and getattr(ctx.module, '_spg_direct_grads', False):
+            raise RuntimeError('FlatParameters mode: a parameter has no contiguous .grad view into the gradient arena '
+                               '(optimizer.zero_grad(set_to_none=True) or a frozen parameter?); use FlatParameters.zero_grad()')
         grad_h0, gg = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out)
         flat = []
         for li, g in enumerate(gg):
@@ -187,6 +190,9 @@ class RNNGraphConvModule(nn.Module):
         nc = self._cell.hidden_size
         matrix = widths[-1] == nc * nc and widths[-1] != nc
         bn = next((b for _, b in fg if b is not None), None)
+        if bn is not None:
+            from .pointnet import _bn_momentum
+            _bn_momentum(bn)
         cfg = ops.make_eccrnn_cfg(nc, self._nrepeats, matrix, self._cell._layernorm, self._cell._ingate, self._cat_all,
                                   widths, bnidx, fg[-1][0].bias is not None,
                                   1e-5 if bn is None else bn.eps, 0.1 if bn is None or bn.momentum is None else bn.momentum,

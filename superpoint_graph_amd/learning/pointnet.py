@@ -27,6 +27,16 @@ def _seq_groups(seq):
     return groups
 
 
+def _bn_momentum(bn):
+    """BatchNorm1d(momentum=None) means a cumulative moving average and track_running_stats=False means batch statistics
+    in eval mode: neither is implemented by the kernels (exponential average only) -- refuse instead of silently using 0.1."""
+    if bn.momentum is None:
+        raise NotImplementedError('BatchNorm1d(momentum=None) (cumulative average) is not implemented on the HIP path')
+    if not bn.track_running_stats or bn.running_mean is None:
+        raise NotImplementedError('BatchNorm1d(track_running_stats=False) is not implemented on the HIP path')
+    return bn.momentum
+
+
 def _tensors(lin, bn):
     w = lin.weight
     return (w, lin.bias, None if bn is None else bn.weight, None if bn is None else bn.bias,
@@ -78,7 +88,7 @@ class STNkD(nn.Module):
     def _cfg(self, npts):
         bn0 = self.convs[1]
         return ops.make_pointnet_cfg(self._nfeat, 0, 0, npts, [], [], self._nf_conv, self._nf_fc + [self._K * self._K], False,
-                                     bn0.eps, 0.1 if bn0.momentum is None else bn0.momentum)
+                                     bn0.eps, _bn_momentum(bn0))
 
     def forward(self, input):
         """[B, nfeat, P] -> [B, K, K] transformation matrices (reference learning/pointnet.py:55-61)."""
@@ -144,6 +154,9 @@ class _PointNetFunction(torch.autograd.Function):
         if direct is not None:      # gradients are written straight into the pre-assigned .grad views (FlatParameters)
             ops.pointnet_backward(ctx.state, ctx.groups, grad_emb, direct)
             return (None,) * (5 + ctx.nflat)
+        if ctx.nflat == 1 and getattr(ctx.module, '_spg_direct_grads', False):
+            raise RuntimeError('FlatParameters mode: a parameter has no contiguous .grad view into the gradient arena '
+                               '(optimizer.zero_grad(set_to_none=True) or a frozen parameter?); use FlatParameters.zero_grad()')
         gg = ops.pointnet_backward(ctx.state, ctx.groups, grad_emb)
         flat = []
         for (gw, gb, ggam, gbet) in gg:
@@ -211,8 +224,7 @@ class PointNet(nn.Module):
             stn_fc = self.stn._nf_fc if self.nfeat_stn > 0 else []
             bn0 = self.convs[1]
             cache[npts] = ops.make_pointnet_cfg(self._nfeat, self.nfeat_stn, self._nfeat_global, npts, stn_conv, stn_fc,
-                                                self._nf_conv, self._nf_fc, self._last_ac, bn0.eps,
-                                                0.1 if bn0.momentum is None else bn0.momentum)
+                                                self._nf_conv, self._nf_fc, self._last_ac, bn0.eps, _bn_momentum(bn0))
         return cache[npts]
 
     def _bump_batches_tracked(self, times):

@@ -25,6 +25,10 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 def _req(t: torch.Tensor, dtype=None, name='tensor'):
     if not t.is_cuda:
         raise RuntimeError(f'{name} must live on the GPU: the superpoint_graph_amd kernels have no CPU path')
+    if t.device.index != torch.cuda.current_device():
+        # the kernels are launched on the CURRENT device's stream; a tensor of another GPU would be an invalid access
+        raise RuntimeError(f'{name} lives on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}; '
+                           'call torch.cuda.set_device() (or use `with torch.cuda.device_of(tensor):`) first')
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
     if not t.is_contiguous():
@@ -187,11 +191,22 @@ def make_pointnet_cfg(nfeat, nfeat_stn, nfeat_global, npts, stn_conv, stn_fc, co
     return c
 
 
+def _require_training_state(state, what):
+    """The backward kernels read the batch-statistics workspace layout of a TRAINING-mode forward (saved aggregates,
+    BatchNorm mean / rstd).  After an eval-mode forward that layout does not exist: fail loudly instead of reading
+    out of bounds (frozen-BatchNorm fine-tuning is not implemented on the HIP path)."""
+    if not state.training:
+        raise RuntimeError(f'{what}: backward() after an eval-mode forward is not supported by the HIP path '
+                           '(the backward implements batch-statistics BatchNorm); call model.train() before the forward, '
+                           'or wrap the eval-mode forward in torch.no_grad()')
+
+
 class PointNetState:
     """Saved forward state (workspace with the raw layer outputs and BatchNorm constants)."""
 
-    def __init__(self, cfg, B, clouds, clouds_global, ws):
+    def __init__(self, cfg, B, clouds, clouds_global, ws, training):
         self.cfg, self.B, self.clouds, self.clouds_global, self.ws = cfg, B, clouds, clouds_global, ws
+        self.training = bool(training)
 
 
 def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Sequence[Optional[torch.Tensor]]],
@@ -202,6 +217,9 @@ def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Seque
     B = clouds.shape[0]
     if clouds.shape[1] != cfg.nfeat or clouds.shape[2] != cfg.npts:
         raise ValueError(f'clouds must be [B, {cfg.nfeat}, {cfg.npts}], got {tuple(clouds.shape)}')
+    if training and B == 1:
+        # torch.nn.BatchNorm1d raises for the FC layers ([1, C] input) in training mode; so do we
+        raise ValueError('Expected more than 1 value per channel when training, got input size [1, C]')
     if clouds_global is not None:
         clouds_global = _req(clouds_global.reshape(B, -1).contiguous(), torch.float32, 'clouds_global')
         if clouds_global.shape[1] != cfg.nfeat_global:
@@ -215,7 +233,7 @@ def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Seque
     flat = [t for g in groups for t in g]
     check(lib().spg_pointnet_forward(ctypes.byref(cfg), B, _ptr(clouds), _ptr(clouds_global), _ptr_array(flat), _ptr(emb),
                                      _ptr(ws), int(training), int(bn_update_times), _stream()), 'spg_pointnet_forward')
-    return emb, PointNetState(cfg, B, clouds, clouds_global, ws)
+    return emb, PointNetState(cfg, B, clouds, clouds_global, ws, training)
 
 
 def pointnet_backward(state: PointNetState, groups, grad_emb, out_grads=None):
@@ -224,6 +242,7 @@ def pointnet_backward(state: PointNetState, groups, grad_emb, out_grads=None):
     `None` entry is skipped by the library (used for the analytically-zero biases in front of a BatchNorm when the
     destination is a pre-zeroed flat gradient buffer)."""
     cfg, B = state.cfg, state.B
+    _require_training_state(state, 'PointNet')
     grad_emb = _req(grad_emb.contiguous(), torch.float32, 'grad_emb')
     nbytes = lib().spg_pointnet_bwd_workspace_bytes(ctypes.byref(cfg), B)
     bws = torch.empty(nbytes, dtype=torch.uint8, device=grad_emb.device)
@@ -260,8 +279,9 @@ def make_eccrnn_cfg(nc, nrepeats, matrix, layernorm, ingate, cat_all, fnet_width
 
 
 class EccRnnState:
-    def __init__(self, cfg, graph, edgefeats, ws):
+    def __init__(self, cfg, graph, edgefeats, ws, training):
         self.cfg, self.graph, self.edgefeats, self.ws = cfg, graph, edgefeats, ws
+        self.training = bool(training)
 
 
 def eccrnn_forward(cfg: EccRnnCfg, graph: DeviceGraph, h0, edgefeats, groups, training: bool, bn_update_times: int = 1):
@@ -269,6 +289,10 @@ def eccrnn_forward(cfg: EccRnnCfg, graph: DeviceGraph, h0, edgefeats, groups, tr
     N, E = graph.N, graph.E
     if h0.shape[0] != N or h0.shape[1] != cfg.nc:
         raise ValueError(f'input must be [{N}, {cfg.nc}], got {tuple(h0.shape)}')
+    if edgefeats.dim() != 2 or edgefeats.shape[0] != E or edgefeats.shape[1] != cfg.fnet_widths[0]:
+        raise ValueError(f'edgefeats must be [{E}, {cfg.fnet_widths[0]}], got {tuple(edgefeats.shape)}')
+    if training and cfg.bnidx >= 0 and E == 1:
+        raise ValueError('Expected more than 1 value per channel when training (filter-network BatchNorm over one edge)')
     nbytes = lib().spg_eccrnn_workspace_bytes(ctypes.byref(cfg), N, E, int(training))
     if nbytes == 0:
         raise RuntimeError('spg_eccrnn_workspace_bytes: ' + lib().spg_last_error().decode())
@@ -278,13 +302,14 @@ def eccrnn_forward(cfg: EccRnnCfg, graph: DeviceGraph, h0, edgefeats, groups, tr
     flat = [t for g in groups for t in g]
     check(lib().spg_eccrnn_forward(ctypes.byref(cfg), N, E, _ptr(graph.ws), _ptr(h0), _ptr(edgefeats), _ptr_array(flat),
                                    _ptr(out), _ptr(ws), int(training), int(bn_update_times), _stream()), 'spg_eccrnn_forward')
-    return out, EccRnnState(cfg, graph, edgefeats, ws)
+    return out, EccRnnState(cfg, graph, edgefeats, ws, training)
 
 
 def eccrnn_backward(state: EccRnnState, groups, grad_out, out_grads=None):
     """out_grads: see pointnet_backward."""
     cfg, graph = state.cfg, state.graph
     N, E = graph.N, graph.E
+    _require_training_state(state, 'RNN-ECC')
     grad_out = _req(grad_out.contiguous(), torch.float32, 'grad_out')
     bws = torch.empty(lib().spg_eccrnn_bwd_workspace_bytes(ctypes.byref(cfg), N, E), dtype=torch.uint8, device=grad_out.device)
     grad_h0 = torch.empty(N, cfg.nc, dtype=torch.float32, device=grad_out.device)
