@@ -47,9 +47,23 @@ def make_batch(seeds, n_sp, n_edges, n_feat=14, n_classes=13):
     return targets, GIs, flag, clouds, diam, scenes
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
-    """The oracle (CPU restatement of the reference, kind "port") timed on this host's cores on the same scene.
-    This is the only place bench.py touches oracle/ -- as the reported CPU baseline, never as the measured path."""
+    """The CPU path timed on this host's cores on the same scene, fwd+bwd like `value`.  With a reference checkout
+    (/root/reference: the build container) the IMPORTED reference modules are timed (kind "reference",
+    oracle/ref_baseline.py); on the GPU box, where the reference does not exist, the oracle port (oracle/spg_oracle.py,
+    kind "port").  This is the only place bench.py touches oracle/ -- as the reported baseline, never as the measured path."""
+    from oracle import ref_baseline
     from oracle import spg_oracle as O
     from superpoint_graph_amd import synth
     spec = O.ModelSpec(model_config=model_config, node_feats=n_feat, ptn_nfeat_stn=n_feat)
@@ -57,39 +71,97 @@ def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(ncpu, 64)))
+    torch.set_num_threads(max(1, ncpu))
     col = synth.collate_numpy(scenes[:1])
     idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
     batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
                  clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
                  edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
     st = {k: v.detach().cpu().clone() for k, v in state.items()}
-    O.train_step(batch, spec, st, None)           # warm-up
-    times = []
-    t_begin = time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_begin) < max_seconds:
-        t0 = time.perf_counter()
-        O.train_step(batch, spec, st, None)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
     n = int(batch['clouds_flag'].numel())
-    return {'value': n / med, 'unit': 'superpoints/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{len(times)} fwd+bwd steps of one {n}-superpoint scene (median {med * 1e3:.0f} ms/step), '
-                      'oracle/spg_oracle.py train_step on torch-CPU'}
+    if ref_baseline.available():
+        med, cnt = ref_baseline.time_reference_step(model_config, batch, n_feat, st, max_seconds)
+        kind, what = 'reference', 'imported reference modules (learning/pointnet.py, graphnet.py, modules.py, ecc/*; restated matrix-filter backward)'
+    else:
+        O.train_step(batch, spec, st, None)           # warm-up
+        times = []
+        t_begin = time.perf_counter()
+        while len(times) < 5 and (time.perf_counter() - t_begin) < max_seconds:
+            t0 = time.perf_counter()
+            O.train_step(batch, spec, st, None)
+            times.append(time.perf_counter() - t0)
+        med, cnt = float(np.median(times)), len(times)
+        kind, what = 'port', 'oracle/spg_oracle.py train_step on torch-CPU (no reference checkout on this machine)'
+    return {'value': n / med, 'unit': 'superpoints/s', 'cores': torch.get_num_threads(), 'cpu_model': cpu_model(), 'kind': kind,
+            'sample': f'{cnt} fwd+bwd steps of one {n}-superpoint scene (median {med * 1e3:.0f} ms/step), {what}'}
 
 
 def gemm_traffic(args):
     """HBM bytes per row-GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    runs, gfx950 correction applied; profiles/*_gemm_traffic.json) -- only for the workload they were collected on."""
+    runs, gfx950 correction applied; profiles/*_gemm_traffic.json) -- only for the workload they were collected on.
+    Returns (bytes per launch, source file) or (None, None): the value is STATIC (read from the file), not measured in
+    this run -- PMC collection needs rocprofv3 around the process."""
     import glob
     default = (args.scenes == 1 and args.n_sp == 1000 and args.n_edges == 5000 and args.model_config == 'gru_10_0,f_13'
                and args.n_feat == 14)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_gemm_traffic.json')))
     if not default or not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
         t = json.load(f)
-    return t['hbm_mb_per_launch'] * 1e6        # bytes per launch, like `achieved` (which is FLOP per launch / duration)
+    return t['hbm_mb_per_launch'] * 1e6, os.path.relpath(files[-1], ROOT)
+
+
+def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, iters=20):
+    """The reference's own "trainer time" window (learning/main.py:192-215): every step gets a FRESH batch -- the clouds
+    come from pinned host memory (H2D on a side stream, overlapped with the previous step), `set_info` uploads the index
+    buffers and builds the device CSR -- then zero_grad ... optimizer step as in the headline measurement.  Reported
+    next to `value` (which keeps its inputs resident, as the metric definition says)."""
+    from superpoint_graph_amd import synth
+    from superpoint_graph_amd.learning import spg
+    nb = 4
+    batches = []
+    for b in range(nb):
+        scenes = [synth.scene(1000 + b * args.scenes + i, n_sp=args.n_sp, n_edges=args.n_edges, n_feat=args.n_feat, n_classes=n_classes)
+                  for i in range(args.scenes)]
+        targets, GIs, (meta, flag, clouds, diam) = spg.eccpc_collate([spg.sample_from_scene(s, f'w{b}_{i}') for i, s in enumerate(scenes)])
+        batches.append((targets, GIs, flag, clouds.pin_memory(), diam.pin_memory()))
+    side = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+
+    def upload(b):
+        targets, GIs, flag, clouds, diam = batches[b % nb]
+        with torch.cuda.stream(side):
+            c, d, lab = clouds.to(dev, non_blocking=True), diam.to(dev, non_blocking=True), targets[:, 0].contiguous().to(dev, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        return c, d, lab, done
+
+    def run(n):
+        nxt = upload(0)
+        for it in range(n):
+            targets, GIs, flag, _, _ = batches[it % nb]
+            c, d, lab, done = nxt
+            nxt = upload(it + 1)                      # H2D of the next batch overlaps this step
+            cur.wait_event(done)
+            model.ecc.set_info(GIs, 1)                # index buffers H2D + device CSR / reverse CSR build
+            arena.zero_grad()
+            emb = embedder.run(model, None, flag, c, d)
+            loss = F.cross_entropy(model.ecc(emb), lab)
+            loss.backward()
+            embedder.bw_hook()
+            arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)
+    run(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(iters)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    n = int(batches[0][2].numel())
+    log(f'trainer window: {dt * 1e3:.3f} ms/step')
+    return {'ms_per_step': dt * 1e3, 'superpoints_per_s': n / dt,
+            'what': 'fresh batch every step: pinned H2D of clouds/labels on a side stream + GraphConvInfo.cuda() (index H2D, device CSR build) + '
+                    'zero_grad..Adam (learning/main.py:192-215)'}
 
 
 def forward_only(dev, flag, clouds_d, diam_d, GIs, n_feat, iters=40):
@@ -133,6 +205,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default: nccl = RCCL); gloo is for the control-flow test on a 1-GPU box')
     ap.add_argument('--device-index', type=int, default=-1, help='GPU of this rank (default: LOCAL_RANK)')
+    ap.add_argument('--no-trainer-window', action='store_true', help='skip the fresh-batch-per-step side measurement (learning/main.py:200-215 window)')
     ap.add_argument('--no-forward-only', action='store_true', help='skip the forward-only side measurement (BASELINE configs[1])')
     ap.add_argument('--sync-bn', type=int, default=0, help='1: BatchNorm statistics all-reduced over the ranks (exact single-process batch semantics); 0: per-rank statistics')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
@@ -231,11 +304,17 @@ def main():
         step()
     barrier()
     log('warm-up done')
+    # per-step device time next to the wall clock of the whole region: one event pair per step on the compute stream (the
+    # events are recorded inside the region; their cost is part of `value`, which stays the wall-clock number)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         step()
+        ev[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -247,6 +326,7 @@ def main():
     result = {
         'metric': 'superpoints/sec (embed+ECC fwd+bwd), S3DIS-shaped SPG', 'value': value, 'unit': 'superpoints/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'ms_per_step_min': step_ms[0], 'ms_per_step_median': step_ms[len(step_ms) // 2], 'ms_per_step_max': step_ms[-1],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x {args.n_feat} feats, '
                                f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config}' + (' (S3DIS production model, matrix filters, 10 GRU iterations)' if args.model_config == 'gru_10_0,f_13' else '') + ', train step fwd+bwd+Adam',
@@ -277,17 +357,26 @@ def main():
         L.spg_prof_enable(0)
         log('instrumented pass done')
         ach = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        traffic, traffic_src = gemm_traffic(args)
+        gflop_step = flops.value / nprof / 1e9
+        # flat keys only (nested objects are dropped by the driver's parser): aggregate over every MFMA GEMM launch of a
+        # step, the dominant instantiation, and the whole step (algorithmic GEMM FLOP / wall time per step)
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': gemm_traffic(args), 'traffic_unit': 'HBM bytes per launch (PMC, profiles/*_gemm_traffic.json)',
+                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                              'traffic_source': ('static:' + traffic_src) if traffic_src else None,
+                              'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes of an earlier run, not measured in this run)',
                               'kernel': 'spg_rowgemm_kernel + spg_wgrad_kernel (fp32 MFMA 32x32x2)',
                               'launches_per_step': launches.value / nprof, 'gemm_ms_per_step': ms.value / nprof,
-                              'algorithmic_gflop_per_step': flops.value / nprof / 1e9}
+                              'algorithmic_gflop_per_step': gflop_step,
+                              'step_achieved': gflop_step / ms_per_step, 'step_frac': gflop_step / ms_per_step / PEAK_FP32_MFMA_TFLOPS}
         if dl.value > 0:
             dach = dfl.value / (dms.value * 1e-3) / 1e12
-            result['roofline']['dominant_kernel'] = {
-                'name': 'spg_rowgemm_kernel<128, 128, 2, 2, false, 1, true>', 'launches_per_step': dl.value / nprof,
-                'avg_us': dms.value / dl.value * 1e3, 'gflop_per_launch': dfl.value / dl.value / 1e9,
-                'achieved': dach, 'frac': dach / PEAK_FP32_MFMA_TFLOPS}
+            result['roofline'].update({
+                'dominant_kernel': 'spg_rowgemm_kernel<128, 128, 2, 2, false, 1, true, true>', 'dominant_launches_per_step': dl.value / nprof,
+                'dominant_avg_us': dms.value / dl.value * 1e3, 'dominant_gflop_per_launch': dfl.value / dl.value / 1e9,
+                'dominant_achieved': dach, 'dominant_frac': dach / PEAK_FP32_MFMA_TFLOPS})
+    if world == 1 and not args.no_trainer_window:
+        result['trainer_window'] = trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log)
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define SPG_MAX_LAYERS 8
-#define SPG_VERSION 104
+#define SPG_VERSION 200
 
 const char* spg_last_error(void);
 int spg_version(void);
@@ -133,6 +133,17 @@ size_t spg_pointnet_bwd_workspace_bytes(const spg_pointnet_cfg* cfg, int B);
 int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
                           const void* const* params, const float* grad_emb, void* const* grads, void* workspace,
                           void* bwd_workspace, void* stream);
+/* The same with an EXTERNALLY evaluated spatial transformer, as LocalCloudEmbedder.run_batch uses the networks
+ * (learning/pointnet.py:182-205: a stand-alone STNkD, then a PointNet built with nfeat_stn = 0).  ext_transform: [B, 4] =
+ * T - I (row-major 2x2 per cloud); the first convolution applies [x y] @ T while it stages the cloud, so the
+ * transformed clouds never exist in HBM.  Backward: grad_transform [B, 4] (gradient wrt T) and grad_global
+ * [B, nfeat_global] (gradient wrt clouds_global, into which the reference concatenates T) are optional outputs. */
+int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
+                             const float* ext_transform, const void* const* params, float* emb, void* workspace, int training,
+                             int bn_update_times, void* stream);
+int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
+                              const float* ext_transform, const void* const* params, const float* grad_emb, void* const* grads,
+                              float* grad_transform, float* grad_global, void* workspace, void* bwd_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RNN-ECC module = RNNGraphConvModule.forward (learning/modules.py:152-183) with a GRUCellEx or LSTMCellEx cell:
@@ -179,6 +190,42 @@ int spg_load_superpoints(const float* points, int ncols, const int64_t* offsets,
                          const double* M, const float* noise, float* clouds, float* diam, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batch construction on the device.
+ * spg_set_batch = GraphConvInfo.set_batch (learning/ecc/GraphConvInfo.py:33-69) for edges already carrying their batch
+ * node offsets: edges int64 [E][2] (source, target) -> idxn int64 [E] (source per edge, edges ordered by target),
+ * degs int64 [N] (in-degree), perm int64 [E] (original index of the edge at every position: apply it to per-edge
+ * data with spg_gather_rows, GraphConvInfo.py:53-56).  The order is the STABLE sort by target (deterministic); the
+ * reference uses numpy's default argsort, whose tie order is unspecified.  error_flag (device int32, may be NULL)
+ * becomes 1 when an endpoint is outside [0, N).  workspace: >= spg_set_batch_workspace_bytes(N, E) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+size_t spg_set_batch_workspace_bytes(int N, int E);
+int spg_set_batch(const int64_t* edges, int N, int E, int64_t* idxn, int64_t* degs, int64_t* perm, void* workspace,
+                  int32_t* error_flag, void* stream);
+/* dst[r, :cols] = src[perm[r], :cols] */
+int spg_gather_rows(const float* src, long ld_src, const int64_t* perm, long rows, int cols, float* dst, long ld_dst,
+                    void* stream);
+
+/* spg_edge_features + scaler01's transform (learning/spg.py:23-64).  One spec per OUTPUT column: COPY takes column
+ * `column` of a per-edge float32 matrix (delta_avg / delta_std); DIFF / LOGDIFF / RATIO combine the per-node attribute
+ * `data[node, column]` of the edge's source and target as attr[s]-attr[t] / log(attr[s]+1e-10)-log(attr[t]+1e-10) /
+ * attr[s]/(attr[t]+1e-10); CONST = 1.  is_f64: the attribute matrix is float64 (the u64 point count promoted like
+ * numpy does) and the arithmetic is float64 with one final rounding; otherwise float32 arithmetic.  mean / scale
+ * (float64 [ncols], device, or both NULL): sklearn StandardScaler.transform on the float32 result. */
+enum { SPG_EF_COPY = 0, SPG_EF_DIFF = 1, SPG_EF_LOGDIFF = 2, SPG_EF_RATIO = 3, SPG_EF_CONST = 4 };
+#define SPG_EF_MAX_COLS 32
+typedef struct {
+  const void* data;
+  long ld;
+  int column, kind, is_f64, pad_;
+} spg_edge_feature_spec;
+typedef struct {
+  int ncols, pad_;
+  spg_edge_feature_spec col[SPG_EF_MAX_COLS];
+} spg_edge_feature_specs;
+int spg_edge_features(const spg_edge_feature_specs* specs, const int64_t* edges, long E, const double* mean,
+                      const double* scale, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Evaluation accounting on the device (learning/main.py:246-263, eval_final :267-311, metrics.py:16-18):
  * logits [n_samples][N][C] (sample_stride floats between samples; the mean over the test-time samples is taken in
  * float32 in sample order like np.mean), pred i64 [N] = first arg-max per superpoint, and for superpoints with
@@ -200,6 +247,19 @@ int spg_eval_accumulate(const float* logits, int n_samples, long sample_stride, 
  * ---------------------------------------------------------------------------------------------- */
 typedef int (*spg_allreduce_fn)(void* ctx, double* buf, long n, void* stream);
 int spg_set_bn_allreduce(spg_allreduce_fn fn, void* ctx, double* buf, long buf_doubles);
+
+/* RCCL from inside the library: a communicator of the library's own, bootstrapped by the host --
+ * rank 0 obtains 128 bytes with spg_rccl_unique_id and distributes them (any channel), every rank calls spg_rccl_init
+ * with its HIP device current.  spg_rccl_allreduce_sum_f32: in-place sum all-reduce on `stream` (the flat gradient
+ * arena: ONE collective per step).  spg_rccl_sync_bn(buf, n): the synchronised-BatchNorm all-reduces go through this
+ * communicator, enqueued by the library between the two halves of every BatchNorm finalize (buf as in
+ * spg_set_bn_allreduce; NULL switches the mode off).  librccl is bound with dlopen at the first call. */
+int spg_rccl_unique_id(void* out_128_bytes);
+int spg_rccl_init(const void* unique_id_128_bytes, int world_size, int rank);
+int spg_rccl_world_size(void);
+int spg_rccl_allreduce_sum_f32(float* buf, long n, void* stream);
+int spg_rccl_sync_bn(double* buf, long buf_doubles);
+int spg_rccl_destroy(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise gradient clamp + Adam step on one flat parameter buffer: replaces the per-parameter loop

@@ -37,6 +37,18 @@ class EccRnnCfg(ctypes.Structure):
 
 _i, _l, _p, _sz = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_size_t
 
+SPG_EF_MAX_COLS = 32
+
+
+class EdgeFeatureSpec(ctypes.Structure):
+    _fields_ = [('data', ctypes.c_void_p), ('ld', ctypes.c_long), ('column', ctypes.c_int), ('kind', ctypes.c_int),
+                ('is_f64', ctypes.c_int), ('pad_', ctypes.c_int)]
+
+
+class EdgeFeatureSpecs(ctypes.Structure):
+    _fields_ = [('ncols', ctypes.c_int), ('pad_', ctypes.c_int), ('col', EdgeFeatureSpec * SPG_EF_MAX_COLS)]
+
+
 # name -> (restype, argtypes): every symbol include/spg_hip.h declares
 SIGNATURES = {
     'spg_last_error': (ctypes.c_char_p, []),
@@ -58,6 +70,8 @@ SIGNATURES = {
     'spg_pointnet_num_layers': (_i, [ctypes.POINTER(PointNetCfg)]),
     'spg_pointnet_workspace_bytes': (_sz, [ctypes.POINTER(PointNetCfg), _i, _i]),
     'spg_pointnet_forward': (_i, [ctypes.POINTER(PointNetCfg), _i, _p, _p, c_void_pp, _p, _p, _i, _i, _p]),
+    'spg_pointnet_forward_ext': (_i, [ctypes.POINTER(PointNetCfg), _i, _p, _p, _p, c_void_pp, _p, _p, _i, _i, _p]),
+    'spg_pointnet_backward_ext': (_i, [ctypes.POINTER(PointNetCfg), _i, _p, _p, _p, c_void_pp, _p, c_void_pp, _p, _p, _p, _p, _p]),
     'spg_pointnet_debug_offset': (_l, [ctypes.POINTER(PointNetCfg), _i, _i, _i, _i]),
     'spg_pointnet_bwd_workspace_bytes': (_sz, [ctypes.POINTER(PointNetCfg), _i]),
     'spg_pointnet_backward': (_i, [ctypes.POINTER(PointNetCfg), _i, _p, _p, c_void_pp, _p, c_void_pp, _p, _p, _p]),
@@ -68,8 +82,18 @@ SIGNATURES = {
     'spg_adam_clamp_step': (_i, [_p, _p, _p, _p, _l, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_float, _i, _p]),
     'spg_load_superpoints': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
+    'spg_set_batch_workspace_bytes': (_sz, [_i, _i]),
+    'spg_set_batch': (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'spg_gather_rows': (_i, [_p, _l, _p, _l, _i, _p, _l, _p]),
+    'spg_edge_features': (_i, [ctypes.POINTER(EdgeFeatureSpecs), _p, _l, _p, _p, _p, _p]),
     'spg_eval_accumulate': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
     'spg_set_bn_allreduce': (_i, [_p, _p, _p, _l]),
+    'spg_rccl_unique_id': (_i, [_p]),
+    'spg_rccl_init': (_i, [_p, _i, _i]),
+    'spg_rccl_world_size': (_i, []),
+    'spg_rccl_allreduce_sum_f32': (_i, [_p, _l, _p]),
+    'spg_rccl_sync_bn': (_i, [_p, _l]),
+    'spg_rccl_destroy': (_i, []),
     'spg_prof_enable': (None, [_i]),
     'spg_prof_tag': (_i, [_i, _i, _i, _i, _i, _i]),
     'spg_prof_read_tag': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double)]),

@@ -1,0 +1,177 @@
+// Device-side batch construction:
+//   * spg_set_batch      = GraphConvInfo.set_batch (learning/ecc/GraphConvInfo.py:33-69): edges of the batched graph
+//                          ordered by target, idxn = source per edge, degs = in-degree per node, plus the permutation
+//                          that brings per-edge data (the edge features) into the same order;
+//   * spg_gather_rows    = the edge-feature reordering of :53-56;
+//   * spg_edge_features  = spg_edge_features + the StandardScaler transform of scaler01 (learning/spg.py:23-64).
+// The order by target is STABLE (ties keep the original edge order) and deterministic: a counting sort whose buckets are
+// filled with integer atomics in arbitrary order and then sorted by edge index, one wavefront per target node.  The
+// reference orders with numpy's default argsort, whose tie order is unspecified; every target segment holds the same
+// edges either way (tests/test_gpu_batch.py compares segment-wise and through the model outputs).
+#include "../../include/spg_hip.h"
+#include "spg_common.h"
+
+namespace {
+
+__global__ void count_targets_kernel(const int64_t* __restrict__ edges, int E, int N, int* __restrict__ deg, int* __restrict__ err) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = edges[2 * (long)e], t = edges[2 * (long)e + 1];
+  if (t < 0 || t >= N || s < 0 || s >= N) { *err = 1; return; }
+  atomicAdd(&deg[(int)t], 1);
+}
+
+// exclusive scan of deg[0..N) into rowptr[0..N]; one workgroup (N is a few thousand superpoints per batch)
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ deg, int N, int* __restrict__ rowptr,
+                                                    int64_t* __restrict__ degs64) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, per = (N + 1023) / 1024;
+  const int b = tid * per, e = min(N, b + per);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += deg[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = tid ? part[tid - 1] : 0;
+  for (int i = b; i < e; ++i) {
+    rowptr[i] = run;
+    degs64[i] = deg[i];
+    run += deg[i];
+  }
+  if (tid == 1023) rowptr[N] = part[1023];
+}
+
+__global__ void fill_buckets_kernel(const int64_t* __restrict__ edges, int E, int N, const int* __restrict__ rowptr,
+                                    int* __restrict__ cursor, int* __restrict__ bucket) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t t = edges[2 * (long)e + 1];
+  if (t < 0 || t >= N) return;
+  const int slot = atomicAdd(&cursor[(int)t], 1);          // arrival order is arbitrary: the next kernel sorts the bucket
+  bucket[rowptr[(int)t] + slot] = e;
+}
+
+// one wavefront per target node: its bucket (edge indices) in ascending order = original edge order (stable)
+__global__ __launch_bounds__(256) void sort_buckets_kernel(const int64_t* __restrict__ edges, int N, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ bucket, int64_t* __restrict__ idxn,
+                                                           int64_t* __restrict__ perm) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (node >= N) return;
+  const int b = rowptr[node], d = rowptr[node + 1] - b;
+  for (int i = lane; i < d; i += 64) {                     // rank of element i = number of smaller edge indices in the bucket
+    const int v = bucket[b + i];
+    int rank = 0;
+    for (int j = 0; j < d; ++j) rank += bucket[b + j] < v;
+    perm[b + rank] = v;
+    idxn[b + rank] = edges[2 * (long)v];
+  }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, long lds_, const int64_t* __restrict__ perm, long rows, int cols,
+                                   float* __restrict__ dst, long ldd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long r = i / cols;
+  const int c = (int)(i - r * cols);
+  dst[r * ldd + c] = src[perm[r] * lds_ + c];
+}
+
+__global__ void edge_features_kernel(const spg_edge_feature_spec* __restrict__ specs_unused, spg_edge_feature_specs S,
+                                     const int64_t* __restrict__ edges, long E, const double* __restrict__ mean,
+                                     const double* __restrict__ scale, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * S.ncols) return;
+  const long e = i / S.ncols;
+  const int c = (int)(i - e * S.ncols);
+  const spg_edge_feature_spec sp = S.col[c];
+  const long a = edges[2 * e], b = edges[2 * e + 1];
+  float v;
+  if (sp.kind == SPG_EF_COPY) {
+    v = ((const float*)sp.data)[e * sp.ld + sp.column];
+  } else if (sp.kind == SPG_EF_CONST) {
+    v = 1.f;
+  } else if (sp.is_f64) {                                   // e.g. the point count (u64 in the file): float64 arithmetic, one final rounding
+    const double* d = (const double*)sp.data;
+    const double x = d[a * sp.ld + sp.column], y = d[b * sp.ld + sp.column];
+    double r;
+    if (sp.kind == SPG_EF_DIFF) r = x - y;
+    else if (sp.kind == SPG_EF_LOGDIFF) r = log(x + 1e-10) - log(y + 1e-10);
+    else r = x / (y + 1e-10);
+    v = (float)r;
+  } else {                                                  // float32 attributes: float32 arithmetic like numpy
+    const float* d = (const float*)sp.data;
+    const float x = d[a * sp.ld + sp.column], y = d[b * sp.ld + sp.column];
+    if (sp.kind == SPG_EF_DIFF) v = x - y;
+    else if (sp.kind == SPG_EF_LOGDIFF) v = logf(x + 1e-10f) - logf(y + 1e-10f);
+    else v = x / (y + 1e-10f);
+  }
+  if (mean != nullptr) {                                    // StandardScaler.transform on a float32 array (in place: two roundings)
+    v = (float)((double)v - mean[c]);
+    v = (float)((double)v / scale[c]);
+  }
+  out[i] = v;
+}
+
+}  // namespace
+
+extern "C" size_t spg_set_batch_workspace_bytes(int N, int E) {
+  // deg[N] | cursor[N] | rowptr[N+1] | bucket[E] | err
+  return ((size_t)3 * (N + 1) + (size_t)E + 8) * sizeof(int) + 256;
+}
+
+extern "C" int spg_set_batch(const int64_t* edges, int N, int E, int64_t* idxn, int64_t* degs, int64_t* perm, void* workspace,
+                             int32_t* error_flag, void* stream) {
+  SPG_CHECK_ARG(N > 0 && E >= 0 && degs && workspace && (E == 0 || (edges && idxn && perm)), "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int* deg = (int*)workspace;
+  int* cursor = deg + (N + 1);
+  int* rowptr = cursor + (N + 1);
+  int* bucket = rowptr + (N + 1);
+  int* err = bucket + E;
+  hipError_t rc = hipMemsetAsync(workspace, 0, ((size_t)2 * (N + 1)) * sizeof(int), st);
+  if (rc == hipSuccess) rc = hipMemsetAsync(err, 0, sizeof(int), st);
+  if (rc != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(rc)); return (int)rc; }
+  if (E > 0) {
+    hipLaunchKernelGGL(count_targets_kernel, dim3(spg_cdiv(E, 256)), dim3(256), 0, st, edges, E, N, deg, err);
+    SPG_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, deg, N, rowptr, degs);
+  SPG_LAUNCH_CHECK();
+  if (E > 0) {
+    hipLaunchKernelGGL(fill_buckets_kernel, dim3(spg_cdiv(E, 256)), dim3(256), 0, st, edges, E, N, rowptr, cursor, bucket);
+    SPG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sort_buckets_kernel, dim3(spg_cdiv(N, 4)), dim3(256), 0, st, edges, N, rowptr, bucket, idxn, perm);
+    SPG_LAUNCH_CHECK();
+  }
+  if (error_flag != nullptr) {
+    rc = hipMemcpyAsync(error_flag, err, sizeof(int), hipMemcpyDeviceToDevice, st);
+    if (rc != hipSuccess) { spg_set_error("hipMemcpyAsync: %s", hipGetErrorString(rc)); return (int)rc; }
+  }
+  return 0;
+}
+
+extern "C" int spg_gather_rows(const float* src, long ld_src, const int64_t* perm, long rows, int cols, float* dst, long ld_dst,
+                               void* stream) {
+  SPG_CHECK_ARG(rows == 0 || (src && perm && dst && cols > 0), "bad argument");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(spg_cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, perm,
+                     rows, cols, dst, ld_dst);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spg_edge_features(const spg_edge_feature_specs* specs, const int64_t* edges, long E, const double* mean,
+                                 const double* scale, float* out, void* stream) {
+  SPG_CHECK_ARG(specs && out && (E == 0 || edges) && specs->ncols > 0 && specs->ncols <= SPG_EF_MAX_COLS, "bad argument");
+  SPG_CHECK_ARG((mean == nullptr) == (scale == nullptr), "mean and scale go together");
+  if (E == 0) return 0;
+  hipLaunchKernelGGL(edge_features_kernel, dim3(spg_cdiv(E * specs->ncols, 256)), dim3(256), 0, (hipStream_t)stream, nullptr, *specs,
+                     edges, E, mean, scale, out);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}

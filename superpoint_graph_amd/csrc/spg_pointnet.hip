@@ -14,6 +14,7 @@
 //   min of the raw output: after the batch statistics are known, sign(s) decides which one is the
 //   max of the normalised value -- BatchNorm is monotone per channel).
 #include "../../include/spg_hip.h"
+#include "spg_ecc.h"
 #include "spg_gemm.h"
 #include <vector>
 
@@ -261,6 +262,7 @@ struct BwdScratch {
   float* stat = nullptr;                    // [ntile][2][cmax]
   float* dxy = nullptr;                     // [M, 2]
   float* dT = nullptr;                      // [B, 4]
+  float* grad_global = nullptr;             // optional output [B, nextra]: gradient wrt the concatenated global features
   size_t bytes = 0;
 };
 
@@ -332,6 +334,8 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     SPG_TRY(spg_launch_gemm(g, st));
     // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
     const int C = prod.cout;
+    if (first && s.grad_global != nullptr && sg.nextra > 0)     // columns >= C pass through: gradient wrt the global features
+      SPG_TRY(spg_launch_copy2d(out + C, sg.ldpool, s.grad_global, sg.nextra, B, sg.nextra, st));
     SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(B, SPG_FC_ROWS) * spg_gemm_row_waves(SPG_FC_ROWS, l.cin), l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
                                        prod.rstd, s.consts, prod.dgamma, prod.dbeta, s.fin, st));
     if (!first) {
@@ -397,7 +401,14 @@ extern "C" size_t spg_pointnet_workspace_bytes(const spg_pointnet_cfg* cfg, int 
 extern "C" int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
                                     const void* const* params, float* emb, void* workspace, int training,
                                     int bn_update_times, void* stream) {
+  return spg_pointnet_forward_ext(cfg, B, clouds, clouds_global, nullptr, params, emb, workspace, training, bn_update_times, stream);
+}
+
+extern "C" int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
+                                        const float* ext_transform, const void* const* params, float* emb, void* workspace,
+                                        int training, int bn_update_times, void* stream) {
   SPG_CHECK_ARG(clouds && params && emb && workspace, "null pointer");
+  SPG_CHECK_ARG(ext_transform == nullptr || cfg->nfeat_stn == 0, "an external transform replaces the inner STN (nfeat_stn must be 0)");
   hipStream_t st = (hipStream_t)stream;
   Plan pl;
   SPG_TRY(make_plan(cfg, B, training, workspace, params, emb, pl));
@@ -412,7 +423,7 @@ extern "C" int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const fl
       }
     SPG_TRY(spg_launch_bn_eval_batch(eb, pl.cfg.bn_eps, st));
   }
-  const float* stnT = nullptr;
+  const float* stnT = ext_transform;      // [B, 4] = T - I of an externally evaluated STN (LocalCloudEmbedder), or null
   if (pl.has_stn) {
     SPG_TRY(forward_segment(pl, pl.stn, clouds, nullptr, bn_update_times, st));
     stnT = pl.L[pl.stn.fcs.back()].y;
@@ -451,7 +462,17 @@ extern "C" size_t spg_pointnet_bwd_workspace_bytes(const spg_pointnet_cfg* cfg, 
 extern "C" int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
                                      const void* const* params, const float* grad_emb, void* const* grads,
                                      void* workspace, void* bwd_workspace, void* stream) {
+  return spg_pointnet_backward_ext(cfg, B, clouds, clouds_global, nullptr, params, grad_emb, grads, nullptr, nullptr, workspace,
+                                   bwd_workspace, stream);
+}
+
+extern "C" int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
+                                         const float* ext_transform, const void* const* params, const float* grad_emb,
+                                         void* const* grads, float* grad_transform, float* grad_global, void* workspace,
+                                         void* bwd_workspace, void* stream) {
   SPG_CHECK_ARG(clouds && params && grad_emb && grads && workspace && bwd_workspace, "null pointer");
+  SPG_CHECK_ARG((ext_transform == nullptr && grad_transform == nullptr) || cfg->nfeat_stn == 0, "external transform with an inner STN");
+  SPG_CHECK_ARG(grad_transform == nullptr || ext_transform != nullptr, "grad_transform needs the external transform");
   hipStream_t st = (hipStream_t)stream;
   Plan pl;
   // the forward wrote the last fc output to `emb`; it is not needed by the backward, so pass a dummy
@@ -460,11 +481,14 @@ extern "C" int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const f
   bind_grads(pl, grads);
   BwdScratch s;
   carve_bwd(pl, bwd_workspace, s);
-  const float* stnT = pl.has_stn ? pl.L[pl.stn.fcs.back()].y : nullptr;
+  const float* stnT = pl.has_stn ? pl.L[pl.stn.fcs.back()].y : ext_transform;
   const int cout = pl.L[pl.main.fcs.back()].cout;
   SpgReduceQueue rq;
   rq.arena = s.work; rq.arena_floats = s.work_floats;
-  SPG_TRY(backward_segment(pl, pl.main, s, rq, op_ident(grad_emb, cout), clouds, stnT, pl.has_stn, st));
+  s.grad_global = grad_global;
+  SPG_TRY(backward_segment(pl, pl.main, s, rq, op_ident(grad_emb, cout), clouds, stnT, pl.has_stn || grad_transform != nullptr, st));
+  if (grad_transform != nullptr)      // gradient wrt the external 2x2 transforms (learning/pointnet.py:196-198)
+    SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, grad_transform, st));
   if (pl.has_stn) {
     SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, s.dT, st));
     SPG_TRY(backward_segment(pl, pl.stn, s, rq, op_ident(s.dT, 4), clouds, nullptr, false, st));

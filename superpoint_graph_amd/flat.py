@@ -55,6 +55,35 @@ class FlatParameters:
                                                   grad_clip, self._t, torch.cuda.current_stream().cuda_stream),
                    'spg_adam_clamp_step')
 
+    def attach_optimizer(self, optimizer):
+        """Keeps a `torch.optim.Adam` as the owner of the hyper-parameters (learning-rate schedulers keep working) and of the
+        state dict (checkpoints stay in torch's format, both ways): its per-parameter moments become views of the arena's
+        flat moment buffers -- moments loaded from a checkpoint are copied in -- and `optimizer_step()` replaces
+        `optimizer.step()`."""
+        if not isinstance(optimizer, torch.optim.Adam) or len(optimizer.param_groups) != 1:
+            raise TypeError('the fused update implements torch.optim.Adam with one parameter group')
+        if optimizer.param_groups[0].get('amsgrad', False) or optimizer.param_groups[0].get('maximize', False):
+            raise NotImplementedError('amsgrad / maximize are not implemented by the fused update')
+        self._opt = optimizer
+        self._m = torch.zeros_like(self.flat.data)
+        self._v = torch.zeros_like(self.flat.data)
+        self._t = 0
+        self._step_t = torch.tensor(0.0)               # ONE step tensor shared by every parameter's state
+        for p, off in zip(self.params, self._offsets):
+            n = p.numel()
+            m, v = self._m[off:off + n].view(p.shape), self._v[off:off + n].view(p.shape)
+            st = optimizer.state.get(p)
+            if st:                                     # resumed run
+                m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
+                self._t = int(st['step'])
+            optimizer.state[p] = {'step': self._step_t, 'exp_avg': m, 'exp_avg_sq': v}
+        self._step_t.fill_(float(self._t))
+
+    def optimizer_step(self, grad_clip=0.0):
+        g = self._opt.param_groups[0]
+        self.adam_step(lr=g['lr'], betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'], grad_clip=grad_clip)
+        self._step_t.add_(1.0)
+
     def zero_grad(self):
         self._gbuf.zero_()
 

@@ -45,6 +45,37 @@ class GraphConvInfo(object):
         self._edge_indexes = torch.LongTensor(np.concatenate(edge_indexes).T)
         self._graph = None
 
+    def set_batch_device(self, graphs, edge_feat_func, device=None):
+        """`set_batch` with the ordering work on the GPU (spg_set_batch): the host only concatenates the edge lists and
+        edge attributes in their original order.  Buffers come out device-resident (`degs` is fetched back because the
+        contract keeps a host copy); the order inside a target segment is the STABLE one (the reference's numpy argsort
+        leaves ties unspecified), everything else is identical to `set_batch`."""
+        from ... import ops
+        graphs = graphs if isinstance(graphs, (list, tuple)) else [graphs]
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        p, edges = 0, []
+        edgeattrs = defaultdict(list)
+        for G in graphs:
+            E = getattr(G, '_edges', None)
+            E = np.asarray(G.get_edgelist()).reshape(-1, 2) if E is None else np.asarray(E).reshape(-1, 2)
+            edges.append(E.astype(np.int64) + p)
+            for a in G.es.attributes():
+                edgeattrs[a] += G.es.get_attribute_values(a)
+            p += G.vcount()
+        edges_d = torch.from_numpy(np.concatenate(edges) if edges else np.zeros((0, 2), dtype=np.int64)).to(dev)
+        feats, self._idxe = edge_feat_func(edgeattrs)
+        if self._idxe is not None:
+            raise NotImplementedError('filter sharing (idxe) is not supported by set_batch_device')
+        idxn, degs_gpu, perm, err = ops.set_batch(edges_d, p)
+        self._idxn, self._degrees_gpu = idxn, degs_gpu
+        self._edgefeats = ops.gather_rows(feats.to(dev).float().contiguous(), perm) if idxn.numel() else feats.to(dev).float()
+        self._degrees = degs_gpu.cpu()
+        if int(err.item()) != 0:
+            raise IndexError('GraphConvInfo.set_batch_device: an edge endpoint is outside [0, number of nodes)')
+        tgt = torch.repeat_interleave(torch.arange(p, device=dev), degs_gpu)
+        self._edge_indexes = torch.stack([idxn, tgt], 0)
+        self._graph = ops.DeviceGraph(self._idxn, self._degrees_gpu)
+
     @classmethod
     def from_buffers(cls, idxn, degs, edgefeats, idxe=None, edge_indexes=None):
         """Build directly from already-batched buffers (synthetic scenes, tests)."""
@@ -68,6 +99,8 @@ class GraphConvInfo(object):
 
     def cuda(self):
         from ... import ops
+        if self._graph is not None and self._idxn.is_cuda:
+            return            # built by set_batch_device: already resident
         self._validate()
         self._idxn = self._idxn.cuda()
         if self._idxe is not None:

@@ -1,0 +1,403 @@
+"""Training / evaluation CLI of the superpoint-graph network on the HIP kernels: the command line, checkpoint format,
+random streams and printed scores of the reference's `learning/main.py` (file:line cited per function), so that a user of
+
+    python learning/main.py --dataset s3dis --S3DIS_PATH ... --cvfold 5 --epochs 350 ...      (reference)
+
+runs the same experiment with
+
+    python -m superpoint_graph_amd.learning.main --dataset s3dis --S3DIS_PATH ... --cvfold 5 --epochs 350 ...
+
+What is different underneath: the model is built from this package's modules (libspg_hip.so), the superpoint clouds are
+built on the GPU from scenes resident in HBM (`--loader_device`), the evaluation accounting runs on the device, and with
+`--fused_optim 1` the clamp + Adam update is one launch over a flat parameter arena.  There is no CPU execution path:
+`--cuda 0` raises."""
+import argparse
+import ast
+import json
+import logging
+import math
+import os
+import random
+import sys
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+from torch.optim.lr_scheduler import MultiStepLR
+
+from . import datasets, graphnet, meters, metrics, pointnet, spg
+
+
+def build_parser():
+    """Flags of learning/main.py:41-120, same names / defaults / help, plus the three HIP-specific ones at the end."""
+    p = argparse.ArgumentParser(description='Large-scale Point Cloud Semantic Segmentation with Superpoint Graphs (MI355X / HIP)')
+    a = p.add_argument
+    # optimisation
+    a('--wd', default=0, type=float, help='Weight decay')
+    a('--lr', default=1e-2, type=float, help='Initial learning rate')
+    a('--lr_decay', default=0.7, type=float, help='Multiplicative factor used on learning rate at `lr_steps`')
+    a('--lr_steps', default='[]', help='List of epochs where the learning rate is decreased by `lr_decay`')
+    a('--momentum', default=0.9, type=float, help='Momentum')
+    a('--epochs', default=10, type=int, help='Number of epochs to train. If <=0, only testing will be done.')
+    a('--batch_size', default=2, type=int, help='Batch size')
+    a('--optim', default='adam', help='Optimizer: sgd|adam')
+    a('--grad_clip', default=1, type=float, help='Element-wise clipping of gradient. If 0, does not clip')
+    a('--loss_weights', default='none', help='[none, proportional, sqrt] how to weight the loss function')
+    # learning process
+    a('--cuda', default=1, type=int, help='Bool, use cuda')
+    a('--nworkers', default=0, type=int, help='Num subprocesses to use for data loading. 0 means that the data will be loaded in the main process')
+    a('--test_nth_epoch', default=1, type=int, help='Test each n-th epoch during training')
+    a('--save_nth_epoch', default=1, type=int, help='Save model each n-th epoch during training')
+    a('--test_multisamp_n', default=10, type=int, help='Average logits obtained over runs with different seeds')
+    # dataset
+    a('--dataset', default='sema3d', help='Dataset name: sema3d|s3dis|vkitti|custom_dataset|<registered name>')
+    a('--cvfold', default=0, type=int, help='Fold left-out for testing in leave-one-out setting (S3DIS)')
+    a('--odir', default='results', help='Directory to store results')
+    a('--resume', default='', help='Loads a previously saved model.')
+    a('--db_train_name', default='train')
+    a('--db_test_name', default='test')
+    a('--use_val_set', type=int, default=0)
+    a('--SEMA3D_PATH', default='datasets/semantic3d')
+    a('--S3DIS_PATH', default='datasets/s3dis')
+    a('--VKITTI_PATH', default='datasets/vkitti')
+    a('--CUSTOM_SET_PATH', default='datasets/custom_set')
+    a('--use_pyg', default=0, type=int, help='Wether to use Pytorch Geometric for graph convolutions (not available on the HIP path)')
+    # model
+    a('--model_config', default='gru_10,f_8', help='Sequence of layers, see graphnet.py: rectype_repeats_mv_layernorm_ingate_concat ...')
+    a('--seed', default=1, type=int, help='Seed for random initialisation')
+    a('--edge_attribs', default='delta_avg,delta_std,nlength/ld,surface/ld,volume/ld,size/ld,xyz/d', help='Edge attribute definition, see spg_edge_features() in spg.py for definitions.')
+    # point clouds
+    a('--pc_attribs', default='xyzrgbelpsvXYZ', help='Point attributes fed to PointNets, if empty then all possible.')
+    a('--pc_augm_scale', default=0, type=float, help='Training augmentation: Uniformly random scaling in [1/scale, scale]')
+    a('--pc_augm_rot', default=1, type=int, help='Training augmentation: Bool, random rotation around z-axis')
+    a('--pc_augm_mirror_prob', default=0, type=float, help='Training augmentation: Probability of mirroring about x or y axes')
+    a('--pc_augm_jitter', default=1, type=int, help='Training augmentation: Bool, Gaussian jittering of all attributes')
+    a('--pc_xyznormalize', default=1, type=int, help='Bool, normalize xyz into unit ball, i.e. in [-0.5,0.5]')
+    # filter generating network
+    a('--fnet_widths', default='[32,128,64]', help='List of width of hidden filter gen net layers')
+    a('--fnet_llbias', default=0, type=int, help='Bool, use bias in the last layer in filter gen net')
+    a('--fnet_orthoinit', default=1, type=int, help='Bool, use orthogonal weight initialization for filter gen net.')
+    a('--fnet_bnidx', default=2, type=int, help='Layer index to insert batchnorm to. -1=do not insert.')
+    a('--edge_mem_limit', default=30000, type=int, help='Accepted for compatibility (the HIP kernels do not shard edges)')
+    # superpoint graph
+    a('--spg_attribs01', default=1, type=int, help='Bool, normalize edge features to 0 mean 1 deviation')
+    a('--spg_augm_nneigh', default=100, type=int, help='Number of neighborhoods to sample in SPG')
+    a('--spg_augm_order', default=3, type=int, help='Order of neighborhoods to sample in SPG')
+    a('--spg_augm_hardcutoff', default=512, type=int, help='Maximum number of superpoints larger than args.ptn_minpts to sample in SPG')
+    a('--spg_superedge_cutoff', default=-1, type=float, help='Artificially constrained maximum length of superedge, -1=do not constrain')
+    # PointNet
+    a('--ptn_minpts', default=40, type=int, help='Minimum number of points in a superpoint for computing its embedding.')
+    a('--ptn_npts', default=128, type=int, help='Number of input points for PointNet.')
+    a('--ptn_widths', default='[[64,64,128,128,256], [256,64,32]]', help='PointNet widths')
+    a('--ptn_widths_stn', default='[[64,64,128], [128,64]]', help='PointNet\'s Transformer widths')
+    a('--ptn_nfeat_stn', default=11, type=int, help='PointNet\'s Transformer number of input features')
+    a('--ptn_prelast_do', default=0, type=float)
+    a('--ptn_mem_monger', default=1, type=int, help='Kept for compatibility: activations stay in HBM, nothing is recomputed')
+    a('--sp_decoder_config', default='[]', type=str, help='Size of the decoder : sp_embedding -> sp_class.')
+    # HIP path
+    a('--loader_device', default=1, type=int, help='Bool, build the superpoint clouds on the GPU from scenes resident in HBM')
+    a('--fused_optim', default=1, type=int, help='Bool, clamp + Adam as one launch over a flat parameter arena (adam only)')
+    a('--max_train_iters', default=0, type=int, help='Stop every training epoch after this many batches (0 = whole epoch)')
+    return p
+
+
+def parse_args(argv=None):
+    args = build_parser().parse_args(argv)
+    args.start_epoch = 0
+    for k in ('lr_steps', 'fnet_widths', 'ptn_widths', 'sp_decoder_config', 'ptn_widths_stn'):
+        setattr(args, k, ast.literal_eval(getattr(args, k)))
+    return args
+
+
+def set_seed(seed, cuda=True):
+    """Sets the seeds of all frameworks (learning/main.py:439-445)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if cuda:
+        torch.cuda.manual_seed(seed)
+
+
+def filter_valid(output, target, other=None):
+    """Removes predictions for nodes without ground truth (learning/main.py:447-452)."""
+    idx = target != -100
+    if other is not None:
+        return output[idx, :], target[idx], other[idx, ...]
+    return output[idx, :], target[idx]
+
+
+def meter_value(meter):
+    return meter.value()[0] if meter.n > 0 else 0
+
+
+def create_model(args, dbinfo):
+    """ecc first, then ptn -- the order fixes the parameter initialisation under a seed (learning/main.py:414-431)."""
+    if 'use_pyg' not in args:
+        args.use_pyg = 0
+    model = nn.Module()
+    nfeat = args.ptn_widths[1][-1]
+    model.ecc = graphnet.GraphNetwork(args.model_config, nfeat, [dbinfo['edge_feats']] + args.fnet_widths, args.fnet_orthoinit,
+                                      args.fnet_llbias, args.fnet_bnidx, args.edge_mem_limit, use_pyg=args.use_pyg, cuda=args.cuda)
+    model.ptn = pointnet.PointNet(args.ptn_widths[0], args.ptn_widths[1], args.ptn_widths_stn[0], args.ptn_widths_stn[1],
+                                  dbinfo['node_feats'], args.ptn_nfeat_stn, prelast_do=args.ptn_prelast_do)
+    print('Total number of parameters: {}'.format(sum([p.numel() for p in model.parameters()])))
+    print(model)
+    if args.cuda:
+        model.cuda()
+    return model
+
+
+def create_optimizer(args, model):
+    if args.optim == 'sgd':
+        return optim.SGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.wd)
+    if args.optim == 'adam':
+        return optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    raise NotImplementedError(args.optim)
+
+
+_STALE_KEYS = ('ecc.0._cell.inh.running_mean', 'ecc.0._cell.inh.running_var', 'ecc.0._cell.ini.running_mean', 'ecc.0._cell.ini.running_var')
+
+
+def resume(args, dbinfo):
+    """Loads model and optimizer state from a checkpoint written by this CLI or by the reference (learning/main.py:390-412)."""
+    print("=> loading checkpoint '{}'".format(args.resume))
+    checkpoint = torch.load(args.resume, weights_only=False)
+    checkpoint['args'].model_config = args.model_config
+    checkpoint['args'].cuda = args.cuda
+    model = create_model(checkpoint['args'], dbinfo)
+    optimizer = create_optimizer(args, model)
+    model.load_state_dict({k: v for k, v in checkpoint['state_dict'].items() if k not in _STALE_KEYS})
+    if 'optimizer' in checkpoint:
+        optimizer.load_state_dict(checkpoint['optimizer'])
+    for group in optimizer.param_groups:
+        group['initial_lr'] = args.lr
+    args.start_epoch = checkpoint['epoch']
+    try:
+        with open(os.path.join(os.path.dirname(args.resume), 'trainlog.json')) as f:
+            stats = json.loads(f.read())
+    except Exception:
+        stats = []
+    return model, optimizer, stats
+
+
+class Session:
+    """One run of the CLI: model, optimiser, datasets and the three loops of learning/main.py:176-311."""
+
+    def __init__(self, args, dbinfo, create_dataset, model, optimizer, stats):
+        self.args, self.dbinfo, self.create_dataset = args, dbinfo, create_dataset
+        self.model, self.optimizer, self.stats = model, optimizer, stats
+        self.train_dataset, self.test_dataset, self.valid_dataset, self.scaler = create_dataset(args)
+        print('Train dataset: %i elements - Test dataset: %i elements - Validation dataset: %i elements' %
+              (len(self.train_dataset), len(self.test_dataset), len(self.valid_dataset)))
+        self.embedder = pointnet.CloudEmbedder(args)
+        self.scheduler = MultiStepLR(optimizer, milestones=args.lr_steps, gamma=args.lr_decay, last_epoch=args.start_epoch - 1)
+        self.arena = None
+        if args.fused_optim and args.optim == 'adam':
+            from ..flat import FlatParameters
+            self.arena = FlatParameters(model)        # parameters / gradients become views of one flat buffer each
+            self.arena.attach_optimizer(optimizer)    # the Adam moments live in `optimizer.state` (checkpoint format kept)
+        self.iter_log = []                            # (loss, trainer ms) per training batch, for tests and tools
+        self.eval_log = []                            # loss per evaluation batch
+
+    def _loader(self, dataset, train):
+        a = self.args
+        if train:
+            return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=spg.eccpc_collate, num_workers=a.nworkers,
+                                               shuffle=True, drop_last=True)
+        return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=spg.eccpc_collate, num_workers=a.nworkers)
+
+    def _forward(self, targets, GIs, clouds_data):
+        self.model.ecc.set_info(GIs, self.args.cuda)
+        label_mode = targets[:, 0].contiguous().cuda(non_blocking=True)
+        label_vec = targets[:, 2:].contiguous().cuda(non_blocking=True)
+        embeddings = self.embedder.run(self.model, *clouds_data)
+        outputs = self.model.ecc(embeddings)
+        return outputs, label_mode, label_vec
+
+    # ---- learning/main.py:176-226 ----
+    def train(self):
+        """Trains for one epoch -> (accuracy, mean loss, overall accuracy, mean IoU) over the training batches."""
+        a = self.args
+        self.model.train()
+        loss_meter, acc_meter = meters.AverageValueMeter(), meters.ClassErrorMeter(accuracy=True)
+        cm = metrics.ConfusionMatrix(self.dbinfo['classes'])
+        t0 = time.time()
+        for bidx, (targets, GIs, clouds_data) in enumerate(self._loader(self.train_dataset, True)):
+            t_loader = 1000 * (time.time() - t0)
+            t0 = time.time()
+            if self.arena is not None:
+                self.arena.zero_grad()
+            else:
+                self.optimizer.zero_grad()
+            outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
+            loss = nn.functional.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])
+            loss.backward()
+            self.embedder.bw_hook()
+            if self.arena is not None:
+                self.arena.optimizer_step(grad_clip=a.grad_clip)          # clamp (main.py:210-212) + Adam in one launch
+            else:
+                if a.grad_clip > 0:
+                    for p in self.model.parameters():
+                        p.grad.data.clamp_(-a.grad_clip, a.grad_clip)
+                self.optimizer.step()
+            t_trainer = 1000 * (time.time() - t0)
+            loss_meter.add(loss.detach())
+            cm.count_predicted_batch_device(label_vec, outputs.detach(), label_mode)   # filter_valid + argmax + counts, on the GPU
+            self.iter_log.append((loss.detach(), t_trainer))
+            logging.debug('Batch loader time %f ms, trainer time %f ms.', t_loader, t_trainer)
+            t0 = time.time()
+            if a.max_train_iters and bidx + 1 >= a.max_train_iters:
+                break
+        acc_meter.add_counts(*cm.accuracy_counts())
+        return acc_meter.value()[0], loss_meter.value()[0], cm.get_overall_accuracy(), cm.get_average_intersection_union()
+
+    # ---- learning/main.py:229-264 ----
+    def eval(self, is_valid=False):
+        """Evaluates the model on the test (or validation) set."""
+        self.model.eval()
+        loss_meter, acc_meter = meters.AverageValueMeter(), meters.ClassErrorMeter(accuracy=True)
+        cm = metrics.ConfusionMatrix(self.dbinfo['classes'])
+        for targets, GIs, clouds_data in self._loader(self.valid_dataset if is_valid else self.test_dataset, False):
+            with torch.no_grad():
+                outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
+                loss = nn.functional.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])
+            loss_meter.add(loss)
+            self.eval_log.append(loss)
+            cm.count_predicted_batch_device(label_vec, outputs, label_mode)
+        acc_meter.add_counts(*cm.accuracy_counts())
+        return (meter_value(acc_meter), loss_meter.value()[0], cm.get_overall_accuracy(), cm.get_average_intersection_union(),
+                cm.get_mean_class_accuracy())
+
+    # ---- learning/main.py:267-311 ----
+    def eval_final(self):
+        """Multi-sample evaluation: the logits of `test_multisamp_n` differently seeded samplings of every scene are
+        averaged (on the device, in sample order) before the arg-max; returns the predictions per scene as well."""
+        a = self.args
+        self.model.eval()
+        acc_meter = meters.ClassErrorMeter(accuracy=True)
+        cm = metrics.ConfusionMatrix(self.dbinfo['classes'])
+        collected, labels, predictions = defaultdict(list), {}, {}
+        for ss in range(a.test_multisamp_n):
+            test_dataset_ss = self.create_dataset(a, ss)[1]
+            for targets, GIs, clouds_data in self._loader(test_dataset_ss, False):
+                with torch.no_grad():
+                    outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
+                fname = clouds_data[0][0][:clouds_data[0][0].rfind('.')]
+                collected[fname].append(outputs)
+                labels.setdefault(fname, (label_mode, label_vec))
+        for fname, outs in collected.items():
+            label_mode, label_vec = labels[fname]
+            logits = torch.stack(outs, 0) if a.test_multisamp_n > 1 else outs[0]
+            predictions[fname] = cm.count_predicted_batch_device(label_vec, logits.contiguous(), label_mode).cpu().numpy()
+        acc_meter.add_counts(*cm.accuracy_counts())
+        per_class_iou = {name: cm.get_intersection_union_per_class()[c] for c, name in self.dbinfo['inv_class_map'].items()}
+        return (meter_value(acc_meter), cm.get_overall_accuracy(), cm.get_average_intersection_union(), per_class_iou, predictions,
+                cm.get_mean_class_accuracy(), cm.confusion_matrix)
+
+    def checkpoint(self, epoch, with_scaler=True):
+        state = {'epoch': epoch + 1, 'args': self.args, 'state_dict': self.model.state_dict(), 'optimizer': self.optimizer.state_dict()}
+        if with_scaler:
+            state['scaler'] = self.scaler
+        cache = self.args.__dict__.pop('_device_point_cache', None)        # device buffers do not belong into the checkpoint
+        try:
+            torch.save(state, os.path.join(self.args.odir, 'model.pth.tar'))
+        finally:
+            if cache is not None:
+                self.args._device_point_cache = cache
+
+    # ---- learning/main.py:313-388 ----
+    def run(self):
+        a = self.args
+        try:
+            best_iou = self.stats[-1]['best_iou']
+        except Exception:
+            best_iou = 0
+        epoch = a.start_epoch
+        for epoch in range(a.start_epoch, a.epochs):
+            print('Epoch {}/{} ({}):'.format(epoch, a.epochs, a.odir))
+            self.scheduler.step()
+            acc, loss, oacc, avg_iou = self.train()
+            print('-> Train Loss: %1.4f   Train accuracy: %3.2f%%' % (loss, acc))
+            new_best = False
+            if a.use_val_set:
+                acc_val, loss_val, oacc_val, avg_iou_val, avg_acc_val = self.eval(True)
+                print('-> Val Loss: %1.4f  Val accuracy: %3.2f%%  Val oAcc: %3.2f%%  Val IoU: %3.2f%%  best ioU: %3.2f%%' %
+                      (loss_val, acc_val, 100 * oacc_val, 100 * avg_iou_val, 100 * max(best_iou, avg_iou_val)))
+                if avg_iou_val > best_iou:
+                    print('-> New best model achieved!')
+                    best_iou, new_best = avg_iou_val, True
+                    self.checkpoint(epoch)
+            elif epoch % a.save_nth_epoch == 0 or epoch == a.epochs - 1:
+                self.checkpoint(epoch)
+            if (not a.use_val_set and (epoch + 1) % a.test_nth_epoch == 0) or (a.use_val_set and new_best and epoch > 5):
+                acc_test, loss_test, oacc_test, avg_iou_test, avg_acc_test = self.eval(False)
+                print('-> Test Loss: %1.4f  Test accuracy: %3.2f%%  Test oAcc: %3.2f%%  Test avgIoU: %3.2f%%' %
+                      (loss_test, acc_test, 100 * oacc_test, 100 * avg_iou_test))
+            else:
+                acc_test, loss_test, oacc_test, avg_iou_test, avg_acc_test = 0, 0, 0, 0, 0
+            self.stats.append({'epoch': epoch, 'acc': acc, 'loss': loss, 'oacc': oacc, 'avg_iou': avg_iou, 'acc_test': acc_test,
+                               'oacc_test': oacc_test, 'avg_iou_test': avg_iou_test, 'avg_acc_test': avg_acc_test, 'best_iou': best_iou})
+            if math.isnan(loss):
+                break
+            with open(os.path.join(a.odir, 'trainlog.json'), 'w') as outfile:
+                json.dump(self.stats, outfile, indent=4)
+        if a.use_val_set:
+            a.resume = a.odir + '/model.pth.tar'
+            self.model, self.optimizer, self.stats = resume(a, self.dbinfo)
+            self.arena = None
+            self.checkpoint(epoch, with_scaler=False)
+        if a.test_multisamp_n > 0 and 'test' in a.db_test_name:
+            acc_test, oacc_test, avg_iou_test, per_class_iou_test, predictions_test, avg_acc_test, confusion = self.eval_final()
+            print('-> Multisample {}: Test accuracy: {}, \tTest oAcc: {}, \tTest avgIoU: {}, \tTest mAcc: {}'.format(
+                a.test_multisamp_n, acc_test, oacc_test, avg_iou_test, avg_acc_test))
+            write_predictions(os.path.join(a.odir, 'predictions_' + a.db_test_name), predictions_test)
+            with open(os.path.join(a.odir, 'scores_' + a.db_test_name + '.json'), 'w') as outfile:
+                json.dump([{'epoch': a.start_epoch, 'acc_test': acc_test, 'oacc_test': oacc_test, 'avg_iou_test': avg_iou_test,
+                            'per_class_iou_test': per_class_iou_test, 'avg_acc_test': avg_acc_test}], outfile)
+            np.save(os.path.join(a.odir, 'pointwise_cm.npy'), confusion)
+
+
+def write_predictions(stem, predictions):
+    """predictions_<db_test_name>.h5: one dataset of 0-based class ids per scene (learning/main.py:383-385; read by
+    partition/visualize.py:74-77).  Without h5py the same arrays go to <stem>.npz."""
+    try:
+        import h5py
+    except ImportError:
+        np.savez(stem + '.npz', **predictions)
+        return stem + '.npz'
+    with h5py.File(stem + '.h5', 'w') as hf:
+        for fname, o_cpu in predictions.items():
+            hf.create_dataset(name=fname, data=o_cpu)
+    return stem + '.h5'
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if not args.cuda:
+        raise RuntimeError('superpoint_graph_amd has no CPU execution path: run with --cuda 1 on a ROCm device')
+    print('Will save to ' + args.odir)
+    os.makedirs(args.odir, exist_ok=True)
+    with open(os.path.join(args.odir, 'cmdline.txt'), 'w') as f:
+        f.write(' '.join(["'" + a + "'" if (len(a) == 0 or a[0] != '-') else a for a in (argv if argv is not None else sys.argv)]))
+    set_seed(args.seed, args.cuda)
+    logging.getLogger().setLevel(logging.INFO)
+    get_info, create_dataset = datasets.provider(args.dataset)
+    dbinfo = get_info(args)
+    if args.resume != '':
+        if args.resume == 'RESUME':
+            args.resume = args.odir + '/model.pth.tar'
+        model, optimizer, stats = resume(args, dbinfo)
+    else:
+        model = create_model(args, dbinfo)
+        optimizer = create_optimizer(args, model)
+        stats = []
+    session = Session(args, dbinfo, create_dataset, model, optimizer, stats)
+    session.run()
+    return session
+
+
+if __name__ == '__main__':
+    main()

@@ -165,6 +165,30 @@ class _PointNetFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(flat)
 
 
+class _LocalPointNetFunction(torch.autograd.Function):
+    """PointNet WITHOUT inner STN whose xy channels are transformed by externally computed 2x2 matrices, differentiable
+    wrt those matrices and wrt the global features (what LocalCloudEmbedder.run_batch composes, learning/pointnet.py:188-205)."""
+
+    @staticmethod
+    def forward(ctx, module, clouds, clouds_global, T, training, *flat_params):
+        groups = module._groups_tensors()
+        eye = torch.eye(2, device=T.device, dtype=T.dtype).reshape(1, 4)
+        emb, state = ops.pointnet_forward(module._cfg(clouds.shape[2]), clouds, clouds_global, groups, training, 1,
+                                          ext_transform=T.reshape(-1, 4) - eye)
+        ctx.module, ctx.state, ctx.groups, ctx.nflat = module, state, groups, len(flat_params)
+        return emb
+
+    @staticmethod
+    def backward(ctx, grad_emb):
+        direct = _direct_grad_targets(ctx.module, ctx.groups, 4)
+        gg, g_T, g_glob = ops.pointnet_backward(ctx.state, ctx.groups, grad_emb, direct, want_input_grads=True)
+        g_T = g_T.view(-1, 2, 2)
+        if direct is not None:
+            return (None, None, g_glob, g_T, None) + (None,) * ctx.nflat
+        flat = [g for row in gg for g in row if g is not None]
+        return (None, None, g_glob, g_T, None) + tuple(flat)
+
+
 class PointNet(nn.Module):
     """PointNet with one spatial transformer and a "global" input concatenated after the max-pool
     (reference learning/pointnet.py:63-133; same constructor signature)."""
@@ -250,6 +274,43 @@ class PointNet(nn.Module):
             # differentiable input to create the node (instead of tracking ~60 parameter tensors)
             return _PointNetFunction.apply(self, input, input_global, self.training, bn_update_times, _grad_anchor(input.device))
         return _PointNetFunction.apply(self, input, input_global, self.training, bn_update_times, *self._flat_params())
+
+
+class LocalCloudEmbedder():
+    """Local PointNet of the supervised partition (reference learning/pointnet.py:182-218, used by
+    supervized_partition/supervized_partition.py:184,218): millions of k-nearest-neighbour clouds [n, nfeat, k] through a
+    stand-alone STN (`model.stn`) and a PointNet built with nfeat_stn = 0 (`model.ptn`), embeddings L2-normalised.  The
+    reference chunks the batch for cuDNN (2^16 - 1 clouds per call) and materialises the transformed clouds; here the
+    2x2 transform is applied by the first convolution while it stages the cloud, and there is no chunk limit."""
+
+    def __init__(self, args):
+        self.nfeat_stn = args.ptn_nfeat_stn
+        self.stn_as_global = args.stn_as_global
+
+    def run_batch(self, model, clouds, clouds_global, *excess):
+        if not clouds.is_cuda:
+            raise RuntimeError('superpoint_graph_amd.LocalCloudEmbedder has no CPU path')
+        ptn = model.ptn
+        if ptn.nfeat_stn > 0:
+            raise ValueError('LocalCloudEmbedder expects model.ptn without an inner STN (nfeat_stn = 0) and a separate model.stn')
+        clouds = clouds.contiguous().float()
+        clouds_global = clouds_global.float().reshape(clouds.shape[0], -1)
+        if self.nfeat_stn > 0:
+            T = model.stn(clouds[:, :self.nfeat_stn, :].contiguous())
+            if self.stn_as_global:
+                clouds_global = torch.cat([clouds_global, T.reshape(-1, 4)], 1)
+            if ptn.training:
+                ptn._bump_batches_tracked(1)
+            extra = (_grad_anchor(clouds.device),) if getattr(ptn, '_spg_direct_grads', False) and torch.is_grad_enabled() else tuple(ptn._flat_params())
+            out = _LocalPointNetFunction.apply(ptn, clouds, clouds_global.contiguous(), T, ptn.training, *extra)
+        else:
+            out = ptn(clouds, clouds_global.contiguous())
+        return nn.functional.normalize(out)
+
+    def run_batch_cpu(self, model, clouds, clouds_global, *excess):
+        """Embeddings on the host (the reference moves 1023-cloud chunks to the CPU as they are computed to bound GPU
+        memory, :207-218); with 288 GB of HBM the whole batch is embedded at once and copied back."""
+        return self.run_batch(model, clouds, clouds_global).cpu()
 
 
 class CloudEmbedder():

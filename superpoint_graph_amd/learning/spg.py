@@ -27,17 +27,43 @@ class _EdgeSeq:
         return [vals[i] for i in idx]
 
 
-class SuperpointGraph:
-    """Directed graph with edge attributes: the subset of igraph.Graph used by
-    learning/ecc/GraphConvInfo.py:48-58 (get_edgelist, es[...], es.attributes, indegree, vcount, vs)."""
+class _Vertex:
+    def __init__(self, g, i):
+        self._g, self.index = g, i
 
-    def __init__(self, n, edges, edge_attrs=None, vertex_attrs=None):
+    def __getitem__(self, a):
+        return self._g._vattrs[a][self.index]
+
+
+class _VertexSeq:
+    def __init__(self, g):
+        self._g = g
+
+    def __len__(self):
+        return self._g._n
+
+    def __iter__(self):
+        return (_Vertex(self._g, i) for i in range(self._g._n))
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return list(self._g._vattrs[key])
+        return _Vertex(self._g, int(key))
+
+
+class SuperpointGraph:
+    """Directed graph with edge / vertex attributes: the subset of the igraph.Graph API that the reference's loader and
+    batching touch (learning/spg.py:109-143,151-166, learning/ecc/GraphConvInfo.py:48-58): `vcount`, `get_edgelist`,
+    `es[...]`, `es.attributes`, `indegree`, `vs[...]`, `permute_vertices`, `neighborhood`, `subgraph`.  Edge order is
+    preserved by `permute_vertices` and `subgraph` (igraph's copy-and-delete implementation)."""
+
+    def __init__(self, n, edges, directed=True, edge_attrs=None, vertex_attrs=None):
         self._n = int(n)
         self._edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
-        self._eattrs = dict(edge_attrs or {})
-        self._vattrs = dict(vertex_attrs or {})
+        self._eattrs = {k: list(v) for k, v in dict(edge_attrs or {}).items()}
+        self._vattrs = {k: list(v) for k, v in dict(vertex_attrs or {}).items()}
         self.es = _EdgeSeq(self)
-        self.vs = list(range(self._n))
+        self.vs = _VertexSeq(self)
 
     def get_edgelist(self):
         return [tuple(e) for e in self._edges.tolist()]
@@ -45,8 +71,52 @@ class SuperpointGraph:
     def vcount(self):
         return self._n
 
+    def ecount(self):
+        return len(self._edges)
+
     def indegree(self, vs=None, loops=True):
         return np.bincount(self._edges[:, 1], minlength=self._n).tolist()
+
+    def permute_vertices(self, perm):
+        """Vertex k of this graph becomes vertex perm[k] of the result (igraph semantics); edges keep their order."""
+        perm = np.asarray(perm, dtype=np.int64)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(self._n)
+        vattrs = {k: [v[i] for i in inv] for k, v in self._vattrs.items()}
+        return SuperpointGraph(self._n, perm[self._edges] if len(self._edges) else self._edges, True, self._eattrs, vattrs)
+
+    def neighborhood(self, centers, order=1):
+        """For every center the vertices within `order` steps, direction ignored (igraph mode='all'), itself first."""
+        from scipy import sparse
+        n, e = self._n, self._edges
+        adj = sparse.csr_matrix((np.ones(2 * len(e), dtype=np.int8), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])),
+                                shape=(n, n))
+        out = []
+        for c in centers:
+            seen = np.zeros(n, dtype=bool)
+            seen[c] = True
+            order_list, frontier = [int(c)], np.array([c])
+            for _ in range(int(order)):
+                nb = np.unique(adj[frontier].indices)
+                nb = nb[~seen[nb]]
+                if nb.size == 0:
+                    break
+                seen[nb] = True
+                order_list += nb.tolist()
+                frontier = nb
+            out.append(order_list)
+        return out
+
+    def subgraph(self, vertices):
+        """Induced subgraph; kept vertices are renumbered in the order given (increasing in every call site)."""
+        ids = np.asarray(list(vertices), dtype=np.int64)
+        new_id = np.full(self._n, -1, dtype=np.int64)
+        new_id[ids] = np.arange(len(ids))
+        e = self._edges
+        keep = np.nonzero((new_id[e[:, 0]] >= 0) & (new_id[e[:, 1]] >= 0))[0] if len(e) else np.zeros(0, dtype=np.int64)
+        eattrs = {k: [v[i] for i in keep] for k, v in self._eattrs.items()}
+        vattrs = {k: [v[i] for i in ids] for k, v in self._vattrs.items()}
+        return SuperpointGraph(len(ids), new_id[e[keep]] if len(keep) else np.zeros((0, 2), dtype=np.int64), True, eattrs, vattrs)
 
 
 def cloud_edge_feats(edgeattrs):
@@ -55,23 +125,28 @@ def cloud_edge_feats(edgeattrs):
     return torch.from_numpy(edgefeats), None
 
 
+def _as_tensor(x):
+    return x if torch.is_tensor(x) else torch.from_numpy(np.asarray(x))
+
+
 def eccpc_collate(batch):
-    """Collates a list of dataset samples into a single batch (reference learning/spg.py:178-193)."""
+    """Collates a list of dataset samples into a single batch (reference learning/spg.py:178-193).  Clouds produced by
+    the device loader are CUDA tensors already and are concatenated on the device."""
     targets, graphs, clouds_meta, clouds_flag, clouds, clouds_global = list(zip(*batch))
-    targets = torch.cat([torch.from_numpy(t) for t in targets if t is not None], 0).long()
+    targets = torch.cat([_as_tensor(t) for t in targets if t is not None], 0).long()
     graphs = [graph for graph in graphs if graph is not None]
     GIs = [ecc.GraphConvInfo(graphs, cloud_edge_feats)]
     if len(clouds_meta[0]) > 0:
-        clouds = torch.cat([torch.from_numpy(f) for f in clouds if f is not None], 0)
-        clouds_global = torch.cat([torch.from_numpy(f) for f in clouds_global if f is not None], 0)
-        clouds_flag = torch.cat([torch.from_numpy(f) for f in clouds_flag if f is not None], 0)
+        clouds = torch.cat([_as_tensor(f) for f in clouds if f is not None], 0)
+        clouds_global = torch.cat([_as_tensor(f) for f in clouds_global if f is not None], 0)
+        clouds_flag = torch.cat([_as_tensor(f) for f in clouds_flag if f is not None], 0)
         clouds_meta = [item for sublist in clouds_meta if sublist is not None for item in sublist]
     return targets, GIs, (clouds_meta, clouds_flag, clouds, clouds_global)
 
 
 def sample_from_scene(scene, name='synthetic'):
     """A loader sample (reference learning/spg.py:166) from a synthetic scene of superpoint_graph_amd.synth."""
-    G = SuperpointGraph(scene['n_sp'], scene['edges'], {'f': list(scene['edge_feats'])})
+    G = SuperpointGraph(scene['n_sp'], scene['edges'], True, {'f': list(scene['edge_feats'])})
     meta = ['{}.{:d}'.format(name, i) for i in range(scene['n_sp'])]
     return scene['targets'], G, meta, scene['flag'], scene['clouds'], scene['diam']
 
@@ -109,8 +184,12 @@ def load_superpoints_device(args, points, offsets, ids, train, test_seed_offset=
     if not points.is_cuda:
         raise RuntimeError('superpoint_graph_amd.load_superpoints_device has no CPU path')
     off_h = offsets.cpu().numpy() if torch.is_tensor(offsets) else np.asarray(offsets, dtype=np.int64)
+    if counts is None:                        # offsets [S+1]: superpoints back to back
+        counts = np.diff(off_h)
+    else:                                     # offsets [S] = first row of each (arbitrary subset / order of a resident scene)
+        counts = np.asarray(counts, dtype=np.int64)
+        off_h = np.concatenate([off_h, off_h[-1:] + counts[-1:]]) if len(off_h) else np.zeros(1, dtype=np.int64)
     S, npts = len(off_h) - 1, int(args.ptn_npts)
-    counts = np.diff(off_h)
     cols = pc_attribs_columns(args.pc_attribs) if args.pc_attribs != '' else list(range(points.shape[1]))
     F = len(cols)
     flag = np.where(counts < args.ptn_minpts, -1, 0).astype(np.int64)           # :203
@@ -156,3 +235,290 @@ def load_superpoints_device(args, points, offsets, ids, train, test_seed_offset=
         torch.from_numpy(sidx).to(dev), cols, bool(args.pc_xyznormalize), nv,
         None if Ms is None else torch.from_numpy(Ms).to(dev), None if noise is None else torch.from_numpy(noise).to(dev))
     return torch.from_numpy(flag), clouds, diam
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# superpoint-graph files -> graphs, edge features, loader  (reference learning/spg.py:23-171)
+# --------------------------------------------------------------------------------------------------------------------
+def spg_edge_features(edges, node_att, edge_att, args):
+    """Assembles the superedge features from edge attributes and differences of node attributes (reference
+    learning/spg.py:23-49): `delta_avg`, `delta_std` copied, `X/d` difference, `X/ld` log ratio, `X/r` ratio,
+    `constant`; float32 result in the order of `args.edge_attribs`."""
+    src, dst = edges[:, 0], edges[:, 1]
+    cols = []
+    for attrib in args.edge_attribs.split(','):
+        a, _, opt = attrib.partition('/')
+        opt = opt.lower()
+        if a in ('delta_avg', 'delta_std'):
+            cols.append(edge_att[a])
+        elif a == 'constant':
+            cols.append(np.ones((edges.shape[0], 1), dtype=np.float32))
+        elif a in ('nlength', 'surface', 'volume', 'size', 'xyz'):
+            v = node_att[a]
+            if opt == 'd':
+                v = v[src, :] - v[dst, :]
+            elif opt == 'ld':
+                v = np.log(v + 1e-10)
+                v = v[src, :] - v[dst, :]
+            elif opt == 'r':
+                v = v[src, :] / (v[dst, :] + 1e-10)
+            else:
+                raise NotImplementedError(attrib)
+            cols.append(v)
+        else:
+            raise NotImplementedError(attrib)
+    return np.concatenate(cols, axis=1).astype(np.float32)
+
+
+def spg_edge_features_device(edges, node_att, edge_att, args, scaler=None, device=None):
+    """`spg_edge_features` (+ the `scaler01` transform when a fitted sklearn StandardScaler is given) on the GPU: one
+    thread per (edge, feature); float32 node attributes are combined in float32 and the u64 point count in float64 with
+    one final rounding, exactly like the numpy expressions of the reference (learning/spg.py:23-64).  Copies, differences
+    and ratios are bit-identical to the host function; the logarithms are the device's logf / log."""
+    from .. import ops
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+
+    def up(a):
+        a = np.asarray(a)
+        a = a.astype(np.float64) if a.dtype not in (np.float32, np.float64) else a      # u64 counts promote like numpy does
+        return torch.from_numpy(np.ascontiguousarray(a.reshape(a.shape[0], -1))).to(dev)
+    cache, cols = {}, []
+    for attrib in args.edge_attribs.split(','):
+        a, _, opt = attrib.partition('/')
+        opt = opt.lower()
+        if a in ('delta_avg', 'delta_std'):
+            t = cache.setdefault(a, up(edge_att[a]))
+            cols += [('copy', t, c) for c in range(t.shape[1])]
+        elif a == 'constant':
+            cols.append(('const', None, 0))
+        elif a in ('nlength', 'surface', 'volume', 'size', 'xyz'):
+            if opt not in ('d', 'ld', 'r'):
+                raise NotImplementedError(attrib)
+            t = cache.setdefault(a, up(node_att[a]))
+            cols += [(opt, t, c) for c in range(t.shape[1])]
+        else:
+            raise NotImplementedError(attrib)
+    e = torch.from_numpy(np.ascontiguousarray(np.asarray(edges, dtype=np.int64))).to(dev)
+    mean = scale = None
+    if scaler is not None:
+        mean = torch.from_numpy(np.asarray(scaler.mean_, dtype=np.float64)).to(dev)
+        scale = torch.from_numpy(np.asarray(scaler.scale_, dtype=np.float64)).to(dev)
+    return ops.edge_features(cols, e, mean, scale)
+
+
+def scaler01(trainlist, testlist, transform_train=True, validlist=[]):
+    """Standardises the edge features (column 3 of every `spg_reader` tuple) with the statistics of the TRAINING edges
+    (reference learning/spg.py:51-64; sklearn's StandardScaler, in place)."""
+    from sklearn import preprocessing
+    scaler = preprocessing.StandardScaler().fit(np.concatenate([t[3] for t in trainlist], 0))
+    for lst in ((trainlist if transform_train else []), testlist, validlist):
+        for t in lst:
+            scaler.transform(t[3], copy=False)
+    return trainlist, testlist, validlist, scaler
+
+
+def spg_from_arrays(args, f, name):
+    """The superpoint-graph record of one scene from the arrays of its file (`f`: mapping name -> array with the datasets
+    that partition/provider.py:558-600 writes) -> (node_gt, node_gt_size, edges, edge_feats, name); the body of the
+    reference's spg_reader (learning/spg.py:68-103)."""
+    sp_labels = np.asarray(f['sp_labels'])
+    if sp_labels.size > 0:
+        node_gt_size = sp_labels.astype(np.int64)               # col 0: unlabelled points, col 1+: points per class
+        node_gt = np.argmax(node_gt_size[:, 1:], 1)[:, None]
+        node_gt[node_gt_size[:, 1:].sum(1) == 0, :] = -100      # ignored by the loss
+    else:
+        n = np.asarray(f['sp_point_count']).shape[0]
+        node_gt_size = np.concatenate([np.asarray(f['sp_point_count']).astype(np.int64), np.zeros((n, 8), dtype=np.int64)], 1)
+        node_gt = np.zeros((n, 1), dtype=np.int64)
+    node_att = dict(xyz=np.asarray(f['sp_centroids']), nlength=np.maximum(0, np.asarray(f['sp_length'])),
+                    volume=np.maximum(0, np.asarray(f['sp_volume']) ** 2), surface=np.maximum(0, np.asarray(f['sp_surface']) ** 2),
+                    size=np.asarray(f['sp_point_count']))
+    edges = np.concatenate([np.asarray(f['source']), np.asarray(f['target'])], axis=1).astype(np.int64)
+    edge_att = dict(delta_avg=np.asarray(f['se_delta_mean']), delta_std=np.asarray(f['se_delta_std']))
+    if args.spg_superedge_cutoff > 0:
+        keep = np.linalg.norm(edge_att['delta_avg'], axis=1) < args.spg_superedge_cutoff
+        edges = edges[keep, :]
+        edge_att = {k: v[keep, :] for k, v in edge_att.items()}
+    return node_gt, node_gt_size, edges, spg_edge_features(edges, node_att, edge_att, args), name
+
+
+def spg_reader(args, fname, incl_dir_in_name=False):
+    """Loads a superpoint graph from its HDF5 file (reference learning/spg.py:66-103; needs h5py)."""
+    import os
+    import h5py
+    name = os.path.basename(fname)[:-len('.h5')]
+    if incl_dir_in_name:
+        name = os.path.basename(os.path.dirname(fname)) + '/' + name
+    with h5py.File(fname, 'r') as f:
+        return spg_from_arrays(args, {k: f[k][:] for k in ('sp_labels', 'sp_centroids', 'sp_length', 'sp_volume', 'sp_surface',
+                                                            'sp_point_count', 'source', 'target', 'se_delta_mean', 'se_delta_std')}, name)
+
+
+def spg_to_graph(node_gt, node_gt_size, edges, edge_feats, fname, graph_cls=None):
+    """`spg_to_igraph` (reference learning/spg.py:106-113): vertex attributes v (original id), t (targets row),
+    s (point count).  `graph_cls` defaults to SuperpointGraph; igraph.Graph works as well."""
+    targets = np.concatenate([node_gt, node_gt_size], axis=1)
+    cls = graph_cls or SuperpointGraph
+    G = cls(n=node_gt.shape[0], edges=edges.tolist(), directed=True, edge_attrs={'f': edge_feats},
+            vertex_attrs={'v': list(range(node_gt.shape[0])), 't': targets, 's': node_gt_size.sum(1)})
+    return G, fname
+
+
+spg_to_igraph = spg_to_graph
+
+
+def random_neighborhoods(G, num, order):
+    """`num` random neighbourhoods of `order` hops, merged (reference learning/spg.py:115-122)."""
+    import random
+    centers = random.sample(range(G.vcount()), k=num)
+    members = sorted({v for nb in G.neighborhood(centers, order) for v in nb})
+    return G.subgraph(members)
+
+
+def k_big_enough(G, minpts, k):
+    """Induced graph on the leading vertices that contain at most k superpoints of >= minpts points (reference :124-128)."""
+    big = np.cumsum(np.array(G.vs['s']) >= minpts)
+    n = int(np.argwhere(big <= k)[-1][0]) + 1
+    return G.subgraph(range(n))
+
+
+class MemoryPointStore:
+    """parsed/<scene>.h5 in memory: {scene name: {superpoint id: float array [n, ncols]}}."""
+
+    def __init__(self, scenes):
+        self._scenes = scenes
+
+    def points(self, fname, sp_id):
+        return self._scenes[fname][sp_id]
+
+    def count(self, fname, sp_id):
+        return self._scenes[fname][sp_id].shape[0]
+
+    def ids(self, fname):
+        return sorted(self._scenes[fname].keys())
+
+
+class H5PointStore:
+    """<db_path>/parsed/<scene>.h5 with one dataset per superpoint id (reference learning/spg.py:200-205; needs h5py)."""
+
+    def __init__(self, db_path):
+        self._root, self._open = db_path, {}
+
+    def _file(self, fname):
+        import h5py
+        if fname not in self._open:
+            self._open[fname] = h5py.File(self._root + '/parsed/' + fname + '.h5', 'r')
+        return self._open[fname]
+
+    def points(self, fname, sp_id):
+        return self._file(fname)['{:d}'.format(sp_id)][:]
+
+    def count(self, fname, sp_id):
+        return self._file(fname)['{:d}'.format(sp_id)].shape[0]
+
+    def ids(self, fname):
+        return sorted(int(k) for k in self._file(fname).keys() if k.isdigit())
+
+
+def load_superpoint(args, store, fname, sp_id, train, test_seed_offset):
+    """One superpoint -> ([npts, F] float32 cloud or None, diameter) on the HOST, with the reference's random streams in
+    the reference's order (learning/spg.py:198-258): the parity baseline of the device loader below and the path used when
+    the model runs without a GPU-resident point store."""
+    import math
+    import random
+    n = store.count(fname, sp_id)
+    if n < args.ptn_minpts:
+        return None, n
+    P = np.asarray(store.points(fname, sp_id)).astype(np.float32)
+    rs = np.random if train else np.random.RandomState(seed=sp_id + test_seed_offset)
+    if n > args.ptn_npts:
+        P = P[rs.choice(n, args.ptn_npts), ...]
+    elif n < args.ptn_npts:
+        P = np.concatenate([P, P[rs.choice(n, args.ptn_npts - n), ...]], 0)
+    if args.pc_xyznormalize:
+        diameter = np.max(np.max(P[:, :3], axis=0) - np.min(P[:, :3], axis=0))
+        P[:, :3] = (P[:, :3] - np.mean(P[:, :3], axis=0, keepdims=True)) / (diameter + 1e-10)
+    else:
+        diameter = 0.0
+        P[:, :3] = P[:, :3] - np.mean(P[:, :3], axis=0, keepdims=True)
+    if args.pc_attribs != '':
+        P = P[:, pc_attribs_columns(args.pc_attribs)]
+    if train:
+        M = np.eye(3)
+        if args.pc_augm_scale > 1:
+            M = np.dot(np.eye(3) * random.uniform(1 / args.pc_augm_scale, args.pc_augm_scale), M)
+        if args.pc_augm_rot == 1:
+            a = random.uniform(0, 2 * math.pi)
+            c, sn = math.cos(a), math.sin(a)
+            M = np.dot(np.array([[c, -sn, 0.0], [sn, c, 0.0], [0.0, 0.0, 1.0]]), M)
+        if args.pc_augm_mirror_prob > 0:
+            if random.random() < args.pc_augm_mirror_prob / 2:
+                M = np.dot(np.diag([-1.0, 1.0, 1.0]), M)
+            if random.random() < args.pc_augm_mirror_prob / 2:
+                M = np.dot(np.diag([1.0, -1.0, 1.0]), M)
+        P[:, :3] = np.dot(P[:, :3], M.T)
+        if args.pc_augm_jitter:
+            P = P + np.clip(0.01 * np.random.randn(*P.shape), -0.05, 0.05).astype(np.float32)
+    return P, np.array([diameter], dtype=np.float32)
+
+
+class DevicePointCache:
+    """Scenes' parsed points resident in HBM (288 GB per GPU: the whole training set of S3DIS is a few GB): the first
+    touch of a scene uploads its ragged point buffer once; afterwards a training step only sends indices."""
+
+    def __init__(self, store, device):
+        self._store, self._dev, self._scenes = store, device, {}
+
+    def scene(self, fname):
+        ent = self._scenes.get(fname)
+        if ent is None:
+            ids = self._store.ids(fname)
+            arrs = [np.asarray(self._store.points(fname, i), dtype=np.float32) for i in ids]
+            off = np.zeros(len(ids) + 1, dtype=np.int64)
+            off[1:] = np.cumsum([a.shape[0] for a in arrs])
+            pts = torch.from_numpy(np.concatenate(arrs, 0)).to(self._dev)
+            ent = (pts, off, {i: k for k, i in enumerate(ids)})
+            self._scenes[fname] = ent
+        return ent
+
+
+def loader(entry, train, args, db_path, test_seed_offset=0, store=None, device_cache=None):
+    """Prepares a (possibly sub-sampled) superpoint graph and its superpoint clouds (reference learning/spg.py:130-171).
+    `store`: point store (default: the HDF5 files under db_path); `device_cache`: DevicePointCache -> the clouds are built
+    by ONE launch of the HIP loader kernel from the scene's resident ragged buffer and returned as CUDA tensors."""
+    import random
+    G, fname = entry
+    if train:                                        # 1) neighbourhood sub-sampling of the (permuted) graph, :134-144
+        if 0 < args.spg_augm_hardcutoff < G.vcount():
+            perm = list(range(G.vcount()))
+            random.shuffle(perm)
+            G = G.permute_vertices(perm)
+        if 0 < args.spg_augm_nneigh < G.vcount():
+            G = random_neighborhoods(G, args.spg_augm_nneigh, args.spg_augm_order)
+        if 0 < args.spg_augm_hardcutoff < G.vcount():
+            G = k_big_enough(G, args.ptn_minpts, args.spg_augm_hardcutoff)
+    if len(G.get_edgelist()) == 0:                   # graphs without edges are dropped by the collate, :169-171
+        return None, None, None, None, None, None
+    vids = [G.vs[s]['v'] for s in range(G.vcount())]
+    meta = ['{}.{:d}'.format(fname, v) for v in vids]
+    targets = np.array(G.vs['t'])
+    if device_cache is not None:                     # 2) all clouds of the graph in one kernel launch
+        pts, off, index = device_cache.scene(fname)
+        rows = np.array([index[v] for v in vids], dtype=np.int64)
+        flag, clouds, diam = load_superpoints_device(args, pts, off[rows], vids, train, test_seed_offset,
+                                                     counts=off[rows + 1] - off[rows])
+        return targets, G, meta, flag, clouds, diam
+    store = store if store is not None else H5PointStore(db_path)
+    flag, clouds, diams = [], [], []
+    for v in vids:
+        cloud, diam = load_superpoint(args, store, fname, v, train, test_seed_offset)
+        if cloud is None:
+            flag.append(-1)
+        else:
+            flag.append(0)
+            clouds.append(cloud.T)
+            diams.append(diam)
+    flag = np.array(flag)
+    clouds = np.stack(clouds) if clouds else clouds
+    diams = np.concatenate(diams) if diams else diams
+    return targets, G, meta, flag, clouds, diams

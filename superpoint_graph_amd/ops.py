@@ -204,15 +204,17 @@ def _require_training_state(state, what):
 class PointNetState:
     """Saved forward state (workspace with the raw layer outputs and BatchNorm constants)."""
 
-    def __init__(self, cfg, B, clouds, clouds_global, ws, training):
+    def __init__(self, cfg, B, clouds, clouds_global, ws, training, ext_transform=None):
         self.cfg, self.B, self.clouds, self.clouds_global, self.ws = cfg, B, clouds, clouds_global, ws
         self.training = bool(training)
+        self.ext_transform = ext_transform
 
 
 def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Sequence[Optional[torch.Tensor]]],
-                     training: bool, bn_update_times: int = 1):
+                     training: bool, bn_update_times: int = 1, ext_transform=None):
     """groups: one 6-tuple (weight, bias, bn.weight, bn.bias, running_mean, running_var) per layer in the order
-    of include/spg_hip.h.  Returns (emb [B, D], PointNetState)."""
+    of include/spg_hip.h.  ext_transform: [B, 4] = T - I of an externally evaluated STN (PointNet without inner STN).
+    Returns (emb [B, D], PointNetState)."""
     _req(clouds, torch.float32, 'clouds')
     B = clouds.shape[0]
     if clouds.shape[1] != cfg.nfeat or clouds.shape[2] != cfg.npts:
@@ -231,12 +233,14 @@ def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Seque
     D = cfg.fc[cfg.n_fc - 1]
     emb = torch.empty(B, D, dtype=torch.float32, device=clouds.device)
     flat = [t for g in groups for t in g]
-    check(lib().spg_pointnet_forward(ctypes.byref(cfg), B, _ptr(clouds), _ptr(clouds_global), _ptr_array(flat), _ptr(emb),
-                                     _ptr(ws), int(training), int(bn_update_times), _stream()), 'spg_pointnet_forward')
-    return emb, PointNetState(cfg, B, clouds, clouds_global, ws, training)
+    if ext_transform is not None:
+        ext_transform = _req(ext_transform.reshape(B, 4).contiguous(), torch.float32, 'ext_transform')
+    check(lib().spg_pointnet_forward_ext(ctypes.byref(cfg), B, _ptr(clouds), _ptr(clouds_global), _ptr(ext_transform), _ptr_array(flat),
+                                         _ptr(emb), _ptr(ws), int(training), int(bn_update_times), _stream()), 'spg_pointnet_forward')
+    return emb, PointNetState(cfg, B, clouds, clouds_global, ws, training, ext_transform)
 
 
-def pointnet_backward(state: PointNetState, groups, grad_emb, out_grads=None):
+def pointnet_backward(state: PointNetState, groups, grad_emb, out_grads=None, want_input_grads=False):
     """Returns a list of 4-tuples (d weight, d bias, d bn.weight, d bn.bias) per layer.
     out_grads: optional pre-allocated destination tensors in the same structure (written, not accumulated); a
     `None` entry is skipped by the library (used for the analytically-zero biases in front of a BatchNorm when the
@@ -255,9 +259,17 @@ def pointnet_backward(state: PointNetState, groups, grad_emb, out_grads=None):
         gg.append(tuple(d))
         flatg += d + [None, None]
     flat = [t for g in groups for t in g]
-    check(lib().spg_pointnet_backward(ctypes.byref(cfg), B, _ptr(state.clouds), _ptr(state.clouds_global), _ptr_array(flat),
-                                      _ptr(grad_emb), _ptr_array(flatg), _ptr(state.ws), _ptr(bws), _stream()),
-          'spg_pointnet_backward')
+    g_T = g_glob = None
+    if want_input_grads:          # gradients wrt the external transform and the global features (LocalCloudEmbedder)
+        if state.ext_transform is not None:
+            g_T = torch.empty(B, 4, dtype=torch.float32, device=grad_emb.device)
+        if state.clouds_global is not None:
+            g_glob = torch.empty_like(state.clouds_global)
+    check(lib().spg_pointnet_backward_ext(ctypes.byref(cfg), B, _ptr(state.clouds), _ptr(state.clouds_global), _ptr(state.ext_transform),
+                                          _ptr_array(flat), _ptr(grad_emb), _ptr_array(flatg), _ptr(g_T), _ptr(g_glob), _ptr(state.ws),
+                                          _ptr(bws), _stream()), 'spg_pointnet_backward')
+    if want_input_grads:
+        return gg, g_T, g_glob
     return gg
 
 
@@ -329,6 +341,61 @@ def eccrnn_backward(state: EccRnnState, groups, grad_out, out_grads=None):
                                     _ptr(grad_out), _ptr(grad_h0), _ptr_array(flatg), _ptr(state.ws), _ptr(bws), _stream()),
           'spg_eccrnn_backward')
     return grad_h0, gg
+
+
+# --------------------------------------------------------------------------------------------------
+# batch construction on the device
+# --------------------------------------------------------------------------------------------------
+def set_batch(edges, n_nodes: int):
+    """edges i64 [E, 2] (source, target; batch node offsets applied) on the device -> (idxn i64 [E], degs i64 [N],
+    perm i64 [E]): edges ordered by target (stable), see include/spg_hip.h."""
+    _req(edges, torch.int64, 'edges')
+    E = int(edges.shape[0])
+    dev = edges.device
+    idxn = torch.empty(E, dtype=torch.int64, device=dev)
+    perm = torch.empty(E, dtype=torch.int64, device=dev)
+    degs = torch.empty(n_nodes, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib().spg_set_batch_workspace_bytes(n_nodes, E), dtype=torch.uint8, device=dev)
+    check(lib().spg_set_batch(_ptr(edges) if E else None, n_nodes, E, _ptr(idxn) if E else None, _ptr(degs), _ptr(perm) if E else None,
+                              _ptr(ws), _ptr(err), _stream()), 'spg_set_batch')
+    return idxn, degs, perm, err
+
+
+def gather_rows(src, perm):
+    _req(src, torch.float32, 'src'); _req(perm, torch.int64, 'perm')
+    rows, cols = int(perm.numel()), int(src.shape[1])
+    dst = torch.empty(rows, cols, dtype=torch.float32, device=src.device)
+    check(lib().spg_gather_rows(_ptr(src), cols, _ptr(perm), rows, cols, _ptr(dst), cols, _stream()), 'spg_gather_rows')
+    return dst
+
+
+_EF_KIND = {'': 0, 'copy': 0, 'd': 1, 'ld': 2, 'r': 3, 'const': 4}
+
+
+def edge_features(columns, edges, mean=None, scale=None):
+    """columns: list of (kind, tensor or None, column) per OUTPUT column with kind in copy|d|ld|r|const; the tensor is a
+    float32 / float64 device matrix (per edge for copy, per node otherwise).  edges i64 [E, 2]; mean / scale f64 [ncols]."""
+    _req(edges, torch.int64, 'edges')
+    specs = _lib.EdgeFeatureSpecs()
+    if len(columns) > _lib.SPG_EF_MAX_COLS:
+        raise ValueError('too many edge feature columns')
+    specs.ncols = len(columns)
+    keep = []
+    for i, (kind, t, col) in enumerate(columns):
+        sp = specs.col[i]
+        sp.kind = _EF_KIND[kind]
+        if t is not None:
+            _req(t, name='attribute')
+            if t.dtype not in (torch.float32, torch.float64) or t.dim() != 2:
+                raise TypeError('attributes must be 2-d float32 / float64 matrices')
+            sp.data, sp.ld, sp.column, sp.is_f64 = t.data_ptr(), t.shape[1], int(col), int(t.dtype == torch.float64)
+            keep.append(t)
+    E = int(edges.shape[0])
+    out = torch.empty(E, len(columns), dtype=torch.float32, device=edges.device)
+    check(lib().spg_edge_features(ctypes.byref(specs), _ptr(edges) if E else None, E, _ptr(mean), _ptr(scale), _ptr(out), _stream()),
+          'spg_edge_features')
+    return out
 
 
 # --------------------------------------------------------------------------------------------------

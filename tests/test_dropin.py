@@ -89,3 +89,46 @@ def test_reference_filter_valid_and_collate_contract(ref_main):
     tgt = torch.tensor([1, -100, 3, 4, -100, 0])
     o, t = ref_main.filter_valid(out, tgt)                # learning/main.py:447-452
     assert o.shape == (4, 13) and t.tolist() == [1, 3, 4, 0]
+
+
+def test_loader_and_dataset_plumbing_bit_identical_to_reference():
+    """spg_reader body / spg_edge_features / scaler01 / spg_to_graph / loader (neighbourhood sub-sampling, hard cut-off,
+    load_superpoint, augment_cloud with scale + rotation + mirroring + jitter) of this package against the reference's own
+    learning/spg.py on the in-memory dataset of tests/main_fixture.py, same seeds: every array of every sample identical."""
+    import random
+    import subprocess
+    import sys as _sys
+    code = r'''
+import sys, random, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import main_fixture
+import gen_main_golden as G
+G.install_shims()
+sys.path.insert(0, G.REF)
+import learning
+train, test = main_fixture.make_dataset(0)
+G.install_dataset(train, test)
+from superpoint_graph_amd.learning import main as cli, datasets
+args = cli.parse_args(['--dataset', 'x'] + main_fixture.CLI); args.cuda = 0
+import custom_dataset
+rtr, rte, _, rsc = custom_dataset.get_datasets(args)
+points = {n: p for n, _, p in train + test}
+datasets.register_memory_dataset('memtest', [(n, g) for n, g, _ in train], [(n, g) for n, g, _ in test], [], points, 13, 14)
+atr, ate, _, asc = datasets.provider('memtest')[1](args)
+assert np.array_equal(rsc.mean_, asc.mean_) and np.array_equal(rsc.scale_, asc.scale_)
+n = 0
+for ds_r, ds_a in ((rtr, atr), (rte, ate)):
+    for i in range(len(ds_r)):
+        random.seed(5); np.random.seed(5); r = ds_r[i]
+        random.seed(5); np.random.seed(5); a = ds_a[i]
+        for x, y in ((r[0], a[0]), (r[3], a[3]), (r[4], a[4]), (r[5], a[5])):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+        assert r[2] == a[2] and r[1].get_edgelist() == a[1].get_edgelist()
+        assert np.array_equal(np.asarray(r[1].es.get_attribute_values('f')), np.asarray(a[1].es.get_attribute_values('f')))
+        n += 1
+print('identical samples:', n)
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    out = subprocess.run([_sys.executable, '-c', code], capture_output=True, text=True, timeout=600)   # own process: sys.modules shims stay out of this one
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'identical samples: 6' in out.stdout

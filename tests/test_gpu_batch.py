@@ -1,0 +1,96 @@
+"""Device-side batch construction: set_batch (stable order by target), the edge-feature gather
+and spg_edge_features + StandardScaler, against the host implementations (which are bit-identical to the reference's,
+tests/test_dropin.py / tests/test_host.py)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graphs(seed, sizes):
+    from superpoint_graph_amd.learning import spg
+    rng = np.random.default_rng(seed)
+    out = []
+    for n in sizes:
+        e = int(n * 4.5)
+        edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1)
+        feats = rng.standard_normal((e, 13)).astype(np.float32)
+        out.append(spg.SuperpointGraph(n, edges, True, {'f': list(feats)}))
+    return out
+
+
+@pytest.mark.parametrize('sizes', [[50], [300, 1, 120, 700], [4000, 3000]])
+def test_set_batch_device_matches_host_up_to_tie_order(sizes):
+    from superpoint_graph_amd.learning import ecc, spg
+    graphs = _graphs(3, sizes)
+    host = ecc.GraphConvInfo(graphs, spg.cloud_edge_feats)
+    dev = ecc.GraphConvInfo()
+    dev.set_batch_device(graphs, spg.cloud_edge_feats)
+    idxn_h, _, degs_h, _, ef_h = host.get_buffers()
+    idxn_d, _, degs_d, degs_gpu, ef_d = dev.get_buffers()
+    assert torch.equal(degs_h, degs_d) and torch.equal(degs_gpu.cpu(), degs_h)          # integer contract: exact
+    idxn_d, ef_d = idxn_d.cpu(), ef_d.cpu()
+    assert idxn_d.shape == idxn_h.shape and ef_d.shape == ef_h.shape
+    # every target segment holds the same (source, feature row) multiset; the device order is the stable one
+    off = np.concatenate([[0], np.cumsum(degs_h.numpy())])
+    E = np.concatenate([np.asarray(g.get_edgelist()).reshape(-1, 2) + p for g, p in zip(graphs, np.concatenate([[0], np.cumsum(sizes)[:-1]]))])
+    F = np.concatenate([np.asarray(g.es.get_attribute_values('f')) for g in graphs])
+    stable = np.argsort(E[:, 1], kind='stable')
+    assert np.array_equal(idxn_d.numpy(), E[stable, 0]) and np.array_equal(ef_d.numpy(), F[stable])
+    for i in range(len(off) - 1):
+        a, b = off[i], off[i + 1]
+        key_h = sorted(zip(idxn_h[a:b].tolist(), map(tuple, ef_h[a:b].tolist())))
+        key_d = sorted(zip(idxn_d[a:b].tolist(), map(tuple, ef_d[a:b].tolist())))
+        assert key_h == key_d
+    # the pyg-style edge index list follows the same order
+    assert torch.equal(dev.get_pyg_buffers().cpu()[0], idxn_d)
+
+
+def test_model_outputs_agree_between_host_and_device_batches():
+    """Same graphs through the RNN-ECC module with host-built and device-built index buffers: the only difference is the
+    summation order inside a target segment (fp32 round-off)."""
+    from superpoint_graph_amd.learning import ecc, graphnet, spg
+    graphs = _graphs(5, [400, 250])
+    torch.manual_seed(0)
+    net = graphnet.GraphNetwork('gru_4_0,f_13', 32, [13, 32, 128, 64], 1, 0, 2, 30000, use_pyg=0, cuda=1).cuda().eval()
+    x = torch.randn(650, 32, device='cuda')
+    host = ecc.GraphConvInfo(graphs, spg.cloud_edge_feats)
+    dev = ecc.GraphConvInfo()
+    dev.set_batch_device(graphs, spg.cloud_edge_feats)
+    with torch.no_grad():
+        net.set_info([host], 1)
+        y_h = net(x)
+        net.set_info([dev], 1)
+        y_d = net(x)
+    assert float((y_h - y_d).abs().max()) <= 2e-5 * float(y_h.abs().max())
+
+
+def test_edge_features_device_matches_host():
+    from superpoint_graph_amd.learning import spg
+    from sklearn import preprocessing
+    rng = np.random.default_rng(11)
+    n, e = 500, 2600
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    node_att = dict(xyz=rng.uniform(0, 9, (n, 3)).astype(np.float32), nlength=np.maximum(0, rng.uniform(-0.1, 3, (n, 1)).astype(np.float32)),
+                    volume=rng.uniform(0, 1, (n, 1)).astype(np.float32) ** 2, surface=rng.uniform(0, 2, (n, 1)).astype(np.float32) ** 2,
+                    size=rng.integers(1, 10000, (n, 1)).astype(np.uint64))
+    edge_att = dict(delta_avg=rng.normal(0, 1, (e, 3)).astype(np.float32), delta_std=rng.uniform(0, 1, (e, 3)).astype(np.float32))
+    for attribs in ('delta_avg,delta_std,nlength/ld,surface/ld,volume/ld,size/ld,xyz/d', 'constant,xyz/d,size/r,nlength/d,volume/r'):
+        args = types.SimpleNamespace(edge_attribs=attribs)
+        ref = spg.spg_edge_features(edges, node_att, edge_att, args)
+        out = spg.spg_edge_features_device(edges, node_att, edge_att, args).cpu().numpy()
+        kinds = [a.partition('/')[2] for a in attribs.split(',') for _ in range(3 if a.split('/')[0] in ('delta_avg', 'delta_std', 'xyz') else 1)]
+        for c, k in enumerate(kinds):
+            if k in ('ld',):            # logarithms: the device's log / logf against numpy's (both <= 1 ulp from the true value)
+                np.testing.assert_allclose(out[:, c], ref[:, c], rtol=0, atol=4e-6 * max(1.0, float(np.abs(ref[:, c]).max())))
+            else:                       # copies, differences, ratios: element-wise IEEE operations -> bit-exact
+                assert np.array_equal(out[:, c], ref[:, c]), (attribs, c, k)
+        scaler = preprocessing.StandardScaler().fit(ref)
+        ref_s = scaler.transform(ref.copy(), copy=False)
+        exact_cols = [c for c, k in enumerate(kinds) if k != 'ld']
+        out_s = spg.spg_edge_features_device(edges, node_att, edge_att, args, scaler=scaler).cpu().numpy()
+        assert np.array_equal(out_s[:, exact_cols], ref_s[:, exact_cols])
+        np.testing.assert_allclose(out_s, ref_s, rtol=0, atol=2e-5)

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(hip):
     for name in sorted(declared):
         assert hasattr(hip, name), f'{name} declared in include/spg_hip.h but not exported'
         assert name in _lib.SIGNATURES, f'{name} has no ctypes signature'
-    assert hip.spg_version() == 104
+    assert hip.spg_version() == 200
 
 
 def test_size_queries(hip):
@@ -55,7 +55,7 @@ def test_graphconvinfo_bit_exact_and_collate():
 
 def test_golden_index_buffers_from_graphs():
     spec, batch, state0, g = load_golden('s3dis_gru10_matrix')
-    graphs = [spg.SuperpointGraph(int(g[f'graph/{i}/n']), g[f'graph/{i}/edges'], {'f': list(g[f'graph/{i}/feats'])}) for i in range(2)]
+    graphs = [spg.SuperpointGraph(int(g[f'graph/{i}/n']), g[f'graph/{i}/edges'], True, {'f': list(g[f'graph/{i}/feats'])}) for i in range(2)]
     gi = ecc.GraphConvInfo(graphs, spg.cloud_edge_feats)
     assert torch.equal(gi._idxn, batch['idxn']) and torch.equal(gi._degrees, batch['degs'])
     assert torch.equal(gi._edge_indexes, batch['edge_indexes']) and torch.equal(gi._edgefeats, batch['edgefeats'])
