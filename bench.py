@@ -71,7 +71,9 @@ def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, ncpu))
+    # torch's CPU kernels stop scaling (and oversubscribe badly) beyond a few dozen threads on these small layer shapes:
+    # use up to 64, report both the threads used (`cores`) and what the host has (`host_cores`)
+    torch.set_num_threads(max(1, min(ncpu, 64)))
     col = synth.collate_numpy(scenes[:1])
     idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
     batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
@@ -92,7 +94,7 @@ def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
             times.append(time.perf_counter() - t0)
         med, cnt = float(np.median(times)), len(times)
         kind, what = 'port', 'oracle/spg_oracle.py train_step on torch-CPU (no reference checkout on this machine)'
-    return {'value': n / med, 'unit': 'superpoints/s', 'cores': torch.get_num_threads(), 'cpu_model': cpu_model(), 'kind': kind,
+    return {'value': n / med, 'unit': 'superpoints/s', 'cores': torch.get_num_threads(), 'host_cores': ncpu, 'cpu_model': cpu_model(), 'kind': kind,
             'sample': f'{cnt} fwd+bwd steps of one {n}-superpoint scene (median {med * 1e3:.0f} ms/step), {what}'}
 
 
@@ -208,6 +210,7 @@ def main():
     ap.add_argument('--no-trainer-window', action='store_true', help='skip the fresh-batch-per-step side measurement (learning/main.py:200-215 window)')
     ap.add_argument('--no-forward-only', action='store_true', help='skip the forward-only side measurement (BASELINE configs[1])')
     ap.add_argument('--sync-bn', type=int, default=0, help='1: BatchNorm statistics all-reduced over the ranks (exact single-process batch semantics); 0: per-rank statistics')
+    ap.add_argument('--native-rccl', type=int, default=1, help='1: the C library issues the RCCL collectives itself (own communicator); 0: torch.distributed calls')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
     args = ap.parse_args()
 
@@ -248,6 +251,10 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     n_sp_step = int(flag.numel())
 
+    native = False
+    if world > 1 and args.native_rccl and dist.get_backend() == 'nccl':
+        spd.init_native_rccl()                       # gradient / BatchNorm collectives enqueued by libspg_hip itself
+        native = True
     if args.sync_bn:       # BatchNorm statistics over the scenes of ALL ranks (exact single-process-batch semantics)
         spd.enable_sync_bn(dev)
 
@@ -330,8 +337,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x {args.n_feat} feats, '
                                f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config}' + (' (S3DIS production model, matrix filters, 10 GRU iterations)' if args.model_config == 'gru_10_0,f_13' else '') + ', train step fwd+bwd+Adam',
-                   'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'parallelism': f'dp{world} (one scene shard per GPU, one flat-bucket '
-                                                                              'RCCL all-reduce)' if world > 1 else 'single GPU',
+                   'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'parallelism': (f'dp{world} (one scene shard per GPU, one flat-bucket RCCL all-reduce, ' + ('issued by libspg_hip' if native else 'torch.distributed') + ')') if world > 1 else 'single GPU',
                    'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics'},
     }
 

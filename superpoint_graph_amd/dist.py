@@ -44,6 +44,38 @@ def init_from_env(backend: Optional[str] = None, force: bool = False):
     return rank, local, world
 
 
+def init_native_rccl(group=None):
+    """Gives libspg_hip.so a RCCL communicator of its own over the ranks of `group` (include/spg_hip.h: spg_rccl_*): rank 0
+    draws the unique id, the 128 bytes are broadcast through torch.distributed (any backend), every rank initialises
+    with its CURRENT device.  Afterwards the flat gradient all-reduce (`FlatParameters.allreduce`) and the synchronised
+    BatchNorm all-reduces are enqueued by the C library itself on torch's current stream -- no Python callback, no
+    torch collective on the data path.  Works at world size 1 (smoke test of the native path on a 1-GPU box)."""
+    import ctypes
+    from ._lib import check, lib
+    L = lib()
+    if L.spg_rccl_world_size() > 0:
+        return L.spg_rccl_world_size()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    raw = (ctypes.c_ubyte * 128)()
+    if rank == 0:
+        check(L.spg_rccl_unique_id(ctypes.cast(raw, ctypes.c_void_p)), 'spg_rccl_unique_id')
+    ident = torch.tensor(list(raw), dtype=torch.uint8)
+    if world > 1:
+        on_gpu = dist.get_backend(group) == 'nccl'
+        ident = ident.cuda() if on_gpu else ident
+        dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = ident.cpu()
+    raw = (ctypes.c_ubyte * 128)(*ident.tolist())
+    check(L.spg_rccl_init(ctypes.cast(raw, ctypes.c_void_p), world, rank), 'spg_rccl_init')
+    return world
+
+
+def native_rccl_world_size() -> int:
+    from ._lib import lib
+    return int(lib().spg_rccl_world_size())
+
+
 def shard_scenes(n_scenes: int, rank: int, world: int):
     """Scene indices of this rank: contiguous blocks, as even as possible (scenes are independent units)."""
     base, rem = divmod(n_scenes, world)
@@ -92,10 +124,17 @@ _SYNC_BN = {}
 
 
 def enable_sync_bn(device, group=None, max_channels: int = 1024):
-    """Synchronise the BatchNorm statistics of the HIP path over `group` (all ranks must run the same layers)."""
+    """Synchronise the BatchNorm statistics of the HIP path over `group` (all ranks must run the same layers).  With the
+    library's own communicator (`init_native_rccl`) the all-reduces are issued by the C library directly; otherwise
+    through a callback into torch.distributed (gloo staging for the CPU-side tests)."""
     import ctypes
     from ._lib import check, lib
     buf = torch.zeros(3 * max_channels + 16, dtype=torch.float64, device=device)
+    if lib().spg_rccl_world_size() > 0:
+        check(lib().spg_rccl_sync_bn(buf.data_ptr(), buf.numel()), 'spg_rccl_sync_bn')
+        state = {'calls': None, 'error': None, 'native': True}
+        _SYNC_BN.update(cb=None, buf=buf, state=state)
+        return state
     staged = dist.is_initialized() and dist.get_backend(group) == 'gloo' and buf.is_cuda
     state = {'calls': 0, 'error': None}
 

@@ -94,12 +94,18 @@ class FlatParameters:
     def allreduce(self, local_weight: float = 1.0, group=None, prescaled: bool = False):
         """Weighted data-parallel mean of the gradients (see superpoint_graph_amd/dist.py), in place on the arena.
         prescaled: the loss was already multiplied by local_weight (synchronised-BatchNorm mode)."""
-        if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        from . import _lib
+        native = _lib.lib().spg_rccl_world_size()           # the library's own communicator (dist.init_native_rccl)
+        if native <= 1 and not (dist.is_initialized() and dist.get_world_size(group) > 1):
             if prescaled:
                 self.flat.grad.div_(float(local_weight))
             return
         if not prescaled:
             self.flat.grad.mul_(float(local_weight))
         self._gbuf[self.numel] = float(local_weight)
-        dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
+        if native > 1:            # ONE RCCL all-reduce of the arena, enqueued by the C library on the current stream
+            _lib.check(_lib.lib().spg_rccl_allreduce_sum_f32(self._gbuf.data_ptr(), self.numel + 1,
+                                                             torch.cuda.current_stream().cuda_stream), 'spg_rccl_allreduce_sum_f32')
+        else:
+            dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
         self.flat.grad.div_(self._gbuf[self.numel])

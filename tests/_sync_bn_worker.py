@@ -21,8 +21,15 @@ def main():
     from superpoint_graph_amd.learning import ecc, pointnet
     sync = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    dev = torch.device('cuda', 0)
+    native = os.environ.get('SPG_NATIVE_RCCL', '0') == '1'         # multi-GPU node: one GPU per rank, the library's own RCCL communicator
+    if native:
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+        spd.init_native_rccl()
+        assert spd.native_rccl_world_size() == world
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda', rank if native else 0)
     spec, batch, state0, g = load_golden('s3dis_gru10_matrix')
     # ---- this rank's scene out of the collated batch (nodes / edges of a scene are contiguous) ----
     n_nodes = [int(g[f'graph/{i}/n']) for i in range(2)]
@@ -55,12 +62,13 @@ def main():
     torch.cuda.synchronize()
     if state is not None:
         assert state['error'] is None, state['error']
-        assert state['calls'] >= 26, state['calls']      # 13 BatchNorm layers, forward + backward
+        assert native or state['calls'] >= 26, state['calls']      # 13 BatchNorm layers, forward + backward
 
     ref_logits = torch.from_numpy(g['train/logits'])[n0:n1]
     err_logits = maxrel(logits, ref_logits)
-    wsum = torch.tensor([float(loss) if sync else float(loss) * w, w], dtype=torch.float64)
+    wsum = torch.tensor([float(loss) if sync else float(loss) * w, w], dtype=torch.float64, device=dev if native else 'cpu')
     dist.all_reduce(wsum)
+    wsum = wsum.cpu()
     err_loss = abs(float(wsum[0] / wsum[1]) - float(g['train/loss'])) / abs(float(g['train/loss']))
     worst, worst_k = 0.0, ''
     for k, p in model.named_parameters():

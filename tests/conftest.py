@@ -60,6 +60,16 @@ def maxrel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def assert_elementwise(a, ref, rtol=1e-4, atol_frac=1e-5, what=''):
+    """Element-wise form of the north-star bound: |a - ref| <= rtol * |ref| + atol for EVERY element, with the absolute
+    floor atol = atol_frac * max|ref| for elements near zero (a relative bound alone is undefined there)."""
+    a, ref = a.detach().double().cpu(), (ref if torch.is_tensor(ref) else torch.from_numpy(np.asarray(ref))).detach().double().cpu()
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    bound = rtol * ref.abs() + atol_frac * float(ref.abs().max())
+    excess = ((a - ref).abs() - bound).max()
+    assert float(excess) <= 0.0, f'{what}: worst element exceeds rtol {rtol} + {atol_frac} * max|ref| by {float(excess):.3e}'
+
+
 @pytest.fixture(scope='session')
 def hip():
     """The loaded HIP library; building it first if the .so is absent (build container)."""

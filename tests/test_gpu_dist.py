@@ -20,12 +20,12 @@ def _free_port():
     return port
 
 
-def _run_world2(sync):
+def _run_world2(sync, native=False):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', SPG_NATIVE_RCCL='1' if native else '0')
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, '_sync_bn_worker.py'), str(sync)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -49,6 +49,25 @@ def test_two_ranks_sync_bn_reproduce_single_process_reference(hip):
 
 def test_two_ranks_local_bn_is_a_different_model(hip):
     _run_world2(0)
+
+
+def test_two_gpus_native_rccl_sync_bn_reproduce_single_process_reference(hip):
+    """Two ranks on two GPUs, every collective of the step (26 BatchNorm all-reduces + the flat gradient all-reduce) issued
+    by libspg_hip's own RCCL communicator: must reproduce the reference's single-process 2-scene step.  Needs a
+    multi-GPU node (skipped on the 1-GPU test box; RCCL refuses two ranks on one device)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs')
+    outs = _run_world2(1, native=True)
+    assert all('sync=1' in o for o in outs)
+
+
+def test_native_rccl_single_rank(hip):
+    """The library's own RCCL communicator at world size 1 (the 1-GPU box): bootstrap, the fp32 arena all-reduce and the
+    synchronised-BatchNorm all-reduces issued from C -- the training step must be bit-identical to the local one."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(HERE, '_native_rccl_worker.py')], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'native rccl ok' in out.stdout, (out.stdout + out.stderr)[-3000:]
 
 
 def test_rccl_collectives_single_rank_smoke(hip):
