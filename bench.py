@@ -119,7 +119,7 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
     come from pinned host memory (H2D on a side stream, overlapped with the previous step), `set_info` uploads the index
     buffers and builds the device CSR -- then zero_grad ... optimizer step as in the headline measurement.  Reported
     next to `value` (which keeps its inputs resident, as the metric definition says)."""
-    from superpoint_graph_amd import synth
+    from superpoint_graph_amd import ops, synth
     from superpoint_graph_amd.learning import spg
     nb = 4
     batches = []
@@ -149,7 +149,7 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
             model.ecc.set_info(GIs, 1)                # index buffers H2D + device CSR / reverse CSR build
             arena.zero_grad()
             emb = embedder.run(model, None, flag, c, d)
-            loss = F.cross_entropy(model.ecc(emb), lab)
+            loss = ops.cross_entropy(model.ecc(emb), lab)
             loss.backward()
             embedder.bw_hook()
             arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)
@@ -222,7 +222,7 @@ def main():
         print(f'[bench +{time.perf_counter() - T0:.1f}s] {msg}', file=sys.stderr, flush=True)
 
     T0 = time.perf_counter()
-    from superpoint_graph_amd import _lib, dist as spd
+    from superpoint_graph_amd import _lib, dist as spd, ops
     from superpoint_graph_amd.learning import pointnet
     if args.device_index >= 0:
         torch.cuda.set_device(args.device_index)
@@ -263,7 +263,7 @@ def main():
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
         # sync-BN couples the ranks in the backward: the loss normaliser is applied before it (dist.py)
-        loss = F.cross_entropy(out, label_mode, reduction='sum' if args.sync_bn else 'mean')
+        loss = ops.cross_entropy(out, label_mode, reduction='sum' if args.sync_bn else 'mean')     # learning/main.py:205, one launch each way
         loss.backward()
         embedder.bw_hook()
 

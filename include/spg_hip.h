@@ -226,6 +226,19 @@ int spg_edge_features(const spg_edge_feature_specs* specs, const int64_t* edges,
                       const double* scale, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Weighted cross entropy of the training / evaluation loops (learning/main.py:205,255:
+ * nn.functional.cross_entropy(outputs, label_mode, weight=class_weights); rows with target == ignore_index do not
+ * count): loss (1 float; reduction_mean: sum_i w[t_i] nll_i / sum_i w[t_i], else the plain sum), lse [N] (log-sum-exp
+ * per row, kept for the backward), wsum (1 float, the normaliser).  Backward: grad_logits [N, C] from grad_loss (1 float).
+ * One launch each, fixed summation order.
+ * ---------------------------------------------------------------------------------------------- */
+int spg_cross_entropy_fwd(const float* logits, const int64_t* target, const float* weight, int N, int C, int64_t ignore_index,
+                          int reduction_mean, float* loss, float* lse, float* wsum, void* stream);
+int spg_cross_entropy_bwd(const float* logits, const int64_t* target, const float* weight, const float* lse, const float* wsum,
+                          const float* grad_loss, int N, int C, int64_t ignore_index, int reduction_mean, float* grad_logits,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Evaluation accounting on the device (learning/main.py:246-263, eval_final :267-311, metrics.py:16-18):
  * logits [n_samples][N][C] (sample_stride floats between samples; the mean over the test-time samples is taken in
  * float32 in sample order like np.mean), pred i64 [N] = first arg-max per superpoint, and for superpoints with

@@ -45,7 +45,7 @@ struct Plan {
   bool training = false;
   std::vector<FLayer> F;
   SpgGruParams gru;
-  float *states = nullptr, *agg = nullptr, *stat = nullptr;
+  float *states = nullptr, *agg = nullptr, *stat = nullptr, *stat_cnt = nullptr;
   float* cells = nullptr;       // LSTM cell states c^r, laid out like `states`
   float* cell_grads[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t bytes = 0;
@@ -99,6 +99,7 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
   pl.agg = cv.take<float>((size_t)N * pl.ldS);
   if (pl.lstm) pl.cells = cv.take<float>((size_t)N * pl.ldS);
   pl.stat = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, SPG_FC_ROWS) * 2 * cmax);
+  pl.stat_cnt = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, SPG_FC_ROWS) + 64);
   pl.bytes = cv.off + 256;
   return 0;
 }
@@ -199,11 +200,12 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
       g.a = fnet_input(pl, i, edgefeats);
       g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = E; g.N = l.cout; g.K = l.cin; g.rows_per_tile = SPG_FC_ROWS;
       g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.cout;
-      g.stat = (l.bn && pl.training) ? pl.stat : nullptr;
-      SPG_TRY(spg_launch_gemm(g, st));
+      g.stat = (l.bn && pl.training) ? pl.stat : nullptr; g.stat_cnt = pl.stat_cnt;
+      int nparts = 0;
+      SPG_TRY(spg_launch_gemm(g, st, &nparts));
       if (l.bn) {
         if (pl.training)
-          SPG_TRY(spg_launch_bn_finalize(pl.stat, spg_cdiv(E, SPG_FC_ROWS), SPG_FC_ROWS, E, l.cout, l.gamma, l.beta, l.rm, l.rv,
+          SPG_TRY(spg_launch_bn_finalize(pl.stat, pl.stat_cnt, nparts, E, l.cout, l.gamma, l.beta, l.rm, l.rv,
                                          pl.cfg.bn_momentum, pl.cfg.bn_eps, bn_update_times, l.mean, l.rstd, l.s, l.t, nullptr, st));
         else
           SPG_TRY(spg_launch_bn_eval(l.cout, l.gamma, l.beta, l.rm, l.rv, pl.cfg.bn_eps, l.s, l.t, st));
@@ -331,9 +333,10 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.cout;
     g.mask_relu = prod.relu ? 1 : 0; g.n_mask = prod.cout;
     if (prod.bn) { g.ms = prod.s; g.mt = prod.t; g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat; }
-    SPG_TRY(spg_launch_gemm(g, st));
+    int nparts = 0;
+    SPG_TRY(spg_launch_gemm(g, st, &nparts));
     if (prod.bn) {
-      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(E, SPG_FC_ROWS) * spg_gemm_row_waves(SPG_FC_ROWS, l.cin), l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
+      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
                                          s.consts, prod.dgamma, prod.dbeta, nullptr, st));
       cur = op_bnbwd(out, prod.y, prod.cout, s.consts, prod.cout);
     } else {

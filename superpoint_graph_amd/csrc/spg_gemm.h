@@ -19,11 +19,21 @@ struct SpgGemmParams {
   float* Y;           // [M, ldy] or null (pool-only forward)
   long ldy;
   // SPG_EPI_FWD: per-tile BatchNorm partials (mean, M2) and per-tile max/min pooling of the raw output
-  float* stat;        // [ntile * row_waves][2][N] or null (one partial per wave, see spg_gemm_row_waves)
-  float* pmax;        // [ntile * row_waves][N] or null
-  float* pmin;
-  int* imax;
-  int* imin;
+  float* stat;        // [parts][2][N] or null: per-wave partials (forward: mean, M2; backward: sum dz, sum dz*xhat).  The number
+                      // of parts is decided by the launcher (one per tile and row-wave, or one per persistent workgroup and
+                      // row-wave) and returned through spg_launch_gemm's stat_parts
+  float* stat_cnt;    // forward: [parts] rows behind every partial (required with stat)
+  // max-pool over the rows of a tile (= the points of a superpoint), fused: BatchNorm is monotone per channel, so the
+  // pooled normalised value is the raw MAX where the BatchNorm scale is >= 0 and the raw MIN otherwise, and the sign of
+  // the scale gamma * rstd is the sign of gamma -- known before the statistics are.  pool_out [ntile, pool_ld] receives
+  // the selected raw extremum per (tile, channel), pool_idx the row inside the tile that holds it (first one on ties,
+  // like max_pool1d), columns N .. N + pool_nextra - 1 the concatenated global features.
+  float* pool_out;    // null: no pooling
+  int* pool_idx;      // may be null (inference)
+  const float* pool_sign;   // [N] BatchNorm weight (null: all >= 0)
+  const float* pool_extra;  // [ntile, pool_nextra] or null
+  long pool_ld;
+  int pool_nextra;
   // SPG_EPI_BWD: columns are the channels of the producer layer; ReLU mask and BatchNorm-backward sums
   const float* Yp;    // raw output of the producer layer [M, ldyp] (null: no mask / no stats)
   long ldyp;
@@ -37,6 +47,7 @@ struct SpgGemmParams {
   // set by the launcher (full-tile fast path): work-item map of the persistent chunk stream -- a workgroup handles row
   // tiles tile0, tile0 + rstride, ... (< ntile) of one column tile; remap: XCD-aware block -> (row tile, column tile) map
   int remap, ncol, ntile, rstride;
+  int stat_accum;     // persistent launches: one statistics partial per workgroup and row-wave (accumulated over its tiles)
   int dbg;            // timing-attribution switches (spg_tune key 3), persistent launches only
 };
 
@@ -56,7 +67,7 @@ struct SpgWgradParams {
 int spg_gemm_ntiles(const SpgGemmParams& p);
 // number of statistics / pooling partials per row tile (= waves along the rows of the tile shape used for this problem)
 int spg_gemm_row_waves(int rows_per_tile, int N);
-int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream);
+int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts = nullptr);
 
 // workspace (floats) needed by spg_launch_wgrad for a problem of this size
 size_t spg_wgrad_workspace_floats(long M, int N, int K);
@@ -81,11 +92,11 @@ int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t 
 int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, float* out, hipStream_t stream);
 int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream);
 
-// BatchNorm forward statistics: partials [ntile][2][N] -> mean, rstd, scale s = gamma*rstd, shift t = beta - mean*s;
+// BatchNorm forward statistics: partials [nparts][2][N] (+ rows per partial, stat_cnt [nparts]) -> mean, rstd, scale s = gamma*rstd, shift t = beta - mean*s;
 // running stats updated `update_times` times (run_full_monger re-runs the forward, learning/pointnet.py:167,173)
 // scratch: >= spg_bn_finalize_scratch_doubles(N) doubles (or null: single-slice reduction)
 size_t spg_bn_finalize_scratch_doubles(int N);
-int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,
+int spg_launch_bn_finalize(const float* stat, const float* stat_cnt, int nparts, long M, int N, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                            int update_times, float* mean, float* rstd, float* s, float* t, double* scratch,
                            hipStream_t stream);

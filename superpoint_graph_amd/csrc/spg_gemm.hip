@@ -167,10 +167,21 @@ __device__ __forceinline__ void spg_store_tile_vec(const f32x16 (&acc)[TI][TJ], 
   spg_store_tile_vec_impl<RW, CW, TI, TJ>(acc, st, ybase, ldy, lane);
 }
 
+// Statistics of a persistent workgroup: every wave keeps (rows, mean, M2) of ITS columns over the tiles it has seen
+// (merged tile by tile with Chan's formula) and writes ONE partial when the stream ends -- 4x fewer partials for the
+// finalize kernel, which then needs no slicing / last-arrival ticket.  Backward: plain running sums.
+template <int TJ>
+struct SpgStatAcc {
+  float n;
+  float a[TJ], b[TJ];        // forward: mean, M2 (lane = column); backward (vector epilogue): unused
+  f32x4 s1, s2;              // backward vector epilogue: sum dz, sum dz*xhat of the lane's channel quad
+};
+
 // BIAS_DONE: the accumulators were initialised with the bias (persistent fast path), nothing to add here
 template <int IT, int JT, int WI, int WJ, bool FULL, bool BIAS_DONE = false>
 __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
-                                                 float* __restrict__ red, int tile, long m0, int mvalid, int n0) {
+                                                 float* __restrict__ red, int tile, long m0, int mvalid, int n0,
+                                                 SpgStatAcc<JT / WJ / 32>* sacc = nullptr) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   const int tid = threadIdx.x + spg_opaque_zero(), lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -235,43 +246,85 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
             m2 = fmaf(d, d, m2);
           }
       m2 += __shfl_xor(m2, 32, 64);
-      if (h == 0 && (FULL || col < p.N)) {
+      if (sacc != nullptr) {             // persistent stream: merge into the running (rows, mean, M2) of this column
+        const float na = sacc->n, nb = (float)nvw, nn = na + nb;
+        const float delta = mean - sacc->a[j], f = nn > 0.f ? nb / nn : 0.f;
+        sacc->a[j] += delta * f;
+        sacc->b[j] += m2 + delta * delta * (na * f);
+      } else if (h == 0 && (FULL || col < p.N)) {
         p.stat[(part * 2 + 0) * p.N + col] = mean;
         p.stat[(part * 2 + 1) * p.N + col] = m2;
       }
     }
+    if (sacc != nullptr) sacc->n += (float)nvw;
+    else if (lane == 0 && wj == 0 && n0 == 0) p.stat_cnt[part] = (float)nvw;
   }
-  // ---- per-wave max / min over its rows (first index wins ties); spg_pool_select combines the WI partials ----
-  if (p.pmax != nullptr) {
+  // ---- max-pool over the rows of the tile, fused (see SpgGemmParams): every lane keeps ONE extremum of its column --
+  //      the maximum of key = v * sign, sign = -1 where the BatchNorm scale is negative -- with the first row that
+  //      attains it; the two lane halves and then the WI row-waves of the workgroup are combined through LDS ----
+  if (p.pool_out != nullptr) {
+    float* xch = red + 4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ);        // [WI][JT] keys, [WI][JT] rows: behind the staging regions
+    int* xci = reinterpret_cast<int*>(xch + WI * JT);
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-      const int col = n0 + colw + 32 * j + r;
-      float vmx = -FLT_MAX, vmn = FLT_MAX;
-      int imx = INT_MAX, imn = INT_MAX;
+      const int cl = colw + 32 * j + r, col = n0 + cl;
+      const bool colok = FULL || col < p.N;
+      const float sg = (p.pool_sign != nullptr && p.pool_sign[colok ? col : 0] < 0.f) ? -1.f : 1.f;
+      float kb = -FLT_MAX;
+      int ib = INT_MAX;
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          // rows are visited in increasing order, so a strict comparison keeps the FIRST extremum (torch's max_pool1d
-          // tie rule); written as selects: branch-free v_cmp + v_cndmask
+          // rows are visited in increasing order: a strict comparison keeps the FIRST extremum (torch's tie rule)
           const int row = roww + 32 * i + spg_acc_row(q, h);
-          const float v = acc[i][j][q];
-          const bool ok = FULL || row < mvalid;
-          const bool gt = ok && v > vmx, lt = ok && v < vmn;
-          vmx = gt ? v : vmx; imx = gt ? row : imx;
-          vmn = lt ? v : vmn; imn = lt ? row : imn;
+          const float key = acc[i][j][q] * sg;
+          const bool gt = (FULL || row < mvalid) && key > kb;
+          kb = gt ? key : kb; ib = gt ? row : ib;
         }
-      const float ov = __shfl_xor(vmx, 32, 64);
-      const int oi = __shfl_xor(imx, 32, 64);
-      if (ov > vmx || (ov == vmx && oi < imx)) { vmx = ov; imx = oi; }
-      const float pv = __shfl_xor(vmn, 32, 64);
-      const int pi = __shfl_xor(imn, 32, 64);
-      if (pv < vmn || (pv == vmn && pi < imn)) { vmn = pv; imn = pi; }
-      if (h == 0 && (FULL || col < p.N)) {
-        const long o = part * p.N + col;
-        p.pmax[o] = vmx; p.imax[o] = imx; p.pmin[o] = vmn; p.imin[o] = imn;
-      }
+      const float ok = __shfl_xor(kb, 32, 64);
+      const int oi = __shfl_xor(ib, 32, 64);
+      if (ok > kb || (ok == kb && oi < ib)) { kb = ok; ib = oi; }
+      if (h == 0) { xch[wi * JT + cl] = kb; xci[wi * JT + cl] = ib; }
     }
+    __syncthreads();
+    for (int cl = tid; cl < JT; cl += SPG_THREADS) {
+      const int col = n0 + cl;
+      if (!FULL && col >= p.N) continue;
+      float kb = xch[cl];
+      int ib = xci[cl];
+#pragma unroll
+      for (int w = 1; w < WI; ++w) {
+        const float ok = xch[w * JT + cl];
+        const int oi = xci[w * JT + cl];
+        if (ok > kb || (ok == kb && oi < ib)) { kb = ok; ib = oi; }
+      }
+      const float sg = (p.pool_sign != nullptr && p.pool_sign[col] < 0.f) ? -1.f : 1.f;
+      p.pool_out[(long)tile * p.pool_ld + col] = kb * sg;
+      if (p.pool_idx != nullptr) p.pool_idx[(long)tile * p.pool_ld + col] = ib;
+    }
+    if (n0 == 0 && p.pool_extra != nullptr)
+      for (int e = tid; e < p.pool_nextra; e += SPG_THREADS)
+        p.pool_out[(long)tile * p.pool_ld + p.N + e] = p.pool_extra[(long)tile * p.pool_nextra + e];
+    __syncthreads();       // the exchange area is reused by the next tile of a persistent workgroup
+  }
+}
+
+// per-wave backward sums (channel quads over the lanes, LPR lanes per row) -> one partial row pair
+template <int IT, int JT, int WI, int WJ>
+__device__ __forceinline__ void spg_bwd_stat_store(const SpgGemmParams& p, f32x4 s1, f32x4 s2, long part, int n0) {
+  constexpr int CW = JT / WJ, LPR = CW / 4;
+  const int tid = threadIdx.x + spg_opaque_zero(), lane = tid & 63, wave = tid >> 6;
+  const int wj = wave % WJ;
+  const int col = n0 + wj * CW + 4 * (lane % LPR);
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+  }
+  if (lane < LPR) {
+    *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 0) * p.N + col) = s1;
+    *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 1) * p.N + col) = s2;
   }
 }
 
@@ -281,7 +334,8 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
 // groups that share a channel quad).  16 + 16 memory instructions per lane instead of 64 + 64.
 template <int IT, int JT, int WI, int WJ>
 __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
-                                                     float* __restrict__ red, int tile, long m0, int n0) {
+                                                     float* __restrict__ red, int tile, long m0, int n0,
+                                                     SpgStatAcc<JT / WJ / 32>* sacc = nullptr) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32, RW = IT / WI, CW = JT / WJ;
   constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR, NIT = SPG_EPI_PIECE_ROWS / RPI;
   static_assert(SPG_EPI_PIECE_ROWS % RPI == 0, "a piece is a whole number of store instructions");
@@ -332,17 +386,10 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-  if (p.stat != nullptr) {
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
-    }
-    if (lane < LPR) {
-      const long part = (long)tile * WI + wi;
-      *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 0) * p.N + col) = s1;
-      *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 1) * p.N + col) = s2;
-    }
+  if (sacc != nullptr) {               // persistent stream: running sums, written once when the stream ends
+    sacc->s1 += s1; sacc->s2 += s2;
+  } else if (p.stat != nullptr) {
+    spg_bwd_stat_store<IT, JT, WI, WJ>(p, s1, s2, (long)tile * WI + wi, n0);
   }
 }
 
@@ -415,15 +462,17 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
 }
 
 // epilogue of one finished tile (all variants): `red` = LDS staging region that nobody reads any more
+// sacc != null (persistent streams: whole tiles, vector stores -- host): statistics are accumulated instead of written
 template <int IT, int JT, int WI, int WJ, bool WRED, bool FULL, bool BIAS_DONE>
 __device__ __forceinline__ void spg_tile_epilogue(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
-                                                  float* __restrict__ red, int tile, long m0, int mvalid, int n0) {
+                                                  float* __restrict__ red, int tile, long m0, int mvalid, int n0,
+                                                  SpgStatAcc<JT / WJ / 32>* sacc = nullptr) {
   if constexpr (!WRED) {      // forward kernels: weights [N,K]; backward (dgrad) kernels: untransposed weights [K,N]
-    if (mvalid == IT && n0 + JT <= p.N) spg_epilogue_fwd<IT, JT, WI, WJ, true, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0);
+    if (mvalid == IT && n0 + JT <= p.N) spg_epilogue_fwd<IT, JT, WI, WJ, true, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0, sacc);
     else spg_epilogue_fwd<IT, JT, WI, WJ, false, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0);
   } else {
     const bool full = mvalid == IT && n0 + JT <= p.N && (n0 + JT <= p.n_mask || (p.stat == nullptr && !p.mask_relu));
-    if (FULL && full && p.vec_store) spg_epilogue_bwd_vec<IT, JT, WI, WJ>(p, acc, red, tile, m0, n0);
+    if (FULL && full && p.vec_store) spg_epilogue_bwd_vec<IT, JT, WI, WJ>(p, acc, red, tile, m0, n0, sacc);
     else if (full) spg_epilogue_bwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
     else spg_epilogue_bwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
   }
@@ -456,7 +505,7 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
   f32x16 acc[TI][TJ];
 
   if constexpr (AMODE >= 0 && FULL) {
-    static_assert(4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) <= 4 * (A_F4 + B_F4), "epilogue staging must fit one LDS buffer");
+    static_assert(4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) + 2 * WI * JT <= 4 * (A_F4 + B_F4), "epilogue staging + pooling exchange must fit one LDS buffer");
     int tile = blockIdx.x, ct = blockIdx.y;
     if (p.remap) {
       // XCD-aware item map (workgroup b runs on XCD b % 8): the column tiles of one row tile are consecutive workgroups
@@ -501,6 +550,13 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
     }
     __syncthreads();
     constexpr bool BIAS_IN_ACC = !WRED;
+    SpgStatAcc<TJ> sacc;                         // STREAM: statistics of this workgroup's tiles, one partial at the end
+    sacc.n = 0.f;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) { sacc.a[j] = 0.f; sacc.b[j] = 0.f; }
+    sacc.s1 = f32x4{0.f, 0.f, 0.f, 0.f}; sacc.s2 = sacc.s1;
+    const int tile0 = tile;                      // < rstride: index of this workgroup among those of its column tile
+    const bool accum = STREAM && p.stat != nullptr && p.stat_accum;
     // backward kernels (two operand streams + four constant arrays per register set): the loads of the next tile's SECOND
     // chunk are issued after the epilogue instead of under the last chunk -- nothing but the accumulators and the
     // loop-invariant offsets is then live across the epilogue (no spills)
@@ -587,12 +643,30 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
           SpgGemmParams q = p;
           if (p.dbg & 1) q.Y = nullptr;
           if (p.dbg & 2) q.stat = nullptr;
-          if (p.dbg & 4) q.pmax = nullptr;
+          if (p.dbg & 4) q.pool_out = nullptr;
           spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(q, acc, red, tile, m0, mvalid, n0);
         }
       } else
-      spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(p, acc, red, tile, m0, mvalid, n0);
-      if (!has_next) break;
+      spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(p, acc, red, tile, m0, mvalid, n0, accum ? &sacc : nullptr);
+      if (!has_next) {
+        if (accum) {                             // the workgroup's ONE statistics partial
+          const long part = (long)tile0 * WI + wi;
+          if constexpr (!WRED) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+              const int col = n0 + wj * (JT / WJ) + 32 * j + r;
+              if (h == 0 && col < p.N) {
+                p.stat[(part * 2 + 0) * p.N + col] = sacc.a[j];
+                p.stat[(part * 2 + 1) * p.N + col] = sacc.b[j];
+              }
+            }
+            if (lane == 0 && wj == 0 && n0 == 0) p.stat_cnt[part] = sacc.n;
+          } else {
+            spg_bwd_stat_store<IT, JT, WI, WJ>(p, sacc.s1, sacc.s2, part, n0);
+          }
+        }
+        break;
+      }
       tile = nxt; m0 = m0n;
       if (DEFER2) {
         pa1.prepare(p.a, tile, SPG_KC);
@@ -700,17 +774,18 @@ int spg_gemm_row_waves(int rows_per_tile, int N) {
 }
 
 template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE>
-static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
+static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_parts) {
   // A tile (out-major) + weight tile (out-major [8][JT+1] float4 or red-major [32][JT+4] floats), double-buffered;
   // the epilogue reuses the region for its reductions (<= 4*WI*JT floats)
   size_t lds = (size_t)(SPG_KC / 4) * (IT + 1) * sizeof(f32x4) +
                (WRED ? (size_t)SPG_KC * (JT + 4) * sizeof(float) : (size_t)(SPG_KC / 4) * (JT + 1) * sizeof(f32x4));
   if (AMODE >= 0) lds *= 2;
   size_t epi = (size_t)4 * WI * JT * sizeof(float);
-  const size_t epi_vec = (size_t)4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) * sizeof(float);
+  const size_t epi_vec = ((size_t)4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) + (size_t)2 * WI * JT) * sizeof(float);
   if (epi < epi_vec) epi = epi_vec;
   if (lds < epi) lds = epi;
   dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
+  if (stat_parts != nullptr) *stat_parts = (int)grid.x * WI;      // one statistics partial per tile and row-wave, unless ...
   ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
   prof.r.M = p.M; prof.r.N = p.N; prof.r.K = p.K;
   if constexpr (AMODE >= 0) {
@@ -740,6 +815,9 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
           (p.K / SPG_KC) % 2 == 0 && (long)grid.x * ncol > slots && slots % (8 * ncol) == 0) {
         q.remap = 1; q.rstride = slots / ncol;
         q.dbg = WRED ? 0 : g_tune[SPG_TUNE_DBG];      // attribution switches: forward launches only
+        // ... the persistent workgroups accumulate over their tiles: one partial per workgroup of a column tile and row-wave
+        q.stat_accum = p.stat != nullptr && (!WRED || (q.vec_store && p.N <= p.n_mask));
+        if (q.stat_accum && stat_parts != nullptr) *stat_parts = (int)(q.rstride < q.ntile ? q.rstride : q.ntile) * WI;
         grid = dim3((unsigned)slots, 1);
         if constexpr (IT == 128 && !(WRED && JT == 128)) {
           hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true>), grid, dim3(SPG_THREADS), lds, stream, q);
@@ -759,18 +837,19 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream) {
 }
 
 template <bool WRED, int AMODE>
-static int launch_gemm_shape(const SpgGemmParams& p, hipStream_t stream) {
-  if (p.rows_per_tile <= 32) return launch_gemm_t<32, 128, 1, 4, WRED, AMODE>(p, stream);   // few rows (FC layers, filter net)
-  if (p.N <= 32) return launch_gemm_t<128, 32, 4, 1, WRED, AMODE>(p, stream);
-  if (p.N <= 64) return launch_gemm_t<128, 64, 2, 2, WRED, AMODE>(p, stream);
-  return launch_gemm_t<128, 128, 2, 2, WRED, AMODE>(p, stream);                                // wider outputs: grid.y column tiles
+static int launch_gemm_shape(const SpgGemmParams& p, hipStream_t stream, int* sp) {
+  if (p.rows_per_tile <= 32) return launch_gemm_t<32, 128, 1, 4, WRED, AMODE>(p, stream, sp);   // few rows (FC layers, filter net)
+  if (p.N <= 32) return launch_gemm_t<128, 32, 4, 1, WRED, AMODE>(p, stream, sp);
+  if (p.N <= 64) return launch_gemm_t<128, 64, 2, 2, WRED, AMODE>(p, stream, sp);
+  return launch_gemm_t<128, 128, 2, 2, WRED, AMODE>(p, stream, sp);                                // wider outputs: grid.y column tiles
 }
 
-int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream) {
+int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts) {
   SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   SPG_CHECK_ARG(p.rows_per_tile >= 1 && p.rows_per_tile <= 128, "rows_per_tile must be in [1,128]");
   SPG_CHECK_ARG(p.epi == SPG_EPI_FWD || p.Y != nullptr, "backward epilogue needs an output");
   SPG_CHECK_ARG((p.epi == SPG_EPI_BWD) == (p.w_red != 0), "forward epilogue <-> [N,K] weights, backward epilogue <-> [K,N] weights");
+  SPG_CHECK_ARG(p.epi != SPG_EPI_FWD || p.stat == nullptr || p.stat_cnt != nullptr, "forward statistics need stat_cnt");
   // vector path: 16-byte aligned rows, and every row addressable up to the next multiple of 4 of its logical width
   // (padded leading dimensions; partial quads are masked through the A operand / the store mask)
   const bool walign = (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0 && p.ldw >= (((p.w_red ? p.N : p.K) + 3) & ~3);
@@ -778,16 +857,16 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream) {
   const int mode = vec ? p.a.mode : -1;
   if (!p.w_red) {
     switch (mode) {
-      case SPG_PRO_IDENT: return launch_gemm_shape<false, SPG_PRO_IDENT>(p, stream);
-      case SPG_PRO_AFFINE: return launch_gemm_shape<false, SPG_PRO_AFFINE>(p, stream);
-      default: return launch_gemm_shape<false, -1>(p, stream);
+      case SPG_PRO_IDENT: return launch_gemm_shape<false, SPG_PRO_IDENT>(p, stream, stat_parts);
+      case SPG_PRO_AFFINE: return launch_gemm_shape<false, SPG_PRO_AFFINE>(p, stream, stat_parts);
+      default: return launch_gemm_shape<false, -1>(p, stream, stat_parts);
     }
   }
   switch (mode) {
-    case SPG_PRO_IDENT: return launch_gemm_shape<true, SPG_PRO_IDENT>(p, stream);
-    case SPG_PRO_BNBWD: return launch_gemm_shape<true, SPG_PRO_BNBWD>(p, stream);
-    case SPG_PRO_POOLBWD: return launch_gemm_shape<true, SPG_PRO_POOLBWD>(p, stream);
-    default: return launch_gemm_shape<true, -1>(p, stream);
+    case SPG_PRO_IDENT: return launch_gemm_shape<true, SPG_PRO_IDENT>(p, stream, stat_parts);
+    case SPG_PRO_BNBWD: return launch_gemm_shape<true, SPG_PRO_BNBWD>(p, stream, stat_parts);
+    case SPG_PRO_POOLBWD: return launch_gemm_shape<true, SPG_PRO_POOLBWD>(p, stream, stat_parts);
+    default: return launch_gemm_shape<true, -1>(p, stream, stat_parts);
   }
 }
 
@@ -1239,8 +1318,8 @@ static int spg_sync_allreduce(long n, hipStream_t stream) {
   return 0;
 }
 
-__global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __restrict__ stat, int ntile, int rows_per_tile,
-                                                               int wi, long M, int N, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __restrict__ stat, const float* __restrict__ cnt,
+                                                               int nparts, long M, int N, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* running_mean,
                                                                float* running_var, float momentum, float eps,
                                                                int update_times, float* mean_o, float* rstd_o, float* s_o,
@@ -1251,15 +1330,12 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
   const int cx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cx;
   const int nslices = gridDim.y, slice = blockIdx.y;
-  const int nparts = ntile * wi, per = (nparts + nslices - 1) / nslices;
+  const int per = (nparts + nslices - 1) / nslices;
   const int b0 = slice * per, b1 = min(nparts, b0 + per);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  const int tile_rows = rows_per_tile <= 32 ? 32 : 128, rpw = tile_rows / wi;     // rows per wave of the GEMM tile
   if (c < N)
     for (int b = b0 + ty; b < b1; b += 64) {
-      const int tile = b / wi, w = b - tile * wi;
-      const long tv = min((long)rows_per_tile, M - (long)tile * rows_per_tile);    // valid rows of the tile
-      const double nb = (double)min(max(tv - (long)w * rpw, 0L), (long)rpw);
+      const double nb = (double)cnt[b];                          // rows behind this partial (written by the GEMM)
       const double mb = (double)stat[((long)b * 2) * N + c];
       a0 += nb * mb;
       a1 += nb * mb * mb;
@@ -1329,14 +1405,14 @@ __global__ void spg_bn_finish_kernel(const double* __restrict__ sync, int N, con
 
 size_t spg_bn_finalize_scratch_doubles(int N) { return (size_t)SPG_FIN_SLICES * 3 * N; }
 
-int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long M, int N, const float* gamma,
+int spg_launch_bn_finalize(const float* stat, const float* stat_cnt, int nparts, long M, int N, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                            int update_times, float* mean, float* rstd, float* s, float* t, double* scratch,
                            hipStream_t stream) {
-  const int wi = spg_gemm_row_waves(rows_per_tile, N);
+  SPG_CHECK_ARG(stat != nullptr && stat_cnt != nullptr && nparts > 0, "statistics partials");
   const int gx = spg_cdiv(N, 16);
   // many partials: slice the reduction over more workgroups (one CU cannot pull megabytes of partials quickly)
-  int slices = (scratch != nullptr && (long)ntile * wi >= 512) ? SPG_FIN_SLICES : 1;
+  int slices = (scratch != nullptr && nparts > 1024) ? SPG_FIN_SLICES : 1;
   int* counters = nullptr;
   if (slices > 1) {
     counters = spg_fin_counter_window(gx);
@@ -1347,7 +1423,7 @@ int spg_launch_bn_finalize(const float* stat, int ntile, int rows_per_tile, long
     SPG_CHECK_ARG(3L * N + 1 <= g_sync.ndoubles, "synchronised BatchNorm buffer too small for this layer");
     sync = g_sync.buf;
   }
-  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(gx, slices), dim3(1024), 0, stream, stat, ntile, rows_per_tile, wi, M, N,
+  hipLaunchKernelGGL(spg_bn_finalize_kernel, dim3(gx, slices), dim3(1024), 0, stream, stat, stat_cnt, nparts, M, N,
                      gamma, beta, running_mean, running_var, momentum, eps, update_times, mean, rstd, s, t, scratch, counters,
                      sync);
   SPG_LAUNCH_CHECK();
@@ -1487,7 +1563,7 @@ int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long co
                                const float* mean, const float* rstd, float* consts, float* dgamma, float* dbeta,
                                double* scratch, hipStream_t stream) {
   const int gx = spg_cdiv(N, 16);
-  int slices = (scratch != nullptr && ntile >= 512) ? SPG_FIN_SLICES : 1;
+  int slices = (scratch != nullptr && ntile > 1024) ? SPG_FIN_SLICES : 1;
   int* counters = nullptr;
   if (slices > 1) {
     counters = spg_fin_counter_window(gx);

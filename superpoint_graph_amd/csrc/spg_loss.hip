@@ -1,0 +1,77 @@
+// Weighted cross entropy over the superpoint logits (learning/main.py:205: nn.functional.cross_entropy(outputs,
+// label_mode, weight=class_weights), ignore_index = -100) as ONE forward and ONE backward launch: log-softmax, the
+// weighted negative log-likelihood, its normaliser and the gradient wrt the logits.  N is a few thousand rows of <= 64
+// classes: one workgroup, fixed summation order (deterministic).  torch needs five launches for the same.
+#include "../../include/spg_hip.h"
+#include "spg_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(1024) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                      const float* __restrict__ weight, int N, int C, int64_t ignore_index,
+                                                      int reduction_mean, float* __restrict__ loss, float* __restrict__ lse,
+                                                      float* __restrict__ wsum_out) {
+  __shared__ double s_l[16], s_w[16];
+  double accl = 0.0, accw = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const float* x = logits + (long)i * C;
+    float m = -FLT_MAX;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+    const float l = m + logf(s);
+    lse[i] = l;
+    const int64_t t = target[i];
+    if (t != ignore_index && t >= 0 && t < C) {
+      const float w = weight ? weight[t] : 1.f;
+      accl += (double)(w * (l - x[t]));
+      accw += (double)w;
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) { accl += __shfl_xor(accl, off, 64); accw += __shfl_xor(accw, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = accl; s_w[threadIdx.x >> 6] = accw; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < 16; ++k) { a += s_l[k]; b += s_w[k]; }
+    *wsum_out = (float)b;
+    *loss = (float)(reduction_mean ? a / b : a);
+  }
+}
+
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ weight,
+                              const float* __restrict__ lse, const float* __restrict__ wsum, const float* __restrict__ grad_loss,
+                              int N, int C, int64_t ignore_index, int reduction_mean, float* __restrict__ grad_logits) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * C) return;
+  const int i = (int)(idx / C), c = (int)(idx - (long)i * C);
+  const int64_t t = target[i];
+  float g = 0.f;
+  if (t != ignore_index && t >= 0 && t < C) {
+    const float w = weight ? weight[t] : 1.f;
+    const float scale = (*grad_loss) * w / (reduction_mean ? *wsum : 1.f);
+    g = scale * (expf(logits[idx] - lse[i]) - (c == (int)t ? 1.f : 0.f));
+  }
+  grad_logits[idx] = g;
+}
+
+}  // namespace
+
+extern "C" int spg_cross_entropy_fwd(const float* logits, const int64_t* target, const float* weight, int N, int C,
+                                     int64_t ignore_index, int reduction_mean, float* loss, float* lse, float* wsum, void* stream) {
+  SPG_CHECK_ARG(logits && target && loss && lse && wsum && N > 0 && C > 0, "bad argument");
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, target, weight, N, C, ignore_index,
+                     reduction_mean, loss, lse, wsum);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spg_cross_entropy_bwd(const float* logits, const int64_t* target, const float* weight, const float* lse,
+                                     const float* wsum, const float* grad_loss, int N, int C, int64_t ignore_index,
+                                     int reduction_mean, float* grad_logits, void* stream) {
+  SPG_CHECK_ARG(logits && target && lse && wsum && grad_loss && grad_logits && N > 0 && C > 0, "bad argument");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(spg_cdiv((long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, logits, target, weight,
+                     lse, wsum, grad_loss, N, C, ignore_index, reduction_mean, grad_logits);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}

@@ -53,7 +53,7 @@ struct Plan {
   Segment stn, main;
   bool has_stn = false;
   // shared scratch
-  float *stat = nullptr, *pmax = nullptr, *pmin = nullptr;
+  float *stat = nullptr, *stat_cnt = nullptr, *pmax = nullptr, *pmin = nullptr;
   double* fin = nullptr;    // scratch of the sliced BatchNorm finalize
   int *imax = nullptr, *imin = nullptr;
   size_t bytes = 0;
@@ -152,6 +152,7 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
   if (pl.has_stn) carve_segment(pl.stn, nullptr);
   carve_segment(pl.main, emb);
   pl.stat = cv.take<float>((size_t)B * 4 * 2 * cmax);      // up to 4 per-wave partials per tile
+  pl.stat_cnt = cv.take<float>((size_t)B * 4 + 64);
   pl.fin = cv.take<double>(spg_bn_finalize_scratch_doubles(cmax));
   pl.pmax = cv.take<float>((size_t)B * 4 * cmax); pl.pmin = cv.take<float>((size_t)B * 4 * cmax);
   pl.imax = cv.take<int>((size_t)B * 4 * cmax); pl.imin = cv.take<int>((size_t)B * 4 * cmax);
@@ -190,9 +191,9 @@ SpgOperand input_operand(const Plan& pl, const Segment& sg, bool is_fc, size_t k
   return op_affine(p, p.y, p.ldy, p.cout);
 }
 
-int bn_stats(const Plan& pl, Layer& l, int ntile, int rows_per_tile, long M, int update_times, hipStream_t st) {
+int bn_stats(const Plan& pl, Layer& l, int nparts, long M, int update_times, hipStream_t st) {
   if (pl.training)
-    return spg_launch_bn_finalize(pl.stat, ntile, rows_per_tile, M, l.cout, l.gamma, l.beta, l.rm, l.rv,
+    return spg_launch_bn_finalize(pl.stat, pl.stat_cnt, nparts, M, l.cout, l.gamma, l.beta, l.rm, l.rv,
                                   pl.cfg.bn_momentum, pl.cfg.bn_eps, update_times, l.mean, l.rstd, l.s, l.t, pl.fin, st);
   return 0;     // eval mode: all layers were handled by one spg_launch_bn_eval_batch at the start of the forward
 }
@@ -229,13 +230,14 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = (int)pl.M; g.N = l.cout; g.K = l.cin;
     g.rows_per_tile = pl.P; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
     if (last && !pl.training) g.Y = nullptr;     // inference: only the pooled values of the last conv are consumed
-    g.stat = pl.training ? pl.stat : nullptr;
-    if (last) { g.pmax = pl.pmax; g.pmin = pl.pmin; g.imax = pl.imax; g.imin = pl.imin; }
-    SPG_TRY(spg_launch_gemm(g, st));
-    SPG_TRY(bn_stats(pl, l, pl.B, pl.P, pl.M, update_times, st));
-    if (last)
-      SPG_TRY(spg_launch_pool_select(pl.pmax, pl.pmin, pl.imax, pl.imin, l.s, pl.B, l.cout, pl.P, sg.extra, sg.nextra,
-                                     sg.pooled, sg.ldpool, sg.aidx, st));
+    g.stat = pl.training ? pl.stat : nullptr; g.stat_cnt = pl.stat_cnt;
+    int nparts = 0;
+    if (last) {      // max-pool fused into the epilogue: the sign of the BatchNorm scale is the sign of gamma
+      g.pool_out = sg.pooled; g.pool_idx = sg.aidx; g.pool_ld = sg.ldpool; g.pool_sign = l.gamma;
+      g.pool_extra = sg.extra; g.pool_nextra = sg.nextra;
+    }
+    SPG_TRY(spg_launch_gemm(g, st, &nparts));
+    SPG_TRY(bn_stats(pl, l, nparts, pl.M, update_times, st));
   }
   for (size_t k = 0; k < sg.fcs.size(); ++k) {
     Layer& l = pl.L[sg.fcs[k]];
@@ -244,9 +246,10 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     if (l.Wpad) SPG_TRY(spg_launch_pad_rows(l.W, l.cin, l.Wpad, l.ldw, l.cout, l.cin, st));
     g.W = l.Wpad ? l.Wpad : l.W; g.ldw = l.ldw; g.bias = l.b; g.M = pl.B; g.N = l.cout; g.K = l.cin;
     g.rows_per_tile = SPG_FC_ROWS; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
-    g.stat = (pl.training && l.bn) ? pl.stat : nullptr;
-    SPG_TRY(spg_launch_gemm(g, st));
-    if (l.bn) SPG_TRY(bn_stats(pl, l, spg_cdiv(pl.B, SPG_FC_ROWS), SPG_FC_ROWS, pl.B, update_times, st));
+    g.stat = (pl.training && l.bn) ? pl.stat : nullptr; g.stat_cnt = pl.stat_cnt;
+    int nparts = 0;
+    SPG_TRY(spg_launch_gemm(g, st, &nparts));
+    if (l.bn) SPG_TRY(bn_stats(pl, l, nparts, pl.B, update_times, st));
   }
   return 0;
 }
@@ -331,12 +334,13 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     g.Yp = first ? sg.pooled : prod.y; g.ldyp = first ? sg.ldpool : prod.ldy;
     g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
     g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
-    SPG_TRY(spg_launch_gemm(g, st));
+    int nparts = 0;
+    SPG_TRY(spg_launch_gemm(g, st, &nparts));
     // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
     const int C = prod.cout;
     if (first && s.grad_global != nullptr && sg.nextra > 0)     // columns >= C pass through: gradient wrt the global features
       SPG_TRY(spg_launch_copy2d(out + C, sg.ldpool, s.grad_global, sg.nextra, B, sg.nextra, st));
-    SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, spg_cdiv(B, SPG_FC_ROWS) * spg_gemm_row_waves(SPG_FC_ROWS, l.cin), l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
+    SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
                                        prod.rstd, s.consts, prod.dgamma, prod.dbeta, s.fin, st));
     if (!first) {
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, C);
@@ -365,8 +369,9 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.ldy;
       g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
       g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
-      SPG_TRY(spg_launch_gemm(g, st));
-      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, B * spg_gemm_row_waves(pl.P, l.cin), l.cin, pl.M, prod.cout, prod.s, prod.mean, prod.rstd, s.consts,
+      int nparts = 0;
+      SPG_TRY(spg_launch_gemm(g, st, &nparts));
+      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, pl.M, prod.cout, prod.s, prod.mean, prod.rstd, s.consts,
                                          prod.dgamma, prod.dbeta, s.fin, st));
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, prod.cout);
     } else if (want_dxy) {

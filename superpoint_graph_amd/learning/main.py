@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.optim as optim
 from torch.optim.lr_scheduler import MultiStepLR
 
+from .. import ops
 from . import datasets, graphnet, meters, metrics, pointnet, spg
 
 
@@ -233,7 +234,7 @@ class Session:
             else:
                 self.optimizer.zero_grad()
             outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
-            loss = nn.functional.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])
+            loss = ops.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])      # main.py:205
             loss.backward()
             self.embedder.bw_hook()
             if self.arena is not None:
@@ -263,7 +264,7 @@ class Session:
         for targets, GIs, clouds_data in self._loader(self.valid_dataset if is_valid else self.test_dataset, False):
             with torch.no_grad():
                 outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
-                loss = nn.functional.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])
+                loss = ops.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])
             loss_meter.add(loss)
             self.eval_log.append(loss)
             cm.count_predicted_batch_device(label_vec, outputs, label_mode)

@@ -424,6 +424,45 @@ def load_superpoints(points, offsets, slot, sample_idx, colmap, xyznormalize: bo
 
 
 # --------------------------------------------------------------------------------------------------
+# loss
+# --------------------------------------------------------------------------------------------------
+class _CrossEntropyFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight, ignore_index, mean):
+        logits = _req(logits.contiguous(), torch.float32, 'logits')
+        target = _req(target.contiguous(), torch.int64, 'target')
+        N, C = logits.shape
+        buf = torch.empty(N + 2, dtype=torch.float32, device=logits.device)          # lse [N] | loss | normaliser
+        check(lib().spg_cross_entropy_fwd(_ptr(logits), _ptr(target), _ptr(weight), N, C, int(ignore_index), int(mean),
+                                          buf[N:].data_ptr(), _ptr(buf), buf[N + 1:].data_ptr(), _stream()), 'spg_cross_entropy_fwd')
+        ctx.save_for_backward(logits, target, buf)
+        ctx.weight, ctx.ignore_index, ctx.mean = weight, int(ignore_index), int(mean)
+        return buf[N]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        logits, target, buf = ctx.saved_tensors
+        N, C = logits.shape
+        g = torch.empty_like(logits)
+        grad_loss = grad_loss.contiguous().float()
+        check(lib().spg_cross_entropy_bwd(_ptr(logits), _ptr(target), _ptr(ctx.weight), _ptr(buf), buf[N + 1:].data_ptr(), _ptr(grad_loss),
+                                          N, C, ctx.ignore_index, ctx.mean, _ptr(g), _stream()), 'spg_cross_entropy_bwd')
+        return g, None, None, None, None
+
+
+def cross_entropy(logits, target, weight=None, ignore_index=-100, reduction='mean'):
+    """torch.nn.functional.cross_entropy for [N, C] logits and class-index targets (the form learning/main.py:205 uses),
+    forward and backward one HIP launch each."""
+    if reduction not in ('mean', 'sum'):
+        raise NotImplementedError("reduction must be 'mean' or 'sum'")
+    if logits.dim() != 2 or target.dim() != 1 or target.shape[0] != logits.shape[0]:
+        raise ValueError('cross_entropy expects logits [N, C] and targets [N]')
+    if weight is not None:
+        weight = _req(weight.contiguous(), torch.float32, 'weight')
+    return _CrossEntropyFunction.apply(logits, target, weight, ignore_index, reduction == 'mean')
+
+
+# --------------------------------------------------------------------------------------------------
 # evaluation accounting
 # --------------------------------------------------------------------------------------------------
 def eval_accumulate(logits, label_mode, label_vec, confusion, counters):

@@ -213,3 +213,25 @@ def test_fused_clamp_adam_matches_torch(hip):
         arena.adam_step(lr=1e-2, weight_decay=1e-3, grad_clip=0.5)
         for a, b in zip(mod.parameters(), ref.parameters()):
             assert maxrel(a.grad, b.grad) < 2e-5 and maxrel(a, b) < 2e-5, step   # fp32 trajectories drift by rounding
+
+
+@pytest.mark.parametrize('n,c,weighted,reduction', [(1000, 13, False, 'mean'), (1000, 13, True, 'mean'), (7, 8, True, 'sum'), (4099, 13, True, 'mean')])
+def test_cross_entropy_matches_torch(hip, n, c, weighted, reduction):
+    """ops.cross_entropy (one launch each way) against torch.nn.functional.cross_entropy: loss, gradient, ignore_index."""
+    import torch.nn.functional as F
+    from superpoint_graph_amd import ops
+    g = torch.Generator().manual_seed(n)
+    logits = (torch.randn(n, c, generator=g) * 3).cuda().requires_grad_(True)
+    target = torch.randint(0, c, (n,), generator=g)
+    target[torch.rand(n, generator=g) < 0.1] = -100
+    target = target.cuda()
+    w = (torch.rand(c, generator=g) + 0.5).cuda() if weighted else None
+    loss = ops.cross_entropy(logits, target, weight=w, reduction=reduction)
+    (loss * 1.7).backward()
+    g_ours = logits.grad.clone()
+    logits.grad = None
+    ref = F.cross_entropy(logits, target, weight=w, reduction=reduction)
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert float((g_ours - logits.grad).abs().max()) <= 2e-6 * float(logits.grad.abs().max())
+    assert float(g_ours[target == -100].abs().max()) == 0.0

@@ -20,7 +20,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 import bench  # noqa: E402
-from superpoint_graph_amd import _lib  # noqa: E402
+from superpoint_graph_amd import _lib, ops  # noqa: E402
 from superpoint_graph_amd.flat import FlatParameters  # noqa: E402
 from superpoint_graph_amd.learning import pointnet  # noqa: E402
 
@@ -72,7 +72,7 @@ def main():
         arena.zero_grad()
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
-        loss = F.cross_entropy(out, label_mode)
+        loss = ops.cross_entropy(out, label_mode)
         loss.backward()
         embedder.bw_hook()
         arena.adam_step(lr=1e-3, weight_decay=0.0, grad_clip=1.0)
