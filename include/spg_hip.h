@@ -95,6 +95,10 @@ int spg_lstm_cell_bwd(const float* input, const float* h, const float* c, const 
  * ---------------------------------------------------------------------------------------------- */
 int spg_linear_fwd(const float* X, long ldx, int M, int K, const float* W, const float* bias, int N,
                    const float* in_scale, const float* in_shift, int in_relu, float* Y, long ldy, void* stream);
+/* dX[M,K] = dY[M,N] @ W[N,K] (data gradient of the layer above) and out[N] = column sums of X[M,N] (bias gradient;
+ * work >= 64*N floats): the remaining pieces of nn.Linear's backward (learning/graphnet.py:47-49, the classifier). */
+int spg_linear_dgrad(const float* dY, long lddy, int M, int N, const float* W, int K, float* dX, long ldx, void* stream);
+int spg_colsum(const float* X, long ldx, long M, int N, float* out, float* work, void* stream);
 size_t spg_linear_wgrad_work_floats(int M, int N, int K);
 int spg_linear_wgrad(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K, const float* in_scale,
                      const float* in_shift, int in_relu, float* dW, float* work, void* stream);
@@ -301,7 +305,9 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * one workgroup per tile instead of the persistent chunk stream (A/B timing in tools/); key 3: timing-attribution
  * switches of the persistent forward launches (bit 0 no output store, 1 no BatchNorm partials, 2 no pooling, 3 no
  * epilogue at all, 4 A operand from L2, 5 no main-loop barriers, bits 8-11 extra repetitions of the chunk loop) --
- * results are WRONG while it is non-zero, tools/ only.  Returns the previous value, -1 for an unknown key. */
+ * results are WRONG while it is non-zero, tools/ only; key 4: the BatchNorm finalize kernels slice their reduction over 8
+ * workgroups (last-arrival combine) above this many partials (0 = default 512); key 5: 1 = persistent launches write one
+ * statistics partial per tile instead of one per workgroup.  Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops);
 

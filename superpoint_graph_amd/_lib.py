@@ -65,6 +65,8 @@ SIGNATURES = {
     'spg_lstm_cell_fwd': (_i, [_p, _p, _p, _i, c_void_pp, _i, _i, _p, _p, _p, _p]),
     'spg_lstm_cell_bwd': (_i, [_p, _p, _p, _p, _p, _i, c_void_pp, _i, _i, _p, _p, _p, c_void_pp, _p, _p]),
     'spg_linear_fwd': (_i, [_p, _l, _i, _i, _p, _p, _i, _p, _p, _i, _p, _l, _p]),
+    'spg_linear_dgrad': (_i, [_p, _l, _i, _i, _p, _i, _p, _l, _p]),
+    'spg_colsum': (_i, [_p, _l, _l, _i, _p, _p, _p]),
     'spg_linear_wgrad_work_floats': (_sz, [_i, _i, _i]),
     'spg_linear_wgrad': (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     'spg_pointnet_num_layers': (_i, [ctypes.POINTER(PointNetCfg)]),

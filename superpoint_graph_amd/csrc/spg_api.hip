@@ -324,6 +324,22 @@ extern "C" int spg_linear_fwd(const float* X, long ldx, int M, int K, const floa
   return spg_launch_gemm(g, (hipStream_t)stream);
 }
 
+// dX[M,K] = dY[M,N] @ W[N,K]   (data gradient of Y = X W^T; W is read untransposed)
+extern "C" int spg_linear_dgrad(const float* dY, long lddy, int M, int N, const float* W, int K, float* dX, long ldx, void* stream) {
+  SPG_CHECK_ARG(dY && W && dX, "null pointer");
+  SpgGemmParams g; memset(&g, 0, sizeof(g));
+  g.a = affine_operand(dY, lddy, N, nullptr, nullptr, 0);
+  g.W = W; g.ldw = K; g.w_red = 1; g.M = M; g.N = K; g.K = N; g.rows_per_tile = M <= 8192 ? SPG_FC_ROWS : 128;
+  g.epi = SPG_EPI_BWD; g.Y = dX; g.ldy = ldx; g.n_mask = K;
+  return spg_launch_gemm(g, (hipStream_t)stream);
+}
+
+// out[N] = column sums of X[M,N] (bias gradient); work: >= 64 * N floats
+extern "C" int spg_colsum(const float* X, long ldx, long M, int N, float* out, float* work, void* stream) {
+  SPG_CHECK_ARG(X && out && work && M > 0 && N > 0, "bad argument");
+  return spg_launch_colsum(X, ldx, M, N, out, work, (hipStream_t)stream);
+}
+
 extern "C" size_t spg_linear_wgrad_work_floats(int M, int N, int K) { return spg_wgrad_workspace_floats(M, N, K); }
 
 extern "C" int spg_linear_wgrad(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K,

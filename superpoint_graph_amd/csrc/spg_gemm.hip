@@ -748,6 +748,20 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
       else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
       __syncthreads();
     }
+  } else if constexpr (AMODE == -2) {
+    // channel-major clouds (the first convolution of a segment, <= 32 input channels = one chunk): the A tile through the
+    // vector pipe (4 channel loads per lane, STN transform applied while staging), the tiny unaligned weight tile scalar
+    SpgRowsPipe<SPG_PRO_CLOUD, IT> pa;
+    for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
+      pa.load(p.a, m0, mvalid, k0, p.K);
+      if (WRED) spg_stage_weight_red<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bsr);
+      else spg_stage_weight<JT>(p.W, p.ldw, n0, p.N, k0, p.K, Bs);
+      pa.store(As);
+      __syncthreads();
+      if (WRED) spg_mfma_chunk_or<TI, TJ>(As, Bsr, IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      else spg_mfma_chunk<TI, TJ>(As, Bs, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
+      __syncthreads();
+    }
   } else {
     for (int k0 = 0; k0 < p.K; k0 += SPG_KC) {
       spg_stage_rows<IT>(p.a, m0, mvalid, k0, p.K, As);
@@ -816,7 +830,7 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
         q.remap = 1; q.rstride = slots / ncol;
         q.dbg = WRED ? 0 : g_tune[SPG_TUNE_DBG];      // attribution switches: forward launches only
         // ... the persistent workgroups accumulate over their tiles: one partial per workgroup of a column tile and row-wave
-        q.stat_accum = p.stat != nullptr && (!WRED || (q.vec_store && p.N <= p.n_mask));
+        q.stat_accum = !g_tune[SPG_TUNE_NO_STAT_ACCUM] && p.stat != nullptr && (!WRED || (q.vec_store && p.N <= p.n_mask));
         if (q.stat_accum && stat_parts != nullptr) *stat_parts = (int)(q.rstride < q.ntile ? q.rstride : q.ntile) * WI;
         grid = dim3((unsigned)slots, 1);
         if constexpr (IT == 128 && !(WRED && JT == 128)) {
@@ -856,6 +870,8 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts)
   const bool vec = spg_operand_vec_ok(p.a) && walign && p.a.ld >= ((p.K + 3) & ~3);
   const int mode = vec ? p.a.mode : -1;
   if (!p.w_red) {
+    if (p.a.mode == SPG_PRO_CLOUD && p.rows_per_tile > 32 && p.N > 32 && p.N <= 64)      // first convolution of a segment
+      return launch_gemm_t<128, 64, 2, 2, false, -2>(p, stream, stat_parts);
     switch (mode) {
       case SPG_PRO_IDENT: return launch_gemm_shape<false, SPG_PRO_IDENT>(p, stream, stat_parts);
       case SPG_PRO_AFFINE: return launch_gemm_shape<false, SPG_PRO_AFFINE>(p, stream, stat_parts);
@@ -1334,12 +1350,23 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
   const int b0 = slice * per, b1 = min(nparts, b0 + per);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   if (c < N)
-    for (int b = b0 + ty; b < b1; b += 64) {
-      const double nb = (double)cnt[b];                          // rows behind this partial (written by the GEMM)
-      const double mb = (double)stat[((long)b * 2) * N + c];
-      a0 += nb * mb;
-      a1 += nb * mb * mb;
-      a2 += (double)stat[((long)b * 2 + 1) * N + c];
+    for (int b = b0 + ty; b < b1; b += 256) {                    // four partials in flight per thread (the loop is latency bound)
+      float nb[4], mb[4], qb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int bb = b + 64 * u;
+        const bool ok = bb < b1;
+        const long o = ((long)(ok ? bb : b) * 2) * N + c;
+        nb[u] = ok ? cnt[bb] : 0.f;                              // rows behind this partial (written by the GEMM)
+        mb[u] = stat[o];
+        qb[u] = ok ? stat[o + N] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 += (double)nb[u] * (double)mb[u];
+        a1 += (double)nb[u] * (double)mb[u] * (double)mb[u];
+        a2 += (double)qb[u];
+      }
     }
   a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
   a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
@@ -1412,7 +1439,8 @@ int spg_launch_bn_finalize(const float* stat, const float* stat_cnt, int nparts,
   SPG_CHECK_ARG(stat != nullptr && stat_cnt != nullptr && nparts > 0, "statistics partials");
   const int gx = spg_cdiv(N, 16);
   // many partials: slice the reduction over more workgroups (one CU cannot pull megabytes of partials quickly)
-  int slices = (scratch != nullptr && nparts > 1024) ? SPG_FIN_SLICES : 1;
+  const int slice_min = g_tune[SPG_TUNE_FIN_SLICE_MIN] > 0 ? g_tune[SPG_TUNE_FIN_SLICE_MIN] : 512;     // measured (tools/tune_sweep.py): 256 / 512 equal, 1024 +30 us per step
+  int slices = (scratch != nullptr && nparts > slice_min) ? SPG_FIN_SLICES : 1;
   int* counters = nullptr;
   if (slices > 1) {
     counters = spg_fin_counter_window(gx);
@@ -1490,9 +1518,18 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
   const int t0 = slice * per, t1 = min(ntile, t0 + per);
   double a = 0.0, b = 0.0;
   if (c < N)
-    for (int t = t0 + ty; t < t1; t += 64) {
-      a += (double)stat[((long)t * 2) * ldstat + c];
-      b += (double)stat[((long)t * 2 + 1) * ldstat + c];
+    for (int t = t0 + ty; t < t1; t += 256) {                    // four partials in flight per thread
+      float x[4], y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tt = t + 64 * u;
+        const bool ok = tt < t1;
+        const long o = ((long)(ok ? tt : t) * 2) * ldstat + c;
+        x[u] = ok ? stat[o] : 0.f;
+        y[u] = ok ? stat[o + ldstat] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a += (double)x[u]; b += (double)y[u]; }
     }
   a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
   a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
@@ -1563,7 +1600,8 @@ int spg_launch_bn_bwd_finalize(const float* stat, int ntile, int ldstat, long co
                                const float* mean, const float* rstd, float* consts, float* dgamma, float* dbeta,
                                double* scratch, hipStream_t stream) {
   const int gx = spg_cdiv(N, 16);
-  int slices = (scratch != nullptr && ntile > 1024) ? SPG_FIN_SLICES : 1;
+  const int slice_min = g_tune[SPG_TUNE_FIN_SLICE_MIN] > 0 ? g_tune[SPG_TUNE_FIN_SLICE_MIN] : 512;     // measured (tools/tune_sweep.py): 256 / 512 equal, 1024 +30 us per step
+  int slices = (scratch != nullptr && ntile > slice_min) ? SPG_FIN_SLICES : 1;
   int* counters = nullptr;
   if (slices > 1) {
     counters = spg_fin_counter_window(gx);

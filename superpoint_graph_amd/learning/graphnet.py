@@ -5,7 +5,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from . import ecc  # noqa: F401  (kept for API parity: `learning.graphnet.ecc`)
-from .modules import GRUCellEx, LSTMCellEx, RNNGraphConvModule
+from .modules import GRUCellEx, HipLinear, LSTMCellEx, RNNGraphConvModule
 
 
 def create_fnet(widths, orthoinit, llbias, bnidx=-1):
@@ -38,7 +38,7 @@ class GraphNetwork(nn.Module):
         for d, conf in enumerate(config.split(',')):
             conf = conf.strip().split('_')
             if conf[0] == 'f':
-                self.add_module(str(d), nn.Linear(nfeat, int(conf[1])))
+                self.add_module(str(d), HipLinear(nfeat, int(conf[1])))      # nn.Linear with HIP forward / backward
                 nfeat = int(conf[1])
             elif conf[0] == 'b':
                 self.add_module(str(d), nn.BatchNorm1d(nfeat, eps=1e-5, affine=len(conf) == 1))

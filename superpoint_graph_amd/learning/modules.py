@@ -106,6 +106,46 @@ class _LSTMCellFunction(torch.autograd.Function):
         return (None, gi, gh, gc) + tuple(g for g in grads if g is not None)
 
 
+class _LinearFunction(torch.autograd.Function):
+    """nn.Linear on the few-row MFMA kernels: y = x W^T + b; backward = data gradient, weight gradient, bias column sum."""
+
+    @staticmethod
+    def forward(ctx, module, x, weight, bias):
+        ctx.module = module
+        ctx.save_for_backward(x, weight)
+        return ops.linear_fwd(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        m = ctx.module
+        gy = gy.contiguous()
+        gx = ops.linear_dgrad(gy, weight) if ctx.needs_input_grad[1] else None
+        direct = getattr(m, '_spg_direct_grads', False) and weight.grad is not None and weight.grad.is_contiguous() and \
+            (m.bias is None or (m.bias.grad is not None and m.bias.grad.is_contiguous()))
+        if direct:          # FlatParameters: write into the (zeroed) arena views, nothing for autograd to accumulate
+            ops.linear_wgrad(gy, x, out=weight.grad)
+            if m.bias is not None:
+                ops.colsum(gy, out=m.bias.grad)
+            return None, gx, None, None
+        gw = ops.linear_wgrad(gy, x)
+        gb = ops.colsum(gy) if m.bias is not None else None
+        return None, gx, gw, gb
+
+
+class HipLinear(nn.Linear):
+    """`nn.Linear` (same parameters / state_dict keys / initialisation) whose forward and backward run on the HIP kernels
+    for 2-d float32 CUDA inputs -- the classifier of the graph network (reference learning/graphnet.py:47-49).  torch's
+    path costs three hipBLASLt launches with host-side argument uploads, a reduction and two accumulations per step."""
+
+    def forward(self, input):
+        w = self.weight
+        if (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and w.is_contiguous() and w.shape[1] % 4 == 0
+                and w.data_ptr() % 16 == 0):
+            return _LinearFunction.apply(self, input.contiguous(), w, self.bias)
+        return super(HipLinear, self).forward(input)
+
+
 def _fnet_groups(fnet):
     """(Linear, BatchNorm-or-None) pairs of a create_fnet() Sequential, plus its bnidx."""
     groups, bnidx, mods = [], -1, list(fnet)

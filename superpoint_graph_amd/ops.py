@@ -164,10 +164,29 @@ def linear_fwd(x, w, bias=None, in_scale=None, in_shift=None, in_relu=False):
     return y
 
 
-def linear_wgrad(dy, x, in_scale=None, in_shift=None, in_relu=False):
+def linear_dgrad(dy, w):
+    """dx [M, K] = dy [M, N] @ w [N, K]."""
+    _req(dy, torch.float32, 'dy'); _req(w, torch.float32, 'w')
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    check(lib().spg_linear_dgrad(_ptr(dy), N, M, N, _ptr(w), K, _ptr(dx), K, _stream()), 'spg_linear_dgrad')
+    return dx
+
+
+def colsum(x, out=None):
+    _req(x, torch.float32, 'x')
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device) if out is None else out
+    work = torch.empty(64 * N, dtype=torch.float32, device=x.device)
+    check(lib().spg_colsum(_ptr(x), N, M, N, _ptr(out), _ptr(work), _stream()), 'spg_colsum')
+    return out
+
+
+def linear_wgrad(dy, x, in_scale=None, in_shift=None, in_relu=False, out=None):
     M, N = dy.shape
     K = x.shape[1]
-    dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    dw = torch.empty(N, K, dtype=torch.float32, device=x.device) if out is None else out
     work = torch.empty(max(1, lib().spg_linear_wgrad_work_floats(M, N, K)), dtype=torch.float32, device=x.device)
     check(lib().spg_linear_wgrad(_ptr(dy), N, _ptr(x), K, M, N, K, _ptr(in_scale), _ptr(in_shift), int(in_relu), _ptr(dw),
                                  _ptr(work), _stream()), 'spg_linear_wgrad')

@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
-"""Which host-side ops of the train step launch memcpy / fill kernels (torch.profiler with python stacks)."""
+"""Which host-side ops of the train step issue device copies (hipMemcpyWithStream / hipMemcpyAsync -> __amd_rocclr_copyBuffer
+blit kernels): torch.profiler event tree, every copy API call printed with its chain of enclosing aten / autograd ops."""
 import os
 import sys
 import types
+from collections import Counter
 
 import torch
-import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 
 def main():
-    from superpoint_graph_amd import dist as spd
+    from superpoint_graph_amd import ops
     from superpoint_graph_amd.flat import FlatParameters
     from superpoint_graph_amd.learning import pointnet
     dev = torch.device('cuda')
@@ -24,15 +25,10 @@ def main():
     arena = FlatParameters(model)
 
     def step():
-        if os.environ.get('TRACE_FWD'):
-            model.eval()
-            with torch.no_grad():
-                model.ecc(emb_er.run(model, None, flag, clouds_d, diam_d))
-            return
         arena.zero_grad()
         emb = emb_er.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
-        F.cross_entropy(out, label).backward()
+        ops.cross_entropy(out, label).backward()
         emb_er.bw_hook()
         arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)
 
@@ -40,19 +36,21 @@ def main():
         step()
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-        for _ in range(3):
+    nsteps = 3
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(nsteps):
             step()
         torch.cuda.synchronize()
-    rows = []
+    rows = Counter()
     for e in prof.events():
-        n = e.name
-        if ('Memcpy' in n or 'Memset' in n or 'copyBuffer' in n or 'fillBuffer' in n or n in ('aten::copy_', 'aten::fill_', 'aten::zero_')):
-            st = [s for s in (e.stack or []) if 'superpoint_graph_amd' in s or 'copy_trace' in s or 'bench' in s][:2]
-            rows.append((n[:50], str(e.device_type)[-4:], ' <- '.join(st)))
-    from collections import Counter
-    for (k, c) in Counter(rows).most_common(40):
-        print(c, k)
+        if 'Memcpy' in e.name or 'Memset' in e.name:
+            chain, p = [], e.cpu_parent
+            while p is not None and len(chain) < 6:
+                chain.append(p.name)
+                p = p.cpu_parent
+            rows[(e.name[:40], ' <- '.join(chain))] += 1
+    for (k, c) in rows.most_common(60):
+        print(f'{c / nsteps:6.1f}/step  {k[0]:<40s} {k[1]}')
 
 
 if __name__ == '__main__':

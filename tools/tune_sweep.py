@@ -53,7 +53,7 @@ def read_shapes(L, nprof):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--configs', nargs='*', default=None)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--top', type=int, default=14)
     ap.add_argument('--scenes', type=int, default=1)
     args = ap.parse_args()
@@ -77,8 +77,7 @@ def main():
         embedder.bw_hook()
         arena.adam_step(lr=1e-3, weight_decay=0.0, grad_clip=1.0)
 
-    configs = args.configs or ['persist=', 'one_wg_per_tile=0:1', 'noY=3:1', 'nostat=3:2', 'nopool=3:4', 'noepi=3:8', 'noepi_AfromL2=3:24', 'noepi_nobarrier=3:40',
-                               'noepi_x2=3:264', 'noepi_x4=3:776', 'persist2=']
+    configs = args.configs or ['default=', 'one_wg_per_tile=0:1', 'slice_above_256=4:256', 'slice_above_1024=4:1024', 'no_stat_accum=5:1', 'default2=']
     for cfg in configs:
         name, _, kv = cfg.partition('=')
         for k in range(KNOBS):
