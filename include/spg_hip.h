@@ -229,6 +229,15 @@ typedef struct {
 int spg_edge_features(const spg_edge_feature_specs* specs, const int64_t* edges, long E, const double* mean,
                       const double* scale, float* out, void* stream);
 
+/* Random streams of the loader generated on the device (optional; the default keeps numpy's streams on the host so
+ * that seeded runs reproduce the reference's clouds): Philox4x32-10 keyed by (seed, superpoint id, step).  counts /
+ * ids int64 [S], slot int32 [S] (row of the cloud tensor or -1) -> sample_idx int32 [S, npts] (spg.py:207-214), M
+ * float64 [S, 3, 3] (augment_cloud's matrix, :241-251; may be NULL) and noise float32 [n_valid, npts, nfeat] (clipped
+ * N(0, 0.01^2), :255-257; may be NULL), the inputs of spg_load_superpoints. */
+int spg_loader_random(const int64_t* counts, const int64_t* ids, const int32_t* slot, int n_superpoints, int npts, int nfeat,
+                      uint64_t seed, uint32_t step, int augment, float scale, int rot, float mirror_prob, int jitter,
+                      int32_t* sample_idx, double* M, float* noise, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weighted cross entropy of the training / evaluation loops (learning/main.py:205,255:
  * nn.functional.cross_entropy(outputs, label_mode, weight=class_weights); rows with target == ignore_index do not

@@ -146,6 +146,104 @@ extern "C" int spg_load_superpoints(const float* points, int ncols, const int64_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Device-side random streams of the loader (optional mode, `--loader_rng device`): the resampling indices, the
+// augmentation matrix and the jitter of every superpoint from a counter-based generator (Philox4x32-10, Salmon et al.
+// SC'11) keyed by (seed, superpoint id, step) -- no host loop over the superpoints, reproducible for a given seed, and
+// independent of the batch composition.  It is a DIFFERENT stream from numpy's MT19937 (statistically equivalent draws:
+// uniform indices with replacement, uniform angle / scale, Bernoulli mirrors, clipped N(0, 0.01^2) jitter, spg.py:207-258);
+// the default host-stream mode reproduces the reference's clouds bit for bit.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct U4 { unsigned x, y, z, w; };
+__host__ __device__ inline U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
+    U4 n;
+    n.x = (unsigned)(p1 >> 32) ^ c.y ^ k0; n.y = (unsigned)p1;
+    n.z = (unsigned)(p0 >> 32) ^ c.w ^ k1; n.w = (unsigned)p0;
+    c = n;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+struct RngParams {
+  const int64_t* counts;      // [S] points per superpoint
+  const int64_t* ids;         // [S] superpoint ids (key of the stream)
+  const int* slot;            // [S] row in the cloud tensor or -1
+  int S, npts, nfeat;
+  unsigned seed_lo, seed_hi, step;
+  float scale, mirror_prob;
+  int rot, jitter, augment;
+  int* sidx; double* M; float* noise;
+};
+
+// kinds (counter word 1): 0 indices (element = point / 4), 1 augmentation scalars, 2 jitter (element = value / 4)
+__global__ void spg_loader_rng_kernel(const RngParams p) {
+  const int s = blockIdx.x;
+  const long n = (long)p.counts[s];
+  const unsigned idl = (unsigned)p.ids[s], idh = (unsigned)((unsigned long long)p.ids[s] >> 32) ^ p.step;
+  for (int q4 = threadIdx.x; 4 * q4 < p.npts; q4 += blockDim.x) {
+    const U4 u = philox4x32_10(U4{(unsigned)q4, 0u, idl, idh}, p.seed_lo, p.seed_hi);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    for (int e = 0; e < 4 && 4 * q4 + e < p.npts; ++e) {
+      const int q = 4 * q4 + e;
+      // n > npts: npts draws with replacement; n < npts: all points, then npts - n draws; (uniform in [0, n): high word of u * n)
+      const int v = (n <= p.npts && q < n) ? q : (int)(((unsigned long long)w[e] * (unsigned long long)(n > 0 ? n : 1)) >> 32);
+      p.sidx[(long)s * p.npts + q] = v;
+    }
+  }
+  if (p.augment && p.M != nullptr && threadIdx.x == 0) {
+    const U4 u = philox4x32_10(U4{0u, 1u, idl, idh}, p.seed_lo, p.seed_hi);
+    const double two32 = 4294967296.0;
+    double sc = 1.0;
+    if (p.scale > 1.f) sc = 1.0 / (double)p.scale + ((double)u.x + 0.5) / two32 * ((double)p.scale - 1.0 / (double)p.scale);
+    double c = 1.0, sn = 0.0;
+    if (p.rot) { const double a = ((double)u.y + 0.5) / two32 * 6.283185307179586; c = cos(a); sn = sin(a); }
+    double mx = 1.0, my = 1.0;
+    if (p.mirror_prob > 0.f) {
+      if (((double)u.z + 0.5) / two32 < 0.5 * (double)p.mirror_prob) mx = -1.0;
+      if (((double)u.w + 0.5) / two32 < 0.5 * (double)p.mirror_prob) my = -1.0;
+    }
+    // M = mirror_y * mirror_x * Rz(a) * (sc I)   (composition order of augment_cloud, spg.py:241-251)
+    double* M = p.M + (long)s * 9;
+    M[0] = mx * c * sc;  M[1] = -mx * sn * sc; M[2] = 0.0;
+    M[3] = my * sn * sc; M[4] = my * c * sc;   M[5] = 0.0;
+    M[6] = 0.0;          M[7] = 0.0;           M[8] = sc;
+  }
+  const int slot = p.slot[s];
+  if (p.jitter && p.noise != nullptr && slot >= 0) {
+    const int total = p.npts * p.nfeat;
+    float* out = p.noise + (long)slot * total;
+    for (int q4 = threadIdx.x; 4 * q4 < total; q4 += blockDim.x) {
+      const U4 u = philox4x32_10(U4{(unsigned)q4, 2u, idl, idh}, p.seed_lo, p.seed_hi);
+      // two Box-Muller pairs per block: sigma 0.01, clipped to +-0.05 (spg.py:255-257)
+      const float u1 = ((float)(u.x >> 8) + 0.5f) * 5.9604645e-8f, u2 = ((float)(u.y >> 8) + 0.5f) * 5.9604645e-8f;
+      const float u3 = ((float)(u.z >> 8) + 0.5f) * 5.9604645e-8f, u4 = ((float)(u.w >> 8) + 0.5f) * 5.9604645e-8f;
+      const float r1 = sqrtf(-2.f * logf(u1)), r2 = sqrtf(-2.f * logf(u3));
+      const float z[4] = {r1 * cosf(6.2831853f * u2), r1 * sinf(6.2831853f * u2), r2 * cosf(6.2831853f * u4), r2 * sinf(6.2831853f * u4)};
+      for (int e = 0; e < 4 && 4 * q4 + e < total; ++e) out[4 * q4 + e] = fminf(fmaxf(0.01f * z[e], -0.05f), 0.05f);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int spg_loader_random(const int64_t* counts, const int64_t* ids, const int32_t* slot, int n_superpoints, int npts,
+                                 int nfeat, uint64_t seed, uint32_t step, int augment, float scale, int rot, float mirror_prob,
+                                 int jitter, int32_t* sample_idx, double* M, float* noise, void* stream) {
+  SPG_CHECK_ARG(counts && ids && slot && sample_idx && npts >= 1 && nfeat >= 1, "bad argument");
+  if (n_superpoints == 0) return 0;
+  RngParams p;
+  p.counts = counts; p.ids = ids; p.slot = slot; p.S = n_superpoints; p.npts = npts; p.nfeat = nfeat;
+  p.seed_lo = (unsigned)seed; p.seed_hi = (unsigned)(seed >> 32); p.step = step;
+  p.scale = scale; p.mirror_prob = mirror_prob; p.rot = rot; p.jitter = jitter; p.augment = augment;
+  p.sidx = sample_idx; p.M = M; p.noise = noise;
+  hipLaunchKernelGGL(spg_loader_rng_kernel, dim3(n_superpoints), dim3(128), 0, (hipStream_t)stream, p);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Evaluation accounting on the device (reference learning/main.py:246-263 and eval_final :267-311 with
 // learning/metrics.py:16-18): mean of the logits over the test-time samples, arg-max prediction of every superpoint,
 // and for the superpoints with ground truth (label_mode != -100, main.py:447-452) the confusion-matrix update

@@ -100,6 +100,9 @@ def build_parser():
     a('--sp_decoder_config', default='[]', type=str, help='Size of the decoder : sp_embedding -> sp_class.')
     # HIP path
     a('--loader_device', default=1, type=int, help='Bool, build the superpoint clouds on the GPU from scenes resident in HBM')
+    a('--loader_rng', default='host', choices=['host', 'device'],
+      help="Random streams of the cloud loader: 'host' = numpy / python streams in the reference's order (seeded runs reproduce "
+           "the reference's clouds), 'device' = counter-based generator on the GPU (no per-superpoint host loop)")
     a('--fused_optim', default=1, type=int, help='Bool, clamp + Adam as one launch over a flat parameter arena (adam only)')
     a('--max_train_iters', default=0, type=int, help='Stop every training epoch after this many batches (0 = whole epoch)')
     return p
@@ -120,6 +123,8 @@ def set_seed(seed, cuda=True):
     torch.manual_seed(seed)
     if cuda:
         torch.cuda.manual_seed(seed)
+    from . import spg
+    spg._device_rng_step[0] = 0            # `--loader_rng device`: the call counter is part of the stream key
 
 
 def filter_valid(output, target, other=None):

@@ -168,15 +168,22 @@ def pc_attribs_columns(pc_attribs):
     return cols
 
 
-def load_superpoints_device(args, points, offsets, ids, train, test_seed_offset=0, counts=None):
+_device_rng_step = [0]
+
+
+def load_superpoints_device(args, points, offsets, ids, train, test_seed_offset=0, counts=None, rng=None):
     """All superpoints of a scene in ONE kernel launch: what `loader` does with one `load_superpoint` call per
     superpoint (reference learning/spg.py:150-167, 198-236) plus `augment_cloud` (:239-258) when `train`.
 
     points: device f32 [Ntot, ncols] raw rows of every superpoint back to back (the content of parsed/<scene>.h5),
     offsets: i64 [S+1] (host or device), ids: the superpoint ids (seed of the evaluation stream, :205).
-    The random streams stay on the host and are consumed in the reference's order -- per superpoint: resampling
-    (`rs.choice`, numpy), then the augmentation matrix (python `random`), then the jitter (numpy `randn`) -- so a seeded
-    run yields the reference's clouds.  -> (clouds_flag i64[S] host, clouds f32[Nv, F, npts] device, clouds_global f32[Nv] device)
+    rng='host' (default; `args.loader_rng`): the random streams stay on the host and are consumed in the reference's
+    order -- per superpoint: resampling (`rs.choice`, numpy), then the augmentation matrix (python `random`), then the
+    jitter (numpy `randn`) -- so a seeded run yields the reference's clouds.
+    rng='device': the streams come from a counter-based generator on the GPU (ops.loader_random), keyed by
+    (args.seed [+ test_seed_offset in evaluation], superpoint id, call counter in training / 0 in evaluation): no host
+    loop over the superpoints and no host->device copy of indices / noise; same distributions, different numbers.
+    -> (clouds_flag i64[S] host, clouds f32[Nv, F, npts] device, clouds_global f32[Nv] device)
     """
     import math
     import random
@@ -196,8 +203,25 @@ def load_superpoints_device(args, points, offsets, ids, train, test_seed_offset=
     slot = np.full(S, -1, dtype=np.int32)
     slot[flag == 0] = np.arange(int((flag == 0).sum()), dtype=np.int32)
     nv = int((flag == 0).sum())
-    sidx = np.zeros((S, npts), dtype=np.int32)
     augment = bool(train)
+    rng = rng or getattr(args, 'loader_rng', 'host')
+    if rng == 'device':
+        dev = points.device
+        slot_d = torch.from_numpy(slot).to(dev)
+        if train:
+            _device_rng_step[0] += 1
+        sidx_d, M_d, noise_d = ops.loader_random(
+            torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)).to(dev),
+            torch.from_numpy(np.asarray(ids, dtype=np.int64)).to(dev), slot_d, npts, F, nv,
+            int(getattr(args, 'seed', 0)) + (0 if train else int(test_seed_offset)), _device_rng_step[0] if train else 0, augment,
+            float(args.pc_augm_scale), args.pc_augm_rot == 1, float(args.pc_augm_mirror_prob),
+            bool(getattr(args, 'pc_augm_jitter', 0)))
+        clouds, diam = ops.load_superpoints(points, torch.from_numpy(off_h.astype(np.int64)).to(dev), slot_d, sidx_d, cols,
+                                            bool(args.pc_xyznormalize), nv, M_d, noise_d)
+        return torch.from_numpy(flag), clouds, diam
+    if rng != 'host':
+        raise ValueError(f"loader_rng must be 'host' or 'device', got {rng!r}")
+    sidx = np.zeros((S, npts), dtype=np.int32)
     Ms = np.tile(np.eye(3), (S, 1, 1)) if augment else None
     jitter = augment and bool(getattr(args, 'pc_augm_jitter', 0))
     noise = np.zeros((nv, npts, F), dtype=np.float32) if jitter else None

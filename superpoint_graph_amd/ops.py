@@ -442,6 +442,25 @@ def load_superpoints(points, offsets, slot, sample_idx, colmap, xyznormalize: bo
     return clouds, diam
 
 
+def loader_random(counts, ids, slot, npts: int, nfeat: int, n_valid: int, seed: int, step: int, augment: bool,
+                  scale: float = 0.0, rot: bool = False, mirror_prob: float = 0.0, jitter: bool = False):
+    """The loader's random streams generated on the device (Philox4x32-10 keyed by (seed, superpoint id, step)):
+    counts / ids i64 [S], slot i32 [S] -> sample_idx i32 [S, npts], M f64 [S, 3, 3] or None, noise f32 [n_valid, npts, nfeat]
+    or None -- the inputs of `load_superpoints` (reference learning/spg.py:207-214, 241-257)."""
+    _req(counts, torch.int64, 'counts'); _req(ids, torch.int64, 'ids'); _req(slot, torch.int32, 'slot')
+    S = slot.numel()
+    if counts.numel() != S or ids.numel() != S:
+        raise ValueError('counts / ids / slot disagree on the number of superpoints')
+    dev = counts.device
+    sidx = torch.empty(S, npts, dtype=torch.int32, device=dev)
+    M = torch.empty(S, 3, 3, dtype=torch.float64, device=dev) if augment else None
+    noise = torch.empty(n_valid, npts, nfeat, dtype=torch.float32, device=dev) if (augment and jitter) else None
+    check(lib().spg_loader_random(_ptr(counts), _ptr(ids), _ptr(slot), S, int(npts), int(nfeat), int(seed) & (2 ** 64 - 1),
+                                  int(step) & 0xFFFFFFFF, int(bool(augment)), float(scale), int(bool(rot)), float(mirror_prob),
+                                  int(bool(jitter)), _ptr(sidx), _ptr(M), _ptr(noise), _stream()), 'spg_loader_random')
+    return sidx, M, noise
+
+
 # --------------------------------------------------------------------------------------------------
 # loss
 # --------------------------------------------------------------------------------------------------

@@ -235,3 +235,50 @@ def test_cross_entropy_matches_torch(hip, n, c, weighted, reduction):
     assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
     assert float((g_ours - logits.grad).abs().max()) <= 2e-6 * float(logits.grad.abs().max())
     assert float(g_ours[target == -100].abs().max()) == 0.0
+
+
+def test_backward_after_eval_forward_fails_loudly(hip):
+    """The backward kernels implement batch-statistics BatchNorm: after an eval-mode forward (frozen-BN fine-tuning,
+    saliency) they must refuse instead of reading the training-layout workspace out of bounds."""
+    import types
+    from conftest import build_model, load_golden
+    from superpoint_graph_amd.learning import ecc, pointnet
+    spec, batch, state0, g = load_golden('vector_gru4_small')
+    model = build_model(spec, state0).cuda().eval()
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+    emb = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=0)).run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])
+    out = model.ecc(emb)
+    with pytest.raises(RuntimeError, match='eval-mode forward'):
+        out.sum().backward()
+
+
+def test_graph_index_validation(hip):
+    """GraphConvInfo.cuda() checks the index contract on the host before the device CSR is built from it."""
+    from superpoint_graph_amd.learning import ecc
+    idxn = torch.tensor([0, 1, 2, 1], dtype=torch.int64)
+    degs = torch.tensor([2, 1, 1], dtype=torch.int64)
+    ef = torch.zeros(4, 13)
+    ecc.GraphConvInfo.from_buffers(idxn.clone(), degs.clone(), ef.clone()).cuda()                      # consistent: fine
+    with pytest.raises(ValueError, match='does not match the number of edges'):
+        ecc.GraphConvInfo.from_buffers(idxn.clone(), torch.tensor([2, 1, 2]), ef.clone()).cuda()
+    with pytest.raises(IndexError, match='idxn entries'):
+        ecc.GraphConvInfo.from_buffers(torch.tensor([0, 1, 7, 1]), degs.clone(), ef.clone()).cuda()
+    with pytest.raises(ValueError, match='edge-feature rows'):
+        ecc.GraphConvInfo.from_buffers(idxn.clone(), degs.clone(), torch.zeros(3, 13)).cuda()
+
+
+def test_batchnorm_option_checks(hip):
+    """BatchNorm variants the kernels do not implement are refused, not silently replaced."""
+    from superpoint_graph_amd.learning import pointnet
+    net = pointnet.PointNet([32, 64], [32, 16], [16, 32], [16, 8], 6, 6, prelast_do=0).cuda().train()
+    x, d = torch.randn(5, 6, 128).cuda(), torch.rand(5).cuda()
+    net(x, d)
+    net.convs[1].momentum = None
+    net.__dict__.pop('_cfg_cache', None)
+    with pytest.raises(NotImplementedError, match='momentum=None'):
+        net(x, d)
+    net.convs[1].momentum = 0.1
+    net.__dict__.pop('_cfg_cache', None)
+    with pytest.raises(ValueError, match='more than 1 value per channel'):
+        net(x[:1], d[:1])

@@ -106,3 +106,15 @@ def test_model_config_dsl():
         graphnet.GraphNetwork('crf_3', 32, [13, 32], use_pyg=0)
     with pytest.raises(NotImplementedError):
         graphnet.GraphNetwork('xyz_3', 32, [13, 32], use_pyg=0)
+
+
+def test_philox_oracle_known_answers():
+    """The counter-based generator behind `--loader_rng device`: the three known-answer vectors of the Random123
+    distribution (kat_vectors: philox4x32 10 rounds)."""
+    from oracle.philox_oracle import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(x) for x in philox4x32_10(*ctr, *key))
+        assert got == want
