@@ -1,0 +1,30 @@
+#!/bin/bash
+# Everything the round's measurement deliverables need, in one GPU-box call (run from the repo root):
+#   tools/collect_profiles.sh <tag>            e.g. r02  ->  gpurun_out/<tag>_{bench.json,kernel_stats.txt,pmc_*.txt,gemm_traffic.json}
+# Passes: (1) bench.py (default flags: the driver's command), (2) rocprofv3 --kernel-trace of the train steps, summarised
+# over the steady-state window (tools/prof_summary.py), (3)+(4) --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes
+# (never with other trace domains), each followed by the known-byte-count calibration of tools/pmc_calib.py.
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+STEPS="--no-cpu-baseline --no-forward-only --no-trainer-window --no-roofline"
+db() { find $1 -name '*.db' | head -1; }
+
+timeout 600 python $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+tail -c 2000 $OUT/${TAG}_bench.json
+
+timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_trace -- python $ROOT/bench.py --steps 20 --warmup 5 $STEPS > /dev/null 2> $OUT/${TAG}_trace.err
+python $ROOT/tools/prof_summary.py $(db /tmp/p_trace) 70 > $OUT/${TAG}_kernel_stats.txt
+head -5 $OUT/${TAG}_kernel_stats.txt
+
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format rocpd -d /tmp/p_$C -- python $ROOT/bench.py --steps 4 --warmup 2 $STEPS > /dev/null 2> $OUT/${TAG}_pmc_$C.err
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format rocpd -d /tmp/c_$C -- python $ROOT/tools/pmc_calib.py 1024 > /dev/null 2>> $OUT/${TAG}_pmc_$C.err
+  python $ROOT/tools/pmc_summary.py $(db /tmp/p_$C) 20 > $OUT/${TAG}_pmc_$(echo $C | tr A-Z a-z).txt
+  python $ROOT/tools/pmc_summary.py $(db /tmp/c_$C) 0 > $OUT/${TAG}_pmc_calib_$(echo $C | tr A-Z a-z).txt
+done
+python $ROOT/tools/pmc_traffic.py $(db /tmp/p_FETCH_SIZE) $(db /tmp/p_WRITE_SIZE) $(db /tmp/c_FETCH_SIZE) $(db /tmp/c_WRITE_SIZE) 1024 > $OUT/${TAG}_gemm_traffic.json
+head -c 1500 $OUT/${TAG}_gemm_traffic.json
