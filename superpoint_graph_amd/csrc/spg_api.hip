@@ -111,6 +111,97 @@ __global__ void spg_ecc_generic_bwd_w_kernel(SpgGraph g, const T* __restrict__ x
   else gw[t] = v;
 }
 
+// ---- stand-alone backward at the hot-path shape (32 -> 32 channels, fp32, no filter sharing): the fused forms of the two
+//      generic kernels above.  grad_x: one wavefront per SOURCE node walks its out-edges in the reverse CSR, 4 edges per
+//      batch with all loads issued first (a 4 KB filter = 4 float4 per lane), W_e . (grad_out[dst] / deg[dst]) reduced over
+//      the 8 lanes that share an input channel -- no atomics, deterministic.  grad_w: one wavefront per edge writes the
+//      outer product h_src (x) grad_out[dst] / deg[dst] as 4 float4 per lane.  (reference: GraphConvFunction.backward,
+//      learning/ecc/GraphConvModule.py:92-141, which loops over edge shards and calls its CUDA-string kernels.)
+__global__ __launch_bounds__(256) void spg_ecc32_bwd_x_kernel(SpgGraph g, const float* __restrict__ w, const float* __restrict__ go,
+                                                              int n_x_rows, int matrix, float* __restrict__ gx) {
+  const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n_x_rows) return;
+  const int b = j < g.hdr[1] ? g.rev_rowptr[j] : 0, e_ = j < g.hdr[1] ? g.rev_rowptr[j + 1] : 0;
+  if (matrix) {
+    float pq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = b; t < e_; t += 4) {
+      int eid[4], did[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) eid[u] = g.rev_eid[min(t + u, e_ - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) did[u] = g.dst[eid[u]];
+      f32x4 wv[4][4], g4[4];
+      float inv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g4[u] = *reinterpret_cast<const f32x4*>(go + (long)did[u] * 32 + 4 * (lane & 7));
+        inv[u] = (t + u < e_) ? 1.f / (float)(g.rowptr[did[u] + 1] - g.rowptr[did[u]]) : 0.f;
+        const f32x4* We = reinterpret_cast<const f32x4*>(w + (long)eid[u] * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[u][q] = We[lane + 64 * q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          pq[q] += inv[u] * ((wv[u][q][0] * g4[u][0] + wv[u][q][1] * g4[u][1]) + (wv[u][q][2] * g4[u][2] + wv[u][q][3] * g4[u][3]));
+      }
+    }
+#pragma unroll
+    for (int off = 1; off <= 4; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pq[q] += __shfl_xor(pq[q], off, 64);
+    }
+    if ((lane & 7) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gx[(long)j * 32 + (lane >> 3) + 8 * q] = pq[q];      // input channel k = lane/8 + 8q
+    }
+  } else if (lane < 32) {
+    float sacc = 0.f;
+    for (int t = b; t < e_; ++t) {
+      const int e = g.rev_eid[t], d = g.dst[e];
+      sacc = fmaf(w[(long)e * 32 + lane], go[(long)d * 32 + lane] / (float)(g.rowptr[d + 1] - g.rowptr[d]), sacc);
+    }
+    gx[(long)j * 32 + lane] = sacc;
+  }
+}
+
+__global__ __launch_bounds__(256) void spg_ecc32_bwd_w_kernel(SpgGraph g, const float* __restrict__ x, const float* __restrict__ go,
+                                                              int matrix, float* __restrict__ gw) {
+  const int lane = threadIdx.x & 63, e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= g.E) return;
+  const int d = g.dst[e];
+  const float inv = 1.f / (float)(g.rowptr[d + 1] - g.rowptr[d]);
+  const float* hs = x + (long)g.src[e] * 32;
+  const float* gd = go + (long)d * 32;
+  if (matrix) {
+    f32x4 g4 = *reinterpret_cast<const f32x4*>(gd + 4 * (lane & 7));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) g4[c] *= inv;
+    f32x4* o = reinterpret_cast<f32x4*>(gw + (long)e * 1024);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float hk = hs[(lane >> 3) + 8 * q];
+      o[lane + 64 * q] = f32x4{hk * g4[0], hk * g4[1], hk * g4[2], hk * g4[3]};
+    }
+  } else if (lane < 32) {
+    gw[(long)e * 32 + lane] = hs[lane] * (gd[lane] * inv);
+  }
+}
+
+static int ecc32_bwd(const float* x, const float* w, const SpgGraph& g, int n_x_rows, int matrix, const float* go, float* gx,
+                     float* gw, hipStream_t st) {
+  if (gx && n_x_rows > 0) {
+    hipLaunchKernelGGL(spg_ecc32_bwd_x_kernel, dim3(spg_cdiv(n_x_rows, 4)), dim3(256), 0, st, g, w, go, n_x_rows, matrix, gx);
+    SPG_LAUNCH_CHECK();
+  }
+  if (gw && g.E > 0) {
+    hipLaunchKernelGGL(spg_ecc32_bwd_w_kernel, dim3(spg_cdiv(g.E, 4)), dim3(256), 0, st, g, x, go, matrix, gw);
+    SPG_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 template <typename T>
 static int ecc_generic_fwd(const void* x, const void* w, const int64_t* idxe, const SpgGraph& g, int cin, int cout,
                            int matrix, void* out, hipStream_t st) {
@@ -171,6 +262,10 @@ extern "C" int spg_ecc_aggregate_bwd(int dtype, const void* x, const void* w, co
   SPG_CHECK_ARG(dtype == 0 || dtype == 1, "dtype must be 0 (f32) or 1 (f64)");
   SpgGraph g = spg_graph_view(graph_ws, N, E);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0 && cin == 32 && cout == 32 && idxe == nullptr &&
+      ((((uintptr_t)w) | ((uintptr_t)grad_out) | ((uintptr_t)grad_w)) & 15) == 0)      // hot-path shape: fused kernels
+    return ecc32_bwd((const float*)x, (const float*)w, g, n_x_rows, w_is_matrix, (const float*)grad_out, (float*)grad_x,
+                     (float*)grad_w, st);
   return dtype == 0 ? ecc_generic_bwd<float>(x, w, idxe, g, n_x_rows, n_w_rows, cin, cout, w_is_matrix, grad_out, grad_x,
                                              grad_w, st)
                     : ecc_generic_bwd<double>(x, w, idxe, g, n_x_rows, n_w_rows, cin, cout, w_is_matrix, grad_out,

@@ -78,7 +78,8 @@ def test_generic_ecc_fp64_golden_and_gradcheck(hip):
 @pytest.mark.parametrize('matrix', [True, False])
 @pytest.mark.parametrize('n,e', [(40, 150), (1000, 5000), (7000, 30000)])
 def test_fused_ecc_32_channels(hip, matrix, n, e):
-    """hot-path shape through spg_ecc_aggregate_fwd's fused wave-per-node kernel + the generic backward."""
+    """hot-path shape through the fused kernels of spg_ecc_aggregate_fwd (wave per node) and spg_ecc_aggregate_bwd (wave per
+    source node over the reverse CSR for grad_x, wave per edge for grad_w) against the fp64 oracle."""
     from superpoint_graph_amd.learning import ecc
     idxn, degs = _random_graph(n, e, 7)
     gen = torch.Generator().manual_seed(2)
