@@ -359,6 +359,11 @@ def main():
         # kernel-trace summary in profiles/ lists for spg_rowgemm_kernel<128, 128, 2, 2, false, 1, true>
         dms, dl, dfl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
         L.spg_prof_read_tag(L.spg_prof_tag(1, 128, 128, 0, 1, 1), ctypes.byref(dms), ctypes.byref(dl), ctypes.byref(dfl))
+        # ... and the single heaviest LAUNCH SHAPE of the step (one (instantiation, N, K) row of the per-shape table): the
+        # instantiation average above mixes the MFMA-bound 128->256 layer with HBM-bound 64->128 ones
+        keys, vals = (ctypes.c_int * (4 * 256))(), (ctypes.c_double * (2 * 256))()
+        nshape = L.spg_prof_read_shapes(keys, vals, 256)
+        top = max(range(nshape), key=lambda j: vals[2 * j]) if nshape > 0 else -1
         L.spg_prof_read(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flops), 1)
         L.spg_prof_enable(0)
         log('instrumented pass done')
@@ -370,7 +375,7 @@ def main():
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                               'traffic_source': ('static:' + traffic_src) if traffic_src else None,
-                              'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes of an earlier run, not measured in this run)',
+                              'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes of the same command, tools/collect_profiles.sh; read from the file, not measured in this run)',
                               'kernel': 'spg_rowgemm_kernel + spg_wgrad_kernel (fp32 MFMA 32x32x2)',
                               'launches_per_step': launches.value / nprof, 'gemm_ms_per_step': ms.value / nprof,
                               'algorithmic_gflop_per_step': gflop_step,
@@ -381,6 +386,13 @@ def main():
                 'dominant_kernel': 'spg_rowgemm_kernel<128, 128, 2, 2, false, 1, true, true>', 'dominant_launches_per_step': dl.value / nprof,
                 'dominant_avg_us': dms.value / dl.value * 1e3, 'dominant_gflop_per_launch': dfl.value / dl.value / 1e9,
                 'dominant_achieved': dach, 'dominant_frac': dach / PEAK_FP32_MFMA_TFLOPS})
+        if top >= 0 and vals[2 * top] > 0:
+            tms, tfl, tcnt = vals[2 * top], vals[2 * top + 1], keys[4 * top + 3]
+            result['roofline'].update({
+                'heaviest_shape': f'tag {keys[4 * top]} (tile/mode code of spg_prof_tag), N={keys[4 * top + 1]}, K={keys[4 * top + 2]}',
+                'heaviest_shape_launches_per_step': tcnt / nprof, 'heaviest_shape_avg_us': tms / tcnt * 1e3,
+                'heaviest_shape_gflop_per_launch': tfl / tcnt / 1e9,
+                'heaviest_shape_frac': tfl / (tms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS})
     if world == 1 and not args.no_trainer_window:
         result['trainer_window'] = trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log)
     if world > 1:
