@@ -34,12 +34,13 @@ namespace {
 struct ProfRec { hipEvent_t a, b; double flops; int tag; int M, N, K; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+std::mutex g_prof_mutex;      // host threads may launch on different streams while the instrumentation is on
 struct ProfScope {
   hipStream_t st; bool on; ProfRec r;
   ProfScope(hipStream_t s, double flops, int tag = 0) : st(s), on(g_prof_on) {
     if (on) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.flops = flops; r.tag = tag; r.M = r.N = r.K = 0; (void)hipEventRecord(r.a, st); }
   }
-  ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); } }
+  ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); std::lock_guard<std::mutex> lock(g_prof_mutex); g_prof.push_back(r); } }
 };
 }  // namespace
 extern "C" void spg_prof_enable(int on) { g_prof_on = on != 0; }
@@ -65,6 +66,7 @@ extern "C" int spg_tune(int key, int value) {
 
 // per-(instantiation, shape) totals of the instrumented launches: up to `max` rows {tag, N, K, launches} / {ms, flops}
 extern "C" int spg_prof_read_shapes(int* keys, double* vals, int max) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   int n = 0;
   for (ProfRec& r : g_prof) {
     (void)hipEventSynchronize(r.b);
@@ -87,6 +89,7 @@ extern "C" int spg_prof_read_shapes(int* keys, double* vals, int max) {
 #define SPG_PROF_TAG(kind, IT, JT, X, Y, FULL) ((kind) * 1000000 + ((IT) / 32) * 100000 + ((JT) / 32) * 10000 + ((X) + 1) * 100 + ((Y) + 1) * 10 + (FULL))
 extern "C" int spg_prof_tag(int kind, int it, int jt, int x, int y, int full) { return SPG_PROF_TAG(kind, it, jt, x, y, full ? 1 : 0); }
 extern "C" int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   double t = 0.0, f = 0.0;
   long n = 0;
   for (ProfRec& r : g_prof) {
@@ -102,6 +105,7 @@ extern "C" int spg_prof_read_tag(int tag, double* ms, long* launches, double* fl
   return 0;
 }
 extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int reset) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   double t = 0.0, f = 0.0;
   for (ProfRec& r : g_prof) {
     (void)hipEventSynchronize(r.b);
