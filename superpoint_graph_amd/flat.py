@@ -38,8 +38,10 @@ class FlatParameters:
             p.grad = self._gbuf[off:off + n].view(p.shape)
         self.flat = torch.nn.Parameter(data)             # hand THIS to the optimizer
         self.flat.grad = self._gbuf[:self.numel]
-        for m in model.modules():
+        self._modules = list(model.modules())
+        for m in self._modules:
             m._spg_direct_grads = True                   # the HIP autograd Functions then write into p.grad directly
+            m._spg_grad_written = False
 
     def adam_step(self, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip=0.0):
         """Element-wise gradient clamp (learning/main.py:210-212) + torch.optim.Adam update (learning/main.py:433-437)
@@ -54,6 +56,7 @@ class FlatParameters:
                                                   self._v.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
                                                   grad_clip, self._t, torch.cuda.current_stream().cuda_stream),
                    'spg_adam_clamp_step')
+        self._clear_written()
 
     def attach_optimizer(self, optimizer):
         """Keeps a `torch.optim.Adam` as the owner of the hyper-parameters (learning-rate schedulers keep working) and of the
@@ -86,6 +89,11 @@ class FlatParameters:
 
     def zero_grad(self):
         self._gbuf.zero_()
+        self._clear_written()
+
+    def _clear_written(self):
+        for m in self._modules:
+            m._spg_grad_written = False
 
     def clamp_grad_(self, clip: float):
         if clip > 0:
@@ -109,3 +117,15 @@ class FlatParameters:
         else:
             dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
         self.flat.grad.div_(self._gbuf[self.numel])
+
+
+def mark_direct_write(module):
+    """The HIP backward kernels WRITE the gradient views of a FlatParameters model (they do not accumulate, unlike
+    autograd): a second backward through the same module before `FlatParameters.zero_grad()` / the arena's optimizer step
+    (gradient accumulation over several batches, one module used twice in a graph) would silently drop the first
+    gradients -- raise instead."""
+    if getattr(module, '_spg_grad_written', False):
+        raise RuntimeError(f'{type(module).__name__}: second backward into the flat gradient arena without '
+                           'FlatParameters.zero_grad() in between; the HIP kernels overwrite (do not accumulate) the '
+                           'gradient views -- gradient accumulation is not supported in FlatParameters mode')
+    module._spg_grad_written = True

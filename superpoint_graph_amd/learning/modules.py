@@ -124,6 +124,8 @@ class _LinearFunction(torch.autograd.Function):
         direct = getattr(m, '_spg_direct_grads', False) and weight.grad is not None and weight.grad.is_contiguous() and \
             (m.bias is None or (m.bias.grad is not None and m.bias.grad.is_contiguous()))
         if direct:          # FlatParameters: write into the (zeroed) arena views, nothing for autograd to accumulate
+            from ..flat import mark_direct_write
+            mark_direct_write(m)
             ops.linear_wgrad(gy, x, out=weight.grad)
             if m.bias is not None:
                 ops.colsum(gy, out=m.bias.grad)
@@ -175,6 +177,8 @@ class _EccRnnFunction(torch.autograd.Function):
         d_f = _direct_grad_targets(ctx.module, ctx.groups[:nf], 4)
         d_c = _direct_grad_targets(ctx.module, ctx.groups[nf:], 6)
         if d_f is not None and d_c is not None:
+            from ..flat import mark_direct_write
+            mark_direct_write(ctx.module)
             grad_h0, _ = ops.eccrnn_backward(ctx.state, ctx.groups, grad_out, d_f + d_c)
             return (None, grad_h0, None, None, None) + (None,) * ctx.nflat
         if ctx.nflat == 1 and getattr(ctx.module, '_spg_direct_grads', False):

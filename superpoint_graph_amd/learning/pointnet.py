@@ -152,6 +152,8 @@ class _PointNetFunction(torch.autograd.Function):
     def backward(ctx, grad_emb):
         direct = _direct_grad_targets(ctx.module, ctx.groups, 4)
         if direct is not None:      # gradients are written straight into the pre-assigned .grad views (FlatParameters)
+            from ..flat import mark_direct_write
+            mark_direct_write(ctx.module)
             ops.pointnet_backward(ctx.state, ctx.groups, grad_emb, direct)
             return (None,) * (5 + ctx.nflat)
         if ctx.nflat == 1 and getattr(ctx.module, '_spg_direct_grads', False):
@@ -181,6 +183,9 @@ class _LocalPointNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_emb):
         direct = _direct_grad_targets(ctx.module, ctx.groups, 4)
+        if direct is not None:
+            from ..flat import mark_direct_write
+            mark_direct_write(ctx.module)
         gg, g_T, g_glob = ops.pointnet_backward(ctx.state, ctx.groups, grad_emb, direct, want_input_grads=True)
         g_T = g_T.view(-1, 2, 2)
         if direct is not None:

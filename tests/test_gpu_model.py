@@ -130,6 +130,16 @@ def test_flat_parameters_direct_gradients(hip):
         else:
             assert maxrel(p.grad, ref) < 5e-4, k
     assert sorted(model.state_dict().keys()) == sorted(state0.keys())
+    # a second backward WITHOUT zero_grad would overwrite (not accumulate) the arena views: refused loudly
+    emb, logits, embedder = _run(model, batch, 1)
+    loss = F.cross_entropy(logits, batch['label_mode'].to(DEV), weight=cw)
+    with pytest.raises(RuntimeError, match='second backward'):
+        loss.backward()
+        embedder.bw_hook()
+    arena.zero_grad()                               # ... and accepted again after the arena was re-zeroed
+    emb, logits, embedder = _run(model, batch, 1)
+    F.cross_entropy(logits, batch['label_mode'].to(DEV), weight=cw).backward()
+    embedder.bw_hook()
 
 
 def test_train_forward_vs_fp64_oracle(hip):
