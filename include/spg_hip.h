@@ -11,7 +11,7 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer borrowed for the duration of
  *     the call; the caller -- torch -- owns all memory and sizes workspaces with the *_workspace_bytes queries.  The
- *     library itself owns exactly one device allocation: 16 KB of self-resetting reduction tickets (first launch of a
+ *     library itself owns exactly one device allocation per GPU: 16 KB of self-resetting reduction tickets (first launch of a
  *     sliced BatchNorm finalize), plus -- only after spg_rccl_init -- what RCCL allocates for its communicator;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *   - return value: 0 on success, a hipError_t (>0) if a launch failed, -1 for an argument error;

@@ -1269,19 +1269,22 @@ int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t 
 // result is deterministic, and resets the ticket for the next launch.
 #define SPG_FIN_SLICES 8
 
-static int* g_fin_counters = nullptr;    // 4096 self-resetting tickets (the only device memory the library owns)
-static unsigned g_fin_next = 0;
-static std::mutex g_fin_mutex;           // host threads may drive different streams of the (single) device
+#define SPG_MAX_DEVICES 16
+static int* g_fin_counters[SPG_MAX_DEVICES] = {nullptr};    // per device: 4096 self-resetting tickets (the only device memory the library owns)
+static unsigned g_fin_next[SPG_MAX_DEVICES] = {0};
+static std::mutex g_fin_mutex;           // host threads may drive different streams / devices
 
 static int* spg_fin_counter_window(int n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) return nullptr;
   std::lock_guard<std::mutex> lock(g_fin_mutex);
-  if (g_fin_counters == nullptr) {
-    if (hipMalloc((void**)&g_fin_counters, 4096 * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemset(g_fin_counters, 0, 4096 * sizeof(int)) != hipSuccess) return nullptr;
+  if (g_fin_counters[dev] == nullptr) {     // allocated on the device the launch goes to (the current one)
+    if (hipMalloc((void**)&g_fin_counters[dev], 4096 * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(g_fin_counters[dev], 0, 4096 * sizeof(int)) != hipSuccess) return nullptr;
   }
-  if (g_fin_next + n > 4096) g_fin_next = 0;
-  int* w = g_fin_counters + g_fin_next;     // rotating windows: concurrent launches on other streams do not collide
-  g_fin_next += n;
+  if (g_fin_next[dev] + n > 4096) g_fin_next[dev] = 0;
+  int* w = g_fin_counters[dev] + g_fin_next[dev];     // rotating windows: concurrent launches on other streams do not collide
+  g_fin_next[dev] += n;
   return w;
 }
 
