@@ -211,6 +211,10 @@ def main():
     ap.add_argument('--no-forward-only', action='store_true', help='skip the forward-only side measurement (BASELINE configs[1])')
     ap.add_argument('--sync-bn', type=int, default=0, help='1: BatchNorm statistics all-reduced over the ranks (exact single-process batch semantics); 0: per-rank statistics')
     ap.add_argument('--native-rccl', type=int, default=1, help='1: the C library issues the RCCL collectives itself (own communicator); 0: torch.distributed calls')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
+                    help="arithmetic of the wide row-GEMMs: f32 = fp32 MFMA (default, the headline); bf16x3 = split-bf16 products (three "
+                         "bf16 MFMAs per operand pair, fp32 accumulate, ~2^-16 per product); bf16 = bf16 operands.  A SEPARATE line: never "
+                         "replaces the f32 headline (tolerances: tests/test_gpu_precision.py)")
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
     args = ap.parse_args()
 
@@ -224,6 +228,7 @@ def main():
     T0 = time.perf_counter()
     from superpoint_graph_amd import _lib, dist as spd, ops
     from superpoint_graph_amd.learning import pointnet
+    PREC = {'f32': 0, 'bf16': 1, 'bf16x3': 3}[args.precision]
     if args.device_index >= 0:
         torch.cuda.set_device(args.device_index)
     rank, local, world = spd.init_from_env(args.backend)
@@ -247,6 +252,8 @@ def main():
     embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
     from superpoint_graph_amd.flat import FlatParameters
     arena = FlatParameters(model)                    # parameters / gradients as views of one flat buffer each
+    if _lib.lib().spg_tune(7, PREC) < 0:             # precision mode of the wide row-GEMMs (0 = fp32 MFMA)
+        raise RuntimeError('libspg_hip.so has no precision switch (spg_tune key 7)')
     w_local = spd.loss_weight(label_mode)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     n_sp_step = int(flag.numel())
@@ -334,11 +341,11 @@ def main():
         'metric': 'superpoints/sec (embed+ECC fwd+bwd), S3DIS-shaped SPG', 'value': value, 'unit': 'superpoints/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'ms_per_step_min': step_ms[0], 'ms_per_step_median': step_ms[len(step_ms) // 2], 'ms_per_step_max': step_ms[-1],
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'f32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 MFMA operands of the wide row-GEMMs, f32 accumulate and f32 everywhere else; NOT the headline arithmetic)', 'bf16': 'bf16 (MFMA operands of the wide row-GEMMs, f32 accumulate and f32 everywhere else; NOT the headline arithmetic)'}[args.precision], 'data': 'synthetic',
         'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x {args.n_feat} feats, '
                                f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config}' + (' (S3DIS production model, matrix filters, 10 GRU iterations)' if args.model_config == 'gru_10_0,f_13' else '') + ', train step fwd+bwd+Adam',
                    'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'parallelism': (f'dp{world} (one scene shard per GPU, one flat-bucket RCCL all-reduce, ' + ('issued by libspg_hip' if native else 'torch.distributed') + ')') if world > 1 else 'single GPU',
-                   'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics'},
+                   'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics', 'precision': args.precision},
     }
 
     if not args.no_roofline:
@@ -380,6 +387,13 @@ def main():
                               'launches_per_step': launches.value / nprof, 'gemm_ms_per_step': ms.value / nprof,
                               'algorithmic_gflop_per_step': gflop_step,
                               'step_achieved': gflop_step / ms_per_step, 'step_frac': gflop_step / ms_per_step / PEAK_FP32_MFMA_TFLOPS}
+        if PREC != 0 and traffic:
+            # the bf16 modes move the wide GEMMs under the HBM roof (activations stay fp32 in memory: same bytes, less matrix
+            # time): report the GEMM launches against HBM -- static traffic of the same launches ÷ their measured time
+            gbs = traffic * launches.value / (ms.value * 1e-3) / 1e9
+            result['roofline'].update({'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
+                                       'fp32_equivalent_tflops': ach,
+                                       'kernel': 'spg_rowgemm_kernel (bf16 MFMA 32x32x16, %s) + spg_wgrad_kernel' % args.precision})
         if dl.value > 0:
             dach = dfl.value / (dms.value * 1e-3) / 1e12
             result['roofline'].update({

@@ -725,6 +725,127 @@ struct SpgWeightRedPipe {     // red-major [32 x JT] weight tile: W [kred, nout]
 };
 
 // ----------------------------------------------------------------------------------------------
+// Split-bf16 arithmetic (opt-in precision modes of the wide row-GEMMs, spg_tune key 7 / SpgGemmParams::prec):
+//   prec 3  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi   with x_hi = bf16(x), x_lo = bf16(x - x_hi): three
+//           v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each): 5.3x
+//           the matrix rate, products exact to ~2^-16 relative (the dropped a_lo*b_lo term and the 16-bit residuals),
+//           fp32 accumulation as before;
+//   prec 1  a_hi*b_hi only: plain bf16 operands (2^-9 relative), fp32 accumulation.
+// LDS layout: the SAME planes of 16-byte slots as the fp32 out-major tile -- plane p, slot row -- but a slot holds 8
+// consecutive reduction indices as bf16: planes 0-3 the hi parts of k = 8p .. 8p+7, planes 4-7 the lo parts.  A lane
+// (row r, half h) reads plane 2s+h (hi) / 4+2s+h (lo) with one ds_read_b128 per MFMA operand (s = k-step of 16).
+// ----------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// 4 floats -> 4 bf16 hi (2 dwords) + 4 bf16 lo (2 dwords); 12 VALU instructions
+__device__ __forceinline__ void spg_split_bf16(const f32x4& v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const f32x2 x = {v[2 * e], v[2 * e + 1]};
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+    const f32x2 r = {x[0] - __builtin_bit_cast(float, hp << 16), x[1] - __builtin_bit_cast(float, hp & 0xffff0000u)};
+    hi[e] = hp;
+    lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  }
+}
+
+// out-major tile of an A operand in the bf16 layout: called by the fast rows pipe with its finished float4
+// (k = 4*kq .. 4*kq+3 of `row`): hi -> plane kq/2, lo -> plane 4 + kq/2, byte (kq & 1) * 8 of the slot
+template <int PREC>
+__device__ __forceinline__ void spg_store_bf16_quad(f32x4* __restrict__ lds, int stride, int kq, int row, const f32x4& v) {
+  u32x2 hi, lo;
+  spg_split_bf16(v, hi, lo);
+  u32x2* base = reinterpret_cast<u32x2*>(lds);
+  base[2 * ((kq >> 1) * stride + row) + (kq & 1)] = hi;
+  if (PREC == 3) base[2 * ((4 + (kq >> 1)) * stride + row) + (kq & 1)] = lo;
+}
+
+// weights in the bf16 layout, pre-split in global memory by spg_split_weights_kernel: Wb [2][nout][ldb] bf16 (hi matrix,
+// then lo matrix; reduction index contiguous).  One 16-byte unit (8 reduction indices of one output channel) per load.
+template <int JT, int PREC>
+struct SpgWeightBf16 {
+  static constexpr int UNITS = JT * 4 * (PREC == 3 ? 2 : 1), NI = (UNITS + SPG_THREADS - 1) / SPG_THREADS;
+  f32x4 raw[NI];
+  unsigned voff[NI];
+  // unit u: k8 = u & 3, j = (u >> 2) % JT, part = u / (4 * JT) (0 hi, 1 lo)
+  __device__ __forceinline__ void init(long ldb, int n0, int nout, long part_stride_bytes) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const unsigned u = threadIdx.x + SPG_THREADS * i, uu = u < (unsigned)UNITS ? u : 0u;
+      const unsigned k8 = uu & 3u, j = (uu >> 2) % JT, part = uu / (4u * JT);
+      voff[i] = (unsigned)(part * part_stride_bytes) + (((int)(n0 + j) < nout ? j : 0u) * (unsigned)ldb + 8u * k8) * 2u;
+    }
+  }
+  __device__ __forceinline__ void load_part(const void* __restrict__ Wb, long ldb, int n0, int k0, int i) {
+    raw[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wb) + ((long)n0 * ldb + k0) * 2 + voff[i]);
+  }
+  __device__ __forceinline__ void store_part(f32x4* __restrict__ lds, int i) const {
+    const unsigned u = threadIdx.x + SPG_THREADS * i;
+    if (UNITS % SPG_THREADS != 0 && u >= (unsigned)UNITS) return;
+    const unsigned k8 = u & 3u, j = (u >> 2) % JT, part = u / (4u * JT);
+    lds[(4 * part + k8) * (JT + 1) + j] = raw[i];
+  }
+};
+
+// MFMAs of one reduction chunk (K = 32 = two k-steps of 16) from bf16 tiles; `piece(slot)`, slot 0..15, as in
+// spg_mfma_chunk_il (the staging work of the next chunks, spread between the MFMAs)
+template <int TI, int TJ, int PREC, class Piece>
+__device__ __forceinline__ void spg_mfma_chunk_bf16_il(const f32x4* __restrict__ As, const f32x4* __restrict__ Bs, int strideA,
+                                                       int strideB, int rowA, int rowB, int h, f32x16 (&acc)[TI][TJ], Piece&& piece) {
+  constexpr int NG = 2 * TI * TJ * (PREC == 3 ? 3 : 1);      // MFMA count; the 16 piece slots are spread over them
+  int slot = 0, g = 0;
+  auto after = [&]() __attribute__((always_inline)) {
+    ++g;
+    const int upto = (16 * g) / NG;
+#pragma unroll
+    for (; slot < upto; ++slot) piece(slot);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    // order hi*hi, hi*lo, then lo*hi: the lo fragments of A are loaded into registers only after the B lo fragments are
+    // dead (24 fragment registers live instead of 32 -- the backward instantiations have none to spare)
+    bf16x8 ah[TI], bh[TJ], xl[TI > TJ ? TI : TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) ah[i] = __builtin_bit_cast(bf16x8, As[(2 * s + h) * strideA + rowA + 32 * i]);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bh[j] = __builtin_bit_cast(bf16x8, Bs[(2 * s + h) * strideB + rowB + 32 * j]);
+    if (PREC == 3) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) xl[j] = __builtin_bit_cast(bf16x8, Bs[(4 + 2 * s + h) * strideB + rowB + 32 * j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        after();
+      }
+    if (PREC == 3) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], xl[j], acc[i][j], 0, 0, 0);
+          after();
+        }
+#pragma unroll
+      for (int i = 0; i < TI; ++i) xl[i] = __builtin_bit_cast(bf16x8, As[(4 + 2 * s + h) * strideA + rowA + 32 * i]);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], bh[j], acc[i][j], 0, 0, 0);
+          after();
+        }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Full-tile fast path.  VALU instructions are NOT free next to MFMAs on gfx950 -- they take issue cycles from the same
 // SIMD (measured, tools/probe/mfma_probe.hip: 4 VALU per fp32 MFMA cost 25 % of the MFMA rate) -- and in the masked
 // pipes above most of the VALU work of a chunk is 64-bit address arithmetic, clamps and validity selects.  When every
@@ -812,6 +933,11 @@ struct SpgRowsFast {           // out-major [ROWS x 32] tile, every row and chan
   __device__ __forceinline__ void store_part(f32x4* __restrict__ lds, int i) const {
     const int tid = threadIdx.x;
     lds[(tid & 7) * (ROWS + 1) + (tid >> 3) + 32 * i] = spg_finish_fast<MODE>(q, raw[i], lo, px, pai, (tid >> 3) + 32 * i);
+  }
+  template <int PREC>
+  __device__ __forceinline__ void store_part_bf16(f32x4* __restrict__ lds, int i) const {      // bf16 layout (see spg_store_bf16_quad)
+    const int tid = threadIdx.x;
+    spg_store_bf16_quad<PREC>(lds, ROWS + 1, tid & 7, (tid >> 3) + 32 * i, spg_finish_fast<MODE>(q, raw[i], lo, px, pai, (tid >> 3) + 32 * i));
   }
 };
 

@@ -49,10 +49,14 @@ struct SpgGemmParams {
   int remap, ncol, ntile, rstride;
   int stat_accum;     // persistent launches: one statistics partial per workgroup and row-wave (accumulated over its tiles)
   int dbg;            // timing-attribution switches (spg_tune key 3), persistent launches only
+  // opt-in bf16 / split-bf16 MFMA (spg_common.h): the weights of THIS GEMM's orientation pre-split by
+  // spg_launch_split_weights -- Wb [2][N][ldwb] bf16, reduction index contiguous (hi matrix, then lo matrix); null: fp32 MFMA
+  const void* Wb;
+  long ldwb, wb_part_bytes;
 };
 
 // tuning knobs (process-global; defaults are the production values): see spg_tune in include/spg_hip.h
-enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_FIN_SLICE_MIN = 4, SPG_TUNE_NO_STAT_ACCUM = 5, SPG_TUNE_COUNT = 16 };
+enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_FIN_SLICE_MIN = 4, SPG_TUNE_NO_STAT_ACCUM = 5, SPG_TUNE_PRECISION = 7, SPG_TUNE_COUNT = 16 };
 int spg_tune_get(int key);
 
 // dW[N,K] = sum_m prologue_a(dY)[m, n] * prologue_b(A)[m, k]
@@ -63,6 +67,17 @@ struct SpgWgradParams {
   int rows_per_split; // multiple of 32
   float* partial;     // [nsplit][N][K]
 };
+
+// bf16 copies of a weight matrix W [N, K] (row stride ldw floats) for the bf16 MFMA modes: fwd [2][N][ldk] (hi, lo; the
+// forward GEMM's orientation) and, when `bwd` is given, the transpose [2][K][ldn] (the data gradient's orientation);
+// ldk = roundup8(K), ldn = roundup8(N); all jobs of a network in one launch
+struct SpgSplitJob { const float* W; long ldw; int N, K; void* fwd; void* bwd; };
+#define SPG_SPLIT_MAX_JOBS 40
+struct SpgSplitBatch { SpgSplitJob jobs[SPG_SPLIT_MAX_JOBS]; int njobs = 0; };
+inline long spg_split_ld(int k) { return (k + 7) & ~7; }
+inline size_t spg_split_bytes(int rows, int cols) { return (size_t)2 * rows * spg_split_ld(cols) * 2; }
+int spg_launch_split_weights(const SpgSplitBatch& b, hipStream_t stream);
+int spg_gemm_precision();      // spg_tune key 7: 0 fp32 MFMA, 1 bf16, 3 split-bf16
 
 int spg_gemm_ntiles(const SpgGemmParams& p);
 // number of statistics / pooling partials per row tile (= waves along the rows of the tile shape used for this problem)

@@ -492,7 +492,9 @@ __device__ __forceinline__ void spg_tile_epilogue(const SpgGemmParams& p, f32x16
 // latency is paid per tile (measured before: wave slots empty 20 % of the kernel, conv5 at 0.69 of the MFMA peak even
 // without any epilogue).  A launch with one tile per workgroup (rstride >= ntile) is the degenerate case.
 // STREAM: compiled with the multi-tile stream (persistent launches); without it has_next is a compile-time false
-template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false, bool STREAM = false>
+// PREC: 0 = fp32 MFMA; 1 / 3 = bf16 / split-bf16 MFMA (FULL only; spg_common.h): operands are converted while staging,
+// the weights come pre-split (p.Wb, out-major for both the forward and -- pre-transposed -- the data gradient)
+template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false, bool STREAM = false, int PREC = 0>
 __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGemmParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
   constexpr int A_F4 = (SPG_KC / 4) * (IT + 1);                                  // float4 slots of one A buffer
-  constexpr int B_F4 = WRED ? SPG_KC * (JT + 4) / 4 : (SPG_KC / 4) * (JT + 1);   // float4 slots of one weight buffer
+  constexpr int B_F4 = (WRED && PREC == 0) ? SPG_KC * (JT + 4) / 4 : (SPG_KC / 4) * (JT + 1);   // float4 slots of one weight buffer
   f32x16 acc[TI][TJ];
 
   if constexpr (AMODE >= 0 && FULL) {
@@ -528,29 +530,47 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
     SpgRowsFast<AMODE, IT> pa0, pa1;
     SpgWeightFast<JT> pw0, pw1;
     SpgWeightRedFast<JT> pwr0, pwr1;
+    SpgWeightBf16<JT, PREC ? PREC : 1> pb0, pb1;
     constexpr int NIA = SpgRowsFast<AMODE, IT>::NI;
-    constexpr int NIW = WRED ? SpgWeightRedFast<JT>::NI : SpgWeightFast<JT>::NI;
+    constexpr int NIW = PREC ? SpgWeightBf16<JT, PREC ? PREC : 1>::NI : (WRED ? SpgWeightRedFast<JT>::NI : SpgWeightFast<JT>::NI);
+    // one place per weight-pipe operation: the three layouts (out-major fp32, red-major fp32, out-major bf16) are
+    // compile-time alternatives
+    auto w_load = [&](SpgWeightFast<JT>& pw, SpgWeightRedFast<JT>& pwr, SpgWeightBf16<JT, PREC ? PREC : 1>& pb, int k, int i) __attribute__((always_inline)) {
+      if constexpr (PREC != 0) pb.load_part(p.Wb, p.ldwb, n0, k, i);
+      else if constexpr (WRED) pwr.load_part(p.W, p.ldw, n0, k, i);
+      else pw.load_part(p.W, p.ldw, n0, k, i);
+    };
+    auto w_store = [&](const SpgWeightFast<JT>& pw, const SpgWeightRedFast<JT>& pwr, const SpgWeightBf16<JT, PREC ? PREC : 1>& pb, f32x4* B, int i) __attribute__((always_inline)) {
+      if constexpr (PREC != 0) pb.store_part(B, i);
+      else if constexpr (WRED) pwr.store_part(reinterpret_cast<float*>(B), i);
+      else pw.store_part(B, i);
+    };
+    auto a_store = [&](const SpgRowsFast<AMODE, IT>& pa, f32x4* A, int i) __attribute__((always_inline)) {
+      if constexpr (PREC != 0) pa.template store_part_bf16<PREC ? PREC : 1>(A, i);
+      else pa.store_part(A, i);
+    };
     static_assert(NIA + NIW + 4 <= SPG_KC / 2, "staging pieces must fit the MFMA slots of a chunk");
     const int nchunk = p.K / SPG_KC;
     pa0.init(p.a, mvalid); pa1.init(p.a, mvalid);
-    if (WRED) { pwr0.init(p.ldw, n0, p.N); pwr1.init(p.ldw, n0, p.N); } else { pw0.init(p.ldw, n0, p.N); pw1.init(p.ldw, n0, p.N); }
+    if constexpr (PREC != 0) { pb0.init(p.ldwb, n0, p.N, p.wb_part_bytes); pb1.init(p.ldwb, n0, p.N, p.wb_part_bytes); }
+    else if (WRED) { pwr0.init(p.ldw, n0, p.N); pwr1.init(p.ldw, n0, p.N); } else { pw0.init(p.ldw, n0, p.N); pw1.init(p.ldw, n0, p.N); }
     // chunk 0 -> LDS buffer 0; chunk 1 in flight in set 1
     {
       pa0.prepare(p.a, tile, 0);
 #pragma unroll
       for (int i = 0; i < NIA; ++i) pa0.load_part(p.a, m0, 0, i);
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) { if (WRED) pwr0.load_part(p.W, p.ldw, n0, 0, i); else pw0.load_part(p.W, p.ldw, n0, 0, i); }
+      for (int i = 0; i < NIW; ++i) w_load(pw0, pwr0, pb0, 0, i);
 #pragma unroll
-      for (int i = 0; i < NIA; ++i) pa0.store_part(As, i);
+      for (int i = 0; i < NIA; ++i) a_store(pa0, As, i);
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) { if (WRED) pwr0.store_part(Bsr, i); else pw0.store_part(Bs, i); }
+      for (int i = 0; i < NIW; ++i) w_store(pw0, pwr0, pb0, Bs, i);
       const int k1 = nchunk > 1 ? SPG_KC : 0;
       pa1.prepare(p.a, tile, k1);
 #pragma unroll
       for (int i = 0; i < NIA; ++i) pa1.load_part(p.a, m0, k1, i);
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) { if (WRED) pwr1.load_part(p.W, p.ldw, n0, k1, i); else pw1.load_part(p.W, p.ldw, n0, k1, i); }
+      for (int i = 0; i < NIW; ++i) w_load(pw1, pwr1, pb1, k1, i);
     }
     __syncthreads();
     constexpr bool BIAS_IN_ACC = !WRED;
@@ -590,7 +610,8 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
       // time).  Chunks nchunk, nchunk+1 are chunks 0, 1 of the NEXT tile of this workgroup (clamped re-loads of the last
       // chunk when there is none: harmless).
       auto body = [&](int c, int k2, long ml, int tl, bool noload, SpgRowsFast<AMODE, IT>& paF, SpgWeightFast<JT>& pwF, SpgWeightRedFast<JT>& pwrF,
-                      SpgRowsFast<AMODE, IT>& paL, SpgWeightFast<JT>& pwL, SpgWeightRedFast<JT>& pwrL) __attribute__((always_inline)) {
+                      SpgWeightBf16<JT, PREC ? PREC : 1>& pbF, SpgRowsFast<AMODE, IT>& paL, SpgWeightFast<JT>& pwL, SpgWeightRedFast<JT>& pwrL,
+                      SpgWeightBf16<JT, PREC ? PREC : 1>& pbL) __attribute__((always_inline)) {
         const int buf = c & 1;
         const f32x4* Ac = As + buf * (A_F4 + B_F4);
         const f32x4* Bc = Bs + buf * (A_F4 + B_F4);
@@ -611,15 +632,16 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
           } else if (slot == 2) {
             if (!(DEFER2 && noload)) {
 #pragma unroll
-              for (int i = 0; i < NIW; ++i) { if (WRED) pwrL.load_part(p.W, p.ldw, n0, k2, i); else pwL.load_part(p.W, p.ldw, n0, k2, i); }
+              for (int i = 0; i < NIW; ++i) w_load(pwL, pwrL, pbL, k2, i);
             }
           } else if (slot < 3 + NIA) {
-            paF.store_part(An, slot - 3);
+            a_store(paF, An, slot - 3);
           } else if (slot < 3 + NIA + NIW) {
-            if (WRED) pwrF.store_part(reinterpret_cast<float*>(Bn), slot - 3 - NIA); else pwF.store_part(Bn, slot - 3 - NIA);
+            w_store(pwF, pwrF, pbF, Bn, slot - 3 - NIA);
           }
         };
-        if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+        if constexpr (PREC != 0) spg_mfma_chunk_bf16_il<TI, TJ, PREC>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+        else if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
         else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
         if (!(STREAM && (p.dbg & 32))) __syncthreads();      // (attribution switch: main loop without barriers)
       };
@@ -634,8 +656,8 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
         int ta = tile, tb = tile;
         if (ka >= nchunk) { if (has_next) { ka -= nchunk; ma = (STREAM && (p.dbg & 16)) ? ma : m0n; ta = tilen; } else ka = nchunk - 1; }
         if (kb >= nchunk) { if (has_next) { kb -= nchunk; mb = (STREAM && (p.dbg & 16)) ? mb : m0n; tb = tilen; } else kb = nchunk - 1; }
-        body(c, ka * SPG_KC, ma, ta, false, pa1, pw1, pwr1, pa0, pw0, pwr0);          // set 1 holds chunk c+1; set 0 is free for chunk c+2
-        if (c + 1 < nchunk) body(c + 1, kb * SPG_KC, mb, tb, has_next && c + 2 >= nchunk, pa0, pw0, pwr0, pa1, pw1, pwr1);
+        body(c, ka * SPG_KC, ma, ta, false, pa1, pw1, pwr1, pb1, pa0, pw0, pwr0, pb0);          // set 1 holds chunk c+1; set 0 is free for chunk c+2
+        if (c + 1 < nchunk) body(c + 1, kb * SPG_KC, mb, tb, has_next && c + 2 >= nchunk, pa0, pw0, pwr0, pb0, pa1, pw1, pwr1, pb1);
       }
       // Here (nchunk even when there is a next tile -- host): LDS buffer 0 holds chunk 0 of the next tile, set 1 its chunk
       // 1 (in flight); buffer 1 was read by the last chunk and is free: the epilogue stages through it.
@@ -677,7 +699,7 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
 #pragma unroll
         for (int i = 0; i < NIA; ++i) pa1.load_part(p.a, m0, SPG_KC, i);
 #pragma unroll
-        for (int i = 0; i < NIW; ++i) { if (WRED) pwr1.load_part(p.W, p.ldw, n0, SPG_KC, i); else pw1.load_part(p.W, p.ldw, n0, SPG_KC, i); }
+        for (int i = 0; i < NIW; ++i) w_load(pw1, pwr1, pb1, SPG_KC, i);
       }
       __syncthreads();          // the staging region is overwritten by the next chunk's finish stage
     }
@@ -782,6 +804,45 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
 }
 
 
+// ---- weights for the bf16 MFMA modes: split (hi = bf16(w), lo = bf16(w - hi)) and, for the data gradient, transposed ----
+__global__ __launch_bounds__(256) void spg_split_weights_kernel(const SpgSplitBatch b) {
+  const SpgSplitJob j = b.jobs[blockIdx.y];
+  const long ldk = (j.K + 7) & ~7, ldn = (j.N + 7) & ~7;
+  const long ufwd = (long)j.N * (ldk / 8), ubwd = j.bwd ? (long)j.K * (ldn / 8) : 0;
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < ufwd + ubwd; u += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    char* out;
+    long part;
+    if (u < ufwd) {            // forward orientation: 8 consecutive k of output channel n
+      const long n = u / (ldk / 8), k0 = 8 * (u % (ldk / 8));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = k0 + e < j.K ? j.W[n * j.ldw + k0 + e] : 0.f;
+      out = (char*)j.fwd + (n * ldk + k0) * 2;
+      part = (long)j.N * ldk * 2;
+    } else {                   // transposed: 8 consecutive n of input channel k
+      const long t = u - ufwd, k = t / (ldn / 8), n0 = 8 * (t % (ldn / 8));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = n0 + e < j.N ? j.W[(n0 + e) * j.ldw + k] : 0.f;
+      out = (char*)j.bwd + (k * ldn + n0) * 2;
+      part = (long)j.K * ldn * 2;
+    }
+    u32x2 h0, l0, h1, l1;
+    spg_split_bf16(f32x4{v[0], v[1], v[2], v[3]}, h0, l0);
+    spg_split_bf16(f32x4{v[4], v[5], v[6], v[7]}, h1, l1);
+    *reinterpret_cast<uint4*>(out) = uint4{h0[0], h0[1], h1[0], h1[1]};
+    *reinterpret_cast<uint4*>(out + part) = uint4{l0[0], l0[1], l1[0], l1[1]};
+  }
+}
+
+int spg_launch_split_weights(const SpgSplitBatch& b, hipStream_t stream) {
+  if (b.njobs == 0) return 0;
+  hipLaunchKernelGGL(spg_split_weights_kernel, dim3(64, b.njobs), dim3(256), 0, stream, b);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+int spg_gemm_precision() { return g_tune[SPG_TUNE_PRECISION]; }
+
 int spg_gemm_ntiles(const SpgGemmParams& p) { return spg_cdiv(p.M, p.rows_per_tile); }
 
 // waves along the rows (WI) of the tile shape launch_gemm_shape picks: number of statistics / pooling partials per tile
@@ -838,7 +899,20 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
         if (q.stat_accum && stat_parts != nullptr) *stat_parts = (int)(q.rstride < q.ntile ? q.rstride : q.ntile) * WI;
         grid = dim3((unsigned)slots, 1);
         if constexpr (IT == 128 && !(WRED && JT == 128)) {
-          hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true>), grid, dim3(SPG_THREADS), lds, stream, q);
+          // opt-in bf16 / split-bf16 MFMA (spg_tune key 7): the caller supplied pre-split weights for this orientation
+          const int prec = q.Wb != nullptr ? g_tune[SPG_TUNE_PRECISION] : 0;
+          if (prec == 3) hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true, 3>), grid, dim3(SPG_THREADS), lds, stream, q);
+          else if (prec == 1) hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true, 1>), grid, dim3(SPG_THREADS), lds, stream, q);
+          else hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true>), grid, dim3(SPG_THREADS), lds, stream, q);
+          SPG_LAUNCH_CHECK();
+          return 0;
+        }
+      }
+      if constexpr (IT == 128 && WRED && JT == 128) {      // the one wide shape that is not persistent
+        const int prec = q.Wb != nullptr ? g_tune[SPG_TUNE_PRECISION] : 0;
+        if (prec != 0) {
+          if (prec == 3) hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false, 3>), grid, dim3(SPG_THREADS), lds, stream, q);
+          else hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false, 1>), grid, dim3(SPG_THREADS), lds, stream, q);
           SPG_LAUNCH_CHECK();
           return 0;
         }

@@ -29,6 +29,8 @@ struct Layer {
   float* y = nullptr;           // raw output (workspace or external)
   long ldy = 0;
   float* Wpack = nullptr;       // conv layers, inference: weights in MFMA operand order (spg_convstack.hip)
+  void *Wb_f = nullptr, *Wb_t = nullptr;   // conv layers with whole reduction chunks: bf16 hi/lo copies of W for the opt-in bf16 MFMA
+                                // modes (spg_launch_split_weights): forward orientation [2][cout][cin], transposed [2][cin][cout]
   float* Wpad = nullptr;        // FC layers whose input width is not a multiple of 4: zero-padded copy of W
   long ldw = 0;                 // leading dimension of the weight actually fed to the kernels
   float *mean = nullptr, *rstd = nullptr, *s = nullptr, *t = nullptr;   // BN batch constants
@@ -129,6 +131,10 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
       l.Wpad = cv.take<float>((size_t)l.cout * l.ldw);
     }
     if (l.conv && !pl.training) l.Wpack = cv.take<float>(spg_conv_stack_packed_floats(l.cin, l.cout));
+    if (l.conv && pl.training && l.cin % SPG_KC == 0) {      // layers the full-tile GEMM path can take (whole reduction chunks)
+      l.Wb_f = cv.take<char>(spg_split_bytes(l.cout, l.cin));
+      l.Wb_t = cv.take<char>(spg_split_bytes(l.cin, l.cout));
+    }
   }
   auto carve_segment = [&](Segment& sg, float* final_out) {
     for (size_t k = 0; k < sg.convs.size(); ++k) {
@@ -229,6 +235,7 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     g.a = input_operand(pl, sg, false, k, clouds, stnT);
     g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = (int)pl.M; g.N = l.cout; g.K = l.cin;
     g.rows_per_tile = pl.P; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
+    if (l.Wb_f != nullptr) { g.Wb = l.Wb_f; g.ldwb = spg_split_ld(l.cin); g.wb_part_bytes = (long)l.cout * g.ldwb * 2; }
     if (last && !pl.training) g.Y = nullptr;     // inference: only the pooled values of the last conv are consumed
     g.stat = pl.training ? pl.stat : nullptr; g.stat_cnt = pl.stat_cnt;
     int nparts = 0;
@@ -366,6 +373,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       SpgGemmParams g; memset(&g, 0, sizeof(g));
       g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;
       g.M = (int)pl.M; g.N = l.cin; g.K = l.cout; g.rows_per_tile = pl.P;
+      if (l.Wb_t != nullptr) { g.Wb = l.Wb_t; g.ldwb = spg_split_ld(l.cout); g.wb_part_bytes = (long)l.cin * g.ldwb * 2; }
       g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.ldy;
       g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
       g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
@@ -427,6 +435,15 @@ extern "C" int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, cons
         eb.jobs[eb.njobs++] = SpgBnEvalJob{l.cout, l.gamma, l.beta, l.rm, l.rv, l.s, l.t};
       }
     SPG_TRY(spg_launch_bn_eval_batch(eb, pl.cfg.bn_eps, st));
+  }
+  if (pl.training && spg_gemm_precision() != 0) {      // opt-in bf16 / split-bf16 MFMA: bf16 copies of the conv weights, one launch
+    SpgSplitBatch sb;
+    for (Layer& l : pl.L)
+      if (l.Wb_f != nullptr) {
+        SPG_CHECK_ARG(sb.njobs < SPG_SPLIT_MAX_JOBS, "too many layers");
+        sb.jobs[sb.njobs++] = SpgSplitJob{l.W, l.cin, l.cout, l.cin, l.Wb_f, l.Wb_t};
+      }
+    SPG_TRY(spg_launch_split_weights(sb, st));
   }
   const float* stnT = ext_transform;      // [B, 4] = T - I of an externally evaluated STN (LocalCloudEmbedder), or null
   if (pl.has_stn) {

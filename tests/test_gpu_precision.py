@@ -1,0 +1,97 @@
+"""GPU: the opt-in bf16 / split-bf16 MFMA modes of the wide row-GEMMs (spg_tune key 7; BASELINE.json configs[4] names a
+bf16-MFMA variant) on a BASELINE-size scene (1000 superpoints x 128 points: the persistent wide-GEMM launches the modes
+apply to) against the CPU oracle.  These modes have their OWN tolerances, stated here; the default (fp32 MFMA) is what
+every other test and the headline benchmark use.
+
+  split-bf16 (3): a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (16 mantissa bits per operand), fp32 accumulation:
+                  embeddings / logits 5e-4 (max-norm relative), loss 1e-4; every gradient: cosine > 0.995 to the oracle's and
+                  max-norm difference < 0.15.  The gradient bound looks loose and is not: at this size the training step
+                  is that sensitive -- the fp32 path with 1e-5 relative noise on the input points (tools/precision_check.py)
+                  moves embeddings by 6e-5, logits by 1.5e-4 and the worst gradient tensor (conv5 weight: max-pool arg-max
+                  and ReLU decisions on near-ties) by 4.8e-2; split-bf16 moves them by 3.4e-5, 9.5e-5 and 5.1e-2
+  bf16       (1): 8 mantissa bits per operand: embeddings / logits 8e-2, loss 2e-2, every gradient finite with
+                  cosine > 0.9 to the oracle's"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import build_model, maxrel
+from oracle import spg_oracle as O
+from test_gpu_model import _run, _unit_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def scene():
+    spec = O.ModelSpec()
+    torch.manual_seed(1)
+    model = build_model(spec)
+    with torch.no_grad():                       # non-trivial BN parameters / STN
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.normal_(1, 0.2); m.bias.normal_(0, 0.1)
+        model.ptn.stn.proj.weight.normal_(0, 0.02)
+    batch = _unit_batch([0])
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    loss, logits, emb, grads = O.train_step(batch, spec, dict(state0), None, update_running_stats=False)
+    return spec, batch, state0, (loss, emb, logits, grads)
+
+
+def _step(scene, mode):
+    from superpoint_graph_amd import _lib
+    spec, batch, state0, _ = scene
+    L = _lib.lib()
+    assert L.spg_tune(7, mode) >= 0
+    try:
+        model = build_model(spec, state0).to(DEV).train()
+        model.zero_grad()
+        emb, logits, embedder = _run(model, batch)
+        loss = F.cross_entropy(logits, batch['label_mode'].to(DEV))
+        loss.backward()
+        embedder.bw_hook()
+        torch.cuda.synchronize()
+        return emb.detach(), logits.detach(), loss.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    finally:
+        L.spg_tune(7, 0)
+
+
+def _errors(scene, out):
+    loss_o, emb_o, logits_o, grads_o = scene[3]
+    emb, logits, loss, grads = out
+    keys = [k for k in grads if float(grads_o[k].abs().max()) > 1e-6]
+    g = {k: maxrel(grads[k], grads_o[k]) for k in keys}
+    return maxrel(emb, emb_o), maxrel(logits, logits_o), abs(float(loss) - float(loss_o)) / abs(float(loss_o)), g
+
+
+def test_split_bf16_train_step(hip, scene):
+    f32 = _step(scene, 0)
+    out = _step(scene, 3)
+    assert not torch.equal(out[0], f32[0])                                    # the mode is really on at this size
+    e_emb, e_log, e_loss, g = _errors(scene, out)
+    grads_o = scene[3][3]
+    cos = min((float(F.cosine_similarity(out[3][k].reshape(1, -1).cpu().double(), grads_o[k].reshape(1, -1).double())), k) for k in g)
+    print(f'split-bf16: emb {e_emb:.2e} logits {e_log:.2e} loss {e_loss:.2e} worst grad {max(g.values()):.2e} min cosine {cos}; '
+          f'fp32 mode on the same scene: emb {_errors(scene, f32)[0]:.2e} worst grad {max(_errors(scene, f32)[3].values()):.2e}')
+    assert e_emb < 5e-4 and e_log < 5e-4 and e_loss < 1e-4
+    assert max(g.values()) < 0.15 and cos[0] > 0.995
+
+
+def test_bf16_train_step(hip, scene):
+    out = _step(scene, 1)
+    e_emb, e_log, e_loss, g = _errors(scene, out)
+    grads_o = scene[3][3]
+    cos = min((float(F.cosine_similarity(out[3][k].reshape(1, -1).cpu().double(), grads_o[k].reshape(1, -1).double())), k) for k in g)
+    print(f'bf16: emb {e_emb:.2e} logits {e_log:.2e} loss {e_loss:.2e} worst grad {max(g.values()):.2e} min cosine {cos}')
+    assert all(torch.isfinite(v).all() for v in out[3].values())
+    assert e_emb < 8e-2 and e_log < 8e-2 and e_loss < 2e-2 and cos[0] > 0.9
+
+
+def test_modes_leave_default_untouched(hip, scene):
+    """mode 0 after a detour through the bf16 modes: bit-identical to a run that never left it"""
+    a = _step(scene, 0)
+    _step(scene, 3); _step(scene, 1)
+    b = _step(scene, 0)
+    assert torch.equal(a[1], b[1]) and all(torch.equal(a[3][k], b[3][k]) for k in a[3])
