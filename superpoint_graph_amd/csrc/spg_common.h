@@ -790,11 +790,24 @@ struct SpgWeightBf16 {
   }
 };
 
+__device__ __forceinline__ void spg_split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const f32x2 x = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  const f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
+// slot of a channel inside a plane of the weight-gradient tiles: the 16 slots of a 256-byte LDS row are rotated by the
+// row's index, so that the writes of one instruction (32 channel quads -> channels 4q + e) spread over all banks
+// (unrotated: 8-way conflicts), while 16 consecutive channels -- one pass of a ds_read_b128 -- stay on 16 distinct slots
+__device__ __forceinline__ int spg_swz(int c) { return (c & ~15) | (((c & 15) + (c >> 4)) & 15); }
+
 // MFMAs of one reduction chunk (K = 32 = two k-steps of 16) from bf16 tiles; `piece(slot)`, slot 0..15, as in
 // spg_mfma_chunk_il (the staging work of the next chunks, spread between the MFMAs)
 template <int TI, int TJ, int PREC, class Piece>
 __device__ __forceinline__ void spg_mfma_chunk_bf16_il(const f32x4* __restrict__ As, const f32x4* __restrict__ Bs, int strideA,
-                                                       int strideB, int rowA, int rowB, int h, f32x16 (&acc)[TI][TJ], Piece&& piece) {
+                                                       int strideB, const int (&sa)[TI], const int (&sb)[TJ], int h,
+                                                       f32x16 (&acc)[TI][TJ], Piece&& piece) {
   constexpr int NG = 2 * TI * TJ * (PREC == 3 ? 3 : 1);      // MFMA count; the 16 piece slots are spread over them
   int slot = 0, g = 0;
   auto after = [&]() __attribute__((always_inline)) {
@@ -810,12 +823,12 @@ __device__ __forceinline__ void spg_mfma_chunk_bf16_il(const f32x4* __restrict__
     // dead (24 fragment registers live instead of 32 -- the backward instantiations have none to spare)
     bf16x8 ah[TI], bh[TJ], xl[TI > TJ ? TI : TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) ah[i] = __builtin_bit_cast(bf16x8, As[(2 * s + h) * strideA + rowA + 32 * i]);
+    for (int i = 0; i < TI; ++i) ah[i] = __builtin_bit_cast(bf16x8, As[(2 * s + h) * strideA + sa[i]]);
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) bh[j] = __builtin_bit_cast(bf16x8, Bs[(2 * s + h) * strideB + rowB + 32 * j]);
+    for (int j = 0; j < TJ; ++j) bh[j] = __builtin_bit_cast(bf16x8, Bs[(2 * s + h) * strideB + sb[j]]);
     if (PREC == 3) {
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) xl[j] = __builtin_bit_cast(bf16x8, Bs[(4 + 2 * s + h) * strideB + rowB + 32 * j]);
+      for (int j = 0; j < TJ; ++j) xl[j] = __builtin_bit_cast(bf16x8, Bs[(4 + 2 * s + h) * strideB + sb[j]]);
     }
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -833,7 +846,7 @@ __device__ __forceinline__ void spg_mfma_chunk_bf16_il(const f32x4* __restrict__
           after();
         }
 #pragma unroll
-      for (int i = 0; i < TI; ++i) xl[i] = __builtin_bit_cast(bf16x8, As[(4 + 2 * s + h) * strideA + rowA + 32 * i]);
+      for (int i = 0; i < TI; ++i) xl[i] = __builtin_bit_cast(bf16x8, As[(4 + 2 * s + h) * strideA + sa[i]]);
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -1020,6 +1033,77 @@ struct SpgRedFast {            // red-major [32 x CH] operand tile of the weight
     const int tid = threadIdx.x, row = tid / QUADS + RPP * i;
     *reinterpret_cast<f32x4*>(lds + row * (CH + 4) + 4 * (tid % QUADS)) =
         spg_finish_fast<MODE>(q, raw[i], lo, px, pai, pbase + row);
+  }
+};
+
+// bf16-layout variant of SpgRedFast for the weight gradient (reduction = rows): the MFMA operand of channel c needs 8
+// CONSECUTIVE ROWS of c in one 16-byte slot, the global rows hold consecutive channels -- so a thread takes NI consecutive
+// rows of its channel quad (instead of every RG-th row), finishes them, and for each of its 4 channels packs the NI values
+// into NI*2 bytes of the slot (plane = first row / 8): an in-register transpose, no shuffles.
+template <int MODE, int CH>
+struct SpgRedFastB {
+  static constexpr int QUADS = CH / 4, RG = SPG_THREADS / QUADS, NI = SPG_KC / RG;      // NI = 4 / 2 / 1 for CH = 128 / 64 / 32
+  SpgRaw raw[NI];
+  f32x4 px;
+  int4 pai;
+  unsigned voff[NI], coff, wofs[4];
+  int pbase, row0;
+  float lo;
+  __device__ __forceinline__ void init(const SpgOperand& d, int c0, SpgQuad& q) {
+    const unsigned tid = threadIdx.x, quad = tid % QUADS;
+    row0 = (int)(tid / QUADS) * NI;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) voff[i] = ((unsigned)(row0 + i) * (unsigned)d.ld + 4u * quad) * 4u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      wofs[e] = (unsigned)(((row0 >> 3) * (CH + 1) + spg_swz((int)(4 * quad + e))) * 16 + (row0 & 7) * 2);
+    coff = 16u * quad;
+    lo = d.relu ? 0.f : -FLT_MAX;
+    spg_consts_fast<MODE>(d, c0, coff, q);
+  }
+  __device__ __forceinline__ void load_part(const SpgOperand& d, long mchunk, int c0, int i) {
+    if (MODE == SPG_PRO_POOLBWD) {
+      if (i == 0) {
+        const unsigned g = (unsigned)mchunk / (unsigned)d.P;      // M < 2^32 rows; a chunk lies inside one pooling group
+        pbase = (int)((unsigned)mchunk - g * (unsigned)d.P);
+        px = spg_ld16(d.X + g * d.ldg + c0, coff);
+        pai = spg_ld16i(d.aidx + g * d.ldg + c0, coff);
+      }
+      raw[i].y = spg_ld16(d.X2 + mchunk * d.ld + c0, voff[i]);
+    } else {
+      raw[i].x = spg_ld16(d.X + mchunk * d.ld + c0, voff[i]);
+      if (MODE == SPG_PRO_BNBWD) raw[i].y = spg_ld16(d.X2 + mchunk * d.ld + c0, voff[i]);
+    }
+  }
+  // channels 2*half, 2*half+1 of the thread's quad (two calls per chunk: the conversion work is spread over two slots)
+  template <int PREC>
+  __device__ __forceinline__ void store_half(const SpgQuad& q, f32x4* __restrict__ lds, int half) const {
+    f32x4 v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = spg_finish_fast<MODE>(q, raw[i], lo, px, pai, pbase + row0 + i);
+    char* base = reinterpret_cast<char*>(lds);
+    constexpr unsigned LO = 4u * (CH + 1) * 16u;
+#pragma unroll
+    for (int ee = 0; ee < 2; ++ee) {
+      const int e = 2 * half + ee;
+      if constexpr (NI == 4) {
+        unsigned h0, l0, h1, l1;
+        spg_split_bf16_pair(v[0][e], v[1][e], h0, l0);
+        spg_split_bf16_pair(v[2][e], v[3][e], h1, l1);
+        *reinterpret_cast<u32x2*>(base + wofs[e]) = u32x2{h0, h1};
+        if (PREC == 3) *reinterpret_cast<u32x2*>(base + wofs[e] + LO) = u32x2{l0, l1};
+      } else if constexpr (NI == 2) {
+        unsigned hi, lw;
+        spg_split_bf16_pair(v[0][e], v[1][e], hi, lw);
+        *reinterpret_cast<unsigned*>(base + wofs[e]) = hi;
+        if (PREC == 3) *reinterpret_cast<unsigned*>(base + wofs[e] + LO) = lw;
+      } else {
+        unsigned hi, lw;
+        spg_split_bf16_pair(v[0][e], 0.f, hi, lw);
+        *reinterpret_cast<unsigned short*>(base + wofs[e]) = (unsigned short)hi;
+        if (PREC == 3) *reinterpret_cast<unsigned short*>(base + wofs[e] + LO) = (unsigned short)lw;
+      }
+    }
   }
 };
 

@@ -640,7 +640,14 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
             w_store(pwF, pwrF, pbF, Bn, slot - 3 - NIA);
           }
         };
-        if constexpr (PREC != 0) spg_mfma_chunk_bf16_il<TI, TJ, PREC>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
+        if constexpr (PREC != 0) {
+          int sa[TI], sb[TJ];
+#pragma unroll
+          for (int i = 0; i < TI; ++i) sa[i] = wi * (IT / WI) + r + 32 * i;
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) sb[j] = wj * (JT / WJ) + r + 32 * j;
+          spg_mfma_chunk_bf16_il<TI, TJ, PREC>(Ac, Bc, IT + 1, JT + 1, sa, sb, h, acc, piece);
+        }
         else if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
         else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
         if (!(STREAM && (p.dbg & 32))) __syncthreads();      // (attribution switch: main loop without barriers)
@@ -888,8 +895,11 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
       q.ntile = (int)grid.x; q.rstride = 1 << 30; q.remap = 0; q.ncol = (int)grid.y;
       const int slots = 2 * spg_num_cus();
       const int ncol = (int)grid.y;
+      // opt-in bf16 / split-bf16 MFMA (spg_tune key 7): the caller supplied pre-split weights for this orientation
+      const int prec = (IT == 128 && q.Wb != nullptr) ? g_tune[SPG_TUNE_PRECISION] : 0;
       // (the 128-column backward kernels -- two operand streams, four constant arrays -- have no registers left for the
-      // stream state: measured slower with it, so they keep one workgroup per tile)
+      // stream state: measured slower with it, in fp32 and in the bf16 modes (conv5 dgrad 69 -> 120 us), so they keep one
+      // workgroup per tile)
       if (!g_tune[SPG_TUNE_NO_PERSIST] && IT == 128 && !(WRED && JT == 128) && p.rows_per_tile == IT && p.M % IT == 0 && p.N % JT == 0 &&
           (p.K / SPG_KC) % 2 == 0 && (long)grid.x * ncol > slots && slots % (8 * ncol) == 0) {
         q.remap = 1; q.rstride = slots / ncol;
@@ -899,8 +909,6 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
         if (q.stat_accum && stat_parts != nullptr) *stat_parts = (int)(q.rstride < q.ntile ? q.rstride : q.ntile) * WI;
         grid = dim3((unsigned)slots, 1);
         if constexpr (IT == 128 && !(WRED && JT == 128)) {
-          // opt-in bf16 / split-bf16 MFMA (spg_tune key 7): the caller supplied pre-split weights for this orientation
-          const int prec = q.Wb != nullptr ? g_tune[SPG_TUNE_PRECISION] : 0;
           if (prec == 3) hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true, 3>), grid, dim3(SPG_THREADS), lds, stream, q);
           else if (prec == 1) hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true, 1>), grid, dim3(SPG_THREADS), lds, stream, q);
           else hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true>), grid, dim3(SPG_THREADS), lds, stream, q);
@@ -908,8 +916,7 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
           return 0;
         }
       }
-      if constexpr (IT == 128 && WRED && JT == 128) {      // the one wide shape that is not persistent
-        const int prec = q.Wb != nullptr ? g_tune[SPG_TUNE_PRECISION] : 0;
+      if constexpr (IT == 128 && WRED && JT == 128) {      // the one wide shape that is not persistent in fp32
         if (prec != 0) {
           if (prec == 3) hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false, 3>), grid, dim3(SPG_THREADS), lds, stream, q);
           else hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false, 1>), grid, dim3(SPG_THREADS), lds, stream, q);
@@ -968,7 +975,8 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts)
 // weight-gradient kernel: reduction over the rows (points / superpoints / edges / nodes)
 // ---------------------------------------------------------------------------------------------
 // AMODE / BMODE >= 0: compile-time operand modes, vector + software-pipelined loop; < 0: generic scalar staging.
-template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE, bool FULL = false>
+// PREC (FULL only): 0 fp32 MFMA; 1 / 3 bf16 / split-bf16 MFMA with both operands converted while staging (spg_common.h)
+template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE, bool FULL = false, int PREC = 0>
 __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
@@ -990,7 +998,63 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  if constexpr (AMODE >= 0 && BMODE >= 0 && FULL) {
+  if constexpr (AMODE >= 0 && BMODE >= 0 && FULL && PREC != 0) {
+    // bf16 layout: planes of 16-byte slots, slot = 8 consecutive ROWS of one channel (SpgRedFastB); same pipeline
+    constexpr int BUF4 = (SPG_KC / 4) * (IT + 1 + JT + 1);
+    f32x4* A4 = smem;
+    f32x4* B4 = smem + (SPG_KC / 4) * (IT + 1);
+    SpgRedFastB<AMODE, IT> pa;
+    SpgRedFastB<BMODE, JT> pb;
+    constexpr int NIA = SpgRedFastB<AMODE, IT>::NI, NIB = SpgRedFastB<BMODE, JT>::NI;
+    SpgQuad qa, qb;
+    pa.init(p.a, i0, qa);
+    pb.init(p.b, j0, qb);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) pa.load_part(p.a, ms, i0, i);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) pb.load_part(p.b, ms, j0, i);
+    pa.template store_half<PREC>(qa, A4, 0); pa.template store_half<PREC>(qa, A4, 1);
+    pb.template store_half<PREC>(qb, B4, 0); pb.template store_half<PREC>(qb, B4, 1);
+    const long mlast = me - SPG_KC;                 // first row of the last chunk of this split
+    {
+      const long m1 = ms + SPG_KC <= mlast ? ms + SPG_KC : mlast;
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) pa.load_part(p.a, m1, i0, i);
+#pragma unroll
+      for (int i = 0; i < NIB; ++i) pb.load_part(p.b, m1, j0, i);
+    }
+    int sa[TI], sb[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) sa[i] = spg_swz(wi * (IT / WI) + r + 32 * i);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) sb[j] = spg_swz(wj * (JT / WJ) + r + 32 * j);
+    __syncthreads();
+    int buf = 0;
+    for (long m = ms; m < me; m += SPG_KC) {
+      f32x4* An = A4 + (buf ^ 1) * BUF4;
+      f32x4* Bn = B4 + (buf ^ 1) * BUF4;
+      const long m2 = m + 2 * SPG_KC <= mlast ? m + 2 * SPG_KC : mlast;      // clamped: a harmless re-load past the end
+      auto piece = [&](int slot) __attribute__((always_inline)) {
+        if (slot < 2) {
+          pa.template store_half<PREC>(qa, An, slot);
+        } else if (slot < 4) {
+          pb.template store_half<PREC>(qb, Bn, slot - 2);
+        } else if (slot == 4) {
+#pragma unroll
+          for (int i = 0; i < (NIA + 1) / 2; ++i) pa.load_part(p.a, m2, i0, i);
+        } else if (slot == 5) {
+#pragma unroll
+          for (int i = (NIA + 1) / 2; i < NIA; ++i) pa.load_part(p.a, m2, i0, i);
+        } else if (slot == 6) {
+#pragma unroll
+          for (int i = 0; i < NIB; ++i) pb.load_part(p.b, m2, j0, i);
+        }
+      };
+      spg_mfma_chunk_bf16_il<TI, TJ, PREC>(A4 + buf * BUF4, B4 + buf * BUF4, IT + 1, JT + 1, sa, sb, h, acc, piece);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else if constexpr (AMODE >= 0 && BMODE >= 0 && FULL) {
     // full tiles: the fast pipes (loop-invariant offsets, no masks), same pipeline as below
     constexpr int BUF = SPG_KC * (IT + 4 + JT + 4);
     SpgRedFast<AMODE, IT> pa;
@@ -1177,6 +1241,10 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
                       (long)SPG_KC * p.a.ld < (1L << 29) && (long)SPG_KC * p.b.ld < (1L << 29);
     if (full) {
       prof.r.tag = SPG_PROF_TAG(2, IT, JT, AMODE, BMODE, 1);
+      const int prec = (IT == 128 || JT >= 64) ? g_tune[SPG_TUNE_PRECISION] : 0;      // opt-in bf16 / split-bf16 MFMA (spg_tune key 7)
+      if (prec == 3) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 3>), grid, dim3(SPG_THREADS), lds, stream, p);
+      else if (prec == 1) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 1>), grid, dim3(SPG_THREADS), lds, stream, p);
+      else
       hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true>), grid, dim3(SPG_THREADS), lds, stream, p);
       SPG_LAUNCH_CHECK();
       return 0;
