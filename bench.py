@@ -397,7 +397,7 @@ def main():
         if dl.value > 0:
             dach = dfl.value / (dms.value * 1e-3) / 1e12
             result['roofline'].update({
-                'dominant_kernel': 'spg_rowgemm_kernel<128, 128, 2, 2, false, 1, true, true>', 'dominant_launches_per_step': dl.value / nprof,
+                'dominant_kernel': 'spg_rowgemm_kernel<128, 128, 2, 2, false, 1, true, true, %d>' % PREC, 'dominant_launches_per_step': dl.value / nprof,
                 'dominant_avg_us': dms.value / dl.value * 1e3, 'dominant_gflop_per_launch': dfl.value / dl.value / 1e9,
                 'dominant_achieved': dach, 'dominant_frac': dach / PEAK_FP32_MFMA_TFLOPS})
         if top >= 0 and vals[2 * top] > 0:

@@ -318,7 +318,10 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * epilogue at all, 4 A operand from L2, 5 no main-loop barriers, bits 8-11 extra repetitions of the chunk loop) --
  * results are WRONG while it is non-zero, tools/ only; key 4: the BatchNorm finalize kernels slice their reduction over 8
  * workgroups (last-arrival combine) above this many partials (0 = default 512); key 5: 1 = persistent launches write one
- * statistics partial per tile instead of one per workgroup.  Returns the previous value, -1 for an unknown key. */
+ * statistics partial per tile instead of one per workgroup; key 7: arithmetic of the wide (128-row-tile, full-tile) GEMMs of
+ * spg_pointnet_forward / _backward: 0 = fp32 MFMA (default; the reference's arithmetic), 3 = split-bf16 (three bf16 MFMAs per
+ * operand pair, ~2^-16 per product), 1 = bf16 operands; fp32 accumulation and fp32 tensors in every mode (tolerances:
+ * tests/test_gpu_precision.py).  Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops);
 
