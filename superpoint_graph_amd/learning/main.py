@@ -389,6 +389,9 @@ def main(argv=None):
     with open(os.path.join(args.odir, 'cmdline.txt'), 'w') as f:
         f.write(' '.join(["'" + a + "'" if (len(a) == 0 or a[0] != '-') else a for a in (argv if argv is not None else sys.argv)]))
     set_seed(args.seed, args.cuda)
+    from .. import _lib
+    if _lib.lib().spg_tune(7, {'f32': 0, 'bf16': 1, 'bf16x3': 3}[args.gemm_precision]) < 0:
+        raise RuntimeError('libspg_hip.so has no precision switch (spg_tune key 7)')
     logging.getLogger().setLevel(logging.INFO)
     get_info, create_dataset = datasets.provider(args.dataset)
     dbinfo = get_info(args)
