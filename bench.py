@@ -210,7 +210,7 @@ def main():
     ap.add_argument('--no-trainer-window', action='store_true', help='skip the fresh-batch-per-step side measurement (learning/main.py:200-215 window)')
     ap.add_argument('--no-forward-only', action='store_true', help='skip the forward-only side measurement (BASELINE configs[1])')
     ap.add_argument('--sync-bn', type=int, default=0, help='1: BatchNorm statistics all-reduced over the ranks (exact single-process batch semantics); 0: per-rank statistics')
-    ap.add_argument('--native-rccl', type=int, default=1, help='1: the C library issues the RCCL collectives itself (own communicator); 0: torch.distributed calls')
+    ap.add_argument('--native-rccl', type=int, default=-1, help='1: the C library issues the RCCL collectives itself (own communicator, spg_rccl_*); 0: torch.distributed calls; -1 (default): 1 with --sync-bn 1 (26 small collectives per step: no Python in between), else 0 (one all-reduce per step either way; the torch path is the one exercised on multi-GPU nodes before)')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help="arithmetic of the wide row-GEMMs: f32 = fp32 MFMA (default, the headline); bf16x3 = split-bf16 products (three "
                          "bf16 MFMAs per operand pair, fp32 accumulate, ~2^-16 per product); bf16 = bf16 operands.  A SEPARATE line: never "
@@ -259,6 +259,8 @@ def main():
     n_sp_step = int(flag.numel())
 
     native = False
+    if args.native_rccl < 0:
+        args.native_rccl = 1 if args.sync_bn else 0
     if world > 1 and args.native_rccl and dist.get_backend() == 'nccl':
         spd.init_native_rccl()                       # gradient / BatchNorm collectives enqueued by libspg_hip itself
         native = True
