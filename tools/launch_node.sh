@@ -3,7 +3,7 @@
 #   tools/launch_node.sh [N_GPUS=8] [SYNC_BN=0] [extra bench.py flags]
 # Runs N = 1, 2, 4, ... up to N_GPUS back to back when N_GPUS is "sweep".  The collectives (one flat fp32 gradient
 # all-reduce per step; with SYNC_BN=1 also 26 small fp64 BatchNorm all-reduces) are issued by libspg_hip's own RCCL
-# communicator (--native-rccl 1, default).
+# communicator when SYNC_BN=1 or `--native-rccl 1` is passed, else by torch.distributed (bench.py --native-rccl).
 set -euo pipefail
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
