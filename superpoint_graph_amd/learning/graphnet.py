@@ -1,83 +1,98 @@
-"""GraphNetwork: model-config mini-DSL -> module sequence (reference learning/graphnet.py:17-98), with the
-RNN-ECC layers executed by the HIP kernels."""
-import torch
+"""GraphNetwork: the model-config mini-language -> a sequence of modules, with the RNN-ECC layers and the dense layers
+executed by the HIP kernels.  Interface, state_dict keys and parameter initialisation (the order in which modules are
+constructed and hence the order in which torch's RNG is consumed) follow reference learning/graphnet.py:17-98."""
+import torch  # noqa: F401
 import torch.nn as nn
-import torch.nn.init as init
+from torch.nn import init
 
-from . import ecc  # noqa: F401  (kept for API parity: `learning.graphnet.ecc`)
+from . import ecc  # noqa: F401  (API parity: `learning.graphnet.ecc`)
 from .modules import GRUCellEx, HipLinear, LSTMCellEx, RNNGraphConvModule
 
 
 def create_fnet(widths, orthoinit, llbias, bnidx=-1):
-    """Filter-generating network, a multi-layer perceptron (reference learning/graphnet.py:17-34; identical
-    construction order, hence identical initialisation and state_dict keys)."""
-    fnet_modules = []
-    for k in range(len(widths) - 2):
-        fnet_modules.append(nn.Linear(widths[k], widths[k + 1]))
+    """Filter-generating MLP over the superedge features (reference learning/graphnet.py:17-34): Linear(+BatchNorm at
+    layer `bnidx`)+ReLU for every hidden width, then a Linear with optional bias; orthogonal initialisation (gain of
+    ReLU for the hidden layers) when `orthoinit`."""
+    n_hidden = len(widths) - 2
+    layers = []
+    for idx, (fan_in, fan_out) in enumerate(zip(widths[:n_hidden], widths[1:n_hidden + 1])):
+        lin = nn.Linear(fan_in, fan_out)
         if orthoinit:
-            init.orthogonal_(fnet_modules[-1].weight, gain=init.calculate_gain('relu'))
-        if bnidx == k:
-            fnet_modules.append(nn.BatchNorm1d(widths[k + 1]))
-        fnet_modules.append(nn.ReLU(True))
-    fnet_modules.append(nn.Linear(widths[-2], widths[-1], bias=llbias))
+            init.orthogonal_(lin.weight, gain=init.calculate_gain('relu'))
+        layers.append(lin)
+        if idx == bnidx:
+            layers.append(nn.BatchNorm1d(fan_out))
+        layers.append(nn.ReLU(True))
+    head = nn.Linear(widths[-2], widths[-1], bias=llbias)
     if orthoinit:
-        init.orthogonal_(fnet_modules[-1].weight)
+        init.orthogonal_(head.weight)
+    layers.append(head)
     if bnidx == len(widths) - 1:
-        fnet_modules.append(nn.BatchNorm1d(fnet_modules[-1].weight.size(0)))
-    return nn.Sequential(*fnet_modules)
+        layers.append(nn.BatchNorm1d(widths[-1]))
+    return nn.Sequential(*layers)
+
+
+def _flag(tokens, pos):
+    """optional 0/1 field of a layer token; absent = on"""
+    return bool(int(tokens[pos])) if pos < len(tokens) else True
 
 
 class GraphNetwork(nn.Module):
-    """Constructed from the `config` string of comma-delimited layer tokens (reference
-    learning/graphnet.py:37-98).  Supported tokens: f_K, b[_x], r, d_p, gru_R[_vv][_layernorm][_ingate][_catall]."""
+    """Built from a comma-separated list of layer tokens (reference learning/graphnet.py:37-98):
+    `f_K` linear to K, `b[_x]` BatchNorm (non-affine with a suffix), `r` ReLU, `d_p` dropout,
+    `gru_R[_vv][_layernorm][_ingate][_catall]` / `lstm_R[...]` R iterations of ECC + recurrent cell."""
+
+    _CELLS = {'gru': GRUCellEx, 'lstm': LSTMCellEx}
 
     def __init__(self, config, nfeat, fnet_widths, fnet_orthoinit=True, fnet_llbias=True, fnet_bnidx=-1,
                  edge_mem_limit=1e20, use_pyg=True, cuda=True):
-        super(GraphNetwork, self).__init__()
+        super().__init__()
         self.gconvs = []
-        for d, conf in enumerate(config.split(',')):
-            conf = conf.strip().split('_')
-            if conf[0] == 'f':
-                self.add_module(str(d), HipLinear(nfeat, int(conf[1])))      # nn.Linear with HIP forward / backward
-                nfeat = int(conf[1])
-            elif conf[0] == 'b':
-                self.add_module(str(d), nn.BatchNorm1d(nfeat, eps=1e-5, affine=len(conf) == 1))
-            elif conf[0] == 'r':
-                self.add_module(str(d), nn.ReLU(True))
-            elif conf[0] == 'd':
-                self.add_module(str(d), nn.Dropout(p=float(conf[1]), inplace=False))
-            elif conf[0] == 'crf':
+        width = nfeat
+        for position, token in enumerate(config.split(',')):
+            fields = token.strip().split('_')
+            kind = fields[0]
+            if kind == '':
+                continue
+            if kind == 'f':
+                layer, width = HipLinear(width, int(fields[1])), int(fields[1])      # nn.Linear, HIP forward / backward
+            elif kind == 'b':
+                layer = nn.BatchNorm1d(width, eps=1e-5, affine=(len(fields) == 1))
+            elif kind == 'r':
+                layer = nn.ReLU(True)
+            elif kind == 'd':
+                layer = nn.Dropout(p=float(fields[1]), inplace=False)
+            elif kind in self._CELLS:
+                layer, width = self._recurrent_conv(kind, fields, width, fnet_widths, fnet_orthoinit, fnet_llbias, fnet_bnidx,
+                                                    edge_mem_limit, use_pyg, cuda)
+                self.gconvs.append(layer)
+            elif kind == 'crf':
                 raise NotImplementedError('crf_R (ECC-CRF) is out of scope: the reference implementation itself does '
                                           'not run on torch >= 1.5')
-            elif conf[0] == 'gru' or conf[0] == 'lstm':
-                nrepeats = int(conf[1])
-                vv = bool(int(conf[2])) if len(conf) > 2 else True
-                layernorm = bool(int(conf[3])) if len(conf) > 3 else True
-                ingate = bool(int(conf[4])) if len(conf) > 4 else True
-                cat_all = bool(int(conf[5])) if len(conf) > 5 else True
-                fnet = create_fnet(fnet_widths + [nfeat ** 2 if not vv else nfeat], fnet_orthoinit, fnet_llbias, fnet_bnidx)
-                if conf[0] == 'gru':
-                    cell = GRUCellEx(nfeat, nfeat, bias=True, layernorm=layernorm, ingate=ingate)
-                else:
-                    cell = LSTMCellEx(nfeat, nfeat, bias=True, layernorm=layernorm, ingate=ingate)
-                gconv = RNNGraphConvModule(cell, fnet, nfeat, vv=vv, nrepeats=nrepeats, cat_all=cat_all,
-                                           edge_mem_limit=edge_mem_limit, use_pyg=use_pyg, cuda=cuda)
-                self.add_module(str(d), gconv)
-                self.gconvs.append(gconv)
-                if cat_all:
-                    nfeat *= nrepeats + 1
-            elif len(conf[0]) > 0:
-                raise NotImplementedError('Unknown module: ' + conf[0])
+            else:
+                raise NotImplementedError('Unknown module: ' + kind)
+            self.add_module(str(position), layer)
+
+    def _recurrent_conv(self, kind, fields, width, fnet_widths, orthoinit, llbias, bnidx, edge_mem_limit, use_pyg, cuda):
+        repeats = int(fields[1])
+        vector_filters, layernorm, ingate, cat_all = (_flag(fields, k) for k in (2, 3, 4, 5))
+        # the filter network first, then the cell: the order fixes the random initialisation
+        fnet = create_fnet(fnet_widths + [width if vector_filters else width * width], orthoinit, llbias, bnidx)
+        cell = self._CELLS[kind](width, width, bias=True, layernorm=layernorm, ingate=ingate)
+        conv = RNNGraphConvModule(cell, fnet, width, vv=vector_filters, nrepeats=repeats, cat_all=cat_all,
+                                  edge_mem_limit=edge_mem_limit, use_pyg=use_pyg, cuda=cuda)
+        return conv, width * (repeats + 1) if cat_all else width
 
     def set_info(self, gc_infos, cuda):
-        """Provides the convolution modules with the graph structure of the current batch."""
-        gc_infos = gc_infos if isinstance(gc_infos, (list, tuple)) else [gc_infos]
-        for i, gc in enumerate(self.gconvs):
+        """Hands the graph structure of the current batch to the convolution layers (one info object per layer)."""
+        infos = list(gc_infos) if isinstance(gc_infos, (list, tuple)) else [gc_infos]
+        for conv, info in zip(self.gconvs, infos):
             if cuda:
-                gc_infos[i].cuda()
-            gc.set_info(gc_infos[i])
+                info.cuda()
+            conv.set_info(info)
 
     def forward(self, input):
-        for module in self._modules.values():
-            input = module(input)
-        return input
+        x = input
+        for layer in self.children():
+            x = layer(x)
+        return x
