@@ -100,6 +100,9 @@ def build_parser():
     a('--sp_decoder_config', default='[]', type=str, help='Size of the decoder : sp_embedding -> sp_class.')
     # HIP path
     a('--loader_device', default=1, type=int, help='Bool, build the superpoint clouds on the GPU from scenes resident in HBM')
+    a('--gemm_precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
+      help="Arithmetic of the wide PointNet GEMMs: f32 = fp32 MFMA (the reference's arithmetic, default); bf16x3 = split-bf16 "
+           "products (~2^-16 per product, fp32 accumulate); bf16 = bf16 operands.  Tolerances: tests/test_gpu_precision.py")
     a('--loader_rng', default='host', choices=['host', 'device'],
       help="Random streams of the cloud loader: 'host' = numpy / python streams in the reference's order (seeded runs reproduce "
            "the reference's clouds), 'device' = counter-based generator on the GPU (no per-superpoint host loop)")
