@@ -37,6 +37,7 @@ def time_reference_step(model_config, batch, n_feat, state, max_seconds=25.0):
     model.train()
     gi = ecc.GraphConvInfo()
     gi._idxn, gi._idxe, gi._degrees, gi._degrees_gpu, gi._edgefeats = batch['idxn'], None, batch['degs'], None, batch['edgefeats']
+    gi._edge_indexes = None                         # only read by the --use_pyg 1 path (modules.py:156)
     model.ecc.set_info([gi], 0)
     embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=0, ptn_mem_monger=1))
 
