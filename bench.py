@@ -109,7 +109,7 @@ def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
         med, cnt = float(np.median(times)), len(times)
         sweep = '; one step at ' + ', '.join(f'{k} threads {v * 1e3:.0f} ms' for k, v in trial.items())
         kind, what = 'port', ('oracle/spg_oracle.py train_step on torch-CPU (no reference checkout on this machine; on the build container the '
-                              'port runs at 0.56-0.70x the speed of the imported reference modules, profiles/r02_cpu_reference_vs_port.json)')
+                              'port runs at 0.56-0.70x the speed of the imported reference modules, profiles/r02_cpu_reference_vs_port.json, oracle/devtools/cpu_baseline_compare.py)')
     return {'value': n / med, 'unit': 'superpoints/s', 'cores': torch.get_num_threads(), 'host_cores': ncpu, 'cpu_model': cpu_model(), 'kind': kind,
             'sample': f'{cnt} fwd+bwd steps of one {n}-superpoint scene (median {med * 1e3:.0f} ms/step), {what}{sweep}'}
 

@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 from oracle import ref_baseline, spg_oracle as O  # noqa: E402
 from superpoint_graph_amd import synth  # noqa: E402

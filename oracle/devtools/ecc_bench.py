@@ -7,7 +7,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from superpoint_graph_amd import ops, synth  # noqa: E402
 from superpoint_graph_amd.learning import modules  # noqa: E402
