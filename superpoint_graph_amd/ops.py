@@ -238,9 +238,12 @@ def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Seque
     B = clouds.shape[0]
     if clouds.shape[1] != cfg.nfeat or clouds.shape[2] != cfg.npts:
         raise ValueError(f'clouds must be [B, {cfg.nfeat}, {cfg.npts}], got {tuple(clouds.shape)}')
-    if training and B == 1:
-        # torch.nn.BatchNorm1d raises for the FC layers ([1, C] input) in training mode; so do we
-        raise ValueError('Expected more than 1 value per channel when training, got input size [1, C]')
+    if training and B <= 1:
+        # torch.nn.BatchNorm1d raises for the FC layers ([1, C] / empty input) in training mode; so do we
+        raise ValueError(f'Expected more than 1 value per channel when training, got input size [{B}, C]')
+    if B == 0:      # inference on a batch without a single embeddable superpoint: nothing to launch
+        return (torch.zeros(0, cfg.fc[cfg.n_fc - 1], dtype=torch.float32, device=clouds.device),
+                PointNetState(cfg, 0, clouds, clouds_global, None, training, ext_transform))
     if clouds_global is not None:
         clouds_global = _req(clouds_global.reshape(B, -1).contiguous(), torch.float32, 'clouds_global')
         if clouds_global.shape[1] != cfg.nfeat_global:
