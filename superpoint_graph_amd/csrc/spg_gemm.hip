@@ -681,25 +681,7 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
         }
       } else
       spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(p, acc, red, tile, m0, mvalid, n0, accum ? &sacc : nullptr);
-      if (!has_next) {
-        if (accum) {                             // the workgroup's ONE statistics partial
-          const long part = (long)tile0 * WI + wi;
-          if constexpr (!WRED) {
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-              const int col = n0 + wj * (JT / WJ) + 32 * j + r;
-              if (h == 0 && col < p.N) {
-                p.stat[(part * 2 + 0) * p.N + col] = sacc.a[j];
-                p.stat[(part * 2 + 1) * p.N + col] = sacc.b[j];
-              }
-            }
-            if (lane == 0 && wj == 0 && n0 == 0) p.stat_cnt[part] = sacc.n;
-          } else {
-            spg_bwd_stat_store<IT, JT, WI, WJ>(p, sacc.s1, sacc.s2, part, n0);
-          }
-        }
-        break;
-      }
+      if (!has_next) break;
       tile = nxt; m0 = m0n;
       if (DEFER2) {
         pa1.prepare(p.a, tile, SPG_KC);
@@ -709,6 +691,69 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
         for (int i = 0; i < NIW; ++i) w_load(pw1, pwr1, pb1, SPG_KC, i);
       }
       __syncthreads();          // the staging region is overwritten by the next chunk's finish stage
+    }
+    if (accum) {
+      // The workgroup's ONE statistics partial: the WI row-waves hold (rows, mean, M2) / (sum, sum) of the same columns;
+      // waves 1.. hand theirs to wave 0 through LDS (free now), which merges in fixed order and stores -- WI times fewer
+      // partials for the finalize kernel (<= 512 per layer: no sliced reduction, no last-arrival ticket).
+      float* xch = reinterpret_cast<float*>(smem);             // [WI][JT][2]
+      const long part = tile0;
+      __syncthreads();
+      if constexpr (!WRED) {
+        if (wi != 0 && h == 0) {
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            const int cl = wj * (JT / WJ) + 32 * j + r;
+            xch[(wi * JT + cl) * 2 + 0] = sacc.a[j];
+            xch[(wi * JT + cl) * 2 + 1] = sacc.b[j];
+          }
+        }
+        __syncthreads();
+        if (wi == 0 && h == 0) {
+          const float nb = sacc.n;                             // every row-wave saw the same number of rows
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            const int cl = wj * (JT / WJ) + 32 * j + r, col = n0 + cl;
+            float na = sacc.n, mean = sacc.a[j], m2 = sacc.b[j];
+#pragma unroll
+            for (int w = 1; w < WI; ++w) {
+              const float nn = na + nb, f = nn > 0.f ? nb / nn : 0.f;
+              const float delta = xch[(w * JT + cl) * 2 + 0] - mean;
+              mean += delta * f;
+              m2 += xch[(w * JT + cl) * 2 + 1] + delta * delta * (na * f);
+              na = nn;
+            }
+            if (col < p.N) {
+              p.stat[(part * 2 + 0) * p.N + col] = mean;
+              p.stat[(part * 2 + 1) * p.N + col] = m2;
+            }
+          }
+          if (lane == 0 && wj == 0 && n0 == 0) p.stat_cnt[part] = sacc.n * (float)WI;
+        }
+      } else {
+        constexpr int CW = JT / WJ, LPR = CW / 4;
+        f32x4 s1 = sacc.s1, s2 = sacc.s2;
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+        }
+        const int cl = wj * CW + 4 * (lane % LPR);
+        if (wi != 0 && lane < LPR) {
+          *reinterpret_cast<f32x4*>(xch + (wi * JT + cl) * 2) = s1;
+          *reinterpret_cast<f32x4*>(xch + (wi * JT + cl) * 2 + 4) = s2;
+        }
+        __syncthreads();
+        if (wi == 0 && lane < LPR) {
+#pragma unroll
+          for (int w = 1; w < WI; ++w) {
+            s1 += *reinterpret_cast<const f32x4*>(xch + (w * JT + cl) * 2);
+            s2 += *reinterpret_cast<const f32x4*>(xch + (w * JT + cl) * 2 + 4);
+          }
+          *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 0) * p.N + n0 + cl) = s1;
+          *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 1) * p.N + n0 + cl) = s2;
+        }
+      }
     }
     return;
   }
@@ -906,7 +951,7 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
         q.dbg = WRED ? 0 : g_tune[SPG_TUNE_DBG];      // attribution switches: forward launches only
         // ... the persistent workgroups accumulate over their tiles: one partial per workgroup of a column tile and row-wave
         q.stat_accum = !g_tune[SPG_TUNE_NO_STAT_ACCUM] && p.stat != nullptr && (!WRED || (q.vec_store && p.N <= p.n_mask));
-        if (q.stat_accum && stat_parts != nullptr) *stat_parts = (int)(q.rstride < q.ntile ? q.rstride : q.ntile) * WI;
+        if (q.stat_accum && stat_parts != nullptr) *stat_parts = (int)(q.rstride < q.ntile ? q.rstride : q.ntile);      // one per workgroup
         grid = dim3((unsigned)slots, 1);
         if constexpr (IT == 128 && !(WRED && JT == 128)) {
           if (prec == 3) hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, true, 3>), grid, dim3(SPG_THREADS), lds, stream, q);
