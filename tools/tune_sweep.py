@@ -77,7 +77,7 @@ def main():
         embedder.bw_hook()
         arena.adam_step(lr=1e-3, weight_decay=0.0, grad_clip=1.0)
 
-    configs = args.configs or ['default=', 'one_wg_per_tile=0:1', 'slice_above_256=4:256', 'slice_above_1024=4:1024', 'no_stat_accum=5:1', 'default2=']
+    configs = args.configs or ['default=', 'one_wg_per_tile=0:1', 'slice_above_256=4:256', 'no_stat_accum=5:1', 'bf16x3=7:3', 'bf16=7:1', 'default2=']
     for cfg in configs:
         name, _, kv = cfg.partition('=')
         for k in range(KNOBS):
