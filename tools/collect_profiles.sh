@@ -37,3 +37,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python $ROOT/tools/pmc_traffic.py $(db /tmp/p_FETCH_SIZE) $(db /tmp/p_WRITE_SIZE) $(db /tmp/c_FETCH_SIZE) $(db /tmp/c_WRITE_SIZE) 1024 > $OUT/${TAG}_gemm_traffic.json
 head -c 1500 $OUT/${TAG}_gemm_traffic.json
+
+# MFMA utilisation evidence: SQ counters of the same command (own pass, no other trace domains), f32 and split-bf16
+for P in f32 bf16x3; do
+  timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+    --output-format rocpd -d /tmp/p_sq_$P -- python $ROOT/bench.py --precision $P --steps 4 --warmup 2 $STEPS > /dev/null 2> $OUT/${TAG}_pmc_sq_$P.err
+  python $ROOT/tools/pmc_summary.py $(db /tmp/p_sq_$P) 20 > $OUT/${TAG}_pmc_sq_counters_$P.txt
+done
