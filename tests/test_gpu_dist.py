@@ -139,3 +139,25 @@ def test_bench_two_ranks_control_flow(hip):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['superpoints_per_step'] == 400
     assert 'roofline' in d and 'cpu_baseline' not in d
+
+
+@pytest.mark.parametrize('sync_bn', [0, 1])
+def test_bench_two_ranks_control_flow(hip, sync_bn):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one GPU of the
+    test box with the gloo backend: the data-parallel control flow (scene sharding, barrier + max-over-ranks timing,
+    weighted gradient all-reduce, rank 0 prints ONE JSON line with the whole-job value) without needing two devices."""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+           '--backend', 'gloo', '--device-index', '0', '--sync-bn', str(sync_bn), '--no-cpu-baseline', '--no-forward-only', '--no-roofline']
+    out = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak' and d['unit'] == 'superpoints/s'
+    assert d['config']['superpoints_per_step'] == 2000 and d['value'] > 0
+    assert abs(d['value'] - 2000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    assert ('synchronised' in d['config']['batchnorm']) == bool(sync_bn)
