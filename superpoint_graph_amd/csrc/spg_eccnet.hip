@@ -160,10 +160,12 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   for (const FLayer& l : pl.F) {
     cmax = l.cout > cmax ? l.cout : cmax; cmax = l.cin > cmax ? l.cin : cmax;
     wmax = (size_t)l.cin * l.cout > wmax ? (size_t)l.cin * l.cout : wmax;
-    workmax += ((spg_wgrad_workspace_floats(Er, l.cout, l.cin) + 63) & ~(size_t)63) + 64 * (size_t)l.cout + 128;
+    workmax += ((spg_wgrad_workspace_floats(Er, l.cout, l.cin) + 63) & ~(size_t)63) + 64 * (size_t)l.cout + 128 +
+               ((spg_wgrad_colsum_floats((long)Er, l.cout, l.cin) + 63) & ~(size_t)63);
   }
   // GRU: three weight gradients + three bias column sums over all (node, iteration) rows
-  workmax += 3 * (((spg_wgrad_workspace_floats((long)rows, pl.GW, 32) + 63) & ~(size_t)63) + 64 * (size_t)pl.GW + 128);
+  workmax += 3 * (((spg_wgrad_workspace_floats((long)rows, pl.GW, 32) + 63) & ~(size_t)63) + 64 * (size_t)pl.GW + 128 +
+                  ((spg_wgrad_colsum_floats((long)rows, pl.GW, 32) + 63) & ~(size_t)63));
   int hmax = 4;   // widest hidden activation
   for (int i = 0; i + 1 < (int)pl.F.size(); ++i) hmax = pl.F[i].cout > hmax ? pl.F[i].cout : hmax;
   s.dzA = cv.take<float>(Er * hmax); s.dzB = cv.take<float>(Er * hmax);
@@ -297,8 +299,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     SPG_TRY(spg_queue_colsum(rq, pl.lstm ? s.dgh : s.duh, GW, rows, GW, pl.cell_grads[3], st));
     if (pl.cfg.ingate) {
       w.a = op_ident(s.dpre, 32); w.b = op_ident(pl.states, 32); w.N = 32;
-      SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[4], st));
-      SPG_TRY(spg_queue_colsum(rq, s.dpre, 32, rows, 32, pl.cell_grads[5], st));
+      SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[4], st, pl.cell_grads[5]));      // + column sums = the input gate's bias gradient
     }
   }
   if (E == 0) {   // no edges: the filter network received no gradient
@@ -319,8 +320,9 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     FLayer& l = pl.F[i];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = fnet_input(pl, i, edgefeats); w.M = E; w.N = l.cout; w.K = l.cin;
-    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
-    if (l.db) {
+    const bool bias_rides = l.db != nullptr && !l.bn && cur.mode == SPG_PRO_IDENT;      // bias gradient = column sums of `cur`
+    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st, bias_rides ? l.db : nullptr));
+    if (l.db && !bias_rides) {
       if (l.bn) SPG_TRY(zero_async(l.db, (size_t)l.cout * 4, st));
       else SPG_TRY(spg_queue_colsum(rq, cur.X, cur.ld, E, l.cout, l.db, st));
     }

@@ -66,6 +66,8 @@ struct SpgWgradParams {
   int M, N, K;
   int rows_per_split; // multiple of 32
   float* partial;     // [nsplit][N][K]
+  float* colsum;      // [nsplit][N] or null: column sums of the (finished) `a` operand over each split's rows -- the bias
+                      // gradient of a layer without BatchNorm comes with the weight gradient instead of from its own launch
 };
 
 // bf16 copies of a weight matrix W [N, K] (row stride ldw floats) for the bf16 MFMA modes: fwd [2][N][ldk] (hi, lo; the
@@ -86,6 +88,8 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts 
 
 // workspace (floats) needed by spg_launch_wgrad for a problem of this size
 size_t spg_wgrad_workspace_floats(long M, int N, int K);
+// floats of the per-split column sums when the bias gradient rides along (spg_queue_wgrad with db)
+size_t spg_wgrad_colsum_floats(long M, int N, int K);
 // dW (dense [N,K], ld = K) = reduction; `work` holds the split partials
 int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t stream);
 
@@ -103,7 +107,8 @@ struct SpgReduceQueue {
   float* arena = nullptr;    // scratch for all partials of one backward pass
   size_t arena_floats = 0, used = 0;
 };
-int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream);
+// db (optional): also the column sums of the `a` operand (= bias gradient), from the same launch
+int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream, float* db = nullptr);
 int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, float* out, hipStream_t stream);
 int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream);
 

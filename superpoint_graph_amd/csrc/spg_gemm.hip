@@ -1043,6 +1043,21 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+  // optional by-product: column sums of the `a` operand (bias gradient).  Thread t < IT adds up channel i0 + t of every A
+  // tile right after it became visible in LDS (red-major fp32 tile: 32 conflict-free reads per chunk); only the
+  // workgroups of the first column tile do it.  (Not available in the bf16 modes, whose tiles are not fp32.)
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = PREC == 0 && p.colsum != nullptr && blockIdx.z == 0 && tid < IT;
+  auto colsum_tile = [&](const float* __restrict__ At, int stride) __attribute__((always_inline)) {
+    if (do_colsum) {
+#pragma unroll
+      for (int k = 0; k < SPG_KC; k += 4) {
+        csum[0] += At[(k + 0) * stride + tid]; csum[1] += At[(k + 1) * stride + tid];
+        csum[2] += At[(k + 2) * stride + tid]; csum[3] += At[(k + 3) * stride + tid];
+      }
+    }
+  };
+
   if constexpr (AMODE >= 0 && BMODE >= 0 && FULL && PREC != 0) {
     // bf16 layout: planes of 16-byte slots, slot = 8 consecutive ROWS of one channel (SpgRedFastB); same pipeline
     constexpr int BUF4 = (SPG_KC / 4) * (IT + 1 + JT + 1);
@@ -1147,6 +1162,7 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
           for (int i = 0; i < NIB; ++i) pb.load_part(p.b, m2, j0, i);
         }
       };
+      colsum_tile(As + buf * BUF, IT + 4);
       spg_mfma_chunk_rr_il<TI, TJ>(As + buf * BUF, Bs + buf * BUF, IT + 4, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
       __syncthreads();
       buf ^= 1;
@@ -1196,6 +1212,7 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
           for (int i = (NIB + 1) / 2; i < NIB; ++i) pb.load_part(p.b, qb, m2, me, ms, j0, i);
         }
       };
+      colsum_tile(As + buf * BUF, IT + 4);
       spg_mfma_chunk_rr_il<TI, TJ>(As + buf * BUF, Bs + buf * BUF, IT + 4, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
       __syncthreads();
       buf ^= 1;
@@ -1206,10 +1223,12 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
       spg_stage_red<IT>(p.a, m, me, i0, p.N, As);
       spg_stage_red<JT>(p.b, m, me, j0, p.K, Bs);
       __syncthreads();
+      colsum_tile(As, sa);
       spg_mfma_chunk_rr<TI, TJ>(As, Bs, sa, sb, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc);
       __syncthreads();
     }
   }
+  if (do_colsum && i0 + tid < p.N) p.colsum[(long)split * p.N + i0 + tid] = (csum[0] + csum[1]) + (csum[2] + csum[3]);
   // partial tile of this split: wave-uniform base + 32-bit lane offsets; unconditional stores when the tile is full
   float* pb = p.partial + ((long)split * p.N + i0) * p.K + j0;
   const unsigned ldk = (unsigned)p.K;
@@ -1286,7 +1305,7 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
                       (long)SPG_KC * p.a.ld < (1L << 29) && (long)SPG_KC * p.b.ld < (1L << 29);
     if (full) {
       prof.r.tag = SPG_PROF_TAG(2, IT, JT, AMODE, BMODE, 1);
-      const int prec = (IT == 128 || JT >= 64) ? g_tune[SPG_TUNE_PRECISION] : 0;      // opt-in bf16 / split-bf16 MFMA (spg_tune key 7)
+      const int prec = ((IT == 128 || JT >= 64) && p.colsum == nullptr) ? g_tune[SPG_TUNE_PRECISION] : 0;      // opt-in bf16 / split-bf16 MFMA (spg_tune key 7)
       if (prec == 3) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 3>), grid, dim3(SPG_THREADS), lds, stream, p);
       else if (prec == 1) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 1>), grid, dim3(SPG_THREADS), lds, stream, p);
       else
@@ -1338,8 +1357,15 @@ static int spg_launch_wgrad_partials(SpgWgradParams p, float* part, hipStream_t 
   return launch_wgrad_shape<-1, -1>(p, it, jt, ns, stream);
 }
 
+size_t spg_wgrad_colsum_floats(long M, int N, int K) {
+  int it, jt, ns, rps;
+  wgrad_plan(M, N, K, &it, &jt, &ns, &rps);
+  return (size_t)ns * N;
+}
+
 int spg_launch_wgrad(SpgWgradParams p, float* dW, float* work, hipStream_t stream) {
   SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty wgrad");
+  p.colsum = nullptr;
   int it, jt, ns, rps;
   wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
   SPG_TRY(spg_launch_wgrad_partials(p, ns == 1 ? dW : work, stream));
@@ -1429,16 +1455,26 @@ static int queue_take(SpgReduceQueue& q, size_t floats, float** out, hipStream_t
   return 0;
 }
 
-int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream) {
+int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream, float* db) {
   SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty wgrad");
   int it, jt, ns, rps;
   wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
   float* part = dW;
+  if (q.njobs + 2 > SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(q, stream));
   if (ns > 1) SPG_TRY(queue_take(q, (size_t)ns * p.N * p.K, &part, stream));
+  p.colsum = nullptr;
+  if (db != nullptr) {          // the bias gradient rides along: column sums of the `a` operand per split
+    p.colsum = db;
+    if (ns > 1) SPG_TRY(queue_take(q, (size_t)ns * p.N, &p.colsum, stream));
+  }
   SPG_TRY(spg_launch_wgrad_partials(p, part, stream));
   if (ns > 1) {
     SpgReduceJob& j = q.jobs[q.njobs++];
     j.partial = part; j.out = dW; j.nsplit = ns; j.n = p.N * p.K;
+    if (db != nullptr) {
+      SpgReduceJob& c = q.jobs[q.njobs++];
+      c.partial = p.colsum; c.out = db; c.nsplit = ns; c.n = p.N;
+    }
   }
   return 0;
 }

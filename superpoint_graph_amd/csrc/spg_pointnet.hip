@@ -286,7 +286,8 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
     cmax = l.cout > cmax ? l.cout : cmax; cmax = l.cin > cmax ? l.cin : cmax;
     wmax = (size_t)l.cin * l.cout > wmax ? (size_t)l.cin * l.cout : wmax;
     // every layer gets its own slice of the reduction arena (partials stay alive until the single batched reduce)
-    workmax += ((spg_wgrad_workspace_floats(l.conv ? pl.M : pl.B, l.cout, l.cin) + 63) & ~(size_t)63) + 64 * (size_t)l.cout + 128;
+    workmax += ((spg_wgrad_workspace_floats(l.conv ? pl.M : pl.B, l.cout, l.cin) + 63) & ~(size_t)63) + 64 * (size_t)l.cout + 128 +
+               ((spg_wgrad_colsum_floats(l.conv ? pl.M : pl.B, l.cout, l.cin) + 63) & ~(size_t)63);
   }
   s.dzA = cv.take<float>((size_t)pl.M * cconv); s.dzB = cv.take<float>((size_t)pl.M * cconv);
   s.fzA = cv.take<float>((size_t)pl.B * cfc); s.fzB = cv.take<float>((size_t)pl.B * cfc);
@@ -325,9 +326,12 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     Layer& l = pl.L[sg.fcs[k]];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, true, k, clouds, stnT); w.M = B; w.N = l.cout; w.K = l.cin;
-    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
-    if (l.db) {
-      if (l.bn) SPG_TRY(zero_async(l.db, l.cout, st));   // a bias in front of train-mode BatchNorm has zero gradient
+    // a bias without BatchNorm behind it: its gradient (column sums of `cur`, an IDENT operand here) rides along with the
+    // weight gradient; a bias in front of train-mode BatchNorm has zero gradient
+    const bool bias_rides = l.db != nullptr && !l.bn && cur.mode == SPG_PRO_IDENT;
+    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st, bias_rides ? l.db : nullptr));
+    if (l.db && !bias_rides) {
+      if (l.bn) SPG_TRY(zero_async(l.db, l.cout, st));
       else SPG_TRY(spg_queue_colsum(rq, cur.X, cur.ld, B, l.cout, l.db, st));
     }
     // data gradient -> producer of this layer's input
