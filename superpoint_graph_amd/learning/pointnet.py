@@ -345,7 +345,7 @@ class CloudEmbedder():
         idx_valid, clouds, clouds_global = self._to_device(clouds_flag, clouds, clouds_global)
         out = model.ptn(clouds, clouds_global)
         descriptors = out.new_zeros(clouds_flag.size(0), out.size(1))
-        return descriptors.index_copy(0, idx_valid, out)
+        return descriptors.index_copy_(0, idx_valid, out)      # in place on the fresh zeros: no extra copy of the buffer
 
     def run_full_monger(self, model, clouds_meta, clouds_flag, clouds, clouds_global):
         if not self.args.cuda:
@@ -367,4 +367,4 @@ class CloudEmbedder():
                     live.backward(out.grad)
             self.bw_hook = bw_hook
         descriptors = out.new_zeros(clouds_flag.size(0), out.size(1))
-        return descriptors.index_copy(0, idx_valid, out)
+        return descriptors.index_copy_(0, idx_valid, out)      # in place on the fresh zeros: no extra copy of the buffer
