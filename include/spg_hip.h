@@ -104,6 +104,12 @@ int spg_colsum(const float* X, long ldx, long M, int N, float* out, float* work,
 size_t spg_linear_wgrad_work_floats(int M, int N, int K);
 int spg_linear_wgrad(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K, const float* in_scale,
                      const float* in_shift, int in_relu, float* dW, float* work, void* stream);
+/* weight and bias gradient of a dense layer together (the column sums of dY ride along with the weight-gradient launch):
+ * dbias [N] = sum_m dY[m, :]; work >= spg_linear_wgrad_bias_work_floats(M, N, K) floats.  Replaces the autograd backward
+ * of nn.Linear's weight and bias (classifier, learning/graphnet.py:47-49). */
+size_t spg_linear_wgrad_bias_work_floats(int M, int N, int K);
+int spg_linear_wgrad_bias(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K, const float* in_scale,
+                          const float* in_shift, int in_relu, float* dW, float* dbias, float* work, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PointNet (learning/pointnet.py:16-133): STNkD + per-point MLP + max-pool + FC head, train-mode

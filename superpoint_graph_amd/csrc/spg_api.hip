@@ -448,6 +448,26 @@ extern "C" int spg_linear_wgrad(const float* dY, long lddy, const float* X, long
   return spg_launch_wgrad(w, dW, work, (hipStream_t)stream);
 }
 
+// weight AND bias gradient of a dense layer in two launches (weight-gradient partials with the column sums of dY riding
+// along, one batched reduction) instead of four (spg_linear_wgrad + spg_colsum)
+extern "C" size_t spg_linear_wgrad_bias_work_floats(int M, int N, int K) {
+  return ((spg_wgrad_workspace_floats(M, N, K) + 63) & ~(size_t)63) + ((spg_wgrad_colsum_floats(M, N, K) + 63) & ~(size_t)63) + 128;
+}
+
+extern "C" int spg_linear_wgrad_bias(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K,
+                                     const float* in_scale, const float* in_shift, int in_relu, float* dW, float* dbias,
+                                     float* work, void* stream) {
+  SPG_CHECK_ARG(dY && X && dW && dbias && work, "null pointer");
+  SpgWgradParams w; memset(&w, 0, sizeof(w));
+  w.a = affine_operand(dY, lddy, N, nullptr, nullptr, 0);
+  w.b = affine_operand(X, ldx, K, in_scale, in_shift, in_relu);
+  w.M = M; w.N = N; w.K = K;
+  SpgReduceQueue rq;
+  rq.arena = work; rq.arena_floats = spg_linear_wgrad_bias_work_floats(M, N, K);
+  SPG_TRY(spg_queue_wgrad(rq, w, dW, (hipStream_t)stream, dbias));
+  return spg_flush_reduce(rq, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // element-wise gradient clamp + Adam on one flat buffer (learning/main.py:210-213, torch.optim.Adam semantics:
 // weight decay added to the clamped gradient, bias-corrected moments, denom = sqrt(v)/sqrt(1-b2^t) + eps)

@@ -126,12 +126,15 @@ class _LinearFunction(torch.autograd.Function):
         if direct:          # FlatParameters: write into the (zeroed) arena views, nothing for autograd to accumulate
             from ..flat import mark_direct_write
             mark_direct_write(m)
-            ops.linear_wgrad(gy, x, out=weight.grad)
             if m.bias is not None:
-                ops.colsum(gy, out=m.bias.grad)
+                ops.linear_wgrad_bias(gy, x, out_w=weight.grad, out_b=m.bias.grad)
+            else:
+                ops.linear_wgrad(gy, x, out=weight.grad)
             return None, gx, None, None
-        gw = ops.linear_wgrad(gy, x)
-        gb = ops.colsum(gy) if m.bias is not None else None
+        if m.bias is not None:
+            gw, gb = ops.linear_wgrad_bias(gy, x)
+        else:
+            gw, gb = ops.linear_wgrad(gy, x), None
         return None, gx, gw, gb
 
 

@@ -193,6 +193,19 @@ def linear_wgrad(dy, x, in_scale=None, in_shift=None, in_relu=False, out=None):
     return dw
 
 
+def linear_wgrad_bias(dy, x, out_w=None, out_b=None):
+    """dW [N, K] and dbias [N] of a dense layer in two launches (spg_linear_wgrad_bias)."""
+    _req(dy, torch.float32, 'dy'); _req(x, torch.float32, 'x')
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=x.device) if out_w is None else out_w
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if out_b is None else out_b
+    work = torch.empty(max(1, lib().spg_linear_wgrad_bias_work_floats(M, N, K)), dtype=torch.float32, device=x.device)
+    check(lib().spg_linear_wgrad_bias(_ptr(dy), N, _ptr(x), K, M, N, K, None, None, 0, _ptr(dw), _ptr(db), _ptr(work), _stream()),
+          'spg_linear_wgrad_bias')
+    return dw, db
+
+
 # --------------------------------------------------------------------------------------------------
 # PointNet
 # --------------------------------------------------------------------------------------------------

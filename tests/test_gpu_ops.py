@@ -189,6 +189,10 @@ def test_linear_forward_and_wgrad(hip, M, K, N):
     assert maxrel(dw, dy.double().t() @ x.double()) < 2e-6
     dw2 = ops.linear_wgrad(DY, X, SC, SH, True)
     assert maxrel(dw2, dy.double().t() @ a) < 2e-6
+    # weight and bias gradient together (column sums of dY ride along with the weight-gradient launch)
+    dw3, db3 = ops.linear_wgrad_bias(DY, X)
+    assert torch.equal(dw3, dw)
+    assert maxrel(db3, dy.double().sum(0)) < 2e-6
 
 
 def test_fused_clamp_adam_matches_torch(hip):
