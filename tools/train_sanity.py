@@ -13,7 +13,11 @@ import bench  # noqa: E402
 
 
 def main():
+    from superpoint_graph_amd import _lib
     from superpoint_graph_amd.flat import FlatParameters
+    prec = sys.argv[1] if len(sys.argv) > 1 else 'f32'          # f32 | bf16x3 | bf16 (opt-in arithmetic of the wide GEMMs)
+    assert _lib.lib().spg_tune(7, {'f32': 0, 'bf16': 1, 'bf16x3': 3}[prec]) >= 0
+    print(f'precision mode: {prec}')
     from superpoint_graph_amd.learning import pointnet
     dev = torch.device('cuda')
     model = bench.build_model('gru_10_0,f_13', dev).train()
