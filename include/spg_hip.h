@@ -251,7 +251,8 @@ int spg_loader_random(const int64_t* counts, const int64_t* ids, const int32_t* 
  * nn.functional.cross_entropy(outputs, label_mode, weight=class_weights); rows with target == ignore_index do not
  * count): loss (1 float; reduction_mean: sum_i w[t_i] nll_i / sum_i w[t_i], else the plain sum), lse [N] (log-sum-exp
  * per row, kept for the backward), wsum (1 float, the normaliser).  Backward: grad_logits [N, C] from grad_loss (1 float).
- * One launch each, fixed summation order.
+ * One launch each, fixed summation order.  A target outside [0, C) that is not ignore_index (torch: device-side assert)
+ * makes the loss NaN -- the kernels are asynchronous, so the error surfaces in the value instead of an error code.
  * ---------------------------------------------------------------------------------------------- */
 int spg_cross_entropy_fwd(const float* logits, const int64_t* target, const float* weight, int N, int C, int64_t ignore_index,
                           int reduction_mean, float* loss, float* lse, float* wsum, void* stream);

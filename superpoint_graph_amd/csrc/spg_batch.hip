@@ -91,8 +91,8 @@ __global__ void edge_features_kernel(const spg_edge_feature_spec* __restrict__ s
   const spg_edge_feature_spec sp = S.col[c];
   const long a = edges[2 * e], b = edges[2 * e + 1];
   float v;
-  if (sp.kind == SPG_EF_COPY) {
-    v = ((const float*)sp.data)[e * sp.ld + sp.column];
+  if (sp.kind == SPG_EF_COPY) {      // numpy's .astype(float32) of the attribute column, whatever its storage type
+    v = sp.is_f64 ? (float)((const double*)sp.data)[e * sp.ld + sp.column] : ((const float*)sp.data)[e * sp.ld + sp.column];
   } else if (sp.kind == SPG_EF_CONST) {
     v = 1.f;
   } else if (sp.is_f64) {                                   // e.g. the point count (u64 in the file): float64 arithmetic, one final rounding

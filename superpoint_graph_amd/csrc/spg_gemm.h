@@ -68,6 +68,9 @@ struct SpgWgradParams {
   float* partial;     // [nsplit][N][K]
   float* colsum;      // [nsplit][N] or null: column sums of the (finished) `a` operand over each split's rows -- the bias
                       // gradient of a layer without BatchNorm comes with the weight gradient instead of from its own launch
+                      // (identity `a` operands only)
+  int allow_lowp;     // 1: this launch may use the opt-in bf16 / split-bf16 MFMA mode (spg_tune key 7).  Set by the PointNet
+                      // convolutions only; 0 (memset default) keeps fp32 MFMA whatever the shape (filter net, RNN cell, dense layer)
 };
 
 // bf16 copies of a weight matrix W [N, K] (row stride ldw floats) for the bf16 MFMA modes: fwd [2][N][ldk] (hi, lo; the

@@ -1021,7 +1021,9 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts)
 // ---------------------------------------------------------------------------------------------
 // AMODE / BMODE >= 0: compile-time operand modes, vector + software-pipelined loop; < 0: generic scalar staging.
 // PREC (FULL only): 0 fp32 MFMA; 1 / 3 bf16 / split-bf16 MFMA with both operands converted while staging (spg_common.h)
-template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE, bool FULL = false, int PREC = 0>
+// COLSUM: also the column sums of the `a` operand (bias gradient of a layer without BatchNorm); a compile-time switch so
+// that the main loop of every other instantiation (all wide BatchNorm layers) carries no predicate / accumulators for it
+template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE, bool FULL = false, int PREC = 0, bool COLSUM = false>
 __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradParams p) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
@@ -1046,14 +1048,17 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   // optional by-product: column sums of the `a` operand (bias gradient).  Thread t < IT adds up channel i0 + t of every A
   // tile right after it became visible in LDS (red-major fp32 tile: 32 conflict-free reads per chunk); only the
   // workgroups of the first column tile do it.  (Not available in the bf16 modes, whose tiles are not fp32.)
+  static_assert(!COLSUM || PREC == 0, "column sums ride along with the fp32 tiles only");
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = PREC == 0 && p.colsum != nullptr && blockIdx.z == 0 && tid < IT;
+  const bool do_colsum = COLSUM && blockIdx.z == 0 && tid < IT;
   auto colsum_tile = [&](const float* __restrict__ At, int stride) __attribute__((always_inline)) {
-    if (do_colsum) {
+    if constexpr (COLSUM) {
+      if (do_colsum) {
 #pragma unroll
-      for (int k = 0; k < SPG_KC; k += 4) {
-        csum[0] += At[(k + 0) * stride + tid]; csum[1] += At[(k + 1) * stride + tid];
-        csum[2] += At[(k + 2) * stride + tid]; csum[3] += At[(k + 3) * stride + tid];
+        for (int k = 0; k < SPG_KC; k += 4) {
+          csum[0] += At[(k + 0) * stride + tid]; csum[1] += At[(k + 1) * stride + tid];
+          csum[2] += At[(k + 2) * stride + tid]; csum[3] += At[(k + 3) * stride + tid];
+        }
       }
     }
   };
@@ -1228,7 +1233,9 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
       __syncthreads();
     }
   }
-  if (do_colsum && i0 + tid < p.N) p.colsum[(long)split * p.N + i0 + tid] = (csum[0] + csum[1]) + (csum[2] + csum[3]);
+  if constexpr (COLSUM) {
+    if (do_colsum && i0 + tid < p.N) p.colsum[(long)split * p.N + i0 + tid] = (csum[0] + csum[1]) + (csum[2] + csum[3]);
+  }
   // partial tile of this split: wave-uniform base + 32-bit lane offsets; unconditional stores when the tile is full
   float* pb = p.partial + ((long)split * p.N + i0) * p.K + j0;
   const unsigned ldk = (unsigned)p.K;
@@ -1305,7 +1312,16 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
                       (long)SPG_KC * p.a.ld < (1L << 29) && (long)SPG_KC * p.b.ld < (1L << 29);
     if (full) {
       prof.r.tag = SPG_PROF_TAG(2, IT, JT, AMODE, BMODE, 1);
-      const int prec = ((IT == 128 || JT >= 64) && p.colsum == nullptr) ? g_tune[SPG_TUNE_PRECISION] : 0;      // opt-in bf16 / split-bf16 MFMA (spg_tune key 7)
+      // opt-in bf16 / split-bf16 MFMA (spg_tune key 7): only for launches that asked for it (the PointNet convolutions set
+      // allow_lowp; the filter network, the RNN cell and the stand-alone dense layer stay fp32 whatever their shape)
+      const int prec = ((IT == 128 || JT >= 64) && p.colsum == nullptr && p.allow_lowp) ? g_tune[SPG_TUNE_PRECISION] : 0;
+      if constexpr (AMODE == SPG_PRO_IDENT) {
+        if (p.colsum != nullptr) {
+          hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 0, true>), grid, dim3(SPG_THREADS), lds, stream, p);
+          SPG_LAUNCH_CHECK();
+          return 0;
+        }
+      }
       if (prec == 3) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 3>), grid, dim3(SPG_THREADS), lds, stream, p);
       else if (prec == 1) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 1>), grid, dim3(SPG_THREADS), lds, stream, p);
       else
@@ -1315,6 +1331,14 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
     }
   }
   prof.r.tag = SPG_PROF_TAG(2, IT, JT, AMODE, BMODE, 0);
+  if constexpr (AMODE == SPG_PRO_IDENT || AMODE < 0) {
+    if (p.colsum != nullptr) {
+      hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, false, 0, true>), grid, dim3(SPG_THREADS), lds, stream, p);
+      SPG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  SPG_CHECK_ARG(p.colsum == nullptr, "column sums ride along only with an identity `a` operand");
   hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;

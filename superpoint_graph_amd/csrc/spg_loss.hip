@@ -12,6 +12,9 @@ __global__ __launch_bounds__(1024) void ce_fwd_kernel(const float* __restrict__ 
                                                       int reduction_mean, float* __restrict__ loss, float* __restrict__ lse,
                                                       float* __restrict__ wsum_out) {
   __shared__ double s_l[16], s_w[16];
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
   double accl = 0.0, accw = 0.0;
   for (int i = threadIdx.x; i < N; i += 1024) {
     const float* x = logits + (long)i * C;
@@ -26,6 +29,8 @@ __global__ __launch_bounds__(1024) void ce_fwd_kernel(const float* __restrict__ 
       const float w = weight ? weight[t] : 1.f;
       accl += (double)(w * (l - x[t]));
       accw += (double)w;
+    } else if (t != ignore_index) {
+      s_bad = 1;      // a class index outside [0, C) that is not ignore_index: torch raises a device assert; here the loss becomes NaN
     }
   }
   for (int off = 32; off >= 1; off >>= 1) { accl += __shfl_xor(accl, off, 64); accw += __shfl_xor(accw, off, 64); }
@@ -35,7 +40,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_kernel(const float* __restrict__ 
     double a = 0.0, b = 0.0;
     for (int k = 0; k < 16; ++k) { a += s_l[k]; b += s_w[k]; }
     *wsum_out = (float)b;
-    *loss = (float)(reduction_mean ? a / b : a);
+    *loss = s_bad ? __builtin_nanf("") : (float)(reduction_mean ? a / b : a);
   }
 }
 

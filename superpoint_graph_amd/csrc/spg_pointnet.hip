@@ -369,6 +369,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     Layer& l = pl.L[sg.convs[k]];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, false, k, clouds, stnT); w.M = (int)pl.M; w.N = l.cout; w.K = l.cin;
+    w.allow_lowp = 1;      // the opt-in precision modes act on the PointNet convolutions only
     SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
     if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
     if (k > 0) {

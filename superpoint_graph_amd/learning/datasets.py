@@ -78,7 +78,13 @@ def _loader_backend(args, root, store=None):
     """Where the loader takes the superpoint clouds from: on the GPU the parsed points of every scene stay resident in HBM
     and one kernel builds all clouds of a graph (`--loader_device 1`, the default with --cuda 1); otherwise the
     reference's per-superpoint host path."""
-    store = store if store is not None else spg.H5PointStore(root)
+    if store is None:
+        # ONE store (and therefore one HBM-resident point cache, one set of open HDF5 handles) per dataset root for the whole
+        # process: get_datasets is called once per test-time sample by eval_final (learning/main.py:272), and a fresh store
+        # per call would re-read and re-upload every scene each time
+        store = _H5_STORES.get(root)
+        if store is None:
+            store = _H5_STORES[root] = spg.H5PointStore(root)
     if getattr(args, 'cuda', 0) and getattr(args, 'loader_device', 1):
         cache = getattr(args, '_device_point_cache', None)
         if cache is None or cache._store is not store:
@@ -86,6 +92,9 @@ def _loader_backend(args, root, store=None):
             args._device_point_cache = cache
         return {'device_cache': cache}
     return {'store': store}
+
+
+_H5_STORES = {}
 
 
 # ---- S3DIS (learning/s3dis_dataset.py) ---------------------------------------------------------------------------

@@ -138,6 +138,14 @@ def filter_valid(output, target, other=None):
     return output[idx, :], target[idx]
 
 
+def _log_bounded(log, entry, keep=2048):
+    """Per-batch records for tests and tools: 4-byte device scalars (clones -- a view would keep the loss kernel's whole
+    [N+2] buffer alive), the oldest half dropped beyond `keep` entries so that a 350-epoch run does not grow without bound."""
+    log.append(entry)
+    if len(log) > keep:
+        del log[:keep // 2]
+
+
 def meter_value(meter):
     return meter.value()[0] if meter.n > 0 else 0
 
@@ -211,12 +219,25 @@ class Session:
         self.iter_log = []                            # (loss, trainer ms) per training batch, for tests and tools
         self.eval_log = []                            # loss per evaluation batch
 
+    def _nworkers(self):
+        """--nworkers as given, except with the device loader: `spg.loader` then launches kernels inside `__getitem__`, which
+        cannot run in forked DataLoader workers (the CUDA/HIP context of the parent does not survive a fork) and needs no
+        workers anyway (one launch builds all clouds of a graph).  The reference's documented commands pass --nworkers 2."""
+        a = self.args
+        if a.nworkers > 0 and a.cuda and a.loader_device:
+            if not getattr(self, '_warned_workers', False):
+                logging.warning('--nworkers %d ignored: --loader_device 1 builds the superpoint clouds on the GPU in the main process '
+                                '(use --loader_device 0 for the host loader with worker processes)', a.nworkers)
+                self._warned_workers = True
+            return 0
+        return a.nworkers
+
     def _loader(self, dataset, train):
         a = self.args
         if train:
-            return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=spg.eccpc_collate, num_workers=a.nworkers,
+            return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=spg.eccpc_collate, num_workers=self._nworkers(),
                                                shuffle=True, drop_last=True)
-        return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=spg.eccpc_collate, num_workers=a.nworkers)
+        return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=spg.eccpc_collate, num_workers=self._nworkers())
 
     def _forward(self, targets, GIs, clouds_data):
         self.model.ecc.set_info(GIs, self.args.cuda)
@@ -255,7 +276,7 @@ class Session:
             t_trainer = 1000 * (time.time() - t0)
             loss_meter.add(loss.detach())
             cm.count_predicted_batch_device(label_vec, outputs.detach(), label_mode)   # filter_valid + argmax + counts, on the GPU
-            self.iter_log.append((loss.detach(), t_trainer))
+            _log_bounded(self.iter_log, (loss.detach().clone(), t_trainer))
             logging.debug('Batch loader time %f ms, trainer time %f ms.', t_loader, t_trainer)
             t0 = time.time()
             if a.max_train_iters and bidx + 1 >= a.max_train_iters:
@@ -274,7 +295,7 @@ class Session:
                 outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
                 loss = ops.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])
             loss_meter.add(loss)
-            self.eval_log.append(loss)
+            _log_bounded(self.eval_log, loss.clone())
             cm.count_predicted_batch_device(label_vec, outputs, label_mode)
         acc_meter.add_counts(*cm.accuracy_counts())
         return (meter_value(acc_meter), loss_meter.value()[0], cm.get_overall_accuracy(), cm.get_average_intersection_union(),

@@ -122,7 +122,7 @@ def test_sync_bn_world1_equals_local_bn_at_full_size(hip):
         assert torch.equal(r0[k], r1[k]), k
 
 
-def test_bench_two_ranks_control_flow(hip):
+def test_bench_two_ranks_with_roofline_pass(hip):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank); both ranks
     share the test box's single GPU and talk over gloo, which exercises every rank-dependent branch (sharding, barriers,
     the collectives of the step and of the instrumented pass, rank-0 reporting)."""
