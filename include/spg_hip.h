@@ -139,7 +139,8 @@ int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const float* clouds
                          const void* const* params, float* emb, void* workspace, int training, int bn_update_times,
                          void* stream);
 /* test helper: byte offset of a layer's buffer inside the forward workspace (what: 0 raw output, 1 BN scale,
- * 2 BN shift, 3 batch mean, 4 batch rstd; layer -1 / -2: pooled buffer of the STN / main segment); -1 if absent */
+ * 2 BN shift, 3 batch mean, 4 batch rstd; layer -1 / -2 = STN / main segment: what 0 pooled raw values [B, ld],
+ * 1 arg-max points int32 [B, ld], 2 the leading dimension ld itself); -1 if absent */
 long spg_pointnet_debug_offset(const spg_pointnet_cfg* cfg, int B, int training, int layer, int what);
 size_t spg_pointnet_bwd_workspace_bytes(const spg_pointnet_cfg* cfg, int B);
 int spg_pointnet_backward(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
@@ -180,6 +181,9 @@ size_t spg_eccrnn_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E, int t
 int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0,
                        const float* edgefeats, const void* const* params, float* out, void* workspace, int training,
                        int bn_update_times, void* stream);
+/* test helper: byte offset inside the forward workspace of filter-network layer `layer`'s buffers (what: 0 raw output
+ * [E, cout], 1 / 2 BatchNorm scale / shift of that layer); -1 if absent */
+long spg_eccrnn_debug_offset(const spg_eccrnn_cfg* cfg, int N, int E, int training, int layer, int what);
 size_t spg_eccrnn_bwd_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E);
 int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
                         const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,

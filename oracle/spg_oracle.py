@@ -238,19 +238,27 @@ class EccFunction(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 def batch_norm(x: torch.Tensor, prefix: str, P: Dict[str, torch.Tensor], training: bool,
                stats_out: Optional[dict] = None) -> torch.Tensor:
-    """nn.BatchNorm1d on [M, C] (rows = batch x points).  Train: biased batch variance for the
+    """nn.BatchNorm1d on [M, C] or [B, C, L] (channel = dim 1).  Train: biased batch variance for the
     normalisation; `stats_out[prefix] = (mean, unbiased_var, count)` lets the caller apply the
     running-stat update (momentum 0.1, unbiased variance)."""
+    red = (0,) if x.dim() == 2 else (0, 2)
     if training:
-        mean = x.mean(0)
-        var = x.var(0, unbiased=False)
         if stats_out is not None:
-            m = x.shape[0]
-            stats_out[prefix] = (mean.detach(), (var * (m / max(m - 1, 1))).detach(), m)
-    else:
-        mean = P[prefix + '.running_mean'].to(x.dtype)
-        var = P[prefix + '.running_var'].to(x.dtype)
-    return (x - mean) / torch.sqrt(var + BN_EPS) * P[prefix + '.weight'].to(x.dtype) + P[prefix + '.bias'].to(x.dtype)
+            with torch.no_grad():
+                m = x.numel() // x.shape[1]
+                mean = x.mean(red)
+                var = x.var(red, unbiased=False)
+                stats_out[prefix] = (mean, var * (m / max(m - 1, 1)), m)
+        # the op nn.BatchNorm1d.forward itself calls (learning/pointnet.py:31, graphnet.py:29): batch statistics, and torch's
+        # native backward.  (Until round 3 this was the written-out formula differentiated by autograd: same forward, but
+        # at 128 000 rows its fp32 gradients were 6e-3..3e-2 off the fp64 truth where the reference's are 1e-5..7e-4 --
+        # measured in oracle/validate_against_reference.py::check_baseline_size -- and twice as slow.)
+        return torch.nn.functional.batch_norm(x, None, None, P[prefix + '.weight'].to(x.dtype), P[prefix + '.bias'].to(x.dtype),
+                                              True, 0.0, BN_EPS)
+    shape = (1, -1) if x.dim() == 2 else (1, -1, 1)
+    mean = P[prefix + '.running_mean'].to(x.dtype).view(shape)
+    var = P[prefix + '.running_var'].to(x.dtype).view(shape)
+    return (x - mean) / torch.sqrt(var + BN_EPS) * P[prefix + '.weight'].to(x.dtype).view(shape) + P[prefix + '.bias'].to(x.dtype).view(shape)
 
 
 def apply_running_stats(P: Dict[str, torch.Tensor], stats: dict, times: int = 1):
@@ -273,34 +281,69 @@ def _lin(x, P, prefix, bias=True):
     return y
 
 
-def stn_forward(clouds_stn: torch.Tensor, spec: ModelSpec, P, training: bool, stats=None, pfx='ptn.stn'):
-    """STNkD.forward, learning/pointnet.py:55-61.  clouds_stn: [B, nfeat_stn, Pn] -> T [B,2,2]."""
-    B, F, Pn = clouds_stn.shape
-    h = clouds_stn.permute(0, 2, 1).reshape(B * Pn, F)            # Conv1d(k=1) == per-point Linear
+# Decision hooks (tests only): the two non-smooth operations of PointNet -- ReLU and the max-pool over the points -- are
+# DECISIONS (which side of zero, which point wins).  Two fp32 implementations that agree to round-off can still take a
+# different decision on a near-tie, and then their gradients differ by far more than round-off.  `rec` (a dict) receives,
+# per BatchNorm prefix, the value the ReLU saw -- point layers as [B, Pn, C] (row b*Pn + p of the [M, C] matrices the HIP
+# kernels use), FC layers as [B, C] -- and, per '<segment>.pool', the [B, Pn, C] tensor the max-pool saw; `dec` forces
+# decisions taken elsewhere (ReLU: bool mask [B*Pn, C] / [B, C]; pool: int64 [B, C] point indices), so that a backward
+# pass can be compared with the decisions held equal.
+def _relu_dec(v, key, dec, rec):
+    pts = v.dim() == 3                                   # [B, C, Pn]
+    if rec is not None:
+        rec[key] = v.detach().permute(0, 2, 1) if pts else v.detach()
+    if dec is not None and key in dec:
+        m = dec[key]
+        if pts:
+            m = m.view(v.shape[0], v.shape[2], v.shape[1]).permute(0, 2, 1)
+        return v * m.to(v.dtype)
+    return torch.relu(v)
+
+
+def _pool_dec(h, key, dec, rec):
+    """h [B, C, Pn] -> [B, C]: max over the points (nnf.max_pool1d(input, input.size(2)).squeeze(2))."""
+    if rec is not None:
+        rec[key] = h.detach().permute(0, 2, 1)
+    if dec is not None and key in dec:
+        return h.gather(2, dec[key].unsqueeze(2)).squeeze(2)
+    return torch.nn.functional.max_pool1d(h, h.size(2)).squeeze(2)
+
+
+def _conv1(x, P, prefix):
+    """nn.Conv1d(cin, cout, 1) on [B, C, Pn] (learning/pointnet.py:30,86)."""
+    w = P[prefix + '.weight'].to(x.dtype)
+    return torch.nn.functional.conv1d(x, w if w.dim() == 3 else w.unsqueeze(2), P[prefix + '.bias'].to(x.dtype))
+
+
+def stn_forward(clouds_stn: torch.Tensor, spec: ModelSpec, P, training: bool, stats=None, pfx='ptn.stn', dec=None, rec=None):
+    """STNkD.forward, learning/pointnet.py:55-61.  clouds_stn: [B, nfeat_stn, Pn] -> T [B,2,2].  Same op sequence and
+    tensor layout as the reference ([B, C, Pn] through Conv1d / BatchNorm1d): at 10^5..10^6 points the fp32 statistics of
+    a [M, C] re-layout differ measurably from the reference's (oracle/validate_against_reference.py::check_local_embedder)."""
+    h = clouds_stn
     for i, _w in enumerate(spec.ptn_widths_stn[0]):               # :27-37 (conv, bn, relu) triples
-        h = _lin(h, P, f'{pfx}.convs.{3 * i}')
-        h = torch.relu(batch_norm(h, f'{pfx}.convs.{3 * i + 1}', P, training, stats))
-    h = h.reshape(B, Pn, -1).max(1)[0]                            # :58 max_pool1d over points
+        h = _conv1(h, P, f'{pfx}.convs.{3 * i}')
+        h = _relu_dec(batch_norm(h, f'{pfx}.convs.{3 * i + 1}', P, training, stats), f'{pfx}.convs.{3 * i + 1}', dec, rec)
+    h = _pool_dec(h, f'{pfx}.pool', dec, rec)                     # :58 max_pool1d over points
     for i, _w in enumerate(spec.ptn_widths_stn[1]):               # :39-49
         h = _lin(h, P, f'{pfx}.fcs.{3 * i}')
-        h = torch.relu(batch_norm(h, f'{pfx}.fcs.{3 * i + 1}', P, training, stats))
+        h = _relu_dec(batch_norm(h, f'{pfx}.fcs.{3 * i + 1}', P, training, stats), f'{pfx}.fcs.{3 * i + 1}', dec, rec)
     h = _lin(h, P, f'{pfx}.proj')                                 # :60
     return h.view(-1, 2, 2) + torch.eye(2, dtype=h.dtype).unsqueeze(0)   # :61
 
 
 def pointnet_forward(clouds: torch.Tensor, clouds_global: torch.Tensor, spec: ModelSpec, P,
-                     training: bool, stats=None, pfx='ptn'):
-    """PointNet.forward, learning/pointnet.py:120-133.  clouds [B,F,Pn], clouds_global [B] -> [B,D]."""
+                     training: bool, stats=None, pfx='ptn', dec=None, rec=None):
+    """PointNet.forward, learning/pointnet.py:120-133.  clouds [B,F,Pn], clouds_global [B] or [B,G] -> [B,D]."""
     B, F, Pn = clouds.shape
     if spec.ptn_nfeat_stn > 0:
-        T = stn_forward(clouds[:, :spec.ptn_nfeat_stn, :], spec, P, training, stats, pfx + '.stn')   # :122
+        T = stn_forward(clouds[:, :spec.ptn_nfeat_stn, :], spec, P, training, stats, pfx + '.stn', dec, rec)   # :122
         xy = torch.bmm(clouds[:, :2, :].transpose(1, 2), T).transpose(1, 2)                         # :123
         clouds = torch.cat([xy, clouds[:, 2:, :]], 1)                                                # :124
-    h = clouds.permute(0, 2, 1).reshape(B * Pn, F)
+    h = clouds
     for i, _w in enumerate(spec.ptn_widths[0]):                   # :83-96
-        h = _lin(h, P, f'{pfx}.convs.{3 * i}')
-        h = torch.relu(batch_norm(h, f'{pfx}.convs.{3 * i + 1}', P, training, stats))
-    h = h.reshape(B, Pn, -1).max(1)[0]                            # :127
+        h = _conv1(h, P, f'{pfx}.convs.{3 * i}')
+        h = _relu_dec(batch_norm(h, f'{pfx}.convs.{3 * i + 1}', P, training, stats), f'{pfx}.convs.{3 * i + 1}', dec, rec)
+    h = _pool_dec(h, f'{pfx}.pool', dec, rec)                     # :127
     if clouds_global is not None:
         h = torch.cat([h, clouds_global.view(B, -1).to(h.dtype)], 1)     # :128-132
     nfc = len(spec.ptn_widths[1])
@@ -309,7 +352,7 @@ def pointnet_forward(clouds: torch.Tensor, clouds_global: torch.Tensor, spec: Mo
         h = _lin(h, P, f'{pfx}.fcs.{idx}')
         idx += 1
         if i < nfc - 1:                                           # last_ac=False
-            h = torch.relu(batch_norm(h, f'{pfx}.fcs.{idx}', P, training, stats))
+            h = _relu_dec(batch_norm(h, f'{pfx}.fcs.{idx}', P, training, stats), f'{pfx}.fcs.{idx}', dec, rec)
             idx += 2
         if i == nfc - 2 and spec.ptn_prelast_do > 0:
             idx += 1                                              # nn.Dropout slot (identity here: p must be 0 for parity runs)
@@ -317,16 +360,52 @@ def pointnet_forward(clouds: torch.Tensor, clouds_global: torch.Tensor, spec: Mo
 
 
 def cloud_embed(clouds_flag: torch.Tensor, clouds: torch.Tensor, clouds_global: torch.Tensor,
-                spec: ModelSpec, P, training: bool, stats=None):
+                spec: ModelSpec, P, training: bool, stats=None, dec=None, rec=None):
     """CloudEmbedder.run_full / run_full_monger, learning/pointnet.py:147-180: PointNet over the
     valid superpoints, scattered into a zero [N_total, D] matrix (invalid rows exactly 0)."""
     idx_valid = torch.nonzero(clouds_flag.eq(0)).squeeze(1)       # :149 (0-d squeeze gotcha avoided)
-    out = pointnet_forward(clouds, clouds_global, spec, P, training, stats)
+    out = pointnet_forward(clouds, clouds_global, spec, P, training, stats, dec=dec, rec=rec)
     desc = torch.zeros(clouds_flag.shape[0], out.shape[1], dtype=out.dtype)
     return desc.index_copy(0, idx_valid, out), idx_valid          # :178-179
 
 
-def fnet_forward(edgefeats: torch.Tensor, spec: ModelSpec, nout: int, P, training: bool, stats=None, pfx='ecc.0._fnet'):
+LOCAL_CHUNK = 2 ** 16 - 1      # learning/pointnet.py:193 (a cuDNN workaround in the reference; it also fixes the BatchNorm batches)
+
+
+def local_cloud_embed(clouds: torch.Tensor, clouds_global: torch.Tensor, spec: ModelSpec, P, training: bool,
+                      nfeat_stn: int = 2, stn_as_global: bool = True, update_running: bool = False, dec=None, rec=None):
+    """LocalCloudEmbedder.run_batch, learning/pointnet.py:189-205 (the supervised partition's embedder,
+    supervized_partition.py:411-421): a stand-alone STN (state_dict prefix 'stn') on the first `nfeat_stn` channels, the 2x2
+    transform applied to xy, the transform optionally appended to the global features, a PointNet WITHOUT inner STN
+    (prefix 'ptn'; `spec.ptn_nfeat_stn` must be 0), L2 normalisation.  clouds [n, F, k], clouds_global [n, G] -> [n, D].
+    The reference evaluates chunks of 2^16 - 1 clouds (:193-198, :204-206): in training mode every chunk is its own
+    BatchNorm batch (own statistics, own running-stat update) -- restated here because it is observable.
+    update_running: apply the running-stat updates to P chunk by chunk, in the reference's order (all STN chunks, then all
+    PointNet chunks)."""
+    assert spec.ptn_nfeat_stn == 0, 'the local embedder uses a PointNet without inner STN'
+    n = clouds.shape[0]
+    bounds = [(a, min(n, a + LOCAL_CHUNK)) for a in range(0, n, LOCAL_CHUNK)]      # :193-194 (n_batches = int((n-1)/batch_size))
+
+    def chunked(fn):
+        outs = []
+        for a, b in bounds:
+            stats = {} if (training and update_running) else None
+            outs.append(fn(a, b, stats))
+            if stats:
+                apply_running_stats(P, stats, 1)
+        return torch.cat(outs)
+
+    if nfeat_stn > 0:
+        T = chunked(lambda a, b, st: stn_forward(clouds[a:b, :nfeat_stn, :], spec, P, training, st, 'stn', dec, rec))   # :196-198
+        xy = torch.bmm(clouds[:, :2, :].transpose(1, 2), T).transpose(1, 2)        # :199
+        clouds = torch.cat([xy, clouds[:, 2:, :]], 1)                              # :200
+        if stn_as_global:
+            clouds_global = torch.cat([clouds_global, T.reshape(-1, 4)], 1)        # :201-202
+    out = chunked(lambda a, b, st: pointnet_forward(clouds[a:b], clouds_global[a:b], spec, P, training, st, 'ptn', dec, rec))  # :204-206
+    return torch.nn.functional.normalize(out)                                      # :207
+
+
+def fnet_forward(edgefeats: torch.Tensor, spec: ModelSpec, nout: int, P, training: bool, stats=None, pfx='ecc.0._fnet', dec=None, rec=None):
     """create_fnet product, learning/graphnet.py:17-34: Linear/ReLU stack with one BatchNorm at
     `bnidx`, last Linear without ReLU (bias iff llbias)."""
     widths = [spec.edge_feats] + list(spec.fnet_widths) + [nout]
@@ -338,7 +417,7 @@ def fnet_forward(edgefeats: torch.Tensor, spec: ModelSpec, nout: int, P, trainin
         if spec.fnet_bnidx == k:
             h = batch_norm(h, f'{pfx}.{idx}', P, training, stats)
             idx += 1
-        h = torch.relu(h)
+        h = _relu_dec(h, f'{pfx}.relu{k}', dec, rec)             # decision hook key: the k-th ReLU of the filter network
         idx += 1
     h = _lin(h, P, f'{pfx}.{idx}', bias=bool(spec.fnet_llbias))
     idx += 1
@@ -391,10 +470,10 @@ def lstm_cell_ex(inp, hidden, P, pfx='ecc.0._cell', layernorm=True, ingate=True)
 
 
 def rnn_graph_conv(hx, edgefeats, idxn, degs, spec: ModelSpec, rs: RnnEccSpec, P, training: bool,
-                   stats=None, pfx='ecc.0', idxe=None):
+                   stats=None, pfx='ecc.0', idxe=None, dec=None, rec=None):
     """RNNGraphConvModule.forward (use_pyg=0), learning/modules.py:152-183."""
     nc = hx.shape[1]
-    weights = fnet_forward(edgefeats.to(hx.dtype), spec, nc if rs.vv else nc * nc, P, training, stats, pfx + '._fnet')  # :160
+    weights = fnet_forward(edgefeats.to(hx.dtype), spec, nc if rs.vv else nc * nc, P, training, stats, pfx + '._fnet', dec, rec)  # :160
     if weights.shape[1] != nc:
         weights = weights.view(-1, nc, nc)                        # :163-164
     hxs = [hx]
@@ -409,14 +488,14 @@ def rnn_graph_conv(hx, edgefeats, idxn, degs, spec: ModelSpec, rs: RnnEccSpec, P
     return torch.cat(hxs, 1) if rs.cat_all else hx                # :183
 
 
-def graph_network_forward(x, edgefeats, idxn, degs, spec: ModelSpec, P, training: bool, stats=None):
+def graph_network_forward(x, edgefeats, idxn, degs, spec: ModelSpec, P, training: bool, stats=None, dec=None, rec=None):
     """GraphNetwork.forward, learning/graphnet.py:95-98 (f / gru / lstm / r tokens)."""
     nfeat = spec.ptn_widths[1][-1]
     for d, kind, payload in parse_model_config(spec.model_config, nfeat):
         if kind == 'f':
             x = _lin(x, P, f'ecc.{d}')
         elif kind in ('gru', 'lstm'):
-            x = rnn_graph_conv(x, edgefeats, idxn, degs, spec, payload[1], P, training, stats, f'ecc.{d}')
+            x = rnn_graph_conv(x, edgefeats, idxn, degs, spec, payload[1], P, training, stats, f'ecc.{d}', dec=dec, rec=rec)
         elif kind == 'r':
             x = torch.relu(x)
         elif kind == 'b':
@@ -448,16 +527,16 @@ def is_param_key(k: str) -> bool:
     return k.split('.')[-1] in PARAM_SUFFIXES
 
 
-def model_forward(batch: dict, spec: ModelSpec, P, training: bool, stats=None, dtype=torch.float32):
+def model_forward(batch: dict, spec: ModelSpec, P, training: bool, stats=None, dtype=torch.float32, dec=None, rec=None):
     """embeddings = CloudEmbedder.run(...); outputs = model.ecc(embeddings)  (learning/main.py:202-203)."""
     emb, idx_valid = cloud_embed(batch['clouds_flag'], batch['clouds'].to(dtype), batch['clouds_global'].to(dtype),
-                                 spec, P, training, stats)
-    logits = graph_network_forward(emb, batch['edgefeats'], batch['idxn'], batch['degs'], spec, P, training, stats)
+                                 spec, P, training, stats, dec, rec)
+    logits = graph_network_forward(emb, batch['edgefeats'], batch['idxn'], batch['degs'], spec, P, training, stats, dec, rec)
     return emb, logits
 
 
 def train_step(batch: dict, spec: ModelSpec, state: Dict[str, torch.Tensor], class_weights=None,
-               dtype=torch.float32, update_running_stats: bool = True, monger: bool = True):
+               dtype=torch.float32, update_running_stats: bool = True, monger: bool = True, dec=None, rec=None):
     """One training-step window: forward, weighted CE, backward for every parameter
     (learning/main.py:199-208).  Returns loss, logits, embeddings, {key: grad}.  `state` uses
     reference state_dict keys; running stats in `state` are updated in place like the reference
@@ -472,7 +551,7 @@ def train_step(batch: dict, spec: ModelSpec, state: Dict[str, torch.Tensor], cla
         else:
             P[k] = v
     stats = {}
-    emb, logits = model_forward(batch, spec, P, True, stats, dtype)
+    emb, logits = model_forward(batch, spec, P, True, stats, dtype, dec, rec)      # dec / rec: PointNet decision hooks (see _relu_dec)
     loss = weighted_cross_entropy(logits, batch['label_mode'], class_weights)
     keys = [k for k in leaves]
     grads = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)

@@ -438,6 +438,184 @@ def check_metrics(write):
         print(f'  wrote {path}')
 
 
+LOCAL_SPEC = dict(node_feats=6, ptn_nfeat_stn=0, ptn_widths=((32, 128), (34, 32, 32, 4)), ptn_widths_stn=((16, 64), (32, 16)))
+
+
+def make_local_model(pointnet_mod, seed=3):
+    """create_model of supervized_partition/supervized_partition.py:411-421 with its default flags (ptn_widths [[32,128],[34,32,32,4]],
+    ptn_widths_stn [[16,64],[32,16]], ptn_nfeat_stn 2, stn_as_global 1, global_feat 'eXYrgb' -> 6 + 4 + 1 = 11 global features,
+    xyz + rgb = 6 point features); works for the reference's module and for the product's."""
+    torch.manual_seed(seed)
+    model = torch.nn.Module()
+    model.stn = pointnet_mod.STNkD(2, [16, 64], [32, 16])
+    model.ptn = pointnet_mod.PointNet([32, 128], [34, 32, 32, 4], [], [], 6, 0, prelast_do=0, nfeat_global=11, is_res=False, last_bn=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():             # the zero-initialised projection would hide the transform path; non-trivial BatchNorm
+        model.stn.proj.weight.copy_(0.05 * torch.randn(model.stn.proj.weight.shape, generator=g))
+        model.stn.proj.bias.copy_(0.05 * torch.randn(model.stn.proj.bias.shape, generator=g))
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(1.0 + 0.3 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(1.0 + 0.2 * torch.rand(m.running_var.shape, generator=g))
+    return model
+
+
+def local_inputs(n, k=20, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 6, k, generator=g), torch.randn(n, 7, generator=g), torch.randn(n, 4, generator=g)
+
+
+def check_local_embedder(refmods, write):
+    """LocalCloudEmbedder.run_batch (learning/pointnet.py:182-207) of the IMPORTED reference vs oracle.local_cloud_embed:
+    train-mode forward + all gradients + running statistics at 700 clouds (golden for the GPU test), eval-mode forward, and
+    the chunk boundary (2^16 - 1 clouds per BatchNorm batch in training mode) at 2^16 + 40 clouds."""
+    pointnet = refmods[0]
+    print('== LocalCloudEmbedder (supervised partition embedder)')
+    spec = O.ModelSpec(**LOCAL_SPEC)
+    args = types.SimpleNamespace(ptn_nfeat_stn=2, stn_as_global=1)
+    blob = {}
+    for tag, n in (('n700', 700), ('chunk', 2 ** 16 + 40)):
+        model = make_local_model(pointnet)
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        clouds, cg, w = local_inputs(n)
+        model.train()
+        emb = pointnet.LocalCloudEmbedder(args).run_batch(model, clouds, cg)
+        (emb * w).sum().backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+        state1 = {k: v.clone() for k, v in model.state_dict().items()}
+        # oracle, same state
+        P, leaves = {}, {}
+        for k, v in state0.items():
+            P[k] = v.clone().requires_grad_(True) if O.is_param_key(k) and v.is_floating_point() else v.clone()
+            if P[k].requires_grad:
+                leaves[k] = P[k]
+        emb_o = O.local_cloud_embed(clouds, cg, spec, P, True, 2, True, update_running=True)
+        go = torch.autograd.grad((emb_o * w).sum(), list(leaves.values()), allow_unused=True)
+        check(f'{tag}: train embeddings', emb_o, emb, 2e-5)
+        worst = 0.0
+        for (k, _), g in zip(leaves.items(), go):
+            # biases in front of a train-mode BatchNorm: analytically zero, round-off on both sides
+            if float(grads[k].abs().max()) > 1e-5 * max(float(v.abs().max()) for v in grads.values()):
+                worst = max(worst, maxrel(g, grads[k]))
+        print(f'  {tag}: gradients oracle vs reference worst {worst:.2e}')
+        assert worst < (2e-4 if n < 1000 else 2e-3)
+        for k in state1:
+            if 'running' in k:
+                assert maxrel(P[k].double(), state1[k].double()) < 1e-5, k
+            if 'num_batches' in k:
+                assert int(P[k]) == int(state1[k]), k
+        print(f'  {tag}: running statistics / num_batches_tracked match (one BatchNorm batch per chunk of {O.LOCAL_CHUNK})')
+        model.load_state_dict(state0)
+        model.eval()
+        with torch.no_grad():
+            emb_e = pointnet.LocalCloudEmbedder(args).run_batch(model, clouds, cg)
+        emb_eo = O.local_cloud_embed(clouds, cg, spec, {k: v.clone() for k, v in state0.items()}, False, 2, True)
+        check(f'{tag}: eval embeddings', emb_eo, emb_e, 5e-6)
+        if tag == 'n700':
+            blob.update({'n700/train_emb': emb.detach().numpy(), 'n700/eval_emb': emb_e.numpy(), 'state0_sha256': np.array(state_digest(state0))})
+            for k, v in grads.items():
+                blob['n700/grad/' + k] = v.numpy()
+            for k, v in state1.items():
+                if 'running' in k:
+                    blob['n700/state1/' + k] = v.numpy()
+        else:         # the large case travels as a few rows + checksums (the full [65576, 4] output is regenerable, not needed)
+            rows = torch.tensor([0, 1, 65534, 65535, 65536, n - 1])
+            blob.update({'chunk/n': np.int64(n), 'chunk/rows': rows.numpy(), 'chunk/train_emb_rows': emb.detach()[rows].numpy(),
+                         'chunk/eval_emb_rows': emb_e[rows].numpy(), 'chunk/train_emb_colsum': emb.detach().double().sum(0).numpy(),
+                         'chunk/eval_emb_colsum': emb_e.double().sum(0).numpy()})
+            for k, v in state1.items():
+                if 'running' in k:
+                    blob['chunk/state1/' + k] = v.numpy()
+            for k in ('stn.convs.0.weight', 'ptn.convs.0.weight', 'ptn.fcs.0.weight', 'ptn.fcs.9.weight'):
+                blob['chunk/grad/' + k] = grads[k].numpy()
+    if write:
+        out = os.path.join(ROOT, 'tests', 'golden', 'local_embedder.npz')
+        np.savez_compressed(out, **blob)
+        print(f'  wrote {out} ({os.path.getsize(out) / 1e6:.2f} MB)')
+
+
+def state_digest(state):
+    """sha256 over the float tensors of a state_dict in key order: the GPU-side test regenerates the initial state from the
+    seeds (the 1.1 MB of parameters do not travel) and must prove it holds the same bits before comparing outputs."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(state):
+        v = state[k]
+        if v.is_floating_point():
+            h.update(k.encode())
+            h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def baseline_size_batch(seed=0):
+    """The BASELINE unit scene (1000 superpoints x 128 points x 14 features, 5000 superedges) as a batch."""
+    col = synth.collate_numpy([synth.scene(seed, n_sp=1000, n_edges=5000)])
+    idxn, degs, ef, ei = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    return dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                edgefeats=torch.from_numpy(ef), edge_indexes=torch.from_numpy(ei),
+                label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+
+
+def check_baseline_size(refmods, write):
+    """The IMPORTED reference on the BASELINE-size scene itself (S3DIS production model): eval forward, train forward, loss
+    and all gradients -- the headline configuration's parity is then a direct comparison with the reference instead of
+    reference -> oracle (small fixtures) -> oracle (large) -> HIP.  Stored: outputs and gradients (the initial state is
+    regenerated from its seeds on the GPU box and verified through a digest)."""
+    pointnet, graphnet, modules, ecc = refmods
+    print('== BASELINE-size scene (1000 superpoints x 128 pts, 5000 superedges), gru_10_0,f_13, imported reference')
+    spec = O.ModelSpec()
+    batch = baseline_size_batch(0)
+    model = make_reference_model(spec, 1, refmods)
+    randomize_bn_and_proj(model, 7)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    args = types.SimpleNamespace(cuda=0, ptn_mem_monger=1)
+    cw = torch.linspace(0.5, 1.5, 13)
+    model.eval()
+    model.ecc.set_info([ref_gci(ecc, batch)], 0)
+    with torch.no_grad():
+        emb_e = pointnet.CloudEmbedder(args).run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])
+        logits_e = model.ecc(emb_e)
+    emb_o, logits_o = O.model_forward(batch, spec, {k: v.clone() for k, v in state0.items()}, False)
+    check('eval embeddings (oracle vs reference)', emb_o, emb_e, 5e-6)
+    check('eval logits (oracle vs reference)', logits_o, logits_e, 1e-5)
+    model.load_state_dict(state0)
+    model.train()
+    ecc.GraphConvFunction = O.EccFunction              # matrix-filter backward: restated (header)
+    embedder = pointnet.CloudEmbedder(args)
+    emb_t = embedder.run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])
+    logits_t = model.ecc(emb_t)
+    loss_t = torch.nn.functional.cross_entropy(logits_t, batch['label_mode'], weight=cw)
+    model.zero_grad()
+    loss_t.backward()
+    embedder.bw_hook()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    state1 = {k: v.clone() for k, v in model.state_dict().items()}
+    st = {k: v.clone() for k, v in state0.items()}
+    loss_o, logits_o, emb_o, grads_o = O.train_step(batch, spec, st, cw)
+    check('train embeddings (oracle vs reference)', emb_o, emb_t, 2e-5)
+    check('train logits (oracle vs reference)', logits_o, logits_t, 5e-5)
+    check('train loss (oracle vs reference)', loss_o, loss_t, 1e-5)
+    after_pool = [k for k in grads if (k.startswith('ecc.') or k.startswith('ptn.fcs.')) and float(grads[k].abs().max()) > 1e-6]
+    worst = max(maxrel(grads_o[k], grads[k]) for k in after_pool)
+    print(f'  gradients behind the max-pool (ECC, FC head): oracle vs reference worst {worst:.2e}')
+    assert worst < 2e-4
+    if write:
+        out = os.path.join(ROOT, 'tests', 'golden', 'baseline_size.npz')
+        blob = {'state0_sha256': np.array(state_digest(state0)), 'class_weights': cw.numpy(),
+                'eval/emb': emb_e.numpy(), 'eval/logits': logits_e.numpy(),
+                'train/emb': emb_t.detach().numpy(), 'train/logits': logits_t.detach().numpy(), 'train/loss': loss_t.detach().numpy()}
+        for k, v in grads.items():
+            blob['grad/' + k] = v.numpy()
+        for k, v in state1.items():
+            if 'running' in k:
+                blob['state1/' + k] = v.numpy()
+        np.savez_compressed(out, **blob)
+        print(f'  wrote {out} ({os.path.getsize(out) / 1e6:.2f} MB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--write', action='store_true', help='write tests/golden/*.npz')
@@ -451,6 +629,10 @@ def main():
         check_loader(a.write)
     if a.only in ('', 'metrics'):
         check_metrics(a.write)
+    if a.only in ('', 'baseline_size'):
+        check_baseline_size(refmods, a.write)
+    if a.only in ('', 'local_embedder'):
+        check_local_embedder(refmods, a.write)
     cw = torch.linspace(0.5, 1.5, 13)
     # S3DIS production config (S3DIS.md:26-28): matrix filters, 10 GRU iterations, state concat
     if a.only in ('', 's3dis_gru10_matrix'):

@@ -231,6 +231,15 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
   return 0;
 }
 
+extern "C" long spg_eccrnn_debug_offset(const spg_eccrnn_cfg* cfg, int N, int E, int training, int layer, int what) {
+  Plan pl;
+  char* fake = (char*)(uintptr_t)4096;
+  if (make_plan(cfg, N, E, training, fake, nullptr, pl) != 0 || layer < 0 || layer >= (int)pl.F.size()) return -1;
+  const FLayer& l = pl.F[layer];
+  const void* p = what == 0 ? (const void*)l.y : what == 1 ? l.s : l.t;
+  return p == nullptr ? -1 : (long)((const char*)p - fake);
+}
+
 extern "C" size_t spg_eccrnn_bwd_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E) {
   Plan pl;
   if (make_plan(cfg, N, E, 1, nullptr, nullptr, pl) != 0) return 0;

@@ -461,14 +461,19 @@ extern "C" int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, cons
 
 // debug / test helper: byte offset inside the forward workspace of a layer's buffers
 //   what: 0 raw output y, 1 BN scale s, 2 BN shift t, 3 batch mean, 4 batch rstd;
-//   layer == -1 / -2: pooled (selected raw max/min + globals) of the STN / main segment (what ignored).
+//   layer == -1 / -2: STN / main segment; what 0: pooled [B, ldpool] (selected raw max/min + globals), what 1: aidx [B, ldpool]
+//   (int32: the point that holds the pooled value), what 2: ldpool itself (not an offset).
 extern "C" long spg_pointnet_debug_offset(const spg_pointnet_cfg* cfg, int B, int training, int layer, int what) {
   Plan pl;
   char* fake = (char*)(uintptr_t)4096;
   if (make_plan(cfg, B, training, fake, nullptr, (float*)(uintptr_t)8, pl) != 0) return -1;
   const void* p = nullptr;
-  if (layer == -1) p = pl.has_stn ? pl.stn.pooled : nullptr;
-  else if (layer == -2) p = pl.main.pooled;
+  if (layer == -1 || layer == -2) {
+    const Segment& sg = layer == -1 ? pl.stn : pl.main;
+    if (layer == -1 && !pl.has_stn) return -1;
+    if (what == 2) return sg.ldpool;
+    p = what == 1 ? (const void*)sg.aidx : (const void*)sg.pooled;
+  }
   else if (layer >= 0 && layer < (int)pl.L.size()) {
     const Layer& l = pl.L[layer];
     p = what == 0 ? (const void*)l.y : what == 1 ? l.s : what == 2 ? l.t : what == 3 ? l.mean : l.rstd;

@@ -285,8 +285,13 @@ class LocalCloudEmbedder():
     """Local PointNet of the supervised partition (reference learning/pointnet.py:182-218, used by
     supervized_partition/supervized_partition.py:184,218): millions of k-nearest-neighbour clouds [n, nfeat, k] through a
     stand-alone STN (`model.stn`) and a PointNet built with nfeat_stn = 0 (`model.ptn`), embeddings L2-normalised.  The
-    reference chunks the batch for cuDNN (2^16 - 1 clouds per call) and materialises the transformed clouds; here the
-    2x2 transform is applied by the first convolution while it stages the cloud, and there is no chunk limit."""
+    reference chunks the batch for cuDNN (2^16 - 1 clouds per call, :193) and materialises the transformed clouds; here the
+    2x2 transform is applied by the first convolution while it stages the cloud.  The kernels have no chunk limit, but the
+    reference's chunks are OBSERVABLE in training mode (every chunk is its own BatchNorm batch: own statistics, own
+    running-stat update), so training-mode batches above 2^16 - 1 clouds are processed in the same chunks; in eval mode
+    (running statistics) the whole batch is one launch sequence."""
+
+    CHUNK = 2 ** 16 - 1      # learning/pointnet.py:193
 
     def __init__(self, args):
         self.nfeat_stn = args.ptn_nfeat_stn
@@ -295,6 +300,16 @@ class LocalCloudEmbedder():
     def run_batch(self, model, clouds, clouds_global, *excess):
         if not clouds.is_cuda:
             raise RuntimeError('superpoint_graph_amd.LocalCloudEmbedder has no CPU path')
+        n = clouds.shape[0]
+        if n > self.CHUNK and (model.ptn.training or (self.nfeat_stn > 0 and model.stn.training)):
+            # the reference's order: all STN chunks, then all PointNet chunks (:196-198, :204-206); the two networks share no
+            # BatchNorm layer, so chunk-by-chunk evaluation of the pair gives the same statistics and updates
+            clouds_global = clouds_global.reshape(n, -1)
+            return torch.cat([self._run(model, clouds[a:a + self.CHUNK], clouds_global[a:a + self.CHUNK])
+                              for a in range(0, n, self.CHUNK)])
+        return self._run(model, clouds, clouds_global)
+
+    def _run(self, model, clouds, clouds_global):
         ptn = model.ptn
         if ptn.nfeat_stn > 0:
             raise ValueError('LocalCloudEmbedder expects model.ptn without an inner STN (nfeat_stn = 0) and a separate model.stn')

@@ -1,77 +1,131 @@
 """LocalCloudEmbedder (reference learning/pointnet.py:182-218 as configured by
 supervized_partition/supervized_partition.py:411-421): stand-alone STN + PointNet without inner STN + STN output as
-global feature + L2 normalisation, forward and all gradients against a plain-torch restatement of run_batch built from
-the same parameters."""
+global feature + L2 normalisation.
+
+Pinned (round 3): `oracle.local_cloud_embed` restates `run_batch` (pointnet.py:189-207) and is checked against the IMPORTED
+reference class in oracle/validate_against_reference.py::check_local_embedder, which also writes
+tests/golden/local_embedder.npz (reference outputs, gradients and running statistics).  The HIP path is compared with that
+golden and with the CPU oracle (not with stock torch on the GPU), including a batch beyond the reference's chunk boundary
+(2^16 - 1 clouds per BatchNorm batch in training mode, pointnet.py:193)."""
+import os
 import types
 
+import numpy as np
 import pytest
 import torch
-import torch.nn as nn
-import torch.nn.functional as F
+
+from conftest import GOLDEN, maxrel
+from oracle import spg_oracle as O
+from oracle import validate_against_reference as V
 
 pytestmark = pytest.mark.gpu
+ARGS = types.SimpleNamespace(ptn_nfeat_stn=2, stn_as_global=1)
 
 
-def _torch_reference(model, clouds, clouds_global, nfeat_stn):
-    """run_batch of the reference, op for op (learning/pointnet.py:188-205), on stock torch modules holding the SAME
-    parameter tensors (so autograd accumulates into the same .grad fields)."""
-    def seq(convs, x):
-        for m in convs:
-            if isinstance(m, nn.Conv1d):
-                x = F.conv1d(x, m.weight, m.bias)
-            elif isinstance(m, nn.Linear):
-                x = F.linear(x, m.weight, m.bias)
-            elif isinstance(m, nn.BatchNorm1d):
-                x = F.batch_norm(x, None, None, m.weight, m.bias, True, 0.1, m.eps)
-            elif isinstance(m, nn.ReLU):
-                x = F.relu(x)
-        return x
-    stn = model.stn
-    h = seq(stn.convs, clouds[:, :nfeat_stn, :])
-    h = F.max_pool1d(h, h.size(2)).squeeze(2)
-    h = seq(stn.fcs, h)
-    T = F.linear(h, stn.proj.weight, stn.proj.bias).view(-1, 2, 2) + torch.eye(2, device=clouds.device).unsqueeze(0)
-    xy = torch.bmm(clouds[:, :2, :].transpose(1, 2), T).transpose(1, 2)
-    x = torch.cat([xy, clouds[:, 2:, :]], 1)
-    g = torch.cat([clouds_global, T.reshape(-1, 4)], 1)
-    x = seq(model.ptn.convs, x)
-    x = F.max_pool1d(x, x.size(2)).squeeze(2)
-    x = torch.cat([x, g], 1)
-    return F.normalize(seq(model.ptn.fcs, x))
-
-
-@pytest.mark.parametrize('n,k', [(700, 20), (129, 20), (300, 32)])
-def test_local_cloud_embedder_forward_backward(n, k):
+def _product_model():
     from superpoint_graph_amd.learning import pointnet
-    torch.manual_seed(3)
-    model = nn.Module()
-    model.stn = pointnet.STNkD(2, [16, 64], [32, 16])
-    model.ptn = pointnet.PointNet([32, 128], [34, 32, 32, 4], [], [], 6, 0, prelast_do=0, nfeat_global=11, is_res=False, last_bn=True)
-    nn.init.normal_(model.stn.proj.weight, std=0.05)          # the zero-initialised projection would hide the transform path
-    nn.init.normal_(model.stn.proj.bias, std=0.05)
-    model.cuda().train()
-    g = torch.Generator().manual_seed(1)
-    clouds = torch.randn(n, 6, k, generator=g).cuda()
-    clouds_global = torch.randn(n, 7, generator=g).cuda()
-    w = torch.randn(n, 4, generator=g).cuda()
-    emb = pointnet.LocalCloudEmbedder(types.SimpleNamespace(ptn_nfeat_stn=2, stn_as_global=1)).run_batch(model, clouds, clouds_global)
-    (emb * w).sum().backward()
-    ours = {kk: p.grad.clone() for kk, p in model.named_parameters()}
-    for p in model.parameters():
-        p.grad = None
-    ref = _torch_reference(model, clouds, clouds_global, 2)
-    (ref * w).sum().backward()
-    assert emb.shape == (n, 4)
-    assert float((emb - ref).abs().max()) <= 2e-5
+    return V.make_local_model(pointnet)
+
+
+def _golden():
+    return np.load(os.path.join(GOLDEN, 'local_embedder.npz'))
+
+
+def _grad_check(ours, ref, tol):
+    gmax = max(float(np.abs(v).max()) for v in ref.values())
     worst = 0.0
-    gmax = max(float(p.grad.abs().max()) for p in model.parameters())
-    for kk, p in model.named_parameters():
-        den = float(p.grad.abs().max())
-        if den < 1e-5 * gmax:   # biases in front of a train-mode BatchNorm: exactly zero here, round-off in torch
-            assert float(ours[kk].abs().max()) <= 1e-5 * gmax
+    for k, r in ref.items():
+        den = float(np.abs(r).max())
+        if den < 1e-5 * gmax:        # biases in front of a train-mode BatchNorm: analytically zero, round-off in the reference
+            assert float(ours[k].abs().max()) <= 1e-5 * gmax, k
             continue
-        err = float((ours[kk] - p.grad).abs().max()) / den
-        print(f'  {kk}: {err:.3e} (max|ref| {den:.3e})')
+        err = float((ours[k].cpu().double() - torch.from_numpy(r).double()).abs().max()) / den
+        print(f'  {k}: {err:.3e} (max|ref| {den:.3e})')
         worst = max(worst, err)
     print('worst gradient error (max|d| / max|ref|):', worst)
-    assert worst < 5e-4
+    assert worst < tol
+
+
+def test_local_cloud_embedder_vs_reference_golden(hip):
+    """700 clouds x 6 features x 20 neighbours, the supervised partition's default model: train-mode embeddings, every
+    gradient and the running statistics, then eval-mode embeddings, against what the reference class produced."""
+    from superpoint_graph_amd.learning import pointnet
+    g = _golden()
+    model = _product_model()
+    assert V.state_digest(model.state_dict()) == str(g['state0_sha256'])       # same initial bits as the reference run
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    clouds, cg, w = V.local_inputs(700)
+    model.cuda().train()
+    emb = pointnet.LocalCloudEmbedder(ARGS).run_batch(model, clouds.cuda(), cg.cuda())
+    (emb * w.cuda()).sum().backward()
+    assert emb.shape == (700, 4)
+    e = float((emb.cpu() - torch.from_numpy(g['n700/train_emb'])).abs().max())       # unit vectors: absolute = relative
+    print('train embeddings max|d| =', e)
+    assert e <= 2e-5
+    _grad_check({k: p.grad for k, p in model.named_parameters()}, {k[10:]: g[k] for k in g.files if k.startswith('n700/grad/')}, 2e-4)
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith('n700/state1/'):
+            assert maxrel(sd[k[12:]].double(), torch.from_numpy(g[k]).double()) < 1e-5, k
+    model.load_state_dict(state0)
+    model.eval()
+    with torch.no_grad():
+        emb_e = pointnet.LocalCloudEmbedder(ARGS).run_batch(model, clouds.cuda(), cg.cuda())
+    assert float((emb_e.cpu() - torch.from_numpy(g['n700/eval_emb'])).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize('n,k', [(129, 20), (300, 32)])
+def test_local_cloud_embedder_other_shapes_vs_oracle(hip, n, k):
+    """Other cloud counts / neighbourhood sizes: forward and all gradients against the CPU oracle (pinned above)."""
+    from superpoint_graph_amd.learning import pointnet
+    model = _product_model()
+    state0 = {kk: v.clone() for kk, v in model.state_dict().items()}
+    clouds, cg, w = V.local_inputs(n, k, seed=5)
+    spec = O.ModelSpec(**V.LOCAL_SPEC)
+    P, leaves = {}, {}
+    for kk, v in state0.items():
+        P[kk] = v.clone().requires_grad_(True) if O.is_param_key(kk) and v.is_floating_point() else v.clone()
+        if P[kk].requires_grad:
+            leaves[kk] = P[kk]
+    emb_o = O.local_cloud_embed(clouds, cg, spec, P, True, 2, True)
+    go = torch.autograd.grad((emb_o * w).sum(), list(leaves.values()), allow_unused=True)
+    model.cuda().train()
+    emb = pointnet.LocalCloudEmbedder(ARGS).run_batch(model, clouds.cuda(), cg.cuda())
+    (emb * w.cuda()).sum().backward()
+    assert float((emb.cpu() - emb_o.detach()).abs().max()) <= 2e-5
+    _grad_check({kk: p.grad for kk, p in model.named_parameters()}, {kk: gg.numpy() for kk, gg in zip(leaves, go)}, 5e-4)
+
+
+def test_local_cloud_embedder_beyond_the_chunk_boundary(hip):
+    """2^16 + 40 clouds: in training mode the reference evaluates 2^16 - 1 clouds and then 41 as SEPARATE BatchNorm batches
+    (pointnet.py:193-206); rows on both sides of the boundary, column sums, four gradient tensors and the running
+    statistics (two updates per layer) against the reference's golden; eval mode = one pass over all clouds."""
+    from superpoint_graph_amd.learning import pointnet
+    g = _golden()
+    n = int(g['chunk/n'])
+    model = _product_model()
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    clouds, cg, w = V.local_inputs(n)
+    rows = torch.from_numpy(g['chunk/rows'])
+    model.cuda().train()
+    emb = pointnet.LocalCloudEmbedder(ARGS).run_batch(model, clouds.cuda(), cg.cuda())
+    (emb * w.cuda()).sum().backward()
+    assert emb.shape == (n, 4)
+    d_rows = float((emb[rows.cuda()].cpu() - torch.from_numpy(g['chunk/train_emb_rows'])).abs().max())
+    d_sum = float((emb.double().sum(0).cpu() - torch.from_numpy(g['chunk/train_emb_colsum'])).abs().max())
+    print('rows', d_rows, 'column sums', d_sum)
+    assert d_rows <= 1e-4 and d_sum <= 1e-5 * n           # unit vectors; 1.3 M points per BatchNorm batch in fp32
+    _grad_check({k: p.grad for k, p in model.named_parameters() if ('chunk/grad/' + k) in g.files},
+                {k[11:]: g[k] for k in g.files if k.startswith('chunk/grad/')}, 2e-3)
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith('chunk/state1/'):
+            assert maxrel(sd[k[13:]].double(), torch.from_numpy(g[k]).double()) < 1e-4, k
+    nbt = [int(m.num_batches_tracked) for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    assert all(v == 2 for v in nbt), nbt
+    model.load_state_dict(state0)
+    model.eval()
+    with torch.no_grad():
+        emb_e = pointnet.LocalCloudEmbedder(ARGS).run_batch(model, clouds.cuda(), cg.cuda())
+    assert float((emb_e[rows.cuda()].cpu() - torch.from_numpy(g['chunk/eval_emb_rows'])).abs().max()) <= 1e-5
+    assert float((emb_e.double().sum(0).cpu() - torch.from_numpy(g['chunk/eval_emb_colsum'])).abs().max()) <= 1e-5 * n

@@ -95,3 +95,39 @@ def test_modes_leave_default_untouched(hip, scene):
     _step(scene, 3); _step(scene, 1)
     b = _step(scene, 0)
     assert torch.equal(a[1], b[1]) and all(torch.equal(a[3][k], b[3][k]) for k in a[3])
+
+
+def test_split_bf16_at_semantic3d_scale(hip):
+    """BASELINE.json configs[4] as stated -- "Semantic3D-scale synthetic: ~10k superpoints/scene, bf16 MFMA": 10 000
+    superpoints x 128 points x 11 features, 50 000 superedges, `gru_10,f_8` (vector filters, Semantic3D.md:20-22), the
+    split-bf16 mode against the fp32 CPU oracle on the same seeded scene.  Tolerances of this mode (header): embeddings /
+    logits 5e-4 max-norm relative, loss 1e-4, every gradient cosine > 0.995 to the oracle's."""
+    from superpoint_graph_amd import _lib, synth
+    spec = O.ModelSpec(model_config='gru_10,f_8', node_feats=11, ptn_nfeat_stn=11)
+    torch.manual_seed(1)
+    model = build_model(spec)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.normal_(1, 0.2); m.bias.normal_(0, 0.1)
+        model.ptn.stn.proj.weight.normal_(0, 0.02)
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    col = synth.collate_numpy([synth.scene(0, n_sp=10000, n_edges=50000, n_feat=11, n_classes=8)])
+    idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    loss_o, logits_o, emb_o, grads_o = O.train_step(batch, spec, dict(state0), None, update_running_stats=False)
+    scene = (spec, batch, state0, (loss_o, emb_o, logits_o, grads_o))
+    f32 = _step(scene, 0)
+    out = _step(scene, 3)
+    assert not torch.equal(out[0], f32[0])                                    # the mode is on
+    e_emb, e_log, e_loss, g = _errors(scene, out)
+    cos = min((float(F.cosine_similarity(out[3][k].reshape(1, -1).cpu().double(), grads_o[k].reshape(1, -1).double())), k) for k in g)
+    f_emb, f_log, f_loss, fg = _errors(scene, f32)
+    print(f'Semantic3D scale, split-bf16: emb {e_emb:.2e} logits {e_log:.2e} loss {e_loss:.2e} worst grad {max(g.values()):.2e} min cosine {cos}; '
+          f'fp32 mode: emb {f_emb:.2e} logits {f_log:.2e} worst grad {max(fg.values()):.2e}')
+    assert f_emb < 1e-4 and f_log < 1e-4                                      # the default arithmetic at this scale, for reference
+    assert e_emb < 5e-4 and e_log < 5e-4 and e_loss < 1e-4
+    assert cos[0] > 0.995
