@@ -515,6 +515,7 @@ def check_local_embedder(refmods, write):
         check(f'{tag}: eval embeddings', emb_eo, emb_e, 5e-6)
         if tag == 'n700':
             blob.update({'n700/train_emb': emb.detach().numpy(), 'n700/eval_emb': emb_e.numpy(), 'state0_sha256': np.array(state_digest(state0))})
+            blob.update({'state0/' + k: v.numpy() for k, v in state0.items()})
             for k, v in grads.items():
                 blob['n700/grad/' + k] = v.numpy()
             for k, v in state1.items():
@@ -528,8 +529,20 @@ def check_local_embedder(refmods, write):
             for k, v in state1.items():
                 if 'running' in k:
                     blob['chunk/state1/' + k] = v.numpy()
+            # float64 referee for the gradients at this size: with 1.3 M points / 65 535 clouds per BatchNorm batch the
+            # reference's own fp32 run is 7e-4 .. 3e-3 from float64 on the tensors in front of ReLU near-ties
+            P64, lv64 = {}, {}
+            for k, v in state0.items():
+                P64[k] = v.double() if v.is_floating_point() else v.clone()
+                if O.is_param_key(k) and v.is_floating_point():
+                    P64[k] = P64[k].requires_grad_(True)
+                    lv64[k] = P64[k]
+            e64 = O.local_cloud_embed(clouds.double(), cg.double(), spec, P64, True, 2, True)
+            g64 = dict(zip(lv64, torch.autograd.grad((e64 * w.double()).sum(), list(lv64.values()), allow_unused=True)))
             for k in ('stn.convs.0.weight', 'ptn.convs.0.weight', 'ptn.fcs.0.weight', 'ptn.fcs.9.weight'):
                 blob['chunk/grad/' + k] = grads[k].numpy()
+                blob['chunk/grad64/' + k] = g64[k].numpy()
+                print(f'  chunk: {k}: reference fp32 vs float64 oracle {maxrel(grads[k], g64[k]):.2e}')
     if write:
         out = os.path.join(ROOT, 'tests', 'golden', 'local_embedder.npz')
         np.savez_compressed(out, **blob)
@@ -537,8 +550,10 @@ def check_local_embedder(refmods, write):
 
 
 def state_digest(state):
-    """sha256 over the float tensors of a state_dict in key order: the GPU-side test regenerates the initial state from the
-    seeds (the 1.1 MB of parameters do not travel) and must prove it holds the same bits before comparing outputs."""
+    """sha256 over the float tensors of a state_dict in key order (integrity check of a stored initial state).  The state
+    itself has to travel with the golden: regenerating it from the seeds is NOT portable -- torch's CPU initialisers
+    (vectorised normal_, LAPACK QR of the orthogonal init) give different bits on the GPU box's EPYC than on the build
+    container's Xeon (measured, round 3)."""
     import hashlib
     h = hashlib.sha256()
     for k in sorted(state):
@@ -562,8 +577,7 @@ def baseline_size_batch(seed=0):
 def check_baseline_size(refmods, write):
     """The IMPORTED reference on the BASELINE-size scene itself (S3DIS production model): eval forward, train forward, loss
     and all gradients -- the headline configuration's parity is then a direct comparison with the reference instead of
-    reference -> oracle (small fixtures) -> oracle (large) -> HIP.  Stored: outputs and gradients (the initial state is
-    regenerated from its seeds on the GPU box and verified through a digest)."""
+    reference -> oracle (small fixtures) -> oracle (large) -> HIP.  Stored: the initial state, outputs and gradients."""
     pointnet, graphnet, modules, ecc = refmods
     print('== BASELINE-size scene (1000 superpoints x 128 pts, 5000 superedges), gru_10_0,f_13, imported reference')
     spec = O.ModelSpec()
@@ -605,6 +619,7 @@ def check_baseline_size(refmods, write):
     if write:
         out = os.path.join(ROOT, 'tests', 'golden', 'baseline_size.npz')
         blob = {'state0_sha256': np.array(state_digest(state0)), 'class_weights': cw.numpy(),
+                **{'state0/' + k: v.numpy() for k, v in state0.items()},
                 'eval/emb': emb_e.numpy(), 'eval/logits': logits_e.numpy(),
                 'train/emb': emb_t.detach().numpy(), 'train/logits': logits_t.detach().numpy(), 'train/loss': loss_t.detach().numpy()}
         for k, v in grads.items():

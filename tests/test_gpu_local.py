@@ -22,13 +22,20 @@ pytestmark = pytest.mark.gpu
 ARGS = types.SimpleNamespace(ptn_nfeat_stn=2, stn_as_global=1)
 
 
-def _product_model():
-    from superpoint_graph_amd.learning import pointnet
-    return V.make_local_model(pointnet)
-
-
 def _golden():
     return np.load(os.path.join(GOLDEN, 'local_embedder.npz'))
+
+
+def _product_model():
+    """The supervised partition's default model on the product classes, holding the reference run's initial state (it
+    travels with the golden: torch's CPU initialisers are not bit-portable between hosts)."""
+    from superpoint_graph_amd.learning import pointnet
+    model = V.make_local_model(pointnet)
+    g = _golden()
+    model.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('state0/')})
+    return model
+
+
 
 
 def _grad_check(ours, ref, tol):
@@ -115,8 +122,14 @@ def test_local_cloud_embedder_beyond_the_chunk_boundary(hip):
     d_sum = float((emb.double().sum(0).cpu() - torch.from_numpy(g['chunk/train_emb_colsum'])).abs().max())
     print('rows', d_rows, 'column sums', d_sum)
     assert d_rows <= 1e-4 and d_sum <= 1e-5 * n           # unit vectors; 1.3 M points per BatchNorm batch in fp32
-    _grad_check({k: p.grad for k, p in model.named_parameters() if ('chunk/grad/' + k) in g.files},
-                {k[11:]: g[k] for k in g.files if k.startswith('chunk/grad/')}, 2e-3)
+    # gradients: float64 oracle as referee.  At this batch size the reference's own fp32 run is 7e-4 .. 3e-3 from float64 on
+    # the tensors in front of ReLU near-ties (stored next to its gradients): the HIP path must not be further from the truth
+    # than twice that (+1e-4)
+    for k in [kk[13:] for kk in g.files if kk.startswith('chunk/grad64/')]:
+        ours, ref32, ref64 = dict(model.named_parameters())[k].grad, torch.from_numpy(g['chunk/grad/' + k]), torch.from_numpy(g['chunk/grad64/' + k])
+        e_hip, e_ref = maxrel(ours, ref64), maxrel(ref32, ref64)
+        print(f'  {k}: HIP vs float64 {e_hip:.2e}; reference fp32 vs float64 {e_ref:.2e}; HIP vs reference {maxrel(ours, ref32):.2e}')
+        assert e_hip <= 2 * e_ref + 1e-4, k
     sd = model.state_dict()
     for k in g.files:
         if k.startswith('chunk/state1/'):

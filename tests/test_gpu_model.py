@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_elementwise, build_model, load_golden, maxrel
+from conftest import assert_elementwise, build_model, load_golden, maxrel, noise_grad
 from oracle import spg_oracle as O
 from superpoint_graph_amd import synth
 
@@ -211,7 +211,7 @@ def test_baseline_size_properties(hip):
     l32, _, _, g32 = O.train_step(ba, spec, dict(st), None, update_running_stats=False)
     l64, _, _, g64 = O.train_step(ba, spec, dict(st), None, dtype=torch.float64, update_running_stats=False)
     assert maxrel(l1, l64) < 1e-5
-    keys = [k for k in g1 if float(g64[k].abs().max()) > 1e-6]
+    keys = [k for k in g1 if not noise_grad(k, g64)]
     err_hip = {k: maxrel(g1[k], g64[k]) for k in keys}
     err_o32 = {k: maxrel(g32[k], g64[k]) for k in keys}
     # layers after the max-pool (FC head, RNN-ECC) do not depend on which of two tied points wins: tight tolerance
@@ -273,7 +273,7 @@ def test_odd_shapes_train_step_vs_oracle(hip, name):
     bad = {}
     for k, p in model.named_parameters():
         ref = grads_o[k]
-        if float(ref.abs().max()) < 1e-6:
+        if noise_grad(k, grads_o):
             assert float(p.grad.abs().max()) < 1e-5, k
             continue
         e = maxrel(p.grad, ref)
@@ -368,7 +368,7 @@ def test_large_configs_train_step_vs_oracle(hip, name):
     assert_elementwise(emb, emb_o, what=name + ' embeddings')
     assert_elementwise(logits, logits_o, what=name + ' logits')
     assert maxrel(loss, lo) < 1e-5
-    err = {k: maxrel(p.grad, grads_o[k]) for k, p in model.named_parameters() if float(grads_o[k].abs().max()) > 1e-6}
+    err = {k: maxrel(p.grad, grads_o[k]) for k, p in model.named_parameters() if not noise_grad(k, grads_o)}
     ranked = sorted(err.values())
     print(name, 'gradient error vs the fp32 oracle: median', ranked[len(ranked) // 2], '90th percentile', ranked[int(0.9 * len(ranked))], 'max', ranked[-1])
     # Gradients are compared in bulk.  At 8 000 - 10 000 superpoints (2.5 M ReLU inputs behind every FC layer, 256 k

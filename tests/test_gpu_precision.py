@@ -15,7 +15,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import build_model, maxrel
+from conftest import build_model, maxrel, noise_grad
 from oracle import spg_oracle as O
 from test_gpu_model import _run, _unit_batch
 
@@ -61,7 +61,7 @@ def _step(scene, mode):
 def _errors(scene, out):
     loss_o, emb_o, logits_o, grads_o = scene[3]
     emb, logits, loss, grads = out
-    keys = [k for k in grads if float(grads_o[k].abs().max()) > 1e-6]
+    keys = [k for k in grads if not noise_grad(k, grads_o)]
     g = {k: maxrel(grads[k], grads_o[k]) for k in keys}
     return maxrel(emb, emb_o), maxrel(logits, logits_o), abs(float(loss) - float(loss_o)) / abs(float(loss_o)), g
 
