@@ -332,8 +332,13 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * statistics partial per tile instead of one per workgroup; key 7: arithmetic of the wide (128-row-tile, full-tile) GEMMs of
  * spg_pointnet_forward / _backward: 0 = fp32 MFMA (default; the reference's arithmetic), 3 = split-bf16 (three bf16 MFMAs per
  * operand pair, ~2^-16 per product), 1 = bf16 operands; fp32 accumulation and fp32 tensors in every mode (tolerances:
- * tests/test_gpu_precision.py).  Returns the previous value, -1 for an unknown key. */
+ * tests/test_gpu_precision.py); key 8: 1 = run the GRU recurrence of spg_eccrnn_forward / _backward as one launch per
+ * iteration instead of the persistent dataflow-synchronised launch (A/B timing and the equality test; the two forms give
+ * bit-identical results).  Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
+/* Number of bounded-spin time-outs the persistent RNN-ECC launches of the current device have raised so far (0 in a correct
+ * run; a wave that waits too long for a neighbour's state gives up instead of hanging the GPU).  Synchronises the device. */
+int spg_ecc_persistent_errors(void);
 int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops);
 
 #ifdef __cplusplus

@@ -11,6 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SPG_KC 32          // reduction chunk (floats) staged in LDS per step
+#define SPG_MAX_DEVICES 16
 #define SPG_THREADS 256    // 4 wavefronts per workgroup, one per SIMD
 
 // ----------------------------------------------------------------------------------------------
@@ -18,6 +19,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ----------------------------------------------------------------------------------------------
 extern "C" const char* spg_last_error(void);
 void spg_set_error(const char* fmt, ...);
+// tuning knobs (process-global; defaults are the production values): see spg_tune in include/spg_hip.h
+enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_FIN_SLICE_MIN = 4, SPG_TUNE_NO_STAT_ACCUM = 5, SPG_TUNE_PRECISION = 7,
+       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_COUNT = 16 };
+int spg_tune_get(int key);
 
 #define SPG_CHECK_ARG(cond, msg)                                          \
   do {                                                                    \

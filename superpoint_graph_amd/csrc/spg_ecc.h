@@ -94,3 +94,39 @@ int spg_launch_ecc_step_bwd(const SpgEccStepBwd& p, hipStream_t stream);
 int spg_launch_ecc_edge_wgrad(const SpgGraph& g, int matrix, const float* states, long lds, const float* G, long ldg,
                               int R, float* dW, hipStream_t stream);
 int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream);
+
+// ---- persistent (one launch for all iterations) forms of the GRU recurrence, spg_ecc.hip ----
+struct SpgEccPersistFwd {
+  SpgGraph g;
+  const float* W;
+  int matrix, R;
+  const float* h0;          // [N, 32]
+  float* states; long ldS;  // [N][(R+1)*32]: h^0 .. h^R (kept for the backward)
+  float* agg;               // [N][(R+1)*32] aggregates per iteration, or null (inference)
+  float* out; long ldo;     // cat_all: [N][(R+1)*32], else [N][32] = h^R
+  int cat_all;
+  SpgGruParams gru;
+  unsigned long long* gran; // [SPG_PX_MAX_ITERS][SPG_PX_MAX_NODES][32] granules
+  unsigned* ctl;            // {epoch base, workgroups done, error count, -}
+};
+
+struct SpgEccPersistBwd {
+  SpgGraph g;
+  const float* W;
+  int matrix, R, cat_all;
+  const float* grad_out; long ldgo;   // cat_all: [N][(R+1)*32]; else [N][32] (gradient wrt h^R)
+  const float* states; long ldS;
+  const float* agg;
+  float* G;                 // [N][(R+1)*32]: gradient wrt the aggregate of iteration r (already / deg), slot r
+  float* dgi; float* dgh; float* dui; float* duh; long ld96;    // [N][(R+1)*96]
+  float* dpre; float* xg; long ld32;                            // [N][(R+1)*32]
+  float* gx;                // [N, 32] gradient wrt h^0
+  SpgGruParams gru;
+  unsigned long long* gran;
+  unsigned* ctl;
+};
+
+// return false when the persistent form is not applicable (too many nodes / iterations, switched off, another stream owns
+// the exchange buffer): the caller then runs the per-iteration launches; *err != 0: the launch itself failed
+bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err);
+bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err);

@@ -11,6 +11,7 @@
 //   * no atomics anywhere: the backward walks a reverse CSR (by source) built once per batch, so
 //     results are deterministic.
 #include "spg_ecc.h"
+#include <mutex>
 
 // ---------------------------------------------------------------------------------------------
 // graph build
@@ -168,6 +169,20 @@ int spg_graph_build_impl(const int64_t* idxn, const int64_t* degs, int N, int Ns
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float spg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Synchronisation point of the per-node helpers.  The per-iteration kernels use the workgroup barrier; in the persistent
+// kernels the four waves of a workgroup run on their own (each spins on its own neighbours), every LDS region a helper
+// touches is private to one wave, and LDS operations of one wave execute in order: draining the LDS counter and stopping
+// the compiler from moving memory operations across the point is all that is needed.
+template <bool WAVE>
+__device__ __forceinline__ void spg_node_sync() {
+  if constexpr (WAVE) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
 #define SPG_IN_EPS 1e-5f   // nn.InstanceNorm1d(1, eps=1e-5), learning/modules.py:213-214
 
 // in-edge aggregation for node i; result: every lane of the wave holds, for the matrix mode, the 4
@@ -283,7 +298,7 @@ __device__ __forceinline__ void spg_gru_lds_rows(const float* __restrict__ sw, i
   w.ig = sw + (2 * GW + (lane & 31)) * SPG_WLD;
 }
 
-template <class Rows>
+template <class Rows, bool WAVE = false>
 __device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, const Rows& w, const float* __restrict__ sa,
                                                      const float* __restrict__ sh, float* __restrict__ sx, int lane,
                                                      GruFwdState& st) {
@@ -295,7 +310,7 @@ __device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, cons
     sx[lane] = x;
   }
   st.gin = gin; st.x = x;
-  __syncthreads();
+  spg_node_sync<WAVE>();
   float gi1 = w.dot_ih1(sx), gh1 = w.dot_hh1(sh);
   float gi2 = 0.f, gh2 = 0.f;
   if (lane < 32) { gi2 = w.dot_ih2(sx); gh2 = w.dot_hh2(sh); }
@@ -436,6 +451,107 @@ int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
   else hipLaunchKernelGGL(spg_ecc_step_fwd_kernel<SPG_CELL_GRU>, grid, dim3(256), 0, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
+}
+
+// GRUCellEx backward for one node (one wavefront): recompute of the forward from (aggregate sa[0..31], state sh[0..31]),
+// gate gradients stored for the deferred weight-gradient GEMMs, returns the gradient wrt the hidden state (direct path,
+// dh_acc) and wrt the aggregate (da), lanes 0..31.  sa / sh are GW = 96 floats each (re-used for dgi / dgh), sx and sd 32;
+// sw is the workgroup's padded copy of the cell weights.
+struct SpgGruBwdOut { float *dgi, *dgh, *dui, *duh, *dpre, *xg; long ld96, ld32; };
+
+template <bool WAVE>
+__device__ __forceinline__ void spg_gru_backward_node(const SpgGruParams& G, const float* __restrict__ sw, float* sa, float* sh,
+                                                      float* sx, float* sd, int lane, bool active, long j, float dH,
+                                                      const SpgGruBwdOut& o, float& dh_acc, float& da) {
+  constexpr int GW = 96;
+  const float* sw_ih = sw;
+  const float* sw_hh = sw_ih + GW * SPG_WLD;
+  const float* sw_ig = sw_hh + GW * SPG_WLD;
+  {
+    GruFwdState st;
+    {
+      GruRowsLds wr;
+      spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane, wr);
+      spg_gru_forward_node<GruRowsLds, WAVE>(G, wr, sa, sh, sx, lane, st);
+    }
+    const float a_in = lane < 32 ? sa[lane] : 0.f;
+    const float h_in = lane < 32 ? sh[lane] : 0.f;
+    // gate backward on lanes 0..31 (channel = lane)
+    float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f;
+    dh_acc = 0.f;
+    if (lane < 32) {
+      const float dn = dH * (1.f - st.z);
+      const float dzg = dH * (h_in - st.n);
+      dh_acc = dH * st.z;
+      dn_pre = dn * (1.f - st.n * st.n);
+      const float dr = dn_pre * (st.uh2 + G.b_hh[64 + lane]);
+      dz_pre = dzg * st.z * (1.f - st.z);
+      dr_pre = dr * st.r * (1.f - st.r);
+    }
+    // gradients wrt the normalised pre-activations, in the first/second-value lane layout
+    const float zsh = __shfl(dz_pre, lane & 31, 64);
+    float dui1 = lane < 32 ? dr_pre : zsh;        // index lane
+    float dui2 = lane < 32 ? dn_pre : 0.f;        // index 64 + lane
+    float duh1 = dui1;
+    float duh2 = lane < 32 ? dn_pre * st.r : 0.f;
+    if (active) {
+      o.dui[(long)j * o.ld96 + lane] = dui1;
+      o.duh[(long)j * o.ld96 + lane] = duh1;
+      if (lane < 32) {
+        o.dui[(long)j * o.ld96 + 64 + lane] = dui2;
+        o.duh[(long)j * o.ld96 + 64 + lane] = duh2;
+      }
+    }
+    // through the row normalisation: dg = rstd * (du - mean(du) - u * mean(du*u))
+    float dgi1 = dui1, dgi2 = dui2, dgh1 = duh1, dgh2 = duh2;
+    if (G.layernorm) {
+      const float m1i = spg_wave_sum(dui1 + dui2) * (1.f / 96.f);
+      const float m2i = spg_wave_sum(dui1 * st.ui1 + dui2 * st.ui2) * (1.f / 96.f);
+      const float m1h = spg_wave_sum(duh1 + duh2) * (1.f / 96.f);
+      const float m2h = spg_wave_sum(duh1 * st.uh1 + duh2 * st.uh2) * (1.f / 96.f);
+      dgi1 = st.rstd_i * (dui1 - m1i - st.ui1 * m2i);
+      dgi2 = st.rstd_i * (dui2 - m1i - st.ui2 * m2i);
+      dgh1 = st.rstd_h * (duh1 - m1h - st.uh1 * m2h);
+      dgh2 = st.rstd_h * (duh2 - m1h - st.uh2 * m2h);
+    }
+    spg_node_sync<WAVE>();   // sa/sh (as inputs) are no longer needed by any lane of this wave
+    sa[lane] = dgi1;
+    sh[lane] = dgh1;
+    if (lane < 32) { sa[64 + lane] = dgi2; sh[64 + lane] = dgh2; }
+    if (active) {
+      o.dgi[(long)j * o.ld96 + lane] = dgi1;
+      o.dgh[(long)j * o.ld96 + lane] = dgh1;
+      if (lane < 32) {
+        o.dgi[(long)j * o.ld96 + 64 + lane] = dgi2;
+        o.dgh[(long)j * o.ld96 + 64 + lane] = dgh2;
+      }
+    }
+    spg_node_sync<WAVE>();
+    float dx = 0.f;
+    if (lane < 32) {
+  #pragma unroll 8
+      for (int q = 0; q < 96; ++q) {
+        dx = fmaf(sw_ih[q * SPG_WLD + lane], sa[q], dx);
+        dh_acc = fmaf(sw_hh[q * SPG_WLD + lane], sh[q], dh_acc);
+      }
+    }
+    da = dx;
+    float dpre = 0.f;
+    if (G.ingate) {
+      da = dx * st.gin;
+      dpre = dx * a_in * st.gin * (1.f - st.gin);
+      if (lane < 32) sd[lane] = dpre;
+    }
+    spg_node_sync<WAVE>();
+    if (G.ingate && lane < 32) {
+  #pragma unroll 8
+      for (int q = 0; q < 32; ++q) dh_acc = fmaf(sw_ig[q * SPG_WLD + lane], sd[q], dh_acc);
+    }
+    if (active && lane < 32) {
+      o.dpre[(long)j * o.ld32 + lane] = dpre;
+      o.xg[(long)j * o.ld32 + lane] = st.x;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -620,86 +736,11 @@ __global__ __launch_bounds__(256, 3) void spg_ecc_step_bwd_kernel(const SpgEccSt
       p.Gcur[(long)j * p.ldg + lane] = p.g.invdeg != nullptr ? da * p.g.invdeg[j] : da;
     }
   } else {
-    GruFwdState st;
-    {
-      GruRowsLds wr;
-      spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane, wr);
-      spg_gru_forward_node(G, wr, sa, sh, sx, lane, st);
-    }
-    const float a_in = lane < 32 ? sa[lane] : 0.f;
-    const float h_in = lane < 32 ? sh[lane] : 0.f;
-    // gate backward on lanes 0..31 (channel = lane)
-    float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dh_acc = 0.f;
-    if (lane < 32) {
-      const float dn = dH * (1.f - st.z);
-      const float dzg = dH * (h_in - st.n);
-      dh_acc = dH * st.z;
-      dn_pre = dn * (1.f - st.n * st.n);
-      const float dr = dn_pre * (st.uh2 + G.b_hh[64 + lane]);
-      dz_pre = dzg * st.z * (1.f - st.z);
-      dr_pre = dr * st.r * (1.f - st.r);
-    }
-    // gradients wrt the normalised pre-activations, in the first/second-value lane layout
-    const float zsh = __shfl(dz_pre, lane & 31, 64);
-    float dui1 = lane < 32 ? dr_pre : zsh;        // index lane
-    float dui2 = lane < 32 ? dn_pre : 0.f;        // index 64 + lane
-    float duh1 = dui1;
-    float duh2 = lane < 32 ? dn_pre * st.r : 0.f;
-    if (active) {
-      p.dui[(long)j * p.ld96 + lane] = dui1;
-      p.duh[(long)j * p.ld96 + lane] = duh1;
-      if (lane < 32) {
-        p.dui[(long)j * p.ld96 + 64 + lane] = dui2;
-        p.duh[(long)j * p.ld96 + 64 + lane] = duh2;
-      }
-    }
-    // through the row normalisation: dg = rstd * (du - mean(du) - u * mean(du*u))
-    float dgi1 = dui1, dgi2 = dui2, dgh1 = duh1, dgh2 = duh2;
-    if (G.layernorm) {
-      const float m1i = spg_wave_sum(dui1 + dui2) * (1.f / 96.f);
-      const float m2i = spg_wave_sum(dui1 * st.ui1 + dui2 * st.ui2) * (1.f / 96.f);
-      const float m1h = spg_wave_sum(duh1 + duh2) * (1.f / 96.f);
-      const float m2h = spg_wave_sum(duh1 * st.uh1 + duh2 * st.uh2) * (1.f / 96.f);
-      dgi1 = st.rstd_i * (dui1 - m1i - st.ui1 * m2i);
-      dgi2 = st.rstd_i * (dui2 - m1i - st.ui2 * m2i);
-      dgh1 = st.rstd_h * (duh1 - m1h - st.uh1 * m2h);
-      dgh2 = st.rstd_h * (duh2 - m1h - st.uh2 * m2h);
-    }
-    __syncthreads();   // sa/sh (as inputs) are no longer needed by any lane of this wave
-    sa[lane] = dgi1;
-    sh[lane] = dgh1;
-    if (lane < 32) { sa[64 + lane] = dgi2; sh[64 + lane] = dgh2; }
-    if (active) {
-      p.dgi[(long)j * p.ld96 + lane] = dgi1;
-      p.dgh[(long)j * p.ld96 + lane] = dgh1;
-      if (lane < 32) {
-        p.dgi[(long)j * p.ld96 + 64 + lane] = dgi2;
-        p.dgh[(long)j * p.ld96 + 64 + lane] = dgh2;
-      }
-    }
-    __syncthreads();
-    float dx = 0.f;
-    if (lane < 32) {
-  #pragma unroll 8
-      for (int o = 0; o < 96; ++o) {
-        dx = fmaf(sw_ih[o * SPG_WLD + lane], sa[o], dx);
-        dh_acc = fmaf(sw_hh[o * SPG_WLD + lane], sh[o], dh_acc);
-      }
-    }
-    float da = dx, dpre = 0.f;
-    if (G.ingate) {
-      da = dx * st.gin;
-      dpre = dx * a_in * st.gin * (1.f - st.gin);
-      if (lane < 32) sd[lane] = dpre;
-    }
-    __syncthreads();
-    if (G.ingate && lane < 32) {
-  #pragma unroll 8
-      for (int o = 0; o < 32; ++o) dh_acc = fmaf(sw_ig[o * SPG_WLD + lane], sd[o], dh_acc);
-    }
+    SpgGruBwdOut o;
+    o.dgi = p.dgi; o.dgh = p.dgh; o.dui = p.dui; o.duh = p.duh; o.dpre = p.dpre; o.xg = p.xg; o.ld96 = p.ld96; o.ld32 = p.ld32;
+    float dh_acc, da;
+    spg_gru_backward_node<false>(G, sw, sa, sh, sx, sd, lane, active, j, dH, o, dh_acc, da);
     if (active && lane < 32) {
-      p.dpre[(long)j * p.ld32 + lane] = dpre;
-      p.xg[(long)j * p.ld32 + lane] = st.x;
       p.dhdir[(long)j * 32 + lane] = dh_acc;
       p.Gcur[(long)j * p.ldg + lane] = p.g.invdeg != nullptr ? da * p.g.invdeg[j] : da;
     }
@@ -773,4 +814,448 @@ int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long row
   hipLaunchKernelGGL(spg_copy2d_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
   SPG_LAUNCH_CHECK();
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent RNN-ECC: all R iterations of the recurrence in ONE launch, synchronised by DATAFLOW
+// ---------------------------------------------------------------------------------------------
+// reference: RNNGraphConvModule.forward, learning/modules.py:171-181 (the loop over nrepeats); GraphConvFunction
+// forward / backward, learning/ecc/GraphConvModule.py:44-152; GRUCellEx, learning/modules.py:224-251.
+//
+// Node i at iteration r+1 needs nothing but the iteration-r states of its <= deg(i) in-neighbours -- no grid-wide barrier.
+// One wavefront owns one node for the whole recurrence (N <= 1024 nodes: <= 256 workgroups of 4 waves, all co-resident),
+// publishes every new state as 32 eight-byte {tag, value} granules with write-through (sc1) stores and, for the next
+// iteration, sweeps the granules of its sources until every tag carries the expected epoch (cdna guide, guideline 16,
+// form R2: the data is the flag -- no fences, no separate flag round trip; measured price of a hop ~1 us against ~9 us for a
+// per-iteration launch of this latency-bound step).  What stays on chip for all iterations: the node's in-edge (forward) or
+// out-edge (backward) filters in registers (up to SPG_PX_KMAX edges x 4 KiB per wave; further edges are re-read through L2),
+// its edge list, the cell's weights in LDS, its own state.  The plain outputs the later kernels need (states, aggregates,
+// gate gradients) are written with ordinary stores; only the exchanged vectors travel as granules.
+//
+// The exchange buffer is the second piece of device memory the library owns (per device, 4 MiB + a control block): epochs are
+// drawn from a device-side counter that the last workgroup of a launch advances, so a tag is never reused -- neither across
+// launches nor under hipGraph replay -- and the buffer needs no clearing.  One persistent launch is in flight per device at a
+// time (launches of one stream serialise; a second stream falls back to the per-iteration kernels).  Spins are bounded: a
+// wave that waits longer than SPG_PX_SPIN_LIMIT sweeps raises the error word of the control block (spg_ecc_persistent_errors)
+// and carries on, so a logic error can never hang the GPU.
+#define SPG_PX_MAX_NODES 1024
+#define SPG_PX_MAX_ITERS 16
+#define SPG_PX_KMAX 8          // edges per node whose filters stay in registers (16 VGPRs each in matrix mode)
+#define SPG_PX_CH 32           // edges gathered per pass (wave-private LDS staging)
+#define SPG_PX_SPIN_LIMIT 400000
+
+typedef __attribute__((address_space(1))) unsigned long long spg_gu64;
+typedef __attribute__((address_space(1))) unsigned spg_gu32;
+
+__device__ __forceinline__ void spg_px_store_granule(unsigned long long* g, unsigned tag, float v) {
+  __hip_atomic_store((spg_gu64*)g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave gathers the 32-float vectors of `n` (<= SPG_PX_CH) peers into hs[u][0..31]: lanes 0..31 take even, lanes 32..63 odd
+// list positions.  Plain form (rows of a finished matrix, leading dimension ld) or granule form (tags must equal `tag`;
+// swept until they do).  ids: wave-private LDS list of the peers' node indices.
+__device__ __forceinline__ void spg_px_gather_plain(const float* __restrict__ X, long ld, const int* ids, int n, int lane, float* hs) {
+  const int half = lane >> 5, c = lane & 31;
+  for (int p = 0; p < n; p += 8) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = p + 2 * k + half;
+      v[k] = X[(long)ids[u < n ? u : 0] * ld + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = p + 2 * k + half;
+      if (u < n) hs[u * 32 + c] = v[k];
+    }
+  }
+}
+
+__device__ __forceinline__ void spg_px_gather_granules(const unsigned long long* __restrict__ gran, unsigned tag, const int* ids,
+                                                       int n, int lane, float* hs, unsigned* ctl) {
+  const int half = lane >> 5, c = lane & 31;
+  for (int p = 0; p < n; p += 8) {
+    for (unsigned spins = 0;; ++spins) {
+      unsigned long long x[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int u = p + 2 * k + half;
+        x[k] = __hip_atomic_load((spg_gu64*)(gran + (long)ids[u < n ? u : 0] * 32 + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int u = p + 2 * k + half;
+        if (u < n) ok = ok && (unsigned)(x[k] >> 32) == tag;
+      }
+      if (__all(ok)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int u = p + 2 * k + half;
+          if (u < n) hs[u * 32 + c] = __uint_as_float((unsigned)x[k]);
+        }
+        break;
+      }
+      if (spins > SPG_PX_SPIN_LIMIT) {      // never hang: flag the error and go on with what is there
+        if (lane == 0) atomicAdd(ctl + 2, 1u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int u = p + 2 * k + half;
+          if (u < n) hs[u * 32 + c] = __uint_as_float((unsigned)x[k]);
+        }
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+}
+
+// the last workgroup to finish advances the epoch base past every tag this launch used and re-arms the counter
+// (counted when wave 0 of a workgroup is through -- wave 0 always owns a node; what matters is that every workgroup has
+// read the base before it moves, and the last arrival implies that all have started)
+__device__ __forceinline__ void spg_px_finish(unsigned* ctl, unsigned base, unsigned used) {
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add((spg_gu32*)(ctl + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store((spg_gu32*)(ctl + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((spg_gu32*)ctl, base + used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <bool MATRIX>
+__global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEccPersistFwd p) {
+  __shared__ float sw[(2 * 96 + 32) * SPG_WLD];
+  __shared__ __attribute__((aligned(16))) float lds[4][3][32];
+  __shared__ __attribute__((aligned(16))) float hsb[4][SPG_PX_CH * 32];
+  __shared__ int idb[4][SPG_PX_CH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  const bool active = i < p.g.N;
+  spg_stage_cell_weights<96>(p.gru, sw);
+  const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  GruRowsLds wr;
+  spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane, wr);
+  float* sa = lds[wave][0];
+  float* sh = lds[wave][1];
+  float* sx = lds[wave][2];
+  float* hs = hsb[wave];
+  int* ids = idb[wave];
+  int e0 = 0, deg = 0;
+  float invdeg = 0.f;
+  if (active) { e0 = p.g.rowptr[i]; deg = p.g.rowptr[i + 1] - e0; invdeg = p.g.invdeg[i]; }
+  // resident for all iterations: the filters of the first SPG_PX_KMAX in-edges
+  f32x4 wc[MATRIX ? SPG_PX_KMAX : 1][4];
+  float wv[SPG_PX_KMAX];
+  const int kb = lane >> 3;
+#pragma unroll
+  for (int u = 0; u < SPG_PX_KMAX; ++u) {
+    wv[u] = 0.f;
+    if (u < deg) {
+      if constexpr (MATRIX) {
+        const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)(e0 + u) * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wc[u][q] = We[lane + 64 * q];
+      } else {
+        wv[u] = p.W[(long)(e0 + u) * 32 + (lane & 31)];
+      }
+    }
+  }
+  if (deg <= SPG_PX_CH && lane < deg) ids[lane] = p.g.src[e0 + lane];
+  float hcur = 0.f;
+  if (active && lane < 32) {
+    hcur = p.h0[(long)i * 32 + lane];
+    p.states[(long)i * p.ldS + lane] = hcur;
+    if (p.cat_all) p.out[(long)i * p.ldo + lane] = hcur;
+  }
+  __syncthreads();            // the cell weights are in LDS; from here on the waves run on their own
+  if (!active) return;
+  for (int r = 0; r < p.R; ++r) {
+    // ---- aggregate over the in-edges: mean of h_src (.) W_e ----
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < deg; c0 += SPG_PX_CH) {
+      const int n = min(SPG_PX_CH, deg - c0);
+      if (deg > SPG_PX_CH) {
+        spg_node_sync<true>();
+        if (lane < n) ids[lane] = p.g.src[e0 + c0 + lane];
+      }
+      spg_node_sync<true>();
+      if (r == 0) spg_px_gather_plain(p.h0, 32, ids, n, lane, hs);
+      else spg_px_gather_granules(p.gran + (long)r * SPG_PX_MAX_NODES * 32, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl);
+      spg_node_sync<true>();
+      if constexpr (MATRIX) {
+        if (c0 == 0) {
+#pragma unroll
+          for (int u = 0; u < SPG_PX_KMAX; ++u) {
+            if (u < n) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float xv = hs[u * 32 + kb + 8 * q];
+                a4[0] = fmaf(xv, wc[u][q][0], a4[0]); a4[1] = fmaf(xv, wc[u][q][1], a4[1]);
+                a4[2] = fmaf(xv, wc[u][q][2], a4[2]); a4[3] = fmaf(xv, wc[u][q][3], a4[3]);
+              }
+            }
+          }
+        }
+        for (int u = (c0 == 0 ? SPG_PX_KMAX : 0); u < n; ++u) {      // beyond the register-resident filters: through L2
+          const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)(e0 + c0 + u) * 1024);
+          f32x4 w[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q] = We[lane + 64 * q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float xv = hs[u * 32 + kb + 8 * q];
+            a4[0] = fmaf(xv, w[q][0], a4[0]); a4[1] = fmaf(xv, w[q][1], a4[1]);
+            a4[2] = fmaf(xv, w[q][2], a4[2]); a4[3] = fmaf(xv, w[q][3], a4[3]);
+          }
+        }
+      } else if (lane < 32) {
+        if (c0 == 0) {
+#pragma unroll
+          for (int u = 0; u < SPG_PX_KMAX; ++u)
+            if (u < n) a4[0] = fmaf(hs[u * 32 + lane], wv[u], a4[0]);
+        }
+        for (int u = (c0 == 0 ? SPG_PX_KMAX : 0); u < n; ++u)
+          a4[0] = fmaf(hs[u * 32 + lane], p.W[(long)(e0 + c0 + u) * 32 + lane], a4[0]);
+      }
+    }
+    if constexpr (MATRIX) {
+#pragma unroll
+      for (int off = 8; off <= 32; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a4[c] += __shfl_xor(a4[c], off, 64);
+      }
+      if (lane < 8) {
+        sa[4 * lane + 0] = a4[0] * invdeg; sa[4 * lane + 1] = a4[1] * invdeg;
+        sa[4 * lane + 2] = a4[2] * invdeg; sa[4 * lane + 3] = a4[3] * invdeg;
+      }
+    } else if (lane < 32) {
+      sa[lane] = a4[0] * invdeg;
+    }
+    if (lane < 32) sh[lane] = hcur;
+    spg_node_sync<true>();
+    if (p.agg != nullptr && lane < 32) p.agg[(long)i * p.ldS + (long)r * 32 + lane] = sa[lane];
+    // ---- GRU ----
+    GruFwdState st;
+    spg_gru_forward_node<GruRowsLds, true>(p.gru, wr, sa, sh, sx, lane, st);
+    if (lane < 32) {
+      hcur = st.n + st.z * (hcur - st.n);      // hy = newgate + inputgate * (hidden - newgate), learning/modules.py:250
+      if (r + 1 < p.R) spg_px_store_granule(p.gran + ((long)(r + 1) * SPG_PX_MAX_NODES + i) * 32 + lane, base + (unsigned)r + 2u, hcur);
+      p.states[(long)i * p.ldS + (long)(r + 1) * 32 + lane] = hcur;
+      if (p.cat_all) p.out[(long)i * p.ldo + (long)(r + 1) * 32 + lane] = hcur;
+      else if (r + 1 == p.R) p.out[(long)i * p.ldo + lane] = hcur;
+    }
+    spg_node_sync<true>();      // sa / sh / sx are rewritten by the next iteration
+  }
+  spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
+}
+
+template <bool MATRIX>
+__global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEccPersistBwd p) {
+  constexpr int GW = 96;
+  __shared__ float sw[(2 * GW + 32) * SPG_WLD];
+  __shared__ __attribute__((aligned(16))) float lds[4][4][GW];
+  __shared__ __attribute__((aligned(16))) float hsb[4][SPG_PX_CH * 32];
+  __shared__ int idb[4][SPG_PX_CH];
+  __shared__ int eib[4][SPG_PX_CH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  const bool active = j < p.g.N;
+  spg_stage_cell_weights<GW>(p.gru, sw);
+  const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* sa = lds[wave][0];        // [32] aggregate   | later dgi [96]
+  float* sh = lds[wave][1];        // [32] hidden      | later dgh [96]
+  float* sx = lds[wave][2];        // [32] gated input
+  float* sd = lds[wave][3];        // [32] sum over the out-edges | later dpre [32]
+  float* hs = hsb[wave];
+  int* ids = idb[wave];
+  int* eis = eib[wave];
+  int b0 = 0, odeg = 0;
+  float invdeg = 0.f;
+  if (active) { b0 = p.g.rev_rowptr[j]; odeg = p.g.rev_rowptr[j + 1] - b0; invdeg = p.g.invdeg[j]; }
+  // out-edge list (edge id, destination) and the filters of the first SPG_PX_KMAX out-edges: resident for all iterations
+  if (odeg <= SPG_PX_CH && lane < odeg) {
+    const int e = p.g.rev_eid[b0 + lane];
+    eis[lane] = e; ids[lane] = p.g.dst[e];
+  }
+  spg_node_sync<true>();
+  f32x4 wc[MATRIX ? SPG_PX_KMAX : 1][4];
+  float wv[SPG_PX_KMAX];
+#pragma unroll
+  for (int u = 0; u < SPG_PX_KMAX; ++u) {
+    wv[u] = 0.f;
+    if (u < odeg) {
+      const int e = odeg <= SPG_PX_CH ? eis[u] : p.g.rev_eid[b0 + u];
+      if constexpr (MATRIX) {
+        const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)e * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wc[u][q] = We[lane + 64 * q];
+      } else {
+        wv[u] = p.W[(long)e * 32 + (lane & 31)];
+      }
+    }
+  }
+  __syncthreads();            // cell weights staged; the waves run on their own from here
+  if (!active) return;
+  float dhdir = 0.f;          // direct GRU-path gradient wrt this node's state, carried from iteration to iteration (lanes 0..31)
+  // iterations R-1 .. 0 produce G^r; the extra pass r = -1 only forms the gradient wrt h^0
+  for (int r = p.R - 1; r >= -1; --r) {
+    // ---- phase 1: dH = d(out)/d(h^{r+1}) + dhdir + sum over the out-edges of W_e . G^{r+1}[dst] ----
+    float dH = 0.f;
+    if (lane < 32) {
+      if (p.cat_all) dH = p.grad_out[(long)j * p.ldgo + (long)(r + 1) * 32 + lane];
+      else if (r == p.R - 1) dH = p.grad_out[(long)j * p.ldgo + lane];
+      dH += dhdir;
+    }
+    if (r < p.R - 1) {
+      float pq[4] = {0.f, 0.f, 0.f, 0.f};
+      float acc = 0.f;
+      for (int c0 = 0; c0 < odeg; c0 += SPG_PX_CH) {
+        const int n = min(SPG_PX_CH, odeg - c0);
+        if (odeg > SPG_PX_CH) {
+          spg_node_sync<true>();
+          if (lane < n) { const int e = p.g.rev_eid[b0 + c0 + lane]; eis[lane] = e; ids[lane] = p.g.dst[e]; }
+        }
+        spg_node_sync<true>();
+        spg_px_gather_granules(p.gran + (long)(r + 1) * SPG_PX_MAX_NODES * 32, base + (unsigned)(r + 1) + 1u, ids, n, lane, hs, p.ctl);
+        spg_node_sync<true>();
+        if constexpr (MATRIX) {
+          if (c0 == 0) {
+#pragma unroll
+            for (int u = 0; u < SPG_PX_KMAX; ++u) {
+              if (u < n) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(hs + u * 32 + 4 * (lane & 7));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  pq[q] += (wc[u][q][0] * g4[0] + wc[u][q][1] * g4[1]) + (wc[u][q][2] * g4[2] + wc[u][q][3] * g4[3]);
+              }
+            }
+          }
+          for (int u = (c0 == 0 ? SPG_PX_KMAX : 0); u < n; ++u) {
+            const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)eis[u] * 1024);
+            f32x4 w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = We[lane + 64 * q];
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(hs + u * 32 + 4 * (lane & 7));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pq[q] += (w[q][0] * g4[0] + w[q][1] * g4[1]) + (w[q][2] * g4[2] + w[q][3] * g4[3]);
+          }
+        } else if (lane < 32) {
+          if (c0 == 0) {
+#pragma unroll
+            for (int u = 0; u < SPG_PX_KMAX; ++u)
+              if (u < n) acc = fmaf(wv[u], hs[u * 32 + lane], acc);
+          }
+          for (int u = (c0 == 0 ? SPG_PX_KMAX : 0); u < n; ++u) acc = fmaf(p.W[(long)eis[u] * 32 + lane], hs[u * 32 + lane], acc);
+        }
+      }
+      if constexpr (MATRIX) {
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pq[q] += __shfl_xor(pq[q], off, 64);
+        }
+        spg_node_sync<true>();
+        if ((lane & 7) == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sd[(lane >> 3) + 8 * q] = pq[q];   // input channel k = lane/8 + 8q
+        }
+        spg_node_sync<true>();
+        if (lane < 32) dH += sd[lane];
+      } else {
+        dH += acc;
+      }
+    }
+    if (r < 0) {
+      if (lane < 32) p.gx[(long)j * 32 + lane] = dH;
+      break;
+    }
+    // ---- phase 2: GRU recompute + backward of iteration r ----
+    spg_node_sync<true>();
+    if (lane < 32) {
+      sa[lane] = p.agg[(long)j * p.ldS + (long)r * 32 + lane];
+      sh[lane] = p.states[(long)j * p.ldS + (long)r * 32 + lane];
+    }
+    spg_node_sync<true>();
+    SpgGruBwdOut o;
+    o.dgi = p.dgi + (long)r * GW; o.dgh = p.dgh + (long)r * GW; o.dui = p.dui + (long)r * GW; o.duh = p.duh + (long)r * GW;
+    o.dpre = p.dpre + (long)r * 32; o.xg = p.xg + (long)r * 32; o.ld96 = p.ld96; o.ld32 = p.ld32;
+    float dh_acc, da;
+    spg_gru_backward_node<true>(p.gru, sw, sa, sh, sx, sd, lane, true, j, dH, o, dh_acc, da);
+    if (lane < 32) {
+      dhdir = dh_acc;
+      const float gc = da * invdeg;
+      spg_px_store_granule(p.gran + ((long)r * SPG_PX_MAX_NODES + j) * 32 + lane, base + (unsigned)r + 1u, gc);
+      p.G[(long)j * p.ldS + (long)r * 32 + lane] = gc;
+    }
+  }
+  spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
+}
+
+// ---- host side: the exchange buffer and the launchers ----
+static void* g_px_buf[SPG_MAX_DEVICES] = {nullptr};
+static hipStream_t g_px_stream[SPG_MAX_DEVICES] = {nullptr};
+static bool g_px_stream_set[SPG_MAX_DEVICES] = {false};
+static std::mutex g_px_mutex;
+#define SPG_PX_CTL_BYTES 256
+static size_t px_bytes() { return SPG_PX_CTL_BYTES + (size_t)SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES * 32 * sizeof(unsigned long long); }
+
+// returns the exchange buffer of the current device, or null when the persistent form must not be used for this launch
+static char* px_acquire(int N, int R, hipStream_t stream) {
+  if (spg_tune_get(SPG_TUNE_NO_PERSIST_ECC) || N > SPG_PX_MAX_NODES || R + 1 > SPG_PX_MAX_ITERS || R < 1) return nullptr;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) return nullptr;
+  // every workgroup must be resident at once (the kernels run one 4-wave workgroup per CU): a few CUs of margin
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || spg_cdiv(N, 4) > cus - 4) return nullptr;
+  std::lock_guard<std::mutex> lock(g_px_mutex);
+  if (g_px_buf[dev] == nullptr) {
+    void* b = nullptr;
+    if (hipMalloc(&b, px_bytes()) != hipSuccess) return nullptr;
+    if (hipMemset(b, 0, px_bytes()) != hipSuccess) { (void)hipFree(b); return nullptr; }
+    g_px_buf[dev] = b;
+  }
+  // one stream per device drives the persistent launches (they serialise on it); another stream takes the safe path
+  if (!g_px_stream_set[dev]) { g_px_stream[dev] = stream; g_px_stream_set[dev] = true; }
+  if (g_px_stream[dev] != stream) {
+    if (hipStreamQuery(g_px_stream[dev]) == hipSuccess) g_px_stream[dev] = stream;      // the old owner is idle: hand over
+    else return nullptr;
+  }
+  return (char*)g_px_buf[dev];
+}
+
+extern "C" int spg_ecc_persistent_errors(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES || g_px_buf[dev] == nullptr) return 0;
+  unsigned ctl[4] = {0, 0, 0, 0};
+  if (hipMemcpy(ctl, g_px_buf[dev], sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)ctl[2];
+}
+
+bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err) {
+  *err = 0;
+  char* buf = px_acquire(p.g.N, p.R, stream);
+  if (buf == nullptr) return false;
+  p.ctl = (unsigned*)buf;
+  p.gran = (unsigned long long*)(buf + SPG_PX_CTL_BYTES);
+  const dim3 grid(spg_cdiv(p.g.N, 4));
+  if (p.matrix) hipLaunchKernelGGL(spg_ecc_persist_fwd_kernel<true>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(spg_ecc_persist_fwd_kernel<false>, grid, dim3(256), 0, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { spg_set_error("persistent ECC forward launch failed: %s", hipGetErrorString(e)); *err = (int)e; }
+  return true;
+}
+
+bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err) {
+  *err = 0;
+  char* buf = px_acquire(p.g.N, p.R, stream);
+  if (buf == nullptr) return false;
+  p.ctl = (unsigned*)buf;
+  p.gran = (unsigned long long*)(buf + SPG_PX_CTL_BYTES);
+  const dim3 grid(spg_cdiv(p.g.N, 4));
+  if (p.matrix) hipLaunchKernelGGL(spg_ecc_persist_bwd_kernel<true>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(spg_ecc_persist_bwd_kernel<false>, grid, dim3(256), 0, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { spg_set_error("persistent ECC backward launch failed: %s", hipGetErrorString(e)); *err = (int)e; }
+  return true;
 }

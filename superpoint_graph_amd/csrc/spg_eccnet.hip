@@ -215,8 +215,16 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
     }
   }
   // ---- recurrent part ----
-  SPG_TRY(spg_launch_copy2d(h0, 32, pl.states, pl.ldS, N, 32, st));
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
+  if (!pl.lstm) {      // GRU, <= 1024 nodes: all iterations in one dataflow-synchronised launch (spg_ecc.hip)
+    SpgEccPersistFwd q; memset(&q, 0, sizeof(q));
+    q.g = gr; q.W = pl.F.back().y; q.matrix = pl.cfg.matrix; q.R = pl.R; q.h0 = h0;
+    q.states = pl.states; q.ldS = pl.ldS; q.agg = pl.training ? pl.agg : nullptr;
+    q.out = out; q.cat_all = pl.cfg.cat_all; q.ldo = pl.cfg.cat_all ? pl.ldS : 32; q.gru = pl.gru;
+    int err = 0;
+    if (spg_launch_ecc_persist_fwd(q, st, &err)) return err;
+  }
+  SPG_TRY(spg_launch_copy2d(h0, 32, pl.states, pl.ldS, N, 32, st));
   for (int r = 0; r < pl.R; ++r) {
     SpgEccStepFwd p; memset(&p, 0, sizeof(p));
     p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;
@@ -270,7 +278,19 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
   const int GW = pl.GW;
   const long ldS = pl.ldS, ld96 = (long)(R + 1) * GW;
   // ---- back-propagation through the R iterations ----
-  for (int r = R - 1; r >= 0; --r) {
+  bool persistent = false;
+  if (!pl.lstm) {      // GRU, <= 1024 nodes: one dataflow-synchronised launch for all iterations (spg_ecc.hip)
+    SpgEccPersistBwd q; memset(&q, 0, sizeof(q));
+    q.g = gr; q.W = pl.F.back().y; q.matrix = pl.cfg.matrix; q.R = R; q.cat_all = pl.cfg.cat_all;
+    q.grad_out = grad_out; q.ldgo = pl.cfg.cat_all ? ldS : 32;
+    q.states = pl.states; q.ldS = ldS; q.agg = pl.agg; q.G = s.G;
+    q.dgi = s.dgi; q.dgh = s.dgh; q.dui = s.dui; q.duh = s.duh; q.ld96 = ld96;
+    q.dpre = s.dpre; q.xg = s.xg; q.ld32 = ldS; q.gx = grad_h0; q.gru = pl.gru;
+    int err = 0;
+    persistent = spg_launch_ecc_persist_bwd(q, st, &err);
+    if (err != 0) return err;
+  }
+  for (int r = R - 1; r >= 0 && !persistent; --r) {
     SpgEccStepBwd p; memset(&p, 0, sizeof(p));
     p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;
     if (pl.cfg.cat_all) { p.dcat = grad_out + (size_t)(r + 1) * 32; p.ldc = ldS; }
@@ -287,7 +307,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     if (pl.lstm) { p.cin = r > 0 ? pl.cells + (size_t)r * 32 : nullptr; p.dcdir = s.dcdir; p.use_dcdir = r < R - 1; }
     SPG_TRY(spg_launch_ecc_step_bwd(p, st));
   }
-  {
+  if (!persistent) {
     SpgEccStepBwd p; memset(&p, 0, sizeof(p));
     p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;
     if (pl.cfg.cat_all) { p.dcat = grad_out; p.ldc = ldS; }

@@ -55,10 +55,6 @@ struct SpgGemmParams {
   long ldwb, wb_part_bytes;
 };
 
-// tuning knobs (process-global; defaults are the production values): see spg_tune in include/spg_hip.h
-enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_FIN_SLICE_MIN = 4, SPG_TUNE_NO_STAT_ACCUM = 5, SPG_TUNE_PRECISION = 7, SPG_TUNE_COUNT = 16 };
-int spg_tune_get(int key);
-
 // dW[N,K] = sum_m prologue_a(dY)[m, n] * prologue_b(A)[m, k]
 struct SpgWgradParams {
   SpgOperand a;       // channels -> rows of dW

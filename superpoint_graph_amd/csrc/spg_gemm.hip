@@ -1516,7 +1516,6 @@ int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t 
 // result is deterministic, and resets the ticket for the next launch.
 #define SPG_FIN_SLICES 8
 
-#define SPG_MAX_DEVICES 16
 static int* g_fin_counters[SPG_MAX_DEVICES] = {nullptr};    // per device: 4096 self-resetting tickets (the only device memory the library owns)
 static unsigned g_fin_next[SPG_MAX_DEVICES] = {0};
 static std::mutex g_fin_mutex;           // host threads may drive different streams / devices
