@@ -183,6 +183,13 @@ __device__ __forceinline__ void spg_node_sync() {
   }
 }
 
+// 4-term dot product with a FIXED rounding order (explicit fma placement): the per-iteration and the persistent backward
+// kernels must produce bit-identical results (tests/test_gpu_ecc_persistent.py), which the compiler's own choice of
+// contractions does not guarantee across two different kernels
+__device__ __forceinline__ float spg_dot4(const f32x4& w, const f32x4& g) {
+  return fmaf(w[0], g[0], w[1] * g[1]) + fmaf(w[2], g[2], w[3] * g[3]);
+}
+
 #define SPG_IN_EPS 1e-5f   // nn.InstanceNorm1d(1, eps=1e-5), learning/modules.py:213-214
 
 // in-edge aggregation for node i; result: every lane of the wave holds, for the matrix mode, the 4
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(256, 3) void spg_ecc_step_bwd_kernel(const SpgEccSt
             const float on = (t + u < e_) ? 1.f : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              pq[q] += on * ((w[u][q][0] * g4[u][0] + w[u][q][1] * g4[u][1]) + (w[u][q][2] * g4[u][2] + w[u][q][3] * g4[u][3]));
+              pq[q] += on * spg_dot4(w[u][q], g4[u]);
           }
         }
 #pragma unroll
@@ -1128,7 +1135,7 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(hs + u * 32 + 4 * (lane & 7));
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                  pq[q] += (wc[u][q][0] * g4[0] + wc[u][q][1] * g4[1]) + (wc[u][q][2] * g4[2] + wc[u][q][3] * g4[3]);
+                  pq[q] += spg_dot4(wc[u][q], g4);
               }
             }
           }
@@ -1139,7 +1146,7 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
             for (int q = 0; q < 4; ++q) w[q] = We[lane + 64 * q];
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(hs + u * 32 + 4 * (lane & 7));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pq[q] += (w[q][0] * g4[0] + w[q][1] * g4[1]) + (w[q][2] * g4[2] + w[q][3] * g4[3]);
+            for (int q = 0; q < 4; ++q) pq[q] += spg_dot4(w[q], g4);
           }
         } else if (lane < 32) {
           if (c0 == 0) {
