@@ -108,8 +108,9 @@ def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
             times.append(time.perf_counter() - t0)
         med, cnt = float(np.median(times)), len(times)
         sweep = '; one step at ' + ', '.join(f'{k} threads {v * 1e3:.0f} ms' for k, v in trial.items())
-        kind, what = 'port', ('oracle/spg_oracle.py train_step on torch-CPU (no reference checkout on this machine; on the build container the '
-                              'port runs at 0.56-0.70x the speed of the imported reference modules, profiles/r02_cpu_reference_vs_port.json, oracle/devtools/cpu_baseline_compare.py)')
+        kind, what = 'port', ('oracle/spg_oracle.py train_step on torch-CPU: the reference\'s own op sequence (Conv1d / BatchNorm1d / Linear '
+                              'through torch, restated ECC) -- no reference checkout on this machine; on the build container the port runs at '
+                              '0.9-1.25x the speed of the imported reference modules, profiles/r03_cpu_reference_vs_port.json, oracle/devtools/cpu_baseline_compare.py)')
     return {'value': n / med, 'unit': 'superpoints/s', 'cores': torch.get_num_threads(), 'host_cores': ncpu, 'cpu_model': cpu_model(), 'kind': kind,
             'sample': f'{cnt} fwd+bwd steps of one {n}-superpoint scene (median {med * 1e3:.0f} ms/step), {what}{sweep}'}
 
@@ -132,18 +133,20 @@ def gemm_traffic(args):
 
 def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, iters=20):
     """The reference's own "trainer time" window (learning/main.py:192-215): every step gets a FRESH batch -- the clouds
-    come from pinned host memory (H2D on a side stream, overlapped with the previous step), `set_info` uploads the index
-    buffers and builds the device CSR -- then zero_grad ... optimizer step as in the headline measurement.  Reported
-    next to `value` (which keeps its inputs resident, as the metric definition says)."""
+    come from pinned host memory (H2D on a side stream, overlapped with the previous step) and the batched graph is built
+    anew on the GPU (GraphConvInfo.set_batch_device, as the CLI's collate does: ordering by target, edge-feature reordering,
+    CSR / reverse CSR; the host concatenates and counts degrees) -- then zero_grad ... optimizer step as in the headline
+    measurement.  Reported next to `value` (which keeps its inputs resident, as the metric definition says)."""
     from superpoint_graph_amd import ops, synth
-    from superpoint_graph_amd.learning import spg
+    from superpoint_graph_amd.learning import ecc, spg
     nb = 4
     batches = []
     for b in range(nb):
         scenes = [synth.scene(1000 + b * args.scenes + i, n_sp=args.n_sp, n_edges=args.n_edges, n_feat=args.n_feat, n_classes=n_classes)
                   for i in range(args.scenes)]
-        targets, GIs, (meta, flag, clouds, diam) = spg.eccpc_collate([spg.sample_from_scene(s, f'w{b}_{i}') for i, s in enumerate(scenes)])
-        batches.append((targets, GIs, flag, clouds.pin_memory(), diam.pin_memory()))
+        samples = [spg.sample_from_scene(s, f'w{b}_{i}') for i, s in enumerate(scenes)]
+        targets, _, (meta, flag, clouds, diam) = spg.eccpc_collate(samples)
+        batches.append((targets, [s[1] for s in samples], flag, clouds.pin_memory(), diam.pin_memory()))
     side = torch.cuda.Stream()
     cur = torch.cuda.current_stream()
 
@@ -158,11 +161,13 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
     def run(n):
         nxt = upload(0)
         for it in range(n):
-            targets, GIs, flag, _, _ = batches[it % nb]
+            targets, graphs, flag, _, _ = batches[it % nb]
             c, d, lab, done = nxt
             nxt = upload(it + 1)                      # H2D of the next batch overlaps this step
             cur.wait_event(done)
-            model.ecc.set_info(GIs, 1)                # index buffers H2D + device CSR / reverse CSR build
+            gi = ecc.GraphConvInfo()
+            gi.set_batch_device(graphs, spg.cloud_edge_feats)      # edge list / features H2D + ordering + CSR on the device
+            model.ecc.set_info([gi], 1)
             arena.zero_grad()
             emb = embedder.run(model, None, flag, c, d)
             loss = ops.cross_entropy(model.ecc(emb), lab)
@@ -178,8 +183,8 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
     n = int(batches[0][2].numel())
     log(f'trainer window: {dt * 1e3:.3f} ms/step')
     return {'ms_per_step': dt * 1e3, 'superpoints_per_s': n / dt,
-            'what': 'fresh batch every step: pinned H2D of clouds/labels on a side stream + GraphConvInfo.cuda() (index H2D, device CSR build) + '
-                    'zero_grad..Adam (learning/main.py:192-215)'}
+            'what': 'fresh batch every step: pinned H2D of clouds/labels on a side stream + GraphConvInfo.set_batch_device (edge list / features H2D, '
+                    'ordering by target + CSR / reverse CSR as kernels) + zero_grad..Adam (learning/main.py:192-215)'}
 
 
 def forward_only(dev, flag, clouds_d, diam_d, GIs, n_feat, iters=40):
@@ -267,7 +272,9 @@ def main():
     model.ecc.set_info(GIs, 1)                                             # H2D of the index buffers + device CSR build
     embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
     from superpoint_graph_amd.flat import FlatParameters
-    arena = FlatParameters(model)                    # parameters / gradients as views of one flat buffer each
+    # parameters / gradients as views of one flat buffer each; as in the training CLI (learning/main.py of this package):
+    # zero_grad() launches nothing (the backward kernels overwrite every gradient), BatchNorm batch counters on the host
+    arena = FlatParameters(model, lazy_zero=True, host_counters=True)
     if _lib.lib().spg_tune(7, PREC) < 0:             # precision mode of the wide row-GEMMs (0 = fp32 MFMA)
         raise RuntimeError('libspg_hip.so has no precision switch (spg_tune key 7)')
     w_local = spd.loss_weight(label_mode)

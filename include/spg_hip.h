@@ -217,7 +217,8 @@ int spg_load_superpoints(const float* points, int ncols, const int64_t* offsets,
 size_t spg_set_batch_workspace_bytes(int N, int E);
 int spg_set_batch(const int64_t* edges, int N, int E, int64_t* idxn, int64_t* degs, int64_t* perm, void* workspace,
                   int32_t* error_flag, void* stream);
-/* dst[r, :cols] = src[perm[r], :cols] */
+/* dst[r, :cols] = src[perm[r], :cols]; a negative perm[r] gives a zero row (CloudEmbedder's scatter of the embeddings of
+ * the valid superpoints into the zero-initialised descriptor matrix, learning/pointnet.py:177-179, as ONE launch) */
 int spg_gather_rows(const float* src, long ld_src, const int64_t* perm, long rows, int cols, float* dst, long ld_dst,
                     void* stream);
 

@@ -78,7 +78,8 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, long lds_, con
   if (i >= rows * cols) return;
   const long r = i / cols;
   const int c = (int)(i - r * cols);
-  dst[r * ldd + c] = src[perm[r] * lds_ + c];
+  const long s = perm[r];
+  dst[r * ldd + c] = s >= 0 ? src[s * lds_ + c] : 0.f;      // a negative index = a zero row (embedding scatter)
 }
 
 __global__ void edge_features_kernel(const spg_edge_feature_spec* __restrict__ specs_unused, spg_edge_feature_specs S,

@@ -1115,8 +1115,32 @@ struct SpgRedFastB {
 // C/D fragment of v_mfma_f32_32x32x2_f32: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int spg_acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// Sum over the 64 lanes of a wavefront, the total in every lane.  Data-parallel-primitive moves on the vector ALU (a few
+// cycles each) instead of six dependent LDS-crossbar shuffles (ds_bpermute, ~100 cycles each): the per-node kernels run one
+// wave per SIMD, so the length of the dependent chain is the run time.  Steps: pairs (quad_perm 1,0,3,2), quads (2,3,0,1),
+// eights (row_half_mirror -- the quads are uniform by then, so mirroring equals xor 4), sixteens (row_mirror), then the row
+// totals travel up the rows (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3); lane 63 holds the total, which
+// is broadcast through a scalar register.  Fixed association order: deterministic.
+__device__ __forceinline__ float spg_dpp_add(float v, float src, int ctrl, int row_mask) {
+  // v + (src moved by the DPP pattern; lanes of rows outside row_mask receive 0)
+  int t;
+  switch (ctrl) {      // the control word must be an immediate
+    case 0xB1: t = __builtin_amdgcn_update_dpp(0, __float_as_int(src), 0xB1, 0xF, 0xF, false); break;
+    case 0x4E: t = __builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x4E, 0xF, 0xF, false); break;
+    case 0x141: t = __builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x141, 0xF, 0xF, false); break;
+    case 0x140: t = __builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x140, 0xF, 0xF, false); break;
+    case 0x142: t = __builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x142, 0xA, 0xF, false); break;
+    default: t = __builtin_amdgcn_update_dpp(0, __float_as_int(src), 0x143, 0xC, 0xF, false); break;
+  }
+  (void)row_mask;
+  return v + __int_as_float(t);
+}
 __device__ __forceinline__ float spg_wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v = spg_dpp_add(v, v, 0xB1, 0xF);
+  v = spg_dpp_add(v, v, 0x4E, 0xF);
+  v = spg_dpp_add(v, v, 0x141, 0xF);
+  v = spg_dpp_add(v, v, 0x140, 0xF);
+  v = spg_dpp_add(v, v, 0x142, 0xA);
+  v = spg_dpp_add(v, v, 0x143, 0xC);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }

@@ -534,13 +534,25 @@ __device__ __forceinline__ void spg_gru_backward_node(const SpgGruParams& G, con
       }
     }
     spg_node_sync<WAVE>();
-    float dx = 0.f;
-    if (lane < 32) {
+    // W^T products dx[c] = sum_o W_ih[o][c] dgi[o], dh[c] += sum_o W_hh[o][c] dgh[o]: the 96 gate rows are split over the two
+    // half-waves (48 each) and over two accumulators, so the dependent fma chain is 24 long instead of 96; the halves meet
+    // through one cross-row shuffle
+    float dx;
+    {
+      const int c = lane & 31, q0 = 48 * (lane >> 5);
+      float x0 = 0.f, x1 = 0.f, h0 = 0.f, h1 = 0.f;
   #pragma unroll 8
-      for (int q = 0; q < 96; ++q) {
-        dx = fmaf(sw_ih[q * SPG_WLD + lane], sa[q], dx);
-        dh_acc = fmaf(sw_hh[q * SPG_WLD + lane], sh[q], dh_acc);
+      for (int q = q0; q < q0 + 48; q += 2) {
+        x0 = fmaf(sw_ih[q * SPG_WLD + c], sa[q], x0);
+        x1 = fmaf(sw_ih[(q + 1) * SPG_WLD + c], sa[q + 1], x1);
+        h0 = fmaf(sw_hh[q * SPG_WLD + c], sh[q], h0);
+        h1 = fmaf(sw_hh[(q + 1) * SPG_WLD + c], sh[q + 1], h1);
       }
+      float xs = x0 + x1, hs_ = h0 + h1;
+      xs += __shfl_xor(xs, 32, 64);
+      hs_ += __shfl_xor(hs_, 32, 64);
+      dx = lane < 32 ? xs : 0.f;
+      if (lane < 32) dh_acc += hs_;
     }
     da = dx;
     float dpre = 0.f;
@@ -551,8 +563,13 @@ __device__ __forceinline__ void spg_gru_backward_node(const SpgGruParams& G, con
     }
     spg_node_sync<WAVE>();
     if (G.ingate && lane < 32) {
+      float g0 = 0.f, g1 = 0.f;
   #pragma unroll 8
-      for (int q = 0; q < 32; ++q) dh_acc = fmaf(sw_ig[q * SPG_WLD + lane], sd[q], dh_acc);
+      for (int q = 0; q < 32; q += 2) {
+        g0 = fmaf(sw_ig[q * SPG_WLD + lane], sd[q], g0);
+        g1 = fmaf(sw_ig[(q + 1) * SPG_WLD + lane], sd[q + 1], g1);
+      }
+      dh_acc += g0 + g1;
     }
     if (active && lane < 32) {
       o.dpre[(long)j * o.ld32 + lane] = dpre;
@@ -1105,6 +1122,17 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
   }
   __syncthreads();            // cell weights staged; the waves run on their own from here
   if (!active) return;
+  // slot R of the per-iteration gradient matrices has no producer, but the deferred weight-gradient GEMMs and column sums run
+  // over all N * (R + 1) rows: zero it here (the per-iteration path clears the whole 20 MB region with a memset instead)
+  {
+    const long r96 = (long)j * p.ld96 + (long)p.R * GW, r32 = (long)j * p.ld32 + (long)p.R * 32;
+    p.dgi[r96 + lane] = 0.f; p.dgh[r96 + lane] = 0.f; p.dui[r96 + lane] = 0.f; p.duh[r96 + lane] = 0.f;
+    if (lane < 32) {
+      p.dgi[r96 + 64 + lane] = 0.f; p.dgh[r96 + 64 + lane] = 0.f; p.dui[r96 + 64 + lane] = 0.f; p.duh[r96 + 64 + lane] = 0.f;
+      p.dpre[r32 + lane] = 0.f; p.xg[r32 + lane] = 0.f;
+      p.G[(long)j * p.ldS + (long)p.R * 32 + lane] = 0.f;
+    }
+  }
   float dhdir = 0.f;          // direct GRU-path gradient wrt this node's state, carried from iteration to iteration (lanes 0..31)
   // iterations R-1 .. 0 produce G^r; the extra pass r = -1 only forms the gradient wrt h^0
   for (int r = p.R - 1; r >= -1; --r) {

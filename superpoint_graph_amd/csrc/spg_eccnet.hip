@@ -270,7 +270,6 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
   for (int k = 0; k < 6; ++k) pl.cell_grads[k] = (float*)grads[6 * pl.F.size() + k];
   BwdScratch s;
   carve_bwd(pl, bwd_workspace, s);
-  SPG_TRY(zero_async(bwd_workspace, s.zero_bytes, st));
   SpgReduceQueue rq;
   rq.arena = s.work; rq.arena_floats = s.work_floats;
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
@@ -287,9 +286,10 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     q.dgi = s.dgi; q.dgh = s.dgh; q.dui = s.dui; q.duh = s.duh; q.ld96 = ld96;
     q.dpre = s.dpre; q.xg = s.xg; q.ld32 = ldS; q.gx = grad_h0; q.gru = pl.gru;
     int err = 0;
-    persistent = spg_launch_ecc_persist_bwd(q, st, &err);
+    persistent = spg_launch_ecc_persist_bwd(q, st, &err);      // writes every row of [G .. xg] itself (slot R: zeros)
     if (err != 0) return err;
   }
+  if (!persistent) SPG_TRY(zero_async(bwd_workspace, s.zero_bytes, st));
   for (int r = R - 1; r >= 0 && !persistent; --r) {
     SpgEccStepBwd p; memset(&p, 0, sizeof(p));
     p.g = gr; p.W = pl.F.back().y; p.matrix = pl.cfg.matrix;

@@ -17,8 +17,16 @@ import torch.distributed as dist
 
 
 class FlatParameters:
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, lazy_zero: bool = False, host_counters: bool = False):
+        """lazy_zero: `zero_grad()` does not launch a fill.  The HIP backward kernels OVERWRITE every gradient view of the
+        modules they serve, so zeroing the arena first is redundant work in the fixed loop zero_grad -> forward -> backward ->
+        step (learning/main.py:199-213); the gradients of parameters no kernel wrote since the last zero_grad() (a module that
+        did not take part in the step) are zeroed right before they are consumed (adam_step / allreduce / clamp_grad_).
+        Observable difference: between zero_grad() and backward(), `p.grad` still shows the previous step's values.
+        host_counters: the BatchNorm `num_batches_tracked` buffers (pure bookkeeping on this path: momentum is fixed) move to
+        the host, so advancing them costs no kernel launch; state_dict() / load_state_dict() work as before."""
         self.model = model
+        self.lazy_zero = bool(lazy_zero)
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError('model has no trainable parameters')
@@ -42,6 +50,19 @@ class FlatParameters:
         for m in self._modules:
             m._spg_direct_grads = True                   # the HIP autograd Functions then write into p.grad directly
             m._spg_grad_written = False
+        # for every parameter: the modules on its path (a kernel-backed module writes the gradients of all its descendants)
+        named = dict(model.named_modules())
+        self._cover = []
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            parts = name.split('.')[:-1]
+            self._cover.append([named['.'.join(parts[:k])] for k in range(len(parts) + 1)])
+        self._stale = False
+        if host_counters:
+            for m in self._modules:
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None:
+                    m.num_batches_tracked = m.num_batches_tracked.cpu()
 
     def adam_step(self, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip=0.0):
         """Element-wise gradient clamp (learning/main.py:210-212) + torch.optim.Adam update (learning/main.py:433-437)
@@ -51,6 +72,7 @@ class FlatParameters:
             self._m = torch.zeros_like(self.flat.data)
             self._v = torch.zeros_like(self.flat.data)
             self._t = 0
+        self._resolve_stale()
         self._t += 1
         _lib.check(_lib.lib().spg_adam_clamp_step(self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self._m.data_ptr(),
                                                   self._v.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
@@ -88,14 +110,28 @@ class FlatParameters:
         self._step_t.add_(1.0)
 
     def zero_grad(self):
-        self._gbuf.zero_()
+        if self.lazy_zero:
+            self._stale = True          # resolved by _resolve_stale() before the gradients are consumed
+        else:
+            self._gbuf.zero_()
         self._clear_written()
+
+    def _resolve_stale(self):
+        """lazy_zero: gradients that no kernel has overwritten since zero_grad() still hold the previous step's values --
+        zero exactly those (none in a regular step)."""
+        if not self._stale:
+            return
+        self._stale = False
+        for p, chain in zip(self.params, self._cover):
+            if not any(getattr(m, '_spg_grad_written', False) for m in chain):
+                p.grad.zero_()
 
     def _clear_written(self):
         for m in self._modules:
             m._spg_grad_written = False
 
     def clamp_grad_(self, clip: float):
+        self._resolve_stale()
         if clip > 0:
             self.flat.grad.clamp_(-clip, clip)
 
@@ -103,6 +139,7 @@ class FlatParameters:
         """Weighted data-parallel mean of the gradients (see superpoint_graph_amd/dist.py), in place on the arena.
         prescaled: the loss was already multiplied by local_weight (synchronised-BatchNorm mode)."""
         from . import _lib
+        self._resolve_stale()
         native = _lib.lib().spg_rccl_world_size()           # the library's own communicator (dist.init_native_rccl)
         if native <= 1 and not (dist.is_initialized() and dist.get_world_size(group) > 1):
             if prescaled:

@@ -47,8 +47,9 @@ class GraphConvInfo(object):
 
     def set_batch_device(self, graphs, edge_feat_func, device=None):
         """`set_batch` with the ordering work on the GPU (spg_set_batch): the host only concatenates the edge lists and
-        edge attributes in their original order.  Buffers come out device-resident (`degs` is fetched back because the
-        contract keeps a host copy); the order inside a target segment is the STABLE one (the reference's numpy argsort
+        edge attributes in their original order, counts the in-degrees (the contract keeps a host copy of `degs`;
+        utils.get_edge_shards reads it) and checks the endpoints -- no device-to-host copy, no synchronisation.  Buffers
+        come out device-resident; the order inside a target segment is the STABLE one (the reference's numpy argsort
         leaves ties unspecified), everything else is identical to `set_batch`."""
         from ... import ops
         graphs = graphs if isinstance(graphs, (list, tuple)) else [graphs]
@@ -62,18 +63,19 @@ class GraphConvInfo(object):
             for a in G.es.attributes():
                 edgeattrs[a] += G.es.get_attribute_values(a)
             p += G.vcount()
-        edges_d = torch.from_numpy(np.concatenate(edges) if edges else np.zeros((0, 2), dtype=np.int64)).to(dev)
+        edges_h = np.concatenate(edges) if edges else np.zeros((0, 2), dtype=np.int64)
+        if edges_h.size and (int(edges_h.min()) < 0 or int(edges_h.max()) >= p):
+            raise IndexError('GraphConvInfo.set_batch_device: an edge endpoint is outside [0, number of nodes)')
+        self._degrees = torch.from_numpy(np.bincount(edges_h[:, 1], minlength=p).astype(np.int64))
+        edges_d = torch.from_numpy(edges_h).to(dev, non_blocking=True)
         feats, self._idxe = edge_feat_func(edgeattrs)
         if self._idxe is not None:
             raise NotImplementedError('filter sharing (idxe) is not supported by set_batch_device')
-        idxn, degs_gpu, perm, err = ops.set_batch(edges_d, p)
+        idxn, degs_gpu, perm, _err = ops.set_batch(edges_d, p)      # the device flag duplicates the host check above
         self._idxn, self._degrees_gpu = idxn, degs_gpu
-        self._edgefeats = ops.gather_rows(feats.to(dev).float().contiguous(), perm) if idxn.numel() else feats.to(dev).float()
-        self._degrees = degs_gpu.cpu()
-        if int(err.item()) != 0:
-            raise IndexError('GraphConvInfo.set_batch_device: an edge endpoint is outside [0, number of nodes)')
-        tgt = torch.repeat_interleave(torch.arange(p, device=dev), degs_gpu)
-        self._edge_indexes = torch.stack([idxn, tgt], 0)
+        feats_d = feats.to(dev, non_blocking=True).float().contiguous()
+        self._edgefeats = ops.gather_rows(feats_d, perm) if idxn.numel() else feats_d
+        self._edge_indexes = None                                   # built on demand (get_pyg_buffers): only the pyg path reads it
         self._graph = ops.DeviceGraph(self._idxn, self._degrees_gpu)
 
     @classmethod
@@ -121,4 +123,7 @@ class GraphConvInfo(object):
         return self._idxn, self._idxe, self._degrees, self._degrees_gpu, self._edgefeats
 
     def get_pyg_buffers(self):
+        if self._edge_indexes is None and self._idxn is not None and self._idxn.is_cuda:      # batch built by set_batch_device
+            tgt = torch.repeat_interleave(torch.arange(self._degrees.numel()), self._degrees).to(self._idxn.device)
+            self._edge_indexes = torch.stack([self._idxn, tgt], 0)
         return self._edge_indexes

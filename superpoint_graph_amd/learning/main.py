@@ -13,6 +13,7 @@ built on the GPU from scenes resident in HBM (`--loader_device`), the evaluation
 `--cuda 0` raises."""
 import argparse
 import ast
+import functools
 import json
 import logging
 import math
@@ -100,6 +101,9 @@ def build_parser():
     a('--sp_decoder_config', default='[]', type=str, help='Size of the decoder : sp_embedding -> sp_class.')
     # HIP path
     a('--loader_device', default=1, type=int, help='Bool, build the superpoint clouds on the GPU from scenes resident in HBM')
+    a('--batch_device', default=1, type=int,
+      help='Bool, build the batched graph (edge ordering by target, edge-feature reordering, CSR) on the GPU in eccpc_collate; '
+           'needs collation in the main process, i.e. it is only active together with --loader_device 1')
     a('--gemm_precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
       help="Arithmetic of the wide PointNet GEMMs: f32 = fp32 MFMA (the reference's arithmetic, default); bf16x3 = split-bf16 "
            "products (~2^-16 per product, fp32 accumulate); bf16 = bf16 operands.  Tolerances: tests/test_gpu_precision.py")
@@ -214,7 +218,9 @@ class Session:
         self.arena = None
         if args.fused_optim and args.optim == 'adam':
             from ..flat import FlatParameters
-            self.arena = FlatParameters(model)        # parameters / gradients become views of one flat buffer each
+            # parameters / gradients become views of one flat buffer each; zero_grad() launches nothing (the backward kernels
+            # overwrite every gradient) and the BatchNorm batch counters live on the host
+            self.arena = FlatParameters(model, lazy_zero=True, host_counters=True)
             self.arena.attach_optimizer(optimizer)    # the Adam moments live in `optimizer.state` (checkpoint format kept)
         self.iter_log = []                            # (loss, trainer ms) per training batch, for tests and tools
         self.eval_log = []                            # loss per evaluation batch
@@ -232,12 +238,18 @@ class Session:
             return 0
         return a.nworkers
 
+    def _collate(self):
+        a = self.args
+        if a.cuda and a.loader_device and getattr(a, 'batch_device', 1) and self._nworkers() == 0:
+            return functools.partial(spg.eccpc_collate, device_batch=True)      # GraphConvInfo.set_batch_device
+        return spg.eccpc_collate
+
     def _loader(self, dataset, train):
         a = self.args
         if train:
-            return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=spg.eccpc_collate, num_workers=self._nworkers(),
+            return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=self._collate(), num_workers=self._nworkers(),
                                                shuffle=True, drop_last=True)
-        return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=spg.eccpc_collate, num_workers=self._nworkers())
+        return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=self._collate(), num_workers=self._nworkers())
 
     def _forward(self, targets, GIs, clouds_data):
         self.model.ecc.set_info(GIs, self.args.cuda)

@@ -333,6 +333,20 @@ class LocalCloudEmbedder():
         return self.run_batch(model, clouds, clouds_global).cpu()
 
 
+class _ScatterEmbeddings(torch.autograd.Function):
+    """descriptors[i] = embeddings[slot[i]] for embeddable superpoints, exact zeros for the others (reference
+    learning/pointnet.py:177-179: zero-initialised matrix + index_copy_), one launch each way instead of fill + index_copy_."""
+
+    @staticmethod
+    def forward(ctx, out, slot_of_row, idx_valid):
+        ctx.idx_valid = idx_valid
+        return ops.gather_rows(out.contiguous(), slot_of_row)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ops.gather_rows(grad.contiguous(), ctx.idx_valid), None, None
+
+
 class CloudEmbedder():
     """Evaluates PointNet on superpoints; too small superpoints get zero embeddings (reference
     learning/pointnet.py:138-180).  `ptn_mem_monger` keeps its observable semantics (autograd is cut after
@@ -343,24 +357,30 @@ class CloudEmbedder():
         self.args = args
         self.bw_hook = lambda: None
         self.run = self.run_full_monger if args.ptn_mem_monger else self.run_full
-        self._flag_cache = (None, None)      # (clouds_flag tensor, idx_valid on the device)
+        self._flag_cache = (None, None, None)      # (clouds_flag tensor, idx_valid, slot_of_row on the device)
 
     def _to_device(self, clouds_flag, clouds, clouds_global):
         dev = torch.device('cuda', torch.cuda.current_device())
-        if self._flag_cache[0] is clouds_flag:       # same batch object again (benchmarks, multi-pass evaluation)
-            idx_valid = self._flag_cache[1]
-        else:
-            idx_valid = torch.nonzero(clouds_flag.eq(0)).reshape(-1).to(dev)
-            self._flag_cache = (clouds_flag, idx_valid)
-        return idx_valid, clouds.to(dev, non_blocking=True), clouds_global.to(dev, non_blocking=True)
+        if self._flag_cache[0] is not clouds_flag:       # (same batch object again: benchmarks, multi-pass evaluation)
+            valid = clouds_flag.eq(0)
+            idx_valid = torch.nonzero(valid).reshape(-1)
+            slot = torch.cumsum(valid.to(torch.int64), 0) - 1          # row of the embedding matrix, -1 for too-small superpoints
+            slot[~valid] = -1
+            self._flag_cache = (clouds_flag, idx_valid.to(dev), slot.to(dev))
+        self._slot_of_row = self._flag_cache[2]
+        return self._flag_cache[1], clouds.to(dev, non_blocking=True), clouds_global.to(dev, non_blocking=True)
+
+    def _scatter(self, out, idx_valid, n_rows):
+        if out.shape[0] == 0:                          # no embeddable superpoint in the batch
+            return out.new_zeros(n_rows, out.size(1))
+        return _ScatterEmbeddings.apply(out, self._slot_of_row, idx_valid)
 
     def run_full(self, model, clouds_meta, clouds_flag, clouds, clouds_global):
         if not self.args.cuda:
             raise RuntimeError('superpoint_graph_amd has no CPU path (--cuda 1 required)')
         idx_valid, clouds, clouds_global = self._to_device(clouds_flag, clouds, clouds_global)
         out = model.ptn(clouds, clouds_global)
-        descriptors = out.new_zeros(clouds_flag.size(0), out.size(1))
-        return descriptors.index_copy_(0, idx_valid, out)      # in place on the fresh zeros: no extra copy of the buffer
+        return self._scatter(out, idx_valid, clouds_flag.size(0))
 
     def run_full_monger(self, model, clouds_meta, clouds_flag, clouds, clouds_global):
         if not self.args.cuda:
@@ -381,5 +401,4 @@ class CloudEmbedder():
                 if out.grad is not None:
                     live.backward(out.grad)
             self.bw_hook = bw_hook
-        descriptors = out.new_zeros(clouds_flag.size(0), out.size(1))
-        return descriptors.index_copy_(0, idx_valid, out)      # in place on the fresh zeros: no extra copy of the buffer
+        return self._scatter(out, idx_valid, clouds_flag.size(0))

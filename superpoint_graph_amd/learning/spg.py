@@ -129,13 +129,21 @@ def _as_tensor(x):
     return x if torch.is_tensor(x) else torch.from_numpy(np.asarray(x))
 
 
-def eccpc_collate(batch):
+def eccpc_collate(batch, device_batch=False):
     """Collates a list of dataset samples into a single batch (reference learning/spg.py:178-193).  Clouds produced by
-    the device loader are CUDA tensors already and are concatenated on the device."""
+    the device loader are CUDA tensors already and are concatenated on the device.
+    device_batch: build the batched graph on the GPU (GraphConvInfo.set_batch_device: ordering by target, edge-feature
+    reordering and the CSR / reverse CSR as kernels; the host only concatenates) -- for collation in the main process
+    (`--loader_device 1`); the default is the reference's host construction (safe inside DataLoader workers)."""
     targets, graphs, clouds_meta, clouds_flag, clouds, clouds_global = list(zip(*batch))
     targets = torch.cat([_as_tensor(t) for t in targets if t is not None], 0).long()
     graphs = [graph for graph in graphs if graph is not None]
-    GIs = [ecc.GraphConvInfo(graphs, cloud_edge_feats)]
+    if device_batch:
+        gi = ecc.GraphConvInfo()
+        gi.set_batch_device(graphs, cloud_edge_feats)
+        GIs = [gi]
+    else:
+        GIs = [ecc.GraphConvInfo(graphs, cloud_edge_feats)]
     if len(clouds_meta[0]) > 0:
         clouds = torch.cat([_as_tensor(f) for f in clouds if f is not None], 0)
         clouds_global = torch.cat([_as_tensor(f) for f in clouds_global if f is not None], 0)

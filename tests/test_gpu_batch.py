@@ -94,3 +94,44 @@ def test_edge_features_device_matches_host():
         out_s = spg.spg_edge_features_device(edges, node_att, edge_att, args, scaler=scaler).cpu().numpy()
         assert np.array_equal(out_s[:, exact_cols], ref_s[:, exact_cols])
         np.testing.assert_allclose(out_s, ref_s, rtol=0, atol=2e-5)
+
+
+def test_collate_device_batch_matches_host_collate(hip):
+    """eccpc_collate(device_batch=True) (the CLI's collate with --loader_device 1 --batch_device 1): same degrees, same
+    multiset of sources / edge features per target segment as the host construction, no host copy of the ordering work, and
+    the model outputs agree (sum order inside a segment differs: fp32 round-off only)."""
+    import torch
+    from superpoint_graph_amd import synth
+    from superpoint_graph_amd.learning import spg
+    scenes = [synth.scene(s, n_sp=300, n_edges=1400) for s in (3, 4)]
+    samples = [spg.sample_from_scene(s, f's{i}') for i, s in enumerate(scenes)]
+    t_h, (gi_h,), rest_h = spg.eccpc_collate(samples)
+    t_d, (gi_d,), rest_d = spg.eccpc_collate(samples, device_batch=True)
+    assert torch.equal(t_h, t_d) and torch.equal(rest_h[1], rest_d[1])
+    idxn_h, _, degs_h, _, ef_h = gi_h.get_buffers()
+    idxn_d, _, degs_d, degs_gpu, ef_d = gi_d.get_buffers()
+    assert idxn_d.is_cuda and ef_d.is_cuda and not degs_d.is_cuda
+    assert torch.equal(degs_h, degs_d) and torch.equal(degs_gpu.cpu(), degs_h)
+    rp = torch.cat([torch.zeros(1, dtype=torch.int64), degs_h.cumsum(0)])
+    key_h = torch.cat([idxn_h.double().unsqueeze(1), ef_h.double()], 1)
+    key_d = torch.cat([idxn_d.cpu().double().unsqueeze(1), ef_d.cpu().double()], 1)
+    for i in range(degs_h.numel()):
+        a, b = key_h[rp[i]:rp[i + 1]], key_d[rp[i]:rp[i + 1]]
+        assert torch.equal(a[a[:, 0].argsort(stable=True)][:, 0], b[b[:, 0].argsort(stable=True)][:, 0])
+        assert abs(float(a.sum()) - float(b.sum())) <= 1e-9 * (1 + abs(float(a.sum())))
+    ei = gi_d.get_pyg_buffers()
+    assert ei.shape == (2, idxn_h.numel()) and torch.equal(ei[1].cpu(), torch.repeat_interleave(torch.arange(degs_h.numel()), degs_h))
+    # through the model
+    from conftest import build_model
+    from oracle import spg_oracle as O
+    import types
+    from superpoint_graph_amd.learning import pointnet
+    torch.manual_seed(1)
+    model = build_model(O.ModelSpec()).cuda().eval()
+    outs = []
+    for gi, rest in ((gi_h, rest_h), (gi_d, rest_d)):
+        with torch.no_grad():
+            model.ecc.set_info([gi], 1)
+            emb = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1)).run(model, *rest)
+            outs.append(model.ecc(emb))
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * float(outs[0].abs().max())

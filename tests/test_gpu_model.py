@@ -385,3 +385,38 @@ def test_large_configs_train_step_vs_oracle(hip, name):
     for k, v in st.items():
         if 'running' in k:
             assert maxrel(sd[k].double(), v.double()) < 1e-5, k
+
+
+def test_flat_parameters_lazy_zero_and_host_counters(hip):
+    """FlatParameters(lazy_zero=True, host_counters=True) -- the CLI's and bench's configuration: zero_grad() launches no
+    fill, yet after every step the gradients equal those of the eager arena (the kernels overwrite them), the gradient of a
+    parameter NO kernel wrote in a step reads zero when the optimizer consumes it, and the BatchNorm batch counters advance on
+    the host."""
+    from superpoint_graph_amd.flat import FlatParameters
+    spec, batch, state0, g = load_golden('s3dis_gru10_matrix')
+    cw = torch.from_numpy(g['class_weights']).to(DEV)
+    res = {}
+    for lazy in (False, True):
+        model = build_model(spec, state0).to(DEV).train()
+        arena = FlatParameters(model, lazy_zero=lazy, host_counters=lazy)
+        for _ in range(3):
+            arena.zero_grad()
+            emb, logits, embedder = _run(model, batch, 1)
+            F.cross_entropy(logits, batch['label_mode'].to(DEV), weight=cw).backward()
+            embedder.bw_hook()
+            arena.adam_step(lr=1e-3, grad_clip=1.0)
+        res[lazy] = ({k: p.grad.clone() for k, p in model.named_parameters()}, {k: v.clone() for k, v in model.state_dict().items()})
+        if lazy:
+            nbt = [m.num_batches_tracked for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+            assert all(not t.is_cuda for t in nbt) and sorted(set(int(t) for t in nbt)) == [3, 6]     # filter net 3, PointNet 2 x 3
+            # a step in which only the classifier takes part: every other gradient must read zero at the update
+            arena.zero_grad()
+            x = torch.randn(7, model.ecc[1].in_features, device=DEV)
+            model.ecc[1](x).sum().backward()
+            arena.adam_step(lr=0.0)
+            for k, p in model.named_parameters():
+                assert bool((p.grad == 0).all()) == (not k.startswith('ecc.1.')), k
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k].cpu(), res[True][1][k].cpu()), k
