@@ -171,7 +171,7 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
             arena.zero_grad()
             emb = embedder.run(model, None, flag, c, d)
             loss = ops.cross_entropy(model.ecc(emb), lab)
-            loss.backward()
+            loss.backward(arena.one)
             embedder.bw_hook()
             arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)
     run(4)
@@ -296,7 +296,7 @@ def main():
         out = model.ecc(emb)
         # sync-BN couples the ranks in the backward: the loss normaliser is applied before it (dist.py)
         loss = ops.cross_entropy(out, label_mode, reduction='sum' if args.sync_bn else 'mean')     # learning/main.py:205, one launch each way
-        loss.backward()
+        loss.backward(arena.one)                         # (a cached 1: autograd's implicit ones_like(loss) is a fill launch)
         embedder.bw_hook()
 
     def update():

@@ -59,6 +59,7 @@ class FlatParameters:
             parts = name.split('.')[:-1]
             self._cover.append([named['.'.join(parts[:k])] for k in range(len(parts) + 1)])
         self._stale = False
+        self.one = torch.ones((), dtype=dt, device=dev)      # seed of loss.backward(arena.one): autograd otherwise launches a fill for it
         if host_counters:
             for m in self._modules:
                 if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None:

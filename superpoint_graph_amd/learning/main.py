@@ -276,7 +276,7 @@ class Session:
                 self.optimizer.zero_grad()
             outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
             loss = ops.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])      # main.py:205
-            loss.backward()
+            loss.backward(self.arena.one if self.arena is not None else None)      # cached seed: no fill launch for ones_like(loss)
             self.embedder.bw_hook()
             if self.arena is not None:
                 self.arena.optimizer_step(grad_clip=a.grad_clip)          # clamp (main.py:210-212) + Adam in one launch

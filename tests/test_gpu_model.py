@@ -411,8 +411,9 @@ def test_flat_parameters_lazy_zero_and_host_counters(hip):
             assert all(not t.is_cuda for t in nbt) and sorted(set(int(t) for t in nbt)) == [3, 6]     # filter net 3, PointNet 2 x 3
             # a step in which only the classifier takes part: every other gradient must read zero at the update
             arena.zero_grad()
-            x = torch.randn(7, model.ecc[1].in_features, device=DEV)
-            model.ecc[1](x).sum().backward()
+            fc = dict(model.ecc.named_children())['1']
+            x = torch.randn(7, fc.in_features, device=DEV)
+            fc(x).sum().backward()
             arena.adam_step(lr=0.0)
             for k, p in model.named_parameters():
                 assert bool((p.grad == 0).all()) == (not k.startswith('ecc.1.')), k
