@@ -308,6 +308,12 @@ int spg_rccl_destroy(void);
  * ---------------------------------------------------------------------------------------------- */
 int spg_adam_clamp_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, float grad_clip, int step, void* stream);
+/* the same with every gradient divided by *grad_div (one DEVICE float, may be NULL) before the clamp: the data-parallel
+ * normaliser -- the all-reduced sum of the ranks' loss weights -- is consumed where the collective left it, without a host
+ * round trip or a separate scaling launch */
+int spg_adam_clamp_step_scaled(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float grad_clip, int step, const float* grad_div,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Instrumentation for bench.py: when enabled, every launch of the row-GEMM kernels is bracketed by

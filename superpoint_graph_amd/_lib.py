@@ -87,6 +87,8 @@ SIGNATURES = {
     'spg_eccrnn_backward': (_i, [ctypes.POINTER(EccRnnCfg), _i, _i, _p, _p, c_void_pp, _p, _p, c_void_pp, _p, _p, _p]),
     'spg_adam_clamp_step': (_i, [_p, _p, _p, _p, _l, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_float, _i, _p]),
+    'spg_adam_clamp_step_scaled': (_i, [_p, _p, _p, _p, _l, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_float, _i, _p, _p]),
     'spg_load_superpoints': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
     'spg_set_batch_workspace_bytes': (_sz, [_i, _i]),
     'spg_set_batch': (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),

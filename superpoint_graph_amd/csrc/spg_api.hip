@@ -474,10 +474,11 @@ extern "C" int spg_linear_wgrad_bias(const float* dY, long lddy, const float* X,
 // ---------------------------------------------------------------------------------------------
 __global__ void spg_adam_clamp_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                                      float clip, float bc1, float bc2_sqrt) {
+                                      float clip, float bc1, float bc2_sqrt, const float* __restrict__ grad_div) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float gi = g[i];
+  if (grad_div != nullptr) gi = gi / *grad_div;     // data-parallel normaliser (sum of the ranks' loss weights), still on the device
   if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
   g[i] = gi;                                   // the clamp is observable in p.grad, as in the reference loop
   if (wd != 0.f) gi = fmaf(wd, p[i], gi);
@@ -489,14 +490,21 @@ __global__ void spg_adam_clamp_kernel(float* __restrict__ p, float* __restrict__
   p[i] = p[i] - (lr / bc1) * (mi / denom);
 }
 
-extern "C" int spg_adam_clamp_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, float grad_clip, int step,
-                                   void* stream) {
+extern "C" int spg_adam_clamp_step_scaled(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                                          float beta1, float beta2, float eps, float weight_decay, float grad_clip, int step,
+                                          const float* grad_div, void* stream) {
   SPG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad argument");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(spg_adam_clamp_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, bc1, bc2_sqrt);
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, bc1, bc2_sqrt, grad_div);
   SPG_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int spg_adam_clamp_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, float grad_clip, int step,
+                                   void* stream) {
+  return spg_adam_clamp_step_scaled(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, step,
+                                    nullptr, stream);
 }

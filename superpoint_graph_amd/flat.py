@@ -38,7 +38,7 @@ class FlatParameters:
             off += (p.numel() + 63) // 64 * 64
         self.numel = off
         data = torch.zeros(self.numel, dtype=dt, device=dev)
-        self._gbuf = torch.zeros(self.numel + 1, dtype=dt, device=dev)       # +1: loss-weight slot of the all-reduce
+        self._gbuf = torch.zeros(self.numel + 2, dtype=dt, device=dev)       # +2: loss-weight and loss-sum slots of the all-reduce
         for p, off in zip(self.params, self._offsets):
             n = p.numel()
             data[off:off + n].copy_(p.data.reshape(-1))
@@ -65,9 +65,11 @@ class FlatParameters:
                 if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None:
                     m.num_batches_tracked = m.num_batches_tracked.cpu()
 
-    def adam_step(self, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip=0.0):
+    def adam_step(self, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip=0.0, grad_div=None):
         """Element-wise gradient clamp (learning/main.py:210-212) + torch.optim.Adam update (learning/main.py:433-437)
-        of the whole arena in ONE HIP launch (spg_adam_clamp_step).  The moments live in this object."""
+        of the whole arena in ONE HIP launch (spg_adam_clamp_step).  The moments live in this object.
+        grad_div: [1] device tensor; every gradient is divided by it first (`allreduce_sums` leaves the data-parallel
+        normaliser in `self.normaliser`)."""
         from . import _lib
         if not hasattr(self, '_m'):
             self._m = torch.zeros_like(self.flat.data)
@@ -75,10 +77,10 @@ class FlatParameters:
             self._t = 0
         self._resolve_stale()
         self._t += 1
-        _lib.check(_lib.lib().spg_adam_clamp_step(self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self._m.data_ptr(),
-                                                  self._v.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
-                                                  grad_clip, self._t, torch.cuda.current_stream().cuda_stream),
-                   'spg_adam_clamp_step')
+        _lib.check(_lib.lib().spg_adam_clamp_step_scaled(self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self._m.data_ptr(),
+                                                         self._v.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
+                                                         grad_clip, self._t, None if grad_div is None else grad_div.data_ptr(),
+                                                         torch.cuda.current_stream().cuda_stream), 'spg_adam_clamp_step')
         self._clear_written()
 
     def attach_optimizer(self, optimizer):
@@ -105,10 +107,46 @@ class FlatParameters:
             optimizer.state[p] = {'step': self._step_t, 'exp_avg': m, 'exp_avg_sq': v}
         self._step_t.fill_(float(self._t))
 
-    def optimizer_step(self, grad_clip=0.0):
+    def optimizer_step(self, grad_clip=0.0, grad_div=None):
         g = self._opt.param_groups[0]
-        self.adam_step(lr=g['lr'], betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'], grad_clip=grad_clip)
+        self.adam_step(lr=g['lr'], betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'], grad_clip=grad_clip,
+                       grad_div=grad_div)
         self._step_t.add_(1.0)
+
+    # ---- data parallel, everything on the device ----
+    @property
+    def normaliser(self):
+        """[1] view: after `allreduce_sums` the sum over the ranks of the loss weights (pass it to adam_step(grad_div=...))."""
+        return self._gbuf[self.numel:self.numel + 1]
+
+    @property
+    def loss_sum(self):
+        """[1] view: after `allreduce_sums` the sum over the ranks of the (weighted, un-normalised) losses."""
+        return self._gbuf[self.numel + 1:self.numel + 2]
+
+    def allreduce_sums(self, weight, loss_sum=None, group=None):
+        """The data-parallel exchange of one step as ONE collective and no host synchronisation.  Every rank back-propagated
+        its SUM-reduced loss (gradients g_r already carry the factor w_r of superpoint_graph_amd/dist.py), `weight` is its [1]
+        device tensor w_r (ops.cross_entropy(..., return_normaliser=True)), `loss_sum` optionally its loss.  The arena
+        [gradients | w_r | loss_r] is summed over the ranks in place; the division by sum_r w_r happens inside the clamp + Adam
+        launch (adam_step(grad_div=self.normaliser)).  World size 1 (or no process group): the same code without the
+        collective -- the result is the single-process gradient of the mean-reduced loss."""
+        from . import _lib
+        self._resolve_stale()
+        self._gbuf[self.numel:self.numel + 1].copy_(weight.reshape(1), non_blocking=True)
+        if loss_sum is not None:
+            self._gbuf[self.numel + 1:self.numel + 2].copy_(loss_sum.detach().reshape(1), non_blocking=True)
+        native = _lib.lib().spg_rccl_world_size()
+        if native > 1:
+            _lib.check(_lib.lib().spg_rccl_allreduce_sum_f32(self._gbuf.data_ptr(), self.numel + 2,
+                                                             torch.cuda.current_stream().cuda_stream), 'spg_rccl_allreduce_sum_f32')
+        elif dist.is_initialized() and dist.get_world_size(group) > 1:
+            if dist.get_backend(group) == 'gloo' and self._gbuf.is_cuda:      # CPU-side test backend: staged through the host
+                host = self._gbuf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                self._gbuf.copy_(host)
+            else:
+                dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
 
     def zero_grad(self):
         if self.lazy_zero:

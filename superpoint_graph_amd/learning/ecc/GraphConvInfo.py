@@ -60,9 +60,12 @@ class GraphConvInfo(object):
             E = getattr(G, '_edges', None)
             E = np.asarray(G.get_edgelist()).reshape(-1, 2) if E is None else np.asarray(E).reshape(-1, 2)
             edges.append(E.astype(np.int64) + p)
+            fast = getattr(G, 'edge_attribute_array', None)
             for a in G.es.attributes():
-                edgeattrs[a] += G.es.get_attribute_values(a)
+                # per-graph [E_g, width] arrays when the graph offers them (SuperpointGraph), else igraph's value lists
+                edgeattrs[a].append(fast(a) if fast is not None else np.asarray(G.es.get_attribute_values(a)))
             p += G.vcount()
+        edgeattrs = {a: (np.concatenate(v) if len(v) > 1 else v[0]) for a, v in edgeattrs.items()}
         edges_h = np.concatenate(edges) if edges else np.zeros((0, 2), dtype=np.int64)
         if edges_h.size and (int(edges_h.min()) < 0 or int(edges_h.max()) >= p):
             raise IndexError('GraphConvInfo.set_batch_device: an edge endpoint is outside [0, number of nodes)')

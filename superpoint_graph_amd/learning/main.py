@@ -112,6 +112,15 @@ def build_parser():
            "the reference's clouds), 'device' = counter-based generator on the GPU (no per-superpoint host loop)")
     a('--fused_optim', default=1, type=int, help='Bool, clamp + Adam as one launch over a flat parameter arena (adam only)')
     a('--max_train_iters', default=0, type=int, help='Stop every training epoch after this many batches (0 = whole epoch)')
+    # data parallel (one process per GPU: `python -m torch.distributed.run --nproc-per-node N -m superpoint_graph_amd.learning.main ...`)
+    a('--sync_bn', default=0, type=int, help='Data parallel: BatchNorm statistics over the scenes of ALL ranks (= the single-process '
+      'batch of the reference); 0 = per-rank statistics')
+    a('--dist_backend', default='', help="torch.distributed backend (default: nccl = RCCL; 'gloo' for tests on one GPU)")
+    a('--dist_device', default=-1, type=int, help='GPU of this rank (default: LOCAL_RANK)')
+    a('--dp_replicate_loader', default=0, type=int,
+      help='Data parallel: 1 = every rank runs the loader for the WHOLE batch and keeps its shard, so the random streams of the '
+           'sub-sampling / augmentation are consumed exactly as in a single process (bit-reproducible against it, N-fold loader '
+           'work); 0 = every rank loads only its own scenes')
     return p
 
 
@@ -204,15 +213,56 @@ def resume(args, dbinfo):
     return model, optimizer, stats
 
 
+class _ShardedBatches(torch.utils.data.Sampler):
+    """Batch sampler of one data-parallel rank: the epoch's permutation is drawn from a generator seeded by (seed, epoch) --
+    the same on every rank --, cut into global batches of `batch_size` scenes (incomplete last one dropped, as the
+    reference's drop_last=True), and the rank keeps its contiguous shard of every batch (dist.shard_scenes)."""
+
+    def __init__(self, n, batch_size, rank, world, seed, shuffle):
+        self.n, self.bs, self.rank, self.world, self.seed, self.shuffle, self.epoch = n, batch_size, rank, world, seed, shuffle, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _batches(self):
+        from ..dist import shard_scenes
+        if self.shuffle:
+            order = torch.randperm(self.n, generator=torch.Generator().manual_seed(1000003 * self.seed + self.epoch)).tolist()
+        else:
+            order = list(range(self.n))
+        full = self.n // self.bs if self.shuffle else (self.n + self.bs - 1) // self.bs
+        for b in range(full):
+            chunk = order[b * self.bs:(b + 1) * self.bs]
+            yield [chunk[i] for i in shard_scenes(len(chunk), self.rank, self.world)]
+
+    def __iter__(self):
+        return self._batches()
+
+    def __len__(self):
+        return self.n // self.bs if self.shuffle else (self.n + self.bs - 1) // self.bs
+
+
 class Session:
-    """One run of the CLI: model, optimiser, datasets and the three loops of learning/main.py:176-311."""
+    """One run of the CLI: model, optimiser, datasets and the three loops of learning/main.py:176-311.  Data parallel
+    (WORLD_SIZE > 1, one process per GPU): every global batch of `--batch_size` scenes is sharded over the ranks, the flat
+    gradient arena is summed by ONE all-reduce per step with the loss weights riding along (FlatParameters.allreduce_sums; the
+    normalisation happens inside the clamp + Adam launch), evaluation scenes are dealt round-robin and the confusion matrices /
+    loss sums are all-reduced, rank 0 writes the files."""
 
     def __init__(self, args, dbinfo, create_dataset, model, optimizer, stats):
         self.args, self.dbinfo, self.create_dataset = args, dbinfo, create_dataset
         self.model, self.optimizer, self.stats = model, optimizer, stats
+        self.rank, self.world = getattr(args, 'rank', 0), getattr(args, 'world', 1)
+        self.dp = self.world > 1
         self.train_dataset, self.test_dataset, self.valid_dataset, self.scaler = create_dataset(args)
-        print('Train dataset: %i elements - Test dataset: %i elements - Validation dataset: %i elements' %
-              (len(self.train_dataset), len(self.test_dataset), len(self.valid_dataset)))
+        self.log('Train dataset: %i elements - Test dataset: %i elements - Validation dataset: %i elements' %
+                 (len(self.train_dataset), len(self.test_dataset), len(self.valid_dataset)))
+        if self.dp:
+            if not (args.fused_optim and args.optim == 'adam'):
+                raise NotImplementedError('data parallel training uses the flat gradient arena: --fused_optim 1 --optim adam')
+            if args.batch_size % self.world != 0:
+                raise ValueError(f'--batch_size {args.batch_size} must be a multiple of the number of ranks ({self.world}): scenes are the shards')
+        self._epoch = args.start_epoch
         self.embedder = pointnet.CloudEmbedder(args)
         self.scheduler = MultiStepLR(optimizer, milestones=args.lr_steps, gamma=args.lr_decay, last_epoch=args.start_epoch - 1)
         self.arena = None
@@ -224,6 +274,10 @@ class Session:
             self.arena.attach_optimizer(optimizer)    # the Adam moments live in `optimizer.state` (checkpoint format kept)
         self.iter_log = []                            # (loss, trainer ms) per training batch, for tests and tools
         self.eval_log = []                            # loss per evaluation batch
+
+    def log(self, *a):
+        if self.rank == 0:
+            print(*a)
 
     def _nworkers(self):
         """--nworkers as given, except with the device loader: `spg.loader` then launches kernels inside `__getitem__`, which
@@ -246,10 +300,33 @@ class Session:
 
     def _loader(self, dataset, train):
         a = self.args
+        collate, nw = self._collate(), self._nworkers()
+        if self.dp and a.dp_replicate_loader:
+            # the single-process loaders, unchanged (same sampler, same consumption of the random streams); the collate keeps
+            # this rank's shard of the batch.  Evaluation batches hold ONE scene: rank b % world owns batch b, the others skip it.
+            from ..dist import shard_scenes
+            counter = [0]
+
+            def shard(batch):
+                if train:
+                    return collate([batch[i] for i in shard_scenes(len(batch), self.rank, self.world)])
+                b = counter[0]
+                counter[0] += 1
+                return collate(batch) if b % self.world == self.rank else None
+            if train:
+                return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=shard, num_workers=nw, shuffle=True, drop_last=True)
+            return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=shard, num_workers=nw)
+        if self.dp:
+            if train:
+                sampler = _ShardedBatches(len(dataset), a.batch_size, self.rank, self.world, a.seed, True)
+                sampler.set_epoch(self._epoch)
+                return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=collate, num_workers=nw)
+            own = list(range(self.rank, len(dataset), self.world))              # evaluation: scenes dealt round-robin
+            return torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, own), batch_size=1, collate_fn=collate, num_workers=nw)
         if train:
-            return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=self._collate(), num_workers=self._nworkers(),
+            return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=collate, num_workers=nw,
                                                shuffle=True, drop_last=True)
-        return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=self._collate(), num_workers=self._nworkers())
+        return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=collate, num_workers=nw)
 
     def _forward(self, targets, GIs, clouds_data):
         self.model.ecc.set_info(GIs, self.args.cuda)
@@ -275,6 +352,24 @@ class Session:
             else:
                 self.optimizer.zero_grad()
             outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
+            if self.dp:
+                # data parallel: back-propagate the SUM-reduced loss (gradients carry this rank's loss weight w_r), ONE all-reduce of
+                # [gradients | w_r | loss_r], division by sum_r w_r inside the clamp + Adam launch -- no host synchronisation
+                loss_sum, w = ops.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'], reduction='sum',
+                                                return_normaliser=True)
+                loss_sum.backward(self.arena.one)
+                self.embedder.bw_hook()
+                self.arena.allreduce_sums(w, loss_sum)
+                loss = (self.arena.loss_sum / self.arena.normaliser).reshape(())       # the loss of the WHOLE batch (main.py:205)
+                self.arena.optimizer_step(grad_clip=a.grad_clip, grad_div=self.arena.normaliser)
+                t_trainer = 1000 * (time.time() - t0)
+                loss_meter.add(loss)
+                cm.count_predicted_batch_device(label_vec, outputs.detach(), label_mode)
+                _log_bounded(self.iter_log, (loss.clone(), t_trainer))
+                t0 = time.time()
+                if a.max_train_iters and bidx + 1 >= a.max_train_iters:
+                    break
+                continue
             loss = ops.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])      # main.py:205
             loss.backward(self.arena.one if self.arena is not None else None)      # cached seed: no fill launch for ones_like(loss)
             self.embedder.bw_hook()
@@ -293,6 +388,7 @@ class Session:
             t0 = time.time()
             if a.max_train_iters and bidx + 1 >= a.max_train_iters:
                 break
+        cm.allreduce()
         acc_meter.add_counts(*cm.accuracy_counts())
         return acc_meter.value()[0], loss_meter.value()[0], cm.get_overall_accuracy(), cm.get_average_intersection_union()
 
@@ -302,15 +398,27 @@ class Session:
         self.model.eval()
         loss_meter, acc_meter = meters.AverageValueMeter(), meters.ClassErrorMeter(accuracy=True)
         cm = metrics.ConfusionMatrix(self.dbinfo['classes'])
-        for targets, GIs, clouds_data in self._loader(self.valid_dataset if is_valid else self.test_dataset, False):
+        lsum = torch.zeros(2, dtype=torch.float64, device='cuda')       # data parallel: (sum of the batch losses, batches)
+        for item in self._loader(self.valid_dataset if is_valid else self.test_dataset, False):
+            if item is None:                          # --dp_replicate_loader: a scene of another rank
+                continue
+            targets, GIs, clouds_data = item
             with torch.no_grad():
                 outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
                 loss = ops.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])
             loss_meter.add(loss)
+            lsum += torch.stack([loss.double(), torch.ones((), dtype=torch.float64, device=loss.device)])
             _log_bounded(self.eval_log, loss.clone())
             cm.count_predicted_batch_device(label_vec, outputs, label_mode)
+        cm.allreduce()
         acc_meter.add_counts(*cm.accuracy_counts())
-        return (meter_value(acc_meter), loss_meter.value()[0], cm.get_overall_accuracy(), cm.get_average_intersection_union(),
+        mean_loss = loss_meter.value()[0] if loss_meter.n > 0 else 0.0
+        if self.dp:                                   # mean of the per-scene losses over ALL ranks' scenes
+            import torch.distributed as tdist
+            host = lsum.cpu() if tdist.get_backend() == 'gloo' else lsum
+            tdist.all_reduce(host)
+            mean_loss = float(host[0] / host[1].clamp(min=1))
+        return (meter_value(acc_meter), mean_loss, cm.get_overall_accuracy(), cm.get_average_intersection_union(),
                 cm.get_mean_class_accuracy())
 
     # ---- learning/main.py:267-311 ----
@@ -324,7 +432,10 @@ class Session:
         collected, labels, predictions = defaultdict(list), {}, {}
         for ss in range(a.test_multisamp_n):
             test_dataset_ss = self.create_dataset(a, ss)[1]
-            for targets, GIs, clouds_data in self._loader(test_dataset_ss, False):
+            for item in self._loader(test_dataset_ss, False):
+                if item is None:
+                    continue
+                targets, GIs, clouds_data = item
                 with torch.no_grad():
                     outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
                 fname = clouds_data[0][0][:clouds_data[0][0].rfind('.')]
@@ -334,12 +445,20 @@ class Session:
             label_mode, label_vec = labels[fname]
             logits = torch.stack(outs, 0) if a.test_multisamp_n > 1 else outs[0]
             predictions[fname] = cm.count_predicted_batch_device(label_vec, logits.contiguous(), label_mode).cpu().numpy()
+        cm.allreduce()
+        if self.dp:                                   # every rank predicted its own scenes: rank 0 writes them all
+            import torch.distributed as tdist
+            parts = [None] * self.world
+            tdist.all_gather_object(parts, predictions)
+            predictions = {k: v for part in parts for k, v in part.items()}
         acc_meter.add_counts(*cm.accuracy_counts())
         per_class_iou = {name: cm.get_intersection_union_per_class()[c] for c, name in self.dbinfo['inv_class_map'].items()}
         return (meter_value(acc_meter), cm.get_overall_accuracy(), cm.get_average_intersection_union(), per_class_iou, predictions,
                 cm.get_mean_class_accuracy(), cm.confusion_matrix)
 
     def checkpoint(self, epoch, with_scaler=True):
+        if self.rank != 0:                  # replicas are identical after every step: rank 0 writes
+            return
         state = {'epoch': epoch + 1, 'args': self.args, 'state_dict': self.model.state_dict(), 'optimizer': self.optimizer.state_dict()}
         if with_scaler:
             state['scaler'] = self.scaler
@@ -359,24 +478,25 @@ class Session:
             best_iou = 0
         epoch = a.start_epoch
         for epoch in range(a.start_epoch, a.epochs):
-            print('Epoch {}/{} ({}):'.format(epoch, a.epochs, a.odir))
+            self.log('Epoch {}/{} ({}):'.format(epoch, a.epochs, a.odir))
+            self._epoch = epoch
             self.scheduler.step()
             acc, loss, oacc, avg_iou = self.train()
-            print('-> Train Loss: %1.4f   Train accuracy: %3.2f%%' % (loss, acc))
+            self.log('-> Train Loss: %1.4f   Train accuracy: %3.2f%%' % (loss, acc))
             new_best = False
             if a.use_val_set:
                 acc_val, loss_val, oacc_val, avg_iou_val, avg_acc_val = self.eval(True)
-                print('-> Val Loss: %1.4f  Val accuracy: %3.2f%%  Val oAcc: %3.2f%%  Val IoU: %3.2f%%  best ioU: %3.2f%%' %
+                self.log('-> Val Loss: %1.4f  Val accuracy: %3.2f%%  Val oAcc: %3.2f%%  Val IoU: %3.2f%%  best ioU: %3.2f%%' %
                       (loss_val, acc_val, 100 * oacc_val, 100 * avg_iou_val, 100 * max(best_iou, avg_iou_val)))
                 if avg_iou_val > best_iou:
-                    print('-> New best model achieved!')
+                    self.log('-> New best model achieved!')
                     best_iou, new_best = avg_iou_val, True
                     self.checkpoint(epoch)
             elif epoch % a.save_nth_epoch == 0 or epoch == a.epochs - 1:
                 self.checkpoint(epoch)
             if (not a.use_val_set and (epoch + 1) % a.test_nth_epoch == 0) or (a.use_val_set and new_best and epoch > 5):
                 acc_test, loss_test, oacc_test, avg_iou_test, avg_acc_test = self.eval(False)
-                print('-> Test Loss: %1.4f  Test accuracy: %3.2f%%  Test oAcc: %3.2f%%  Test avgIoU: %3.2f%%' %
+                self.log('-> Test Loss: %1.4f  Test accuracy: %3.2f%%  Test oAcc: %3.2f%%  Test avgIoU: %3.2f%%' %
                       (loss_test, acc_test, 100 * oacc_test, 100 * avg_iou_test))
             else:
                 acc_test, loss_test, oacc_test, avg_iou_test, avg_acc_test = 0, 0, 0, 0, 0
@@ -384,22 +504,27 @@ class Session:
                                'oacc_test': oacc_test, 'avg_iou_test': avg_iou_test, 'avg_acc_test': avg_acc_test, 'best_iou': best_iou})
             if math.isnan(loss):
                 break
-            with open(os.path.join(a.odir, 'trainlog.json'), 'w') as outfile:
-                json.dump(self.stats, outfile, indent=4)
+            if self.rank == 0:
+                with open(os.path.join(a.odir, 'trainlog.json'), 'w') as outfile:
+                    json.dump(self.stats, outfile, indent=4)
         if a.use_val_set:
+            if self.dp:
+                import torch.distributed as tdist
+                tdist.barrier()                       # rank 0 has written the best model
             a.resume = a.odir + '/model.pth.tar'
             self.model, self.optimizer, self.stats = resume(a, self.dbinfo)
             self.arena = None
             self.checkpoint(epoch, with_scaler=False)
         if a.test_multisamp_n > 0 and 'test' in a.db_test_name:
             acc_test, oacc_test, avg_iou_test, per_class_iou_test, predictions_test, avg_acc_test, confusion = self.eval_final()
-            print('-> Multisample {}: Test accuracy: {}, \tTest oAcc: {}, \tTest avgIoU: {}, \tTest mAcc: {}'.format(
+            self.log('-> Multisample {}: Test accuracy: {}, \tTest oAcc: {}, \tTest avgIoU: {}, \tTest mAcc: {}'.format(
                 a.test_multisamp_n, acc_test, oacc_test, avg_iou_test, avg_acc_test))
-            write_predictions(os.path.join(a.odir, 'predictions_' + a.db_test_name), predictions_test)
-            with open(os.path.join(a.odir, 'scores_' + a.db_test_name + '.json'), 'w') as outfile:
-                json.dump([{'epoch': a.start_epoch, 'acc_test': acc_test, 'oacc_test': oacc_test, 'avg_iou_test': avg_iou_test,
-                            'per_class_iou_test': per_class_iou_test, 'avg_acc_test': avg_acc_test}], outfile)
-            np.save(os.path.join(a.odir, 'pointwise_cm.npy'), confusion)
+            if self.rank == 0:
+                write_predictions(os.path.join(a.odir, 'predictions_' + a.db_test_name), predictions_test)
+                with open(os.path.join(a.odir, 'scores_' + a.db_test_name + '.json'), 'w') as outfile:
+                    json.dump([{'epoch': a.start_epoch, 'acc_test': acc_test, 'oacc_test': oacc_test, 'avg_iou_test': avg_iou_test,
+                                'per_class_iou_test': per_class_iou_test, 'avg_acc_test': avg_acc_test}], outfile)
+                np.save(os.path.join(a.odir, 'pointwise_cm.npy'), confusion)
 
 
 def write_predictions(stem, predictions):
@@ -420,10 +545,20 @@ def main(argv=None):
     args = parse_args(argv)
     if not args.cuda:
         raise RuntimeError('superpoint_graph_amd has no CPU execution path: run with --cuda 1 on a ROCm device')
-    print('Will save to ' + args.odir)
-    os.makedirs(args.odir, exist_ok=True)
-    with open(os.path.join(args.odir, 'cmdline.txt'), 'w') as f:
-        f.write(' '.join(["'" + a + "'" if (len(a) == 0 or a[0] != '-') else a for a in (argv if argv is not None else sys.argv)]))
+    # data parallel: one process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE); a plain launch is rank 0 of 1
+    from .. import dist as spd
+    if args.dist_device >= 0:
+        torch.cuda.set_device(args.dist_device)
+    args.rank, local, args.world = spd.init_from_env(args.dist_backend or None)
+    if args.world > 1:
+        torch.cuda.set_device(args.dist_device if args.dist_device >= 0 else local)
+        if args.sync_bn:
+            spd.enable_sync_bn(torch.device('cuda', torch.cuda.current_device()))
+    if args.rank == 0:
+        print('Will save to ' + args.odir)
+        os.makedirs(args.odir, exist_ok=True)
+        with open(os.path.join(args.odir, 'cmdline.txt'), 'w') as f:
+            f.write(' '.join(["'" + a + "'" if (len(a) == 0 or a[0] != '-') else a for a in (argv if argv is not None else sys.argv)]))
     set_seed(args.seed, args.cuda)
     from .. import _lib
     if _lib.lib().spg_tune(7, {'f32': 0, 'bf16': 1, 'bf16x3': 3}[args.gemm_precision]) < 0:
@@ -440,7 +575,11 @@ def main(argv=None):
         optimizer = create_optimizer(args, model)
         stats = []
     session = Session(args, dbinfo, create_dataset, model, optimizer, stats)
-    session.run()
+    try:
+        session.run()
+    finally:
+        if args.world > 1 and args.sync_bn:
+            spd.disable_sync_bn()
     return session
 
 

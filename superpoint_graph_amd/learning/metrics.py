@@ -24,6 +24,28 @@ class ConfusionMatrix:
             self._counters = torch.zeros(2, dtype=torch.int64, device=logits.device)
         return ops.eval_accumulate(logits, label_mode, label_vec, self._dev, self._counters)
 
+    def allreduce(self, group=None):
+        """Data-parallel evaluation: every rank counted its own scenes; the counts are exact integers, so the sum over the ranks
+        equals the single-process matrix bit for bit (reference learning/metrics.py:16-18 adds the same counts sequentially)."""
+        import torch.distributed as dist
+        if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        if self._dev is None:        # a rank without a single evaluated batch still takes part in the collective
+            dev = torch.device('cuda', torch.cuda.current_device())
+            self._dev = torch.zeros(self.number_of_labels, self.number_of_labels, dtype=torch.int64, device=dev)
+            self._counters = torch.zeros(2, dtype=torch.int64, device=dev)
+        buf = torch.cat([self._dev.reshape(-1), self._counters, torch.from_numpy(self._host.astype(np.int64).reshape(-1)).to(self._dev.device)])
+        if dist.get_backend(group) == 'gloo':
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            buf = host.to(self._dev.device)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        n = self.number_of_labels * self.number_of_labels
+        self._dev.copy_(buf[:n].view_as(self._dev))
+        self._counters.copy_(buf[n:n + 2])
+        self._host = buf[n + 2:].cpu().numpy().astype(np.float64).reshape(self._host.shape)
+
     @property
     def confusion_matrix(self):
         """float64 [C, C] like the reference's attribute (host counts + device counts)."""

@@ -62,8 +62,19 @@ class SuperpointGraph:
         self._edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
         self._eattrs = {k: list(v) for k, v in dict(edge_attrs or {}).items()}
         self._vattrs = {k: list(v) for k, v in dict(vertex_attrs or {}).items()}
+        self._earr = {}            # edge attributes as 2-d arrays, built on first use (edge_attribute_array)
         self.es = _EdgeSeq(self)
         self.vs = _VertexSeq(self)
+
+    def edge_attribute_array(self, name):
+        """The edge attribute as ONE [E, width] array in edge order -- what np.asarray(es.get_attribute_values(name)) gives,
+        without the detour through 5 000 Python objects per batch (GraphConvInfo.set_batch_device concatenates these)."""
+        a = self._earr.get(name)
+        if a is None:
+            vals = self._eattrs[name]
+            a = np.asarray(vals) if len(vals) else np.zeros((0, 0), dtype=np.float32)
+            self._earr[name] = a
+        return a
 
     def get_edgelist(self):
         return [tuple(e) for e in self._edges.tolist()]

@@ -491,6 +491,7 @@ class _CrossEntropyFunction(torch.autograd.Function):
                                           buf[N:].data_ptr(), _ptr(buf), buf[N + 1:].data_ptr(), _stream()), 'spg_cross_entropy_fwd')
         ctx.save_for_backward(logits, target, buf)
         ctx.weight, ctx.ignore_index, ctx.mean = weight, int(ignore_index), int(mean)
+        _CrossEntropyFunction.last_normaliser = buf[N + 1:N + 2]      # sum of the class weights of the labelled rows (device)
         return buf[N]
 
     @staticmethod
@@ -504,16 +505,20 @@ class _CrossEntropyFunction(torch.autograd.Function):
         return g, None, None, None, None
 
 
-def cross_entropy(logits, target, weight=None, ignore_index=-100, reduction='mean'):
+def cross_entropy(logits, target, weight=None, ignore_index=-100, reduction='mean', return_normaliser=False):
     """torch.nn.functional.cross_entropy for [N, C] logits and class-index targets (the form learning/main.py:205 uses),
-    forward and backward one HIP launch each."""
+    forward and backward one HIP launch each.  return_normaliser: also the [1] device tensor sum_i weight[target_i] over the
+    labelled rows -- the loss weight w_r of a data-parallel rank (superpoint_graph_amd/dist.py), without a host copy."""
     if reduction not in ('mean', 'sum'):
         raise NotImplementedError("reduction must be 'mean' or 'sum'")
     if logits.dim() != 2 or target.dim() != 1 or target.shape[0] != logits.shape[0]:
         raise ValueError('cross_entropy expects logits [N, C] and targets [N]')
     if weight is not None:
         weight = _req(weight.contiguous(), torch.float32, 'weight')
-    return _CrossEntropyFunction.apply(logits, target, weight, ignore_index, reduction == 'mean')
+    loss = _CrossEntropyFunction.apply(logits, target, weight, ignore_index, reduction == 'mean')
+    if return_normaliser:
+        return loss, _CrossEntropyFunction.last_normaliser
+    return loss
 
 
 # --------------------------------------------------------------------------------------------------
