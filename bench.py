@@ -231,7 +231,7 @@ def main():
     ap.add_argument('--no-trainer-window', action='store_true', help='skip the fresh-batch-per-step side measurement (learning/main.py:200-215 window)')
     ap.add_argument('--no-forward-only', action='store_true', help='skip the forward-only side measurement (BASELINE configs[1])')
     ap.add_argument('--sync-bn', type=int, default=0, help='1: BatchNorm statistics all-reduced over the ranks (exact single-process batch semantics); 0: per-rank statistics')
-    ap.add_argument('--native-rccl', type=int, default=-1, help='1: the C library issues the RCCL collectives itself (own communicator, spg_rccl_*); 0: torch.distributed calls; -1 (default): 1 with --sync-bn 1 (26 small collectives per step: no Python in between), else 0 (one all-reduce per step either way; the torch path is the one exercised on multi-GPU nodes before)')
+    ap.add_argument('--native-rccl', type=int, default=0, help='1: the C library issues the RCCL collectives itself (own communicator, spg_rccl_*: no Python between a BatchNorm finalize kernel and its all-reduce); 0 (default): torch.distributed calls -- the library\'s communicator has only ever run at world size 1 on the 1-GPU test box, so it stays opt-in until it has been exercised on a multi-GPU node (tests/test_gpu_dist.py runs it whenever device_count() > 1)')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help="arithmetic of the wide row-GEMMs: f32 = fp32 MFMA (default, the headline); bf16x3 = split-bf16 products (three "
                          "bf16 MFMAs per operand pair, fp32 accumulate, ~2^-16 per product); bf16 = bf16 operands.  A SEPARATE line: never "
@@ -277,35 +277,40 @@ def main():
     arena = FlatParameters(model, lazy_zero=True, host_counters=True)
     if _lib.lib().spg_tune(7, PREC) < 0:             # precision mode of the wide row-GEMMs (0 = fp32 MFMA)
         raise RuntimeError('libspg_hip.so has no precision switch (spg_tune key 7)')
-    w_local = spd.loss_weight(label_mode)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     n_sp_step = int(flag.numel())
 
     native = False
-    if args.native_rccl < 0:
-        args.native_rccl = 1 if args.sync_bn else 0
     if world > 1 and args.native_rccl and dist.get_backend() == 'nccl':
         spd.init_native_rccl()                       # gradient / BatchNorm collectives enqueued by libspg_hip itself
         native = True
     if args.sync_bn:       # BatchNorm statistics over the scenes of ALL ranks (exact single-process-batch semantics)
         spd.enable_sync_bn(dev)
 
+    dp = world > 1 or bool(args.sync_bn)
+    exchange = {}
+
     def fwd_bwd():
         arena.zero_grad()
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
-        # sync-BN couples the ranks in the backward: the loss normaliser is applied before it (dist.py)
-        loss = ops.cross_entropy(out, label_mode, reduction='sum' if args.sync_bn else 'mean')     # learning/main.py:205, one launch each way
+        if dp:
+            # data parallel: back-propagate the SUM-reduced loss (the gradients carry this rank's loss weight, superpoint_graph_amd/
+            # dist.py); the weight stays on the device and rides along with the gradient all-reduce
+            loss, exchange['w'] = ops.cross_entropy(out, label_mode, reduction='sum', return_normaliser=True)
+        else:
+            loss = ops.cross_entropy(out, label_mode)    # learning/main.py:205, one launch each way
         loss.backward(arena.one)                         # (a cached 1: autograd's implicit ones_like(loss) is a fill launch)
         embedder.bw_hook()
 
     def update():
-        arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)        # clamp (main.py:210-212) + Adam (main.py:213), one launch
+        # clamp (main.py:210-212) + Adam (main.py:213), one launch; data parallel: the division by the summed loss weights is in it
+        arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0, grad_div=arena.normaliser if dp else None)
 
     def eager_step():
         fwd_bwd()
-        if world > 1 or args.sync_bn:
-            arena.allreduce(w_local, prescaled=bool(args.sync_bn))
+        if dp:
+            arena.allreduce_sums(exchange['w'])          # ONE collective: [gradients | loss weight], no host synchronisation
         update()
 
     step = eager_step
@@ -327,8 +332,8 @@ def main():
 
         def graph_step():
             g_fb.replay()
-            if world > 1 or args.sync_bn:
-                arena.allreduce(w_local, prescaled=bool(args.sync_bn))
+            if dp:
+                arena.allreduce_sums(exchange['w'])
             g_up.replay()
         step = graph_step
         log('hipGraph captured')
