@@ -331,12 +331,12 @@ int spg_prof_tag(int kind, int it, int jt, int x, int y, int full);
  * spg_prof_read(..., reset = 1) */
 int spg_prof_read_shapes(int* keys, double* vals, int max);
 /* Tuning knobs of the row-GEMM launches (process-global; the defaults are the production values).  key 0: 1 = launch
- * one workgroup per tile instead of the persistent chunk stream (A/B timing in tools/); key 3: timing-attribution
- * switches of the persistent forward launches (bit 0 no output store, 1 no BatchNorm partials, 2 no pooling, 3 no
- * epilogue at all, 4 A operand from L2, 5 no main-loop barriers, bits 8-11 extra repetitions of the chunk loop) --
- * results are WRONG while it is non-zero, tools/ only; key 4: the BatchNorm finalize kernels slice their reduction over 8
- * workgroups (last-arrival combine) above this many partials (0 = default 512); key 5: 1 = persistent launches write one
- * statistics partial per tile instead of one per workgroup; key 7: arithmetic of the wide (128-row-tile, full-tile) GEMMs of
+ * one workgroup per tile instead of the persistent chunk stream (A/B timing in tools/); key 3 (ONLY in a library built with
+ * `make ATTRIBUTION=1`; the production build rejects it with -1): timing-attribution switches of the persistent forward
+ * launches (bit 0 no output store, 1 no BatchNorm partials, 2 no pooling, 3 no epilogue at all, 4 A operand from L2, 5 no
+ * main-loop barriers, bits 8-11 extra repetitions of the chunk loop) -- results are WRONG while it is non-zero; key 4: the BatchNorm finalize kernels slice their reduction over 8
+ * workgroups (last-arrival combine) above this many partials (0 = default 512); key 5 (attribution build only): 1 = persistent
+ * launches write one statistics partial per tile instead of one per workgroup; key 7: arithmetic of the wide (128-row-tile, full-tile) GEMMs of
  * spg_pointnet_forward / _backward: 0 = fp32 MFMA (default; the reference's arithmetic), 3 = split-bf16 (three bf16 MFMAs per
  * operand pair, ~2^-16 per product), 1 = bf16 operands; fp32 accumulation and fp32 tensors in every mode (tolerances:
  * tests/test_gpu_precision.py); key 8: 1 = run the GRU recurrence of spg_eccrnn_forward / _backward as one launch per

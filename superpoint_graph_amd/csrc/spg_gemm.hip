@@ -30,6 +30,11 @@ void spg_set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 #include <mutex>
 #include <vector>
+#ifdef SPG_ATTRIBUTION
+#define SPG_DBG(p) ((p).dbg)
+#else
+#define SPG_DBG(p) 0
+#endif
 namespace {
 struct ProfRec { hipEvent_t a, b; double flops; int tag; int M, N, K; };
 bool g_prof_on = false;
@@ -46,6 +51,9 @@ struct ProfScope {
 extern "C" void spg_prof_enable(int on) { g_prof_on = on != 0; }
 
 // tuning knobs (spg_tune): process-global, read by the launchers
+// Timing-attribution switches (spg_tune key 3: parts of the persistent forward kernel switched off, results WRONG) and the
+// per-tile statistics switch (key 5) exist only in a build with -DSPG_ATTRIBUTION (`make ATTRIBUTION=1`, used by
+// tools/tune_sweep.py and the r02 attribution records); the production library compiles them to constants.
 static int g_tune[SPG_TUNE_COUNT] = {0};
 static int spg_num_cus() {
   static int n = 0;
@@ -59,6 +67,9 @@ static int spg_num_cus() {
 int spg_tune_get(int key) { return (key >= 0 && key < SPG_TUNE_COUNT) ? g_tune[key] : 0; }
 extern "C" int spg_tune(int key, int value) {
   if (key < 0 || key >= SPG_TUNE_COUNT) return -1;
+#ifndef SPG_ATTRIBUTION
+  if ((key == SPG_TUNE_DBG || key == SPG_TUNE_NO_STAT_ACCUM) && value != 0) return -1;      // not in the production build
+#endif
   const int old = g_tune[key];
   g_tune[key] = value;
   return old;
@@ -650,33 +661,33 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
         }
         else if (WRED) spg_mfma_chunk_or_il<TI, TJ>(Ac, reinterpret_cast<const float*>(Bc), IT + 1, JT + 4, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
         else spg_mfma_chunk_il<TI, TJ>(Ac, Bc, IT + 1, JT + 1, wi * (IT / WI) + r, wj * (JT / WJ) + r, h, acc, piece);
-        if (!(STREAM && (p.dbg & 32))) __syncthreads();      // (attribution switch: main loop without barriers)
+        if (!(STREAM && (SPG_DBG(p) & 32))) __syncthreads();      // (attribution switch: main loop without barriers)
       };
-      const int reps = STREAM ? 1 + ((p.dbg >> 8) & 15) : 1;      // (attribution switch: the chunk loop repeated -> steady-state rate)
+      const int reps = STREAM ? 1 + ((SPG_DBG(p) >> 8) & 15) : 1;      // (attribution switch: the chunk loop repeated -> steady-state rate)
       for (int rep = 0; rep < reps; ++rep)
       for (int c = 0; c < nchunk; c += 2) {
         // where the loads of chunk c+2 / c+3 come from: this tile, the next tile of the stream, or (at the very end) a
         // clamped re-load of the last chunk -- plain scalar values, computed outside the lambdas
         int ka = c + 2, kb = c + 3;
         long ma = m0, mb = m0;
-        if (STREAM && (p.dbg & 16)) ma = mb = (long)(tile & 15) * p.rows_per_tile;     // (attribution switch: A from L2)
+        if (STREAM && (SPG_DBG(p) & 16)) ma = mb = (long)(tile & 15) * p.rows_per_tile;     // (attribution switch: A from L2)
         int ta = tile, tb = tile;
-        if (ka >= nchunk) { if (has_next) { ka -= nchunk; ma = (STREAM && (p.dbg & 16)) ? ma : m0n; ta = tilen; } else ka = nchunk - 1; }
-        if (kb >= nchunk) { if (has_next) { kb -= nchunk; mb = (STREAM && (p.dbg & 16)) ? mb : m0n; tb = tilen; } else kb = nchunk - 1; }
+        if (ka >= nchunk) { if (has_next) { ka -= nchunk; ma = (STREAM && (SPG_DBG(p) & 16)) ? ma : m0n; ta = tilen; } else ka = nchunk - 1; }
+        if (kb >= nchunk) { if (has_next) { kb -= nchunk; mb = (STREAM && (SPG_DBG(p) & 16)) ? mb : m0n; tb = tilen; } else kb = nchunk - 1; }
         body(c, ka * SPG_KC, ma, ta, false, pa1, pw1, pwr1, pb1, pa0, pw0, pwr0, pb0);          // set 1 holds chunk c+1; set 0 is free for chunk c+2
         if (c + 1 < nchunk) body(c + 1, kb * SPG_KC, mb, tb, has_next && c + 2 >= nchunk, pa0, pw0, pwr0, pb0, pa1, pw1, pwr1, pb1);
       }
       // Here (nchunk even when there is a next tile -- host): LDS buffer 0 holds chunk 0 of the next tile, set 1 its chunk
       // 1 (in flight); buffer 1 was read by the last chunk and is free: the epilogue stages through it.
       float* red = reinterpret_cast<float*>(smem + (A_F4 + B_F4));
-      if (STREAM && p.dbg) {       // timing attribution only (spg_tune key 3; results are WRONG): parts of the epilogue off
-        if (p.dbg & 8) {
+      if (STREAM && SPG_DBG(p)) {       // timing attribution only (spg_tune key 3; results are WRONG): parts of the epilogue off
+        if (SPG_DBG(p) & 8) {
           if (acc[0][0][0] + acc[TI - 1][TJ - 1][5] == 123.456f) p.Y[0] = 0.f;
         } else {
           SpgGemmParams q = p;
-          if (p.dbg & 1) q.Y = nullptr;
-          if (p.dbg & 2) q.stat = nullptr;
-          if (p.dbg & 4) q.pool_out = nullptr;
+          if (SPG_DBG(p) & 1) q.Y = nullptr;
+          if (SPG_DBG(p) & 2) q.stat = nullptr;
+          if (SPG_DBG(p) & 4) q.pool_out = nullptr;
           spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(q, acc, red, tile, m0, mvalid, n0);
         }
       } else
@@ -948,9 +959,18 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
       if (!g_tune[SPG_TUNE_NO_PERSIST] && IT == 128 && !(WRED && JT == 128) && p.rows_per_tile == IT && p.M % IT == 0 && p.N % JT == 0 &&
           (p.K / SPG_KC) % 2 == 0 && (long)grid.x * ncol > slots && slots % (8 * ncol) == 0) {
         q.remap = 1; q.rstride = slots / ncol;
-        q.dbg = WRED ? 0 : g_tune[SPG_TUNE_DBG];      // attribution switches: forward launches only
+#ifdef SPG_ATTRIBUTION
+        q.dbg = WRED ? 0 : g_tune[SPG_TUNE_DBG];      // attribution switches: forward launches only (tools/ build)
+#else
+        q.dbg = 0;                                    // compiled out of the production library (make ATTRIBUTION=1 for tools/)
+#endif
         // ... the persistent workgroups accumulate over their tiles: one partial per workgroup of a column tile and row-wave
-        q.stat_accum = !g_tune[SPG_TUNE_NO_STAT_ACCUM] && p.stat != nullptr && (!WRED || (q.vec_store && p.N <= p.n_mask));
+#ifndef SPG_ATTRIBUTION
+        const int no_stat_accum = 0;
+#else
+        const int no_stat_accum = g_tune[SPG_TUNE_NO_STAT_ACCUM];
+#endif
+        q.stat_accum = !no_stat_accum && p.stat != nullptr && (!WRED || (q.vec_store && p.N <= p.n_mask));
         if (q.stat_accum && stat_parts != nullptr) *stat_parts = (int)(q.rstride < q.ntile ? q.rstride : q.ntile);      // one per workgroup
         grid = dim3((unsigned)slots, 1);
         if constexpr (IT == 128 && !(WRED && JT == 128)) {

@@ -54,8 +54,27 @@ class _VertexSeq:
 class SuperpointGraph:
     """Directed graph with edge / vertex attributes: the subset of the igraph.Graph API that the reference's loader and
     batching touch (learning/spg.py:109-143,151-166, learning/ecc/GraphConvInfo.py:48-58): `vcount`, `get_edgelist`,
-    `es[...]`, `es.attributes`, `indegree`, `vs[...]`, `permute_vertices`, `neighborhood`, `subgraph`.  Edge order is
-    preserved by `permute_vertices` and `subgraph` (igraph's copy-and-delete implementation)."""
+    `es[...]`, `es.attributes`, `indegree`, `vs[...]`, `permute_vertices`, `neighborhood`, `subgraph`.
+
+    The igraph semantics this class ASSUMES, method by method (python-igraph's documented behaviour; hand-written expected
+    values in tests/test_host.py::test_superpoint_graph_igraph_semantics), and what the callers rely on:
+      * `permute_vertices(perm)`: "vertex k of the original graph becomes vertex perm[k] in the new graph" (python-igraph
+        Graph.permute_vertices); vertex attributes travel with their vertex, edges keep their order and attributes.  Used by
+        the loader with a random permutation (spg.py:136-137): only the multiset of vertices matters afterwards.
+      * `neighborhood(vertices, order)` (default mode='all'): for every given vertex the vertices reachable in at most
+        `order` steps IGNORING edge direction, the vertex itself included.  igraph returns them in breadth-first order; the only
+        caller turns the result into `sorted(set(...))` (random_neighborhoods, spg.py:118-121), so only MEMBERSHIP is
+        observable -- this class returns the centre first and every further level sorted.
+      * `subgraph(vertices)` (= induced_subgraph): the kept vertices are renumbered 0..k-1 in increasing order of their old
+        ids (igraph keeps the original relative order whatever order the ids are passed in; both call sites pass increasing
+        ids: a sorted set, spg.py:120-121, and range(n), spg.py:127); an edge survives iff both endpoints do; vertex and edge
+        attributes follow.  Edge ORDER of the result: igraph's implementation-dependent ('copy_and_delete' keeps the original
+        relative order, 'create_from_scratch' -- chosen automatically for small selections -- does not); this class keeps the
+        original order.  Nothing downstream observes it: GraphConvInfo.set_batch re-orders the edges by target, the
+        aggregation over a target's in-edges is a mean (order changes fp32 round-off only) and the edge features travel with
+        their edges.
+      * `indegree`, `vcount`, `get_edgelist`, `es.attributes()`, `es[idx].get_attribute_values(a)`, `vs[i][a]`, `vs[a]`:
+        plain accessors (GraphConvInfo.py:48-58, spg.py:153-166)."""
 
     def __init__(self, n, edges, directed=True, edge_attrs=None, vertex_attrs=None):
         self._n = int(n)
@@ -119,8 +138,9 @@ class SuperpointGraph:
         return out
 
     def subgraph(self, vertices):
-        """Induced subgraph; kept vertices are renumbered in the order given (increasing in every call site)."""
-        ids = np.asarray(list(vertices), dtype=np.int64)
+        """Induced subgraph; kept vertices are renumbered in increasing order of their old ids (igraph semantics, see the class
+        docstring; every call site passes increasing ids anyway)."""
+        ids = np.sort(np.asarray(list(vertices), dtype=np.int64))
         new_id = np.full(self._n, -1, dtype=np.int64)
         new_id[ids] = np.arange(len(ids))
         e = self._edges

@@ -118,3 +118,43 @@ def test_philox_oracle_known_answers():
     for ctr, key, want in kat:
         got = tuple(int(x) for x in philox4x32_10(*ctr, *key))
         assert got == want
+
+
+def test_superpoint_graph_igraph_semantics():
+    """The igraph.Graph semantics `SuperpointGraph` stands in for (class docstring), against hand-written expected values
+    taken from python-igraph's documented behaviour -- the stand-in is also what the CLI golden was generated with
+    (oracle/gen_main_golden.py installs it as igraph.Graph for the reference run), so a deviation from real igraph would
+    otherwise be invisible to every other test."""
+    from superpoint_graph_amd.learning.spg import SuperpointGraph, random_neighborhoods, k_big_enough
+    # directed graph on 6 vertices; edge attribute 'f' = edge id, vertex attribute 'v' = letters, 's' = sizes
+    edges = [(0, 1), (1, 2), (2, 4), (4, 1), (3, 0), (5, 4)]
+    G = SuperpointGraph(6, edges, True, {'f': [10, 11, 12, 13, 14, 15]}, {'v': list('abcdef'), 's': [50, 5, 60, 70, 8, 90]})
+    assert G.vcount() == 6 and G.get_edgelist() == edges and G.indegree(G.vs) == [1, 2, 1, 0, 2, 0]
+    assert G.es.attributes() == ['f'] and G.es[[3, 0]].get_attribute_values('f') == [13, 10]
+    assert G.vs[2]['v'] == 'c' and G.vs['s'] == [50, 5, 60, 70, 8, 90]
+    # Graph.neighborhood(vertices, order) with the default mode='all': direction ignored, the vertex itself included.
+    #   igraph docs example shape: g.neighborhood([v], order=1) -> [[v, neighbours...]]
+    nb1 = G.neighborhood([0], 1)
+    assert nb1[0][0] == 0 and sorted(nb1[0]) == [0, 1, 3]                 # 0->1 (out) and 3->0 (in) both count
+    assert sorted(G.neighborhood([2], 1)[0]) == [1, 2, 4]
+    assert sorted(G.neighborhood([0], 2)[0]) == [0, 1, 2, 3, 4]           # via 1: 2 and 4 (4->1 counts); 5 is three steps away
+    assert [sorted(x) for x in G.neighborhood([5, 3], 1)] == [[4, 5], [0, 3]]
+    assert sorted(G.neighborhood([5], 0)[0]) == [5]
+    # Graph.permute_vertices(perm): "vertex k of the original graph becomes vertex perm[k] in the new graph"
+    P = G.permute_vertices([2, 0, 1, 5, 4, 3])
+    assert P.get_edgelist() == [(2, 0), (0, 1), (1, 4), (4, 0), (5, 2), (3, 4)]      # same edges, same order, relabelled
+    assert P.vs['v'] == ['b', 'c', 'a', 'f', 'e', 'd'] and P.es.get_attribute_values('f') == [10, 11, 12, 13, 14, 15]
+    # Graph.subgraph(vertices) (induced_subgraph): survivors renumbered in increasing order of their old ids
+    S = G.subgraph([1, 2, 4])
+    assert S.vcount() == 3 and S.vs['v'] == ['b', 'c', 'e']
+    assert sorted(zip(S.get_edgelist(), S.es.get_attribute_values('f'))) == [((0, 1), 11), ((1, 2), 12), ((2, 0), 13)]
+    S2 = G.subgraph([4, 1, 2])                                            # the order the ids are passed in does not matter in igraph
+    assert S2.vs['v'] == ['b', 'c', 'e'] and sorted(S2.get_edgelist()) == sorted(S.get_edgelist())
+    assert G.subgraph([0, 5]).get_edgelist() == []                        # no edge between the survivors
+    # the two callers (reference learning/spg.py:114-127)
+    import random
+    random.seed(0)
+    R = random_neighborhoods(G, 1, 1)
+    assert R.vcount() in (2, 3, 4) and set(R.vs['v']) <= set('abcdef')
+    K = k_big_enough(G, 40, 2)             # sizes 50, 5, 60, 70, ...: the prefix holding 2 superpoints of >= 40 points = ids 0..2
+    assert K.vs['v'] == ['a', 'b', 'c'] and K.get_edgelist() == [(0, 1), (1, 2)]

@@ -2,6 +2,8 @@
 """Sweep of the row-GEMM tuning knobs (spg_tune) on the real training step of the unit scene: for every setting the
 wall time per step (un-instrumented) and the hipEvent time of every (kernel instantiation, layer shape) of the
 instrumented pass.  Attribution switches (key 3) produce WRONG results by design -- timing only.
+Keys 3 and 5 (timing attribution) exist only in a library built with `make -C superpoint_graph_amd/csrc clean all ATTRIBUTION=1`;
+the production build rejects them.
 Round-2 findings (gpurun_out/r2_tune*.txt, profiles/r02_gemm_attribution.txt): see DESIGN.md section 4.1.
 
     python tools/tune_sweep.py [--configs name=k:v,k:v ...] > gpurun_out/tune.txt
