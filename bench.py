@@ -236,6 +236,7 @@ def main():
                     help="arithmetic of the wide row-GEMMs: f32 = fp32 MFMA (default, the headline); bf16x3 = split-bf16 products (three "
                          "bf16 MFMAs per operand pair, fp32 accumulate, ~2^-16 per product); bf16 = bf16 operands.  A SEPARATE line: never "
                          "replaces the f32 headline (tolerances: tests/test_gpu_precision.py)")
+    ap.add_argument('--tune', default='', help='A/B switches of the library for experiments: comma-separated key:value pairs of spg_tune (include/spg_hip.h), e.g. 8:1 = per-iteration RNN-ECC launches, 9:1 = no side stream')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
     args = ap.parse_args()
 
@@ -277,6 +278,10 @@ def main():
     arena = FlatParameters(model, lazy_zero=True, host_counters=True)
     if _lib.lib().spg_tune(7, PREC) < 0:             # precision mode of the wide row-GEMMs (0 = fp32 MFMA)
         raise RuntimeError('libspg_hip.so has no precision switch (spg_tune key 7)')
+    for kv in [t for t in args.tune.split(',') if t]:
+        k, v = kv.split(':')
+        if _lib.lib().spg_tune(int(k), int(v)) < 0:
+            raise RuntimeError(f'spg_tune rejected {kv}')
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     n_sp_step = int(flag.numel())
 

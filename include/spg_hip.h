@@ -341,7 +341,9 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * operand pair, ~2^-16 per product), 1 = bf16 operands; fp32 accumulation and fp32 tensors in every mode (tolerances:
  * tests/test_gpu_precision.py); key 8: 1 = run the GRU recurrence of spg_eccrnn_forward / _backward as one launch per
  * iteration instead of the persistent dataflow-synchronised launch (A/B timing and the equality test; the two forms give
- * bit-identical results).  Returns the previous value, -1 for an unknown key. */
+ * bit-identical results); key 9: 1 = the recurrent cell's parameter-gradient launches of spg_eccrnn_backward go to a
+ * library-owned side stream next to the filter network's backward chain (experiment; measured slower, off by default).
+ * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* Number of bounded-spin time-outs the persistent RNN-ECC launches of the current device have raised so far (0 in a correct
  * run; a wave that waits too long for a neighbour's state gives up instead of hanging the GPU).  Synchronises the device. */

@@ -4,8 +4,50 @@
 #include "../../include/spg_hip.h"
 #include "spg_ecc.h"
 #include "spg_gemm.h"
+#include <mutex>
 
 extern "C" int spg_version(void) { return SPG_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// side stream (spg_common.h)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct SpgSide { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, tried = false; };
+SpgSide g_side[SPG_MAX_DEVICES];
+std::mutex g_side_mutex;
+SpgSide* side_of_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lock(g_side_mutex);
+  SpgSide& s = g_side[dev];
+  if (!s.tried) {
+    s.tried = true;
+    s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return s.ok ? &s : nullptr;
+}
+}  // namespace
+
+hipStream_t spg_side_fork(hipStream_t main) {
+  if (!spg_tune_get(SPG_TUNE_SIDE_STREAM)) return nullptr;      // opt-in: measured slower (spg_common.h)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;   // hipGraph capture: stay on one stream
+  SpgSide* s = side_of_current_device();
+  if (s == nullptr) return nullptr;
+  if (hipEventRecord(s->fork, main) != hipSuccess || hipStreamWaitEvent(s->stream, s->fork, 0) != hipSuccess) return nullptr;
+  return s->stream;
+}
+
+int spg_side_join(hipStream_t main) {
+  SpgSide* s = side_of_current_device();
+  if (s == nullptr) return 0;
+  hipError_t e = hipEventRecord(s->join, s->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(main, s->join, 0);
+  if (e != hipSuccess) { spg_set_error("side stream join: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // graph

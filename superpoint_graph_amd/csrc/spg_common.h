@@ -21,8 +21,21 @@ extern "C" const char* spg_last_error(void);
 void spg_set_error(const char* fmt, ...);
 // tuning knobs (process-global; defaults are the production values): see spg_tune in include/spg_hip.h
 enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_FIN_SLICE_MIN = 4, SPG_TUNE_NO_STAT_ACCUM = 5, SPG_TUNE_PRECISION = 7,
-       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_COUNT = 16 };
+       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_SIDE_STREAM = 9, SPG_TUNE_COUNT = 16 };
 int spg_tune_get(int key);
+
+// Fork / join of a library-owned side stream (one per device, created on first use): a latency-bound chain of small-grid
+// launches that does not depend on the caller's next launches runs NEXT to them instead of in front of them.  Every launch of
+// this step costs >= ~4.5 us of fixed latency (dispatch, first loads, end-of-kernel release) whatever it computes, and the
+// small grids leave most CUs idle, so two independent small chains genuinely overlap.  fork: the side stream waits for
+// everything enqueued on `main` so far; join: `main` waits for everything enqueued on the side stream.  Both asynchronous; a
+// call that forks always joins before it returns, so the caller's stream semantics are unchanged.  Returns null (and the caller
+// stays on `main`) unless the facility is switched ON (spg_tune key 9 = 1) and a stream can be created.
+// MEASURED (round 3, profiles/r03_side_stream_experiment.txt): with the recurrent cell's five parameter-gradient launches
+// (43 us) forked next to the filter network's backward chain the step got 50 us SLOWER (1.634 -> 1.684 ms, same box,
+// interleaved runs): the two cross-stream dependencies cost more than the overlapped work is worth.  Hence off by default.
+hipStream_t spg_side_fork(hipStream_t main);
+int spg_side_join(hipStream_t main);
 
 #define SPG_CHECK_ARG(cond, msg)                                          \
   do {                                                                    \

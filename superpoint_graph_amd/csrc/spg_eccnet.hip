@@ -138,7 +138,8 @@ struct BwdScratch {
   float *dcdir = nullptr;
   float *dhdir = nullptr, *dWts = nullptr, *dzA = nullptr, *dzB = nullptr, *Wt = nullptr, *consts = nullptr;
   float *work = nullptr, *stat = nullptr;
-  size_t work_floats = 0;
+  float* work2 = nullptr;   // reduction arena of the recurrent cell's parameter gradients (they may run on the side stream)
+  size_t work_floats = 0, work2_floats = 0;
   size_t zero_bytes = 0;   // the leading region [G .. xg] must be zero-initialised
   size_t bytes = 0;
 };
@@ -164,13 +165,14 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
                ((spg_wgrad_colsum_floats((long)Er, l.cout, l.cin) + 63) & ~(size_t)63);
   }
   // GRU: three weight gradients + three bias column sums over all (node, iteration) rows
-  workmax += 3 * (((spg_wgrad_workspace_floats((long)rows, pl.GW, 32) + 63) & ~(size_t)63) + 64 * (size_t)pl.GW + 128 +
-                  ((spg_wgrad_colsum_floats((long)rows, pl.GW, 32) + 63) & ~(size_t)63));
+  const size_t work2max = 16 + 3 * (((spg_wgrad_workspace_floats((long)rows, pl.GW, 32) + 63) & ~(size_t)63) + 64 * (size_t)pl.GW + 128 +
+                                    ((spg_wgrad_colsum_floats((long)rows, pl.GW, 32) + 63) & ~(size_t)63));
   int hmax = 4;   // widest hidden activation
   for (int i = 0; i + 1 < (int)pl.F.size(); ++i) hmax = pl.F[i].cout > hmax ? pl.F[i].cout : hmax;
   s.dzA = cv.take<float>(Er * hmax); s.dzB = cv.take<float>(Er * hmax);
   s.consts = cv.take<float>((size_t)4 * cmax);
   s.work = cv.take<float>(workmax); s.work_floats = workmax;
+  s.work2 = cv.take<float>(work2max); s.work2_floats = work2max;
   s.stat = cv.take<float>((size_t)spg_cdiv(Er, SPG_FC_ROWS) * 2 * cmax);
   s.bytes = cv.off + 256;
 }
@@ -315,22 +317,38 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     p.gru = pl.gru; p.cell = pl.cfg.cell;
     SPG_TRY(spg_launch_ecc_step_bwd(p, st));
   }
-  // ---- GRU parameter gradients: three weight-gradient GEMMs over all (node, iteration) rows ----
+  // ---- GRU parameter gradients: three weight-gradient GEMMs over all (node, iteration) rows.  They depend on nothing but the
+  //      recurrence's outputs and nothing below depends on them: with spg_tune key 9 they run on the library's side stream, next
+  //      to the filter network's backward chain (an experiment: measured 50 us per step slower than one stream, spg_common.h) ----
   const int rows = N * (R + 1);
+  SpgReduceQueue rq2;
+  rq2.arena = s.work2; rq2.arena_floats = s.work2_floats;
+  hipStream_t side = E > 0 ? spg_side_fork(st) : nullptr;
   {
+    hipStream_t sg = side != nullptr ? side : st;
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = op_ident(s.dgi, GW); w.b = op_ident(s.xg, 32); w.M = rows; w.N = GW; w.K = 32;
-    SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[0], st));
+    SPG_TRY(spg_queue_wgrad(rq2, w, pl.cell_grads[0], sg));
     w.a = op_ident(s.dgh, GW); w.b = op_ident(pl.states, 32);
-    SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[1], st));
+    SPG_TRY(spg_queue_wgrad(rq2, w, pl.cell_grads[1], sg));
     // GRU: the biases are added behind the row normalisation; LSTM: in front of it
-    SPG_TRY(spg_queue_colsum(rq, pl.lstm ? s.dgi : s.dui, GW, rows, GW, pl.cell_grads[2], st));
-    SPG_TRY(spg_queue_colsum(rq, pl.lstm ? s.dgh : s.duh, GW, rows, GW, pl.cell_grads[3], st));
+    SPG_TRY(spg_queue_colsum(rq2, pl.lstm ? s.dgi : s.dui, GW, rows, GW, pl.cell_grads[2], sg));
+    SPG_TRY(spg_queue_colsum(rq2, pl.lstm ? s.dgh : s.duh, GW, rows, GW, pl.cell_grads[3], sg));
     if (pl.cfg.ingate) {
       w.a = op_ident(s.dpre, 32); w.b = op_ident(pl.states, 32); w.N = 32;
-      SPG_TRY(spg_queue_wgrad(rq, w, pl.cell_grads[4], st, pl.cell_grads[5]));      // + column sums = the input gate's bias gradient
+      SPG_TRY(spg_queue_wgrad(rq2, w, pl.cell_grads[4], sg, pl.cell_grads[5]));      // + column sums = the input gate's bias gradient
     }
   }
+  // the deferred reductions of both queues leave in ONE launch at the end (after the join)
+  auto flush_all = [&]() -> int {
+    if (side != nullptr) SPG_TRY(spg_side_join(st));
+    for (int j = 0; j < rq2.njobs; ++j) {
+      if (rq.njobs == SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(rq, st));
+      rq.jobs[rq.njobs++] = rq2.jobs[j];
+    }
+    rq2.njobs = 0;
+    return spg_flush_reduce(rq, st);
+  };
   if (E == 0) {   // no edges: the filter network received no gradient
     for (FLayer& l : pl.F) {
       SPG_TRY(zero_async(l.dW, (size_t)l.cin * l.cout * 4, st));
@@ -338,7 +356,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
       SPG_TRY(zero_async(l.dgamma, (size_t)l.cout * 4, st));
       SPG_TRY(zero_async(l.dbeta, (size_t)l.cout * 4, st));
     }
-    return spg_flush_reduce(rq, st);
+    return flush_all();
   }
   // ---- per-edge filter gradients (sum over the iterations), then the filter network backward ----
   SPG_TRY(spg_launch_ecc_edge_wgrad(gr, pl.cfg.matrix, pl.states, ldS, s.G, ldS, R, s.dWts, st));
@@ -374,5 +392,5 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
       cur = op_ident(out, l.cin);
     }
   }
-  return spg_flush_reduce(rq, st);     // ONE launch sums the split partials of all weight / bias gradients
+  return flush_all();     // join, then ONE launch sums the split partials of all weight / bias gradients
 }

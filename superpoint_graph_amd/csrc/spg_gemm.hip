@@ -1555,8 +1555,18 @@ static int* spg_fin_counter_window(int n) {
 }
 
 // (sum n_b m_b, sum n_b m_b^2, sum M2_b, count) of one channel -> the BatchNorm constants + running statistics
-__device__ __forceinline__ void spg_bn_finish(double a0, double a1, double a2, double M, int c,
-                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+// the per-channel parameters a finish needs, fetched by their thread at the START of the kernel: the loads then overlap the
+// reduction instead of adding a dependent memory round trip behind it
+struct SpgBnChannel { float gamma, beta, rm, rv; };
+__device__ __forceinline__ SpgBnChannel spg_bn_channel(int c, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* running_mean, const float* running_var) {
+  SpgBnChannel ch;
+  ch.gamma = gamma ? gamma[c] : 1.f; ch.beta = beta ? beta[c] : 0.f;
+  ch.rm = running_mean ? running_mean[c] : 0.f; ch.rv = running_mean ? running_var[c] : 0.f;
+  return ch;
+}
+
+__device__ __forceinline__ void spg_bn_finish(double a0, double a1, double a2, double M, int c, const SpgBnChannel& ch,
                                               float* running_mean, float* running_var, float momentum, float eps,
                                               int update_times, float* mean_o, float* rstd_o, float* s_o, float* t_o) {
   const double mean = a0 / M;
@@ -1564,14 +1574,14 @@ __device__ __forceinline__ void spg_bn_finish(double a0, double a1, double a2, d
   if (m2 < 0.0) m2 = 0.0;
   const double var = m2 / M;
   const double rstd = 1.0 / sqrt(var + (double)eps);
-  const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+  const double g = (double)ch.gamma, be = (double)ch.beta;
   mean_o[c] = (float)mean;
   rstd_o[c] = (float)rstd;
   s_o[c] = (float)(g * rstd);
   t_o[c] = (float)(be - mean * g * rstd);
   if (running_mean != nullptr && update_times > 0) {
     const double uvar = M > 1.0 ? m2 / (M - 1.0) : var;
-    float rm = running_mean[c], rv = running_var[c];
+    float rm = ch.rm, rv = ch.rv;
     for (int u = 0; u < update_times; ++u) {
       rm = (1.f - momentum) * rm + momentum * (float)mean;
       rv = (1.f - momentum) * rv + momentum * (float)uvar;
@@ -1621,12 +1631,14 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
   const int nslices = gridDim.y, slice = blockIdx.y;
   const int per = (nparts + nslices - 1) / nslices;
   const int b0 = slice * per, b1 = min(nparts, b0 + per);
+  SpgBnChannel ch = {1.f, 0.f, 0.f, 0.f};
+  if (threadIdx.x < 16 && c < N && sync_out == nullptr) ch = spg_bn_channel(c, gamma, beta, running_mean, running_var);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   if (c < N)
-    for (int b = b0 + ty; b < b1; b += 256) {                    // four partials in flight per thread (the loop is latency bound)
-      float nb[4], mb[4], qb[4];
+    for (int b = b0 + ty; b < b1; b += 512) {                    // eight partials in flight per thread: the 512 partials of a
+      float nb[8], mb[8], qb[8];                                 // persistent launch are ONE memory round trip (latency-bound loop)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int bb = b + 64 * u;
         const bool ok = bb < b1;
         const long o = ((long)(ok ? bb : b) * 2) * N + c;
@@ -1635,7 +1647,7 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
         qb[u] = ok ? stat[o + N] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         a0 += (double)nb[u] * (double)mb[u];
         a1 += (double)nb[u] * (double)mb[u] * (double)mb[u];
         a2 += (double)qb[u];
@@ -1688,7 +1700,7 @@ __global__ __launch_bounds__(1024) void spg_bn_finalize_kernel(const float* __re
     if (c == 0) sync_out[3 * (long)N] = (double)M;
     return;
   }
-  spg_bn_finish(a0, a1, a2, (double)M, c, gamma, beta, running_mean, running_var, momentum, eps, update_times, mean_o,
+  spg_bn_finish(a0, a1, a2, (double)M, c, ch, running_mean, running_var, momentum, eps, update_times, mean_o,
                 rstd_o, s_o, t_o);
 }
 
@@ -1699,8 +1711,9 @@ __global__ void spg_bn_finish_kernel(const double* __restrict__ sync, int N, con
                                      float* s_o, float* t_o) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
-  spg_bn_finish(sync[c], sync[(long)N + c], sync[2 * (long)N + c], sync[3 * (long)N], c, gamma, beta, running_mean,
-                running_var, momentum, eps, update_times, mean_o, rstd_o, s_o, t_o);
+  spg_bn_finish(sync[c], sync[(long)N + c], sync[2 * (long)N + c], sync[3 * (long)N], c,
+                spg_bn_channel(c, gamma, beta, running_mean, running_var), running_mean, running_var, momentum, eps, update_times,
+                mean_o, rstd_o, s_o, t_o);
 }
 
 size_t spg_bn_finalize_scratch_doubles(int N) { return (size_t)SPG_FIN_SLICES * 3 * N; }
@@ -1789,12 +1802,14 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
   const int nslices = gridDim.y, slice = blockIdx.y;           // sliced like spg_bn_finalize_kernel
   const int per = (ntile + nslices - 1) / nslices;
   const int t0 = slice * per, t1 = min(ntile, t0 + per);
+  float ps = 0.f, pmean = 0.f, prstd = 0.f;                     // fetched now: in flight during the reduction
+  if (threadIdx.x < 16 && c < N && sync_out == nullptr) { ps = s[c]; pmean = mean[c]; prstd = rstd[c]; }
   double a = 0.0, b = 0.0;
   if (c < N)
-    for (int t = t0 + ty; t < t1; t += 256) {                    // four partials in flight per thread
-      float x[4], y[4];
+    for (int t = t0 + ty; t < t1; t += 512) {                    // eight partials in flight per thread (one round trip for 512)
+      float x[8], y[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int tt = t + 64 * u;
         const bool ok = tt < t1;
         const long o = ((long)(ok ? tt : t) * 2) * ldstat + c;
@@ -1802,7 +1817,7 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
         y[u] = ok ? stat[o + ldstat] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { a += (double)x[u]; b += (double)y[u]; }
+      for (int u = 0; u < 8; ++u) { a += (double)x[u]; b += (double)y[u]; }
     }
   a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
   a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
@@ -1851,10 +1866,10 @@ __global__ __launch_bounds__(1024) void spg_bn_bwd_finalize_kernel(const float* 
     return;
   }
   const double c1 = a / (double)count, c2 = b / (double)count;
-  consts[0 * N + c] = s[c];
+  consts[0 * N + c] = ps;
   consts[1 * N + c] = (float)c1;
-  consts[2 * N + c] = mean[c];
-  consts[3 * N + c] = (float)((double)s[c] * c2 * (double)rstd[c]);
+  consts[2 * N + c] = pmean;
+  consts[3 * N + c] = (float)((double)ps * c2 * (double)prstd);
 }
 
 __global__ void spg_bn_bwd_finish_kernel(const double* __restrict__ sync, int N, const float* __restrict__ s,
