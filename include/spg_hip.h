@@ -343,7 +343,9 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * iteration instead of the persistent dataflow-synchronised launch (A/B timing and the equality test; the two forms give
  * bit-identical results); key 9: 1 = the recurrent cell's parameter-gradient launches of spg_eccrnn_backward go to a
  * library-owned side stream next to the filter network's backward chain (experiment; measured slower, off by default).
- * Returns the previous value, -1 for an unknown key. */
+ * key 10: 1 = train-mode BatchNorm statistics of spg_pointnet_forward go through per-workgroup partials and a finalize launch
+ * per layer (the pre-round-3 path, still used with synchronised BatchNorm) instead of fixed-point slots finished by the
+ * consuming GEMM.  Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* Number of bounded-spin time-outs the persistent RNN-ECC launches of the current device have raised so far (0 in a correct
  * run; a wave that waits too long for a neighbour's state gives up instead of hanging the GPU).  Synchronises the device. */

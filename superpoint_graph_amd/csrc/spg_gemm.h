@@ -4,6 +4,33 @@
 #include "spg_common.h"
 
 enum { SPG_EPI_FWD = 0, SPG_EPI_BWD = 1 };
+
+// ---- BatchNorm statistics WITHOUT a finalize launch (round 3) ----------------------------------------------------------
+// Every small dependent launch of the step costs >= ~4.5 us whatever it computes, and a train-mode BatchNorm layer used to
+// cost two of them (finalize in the forward, finalize in the backward).  Instead the PRODUCER GEMM adds its per-workgroup
+// (sum x, sum x^2) as exactly associative 64-bit FIXED-POINT integers (fire-and-forget agent-scope atomics, 8 slots per
+// channel so that at most ~64 workgroups meet on one address), and the CONSUMER GEMM -- the next layer, which needs the scale /
+// shift anyway -- sums the 8 slots per channel in its prologue, computes mean / rstd / scale / shift in float64 and writes
+// them (every workgroup writes the same bits; workgroup 0 also advances the running statistics).  Integer addition is
+// order-independent, so the result is deterministic (bit-identical from run to run) although the arrival order is not.
+// Representation of a double v: hi = floor(v * 2^8), lo = frac(v * 2^8) * 2^44 (both int64): |v| <= 2^36 per contribution
+// (clamped), resolution 2^-52, up to 2^19 contributions per slot (4 M per layer) without overflow -- the launcher falls back to
+// the finalize path beyond that.  A non-finite contribution raises the flag word behind
+// the slots and the consumer then produces NaN statistics, as the arithmetic it replaces would.
+// Slot layout of one layer: int64 [8 slots][4 limbs: sum x hi, lo, sum x^2 hi, lo][C channels], then one flag word.
+// Measured (tools/probe/bn_atomic_probe.hip): +0.3..0.6 us on the producer's tail at C = 64..256, ~1 us of consumer prologue.
+#define SPG_FOLD_SLOTS 8
+#define SPG_FOLD_MAX_CONTRIBUTIONS (1L << 21)      // (a quarter of the representable count: 8 slots x 2^19)
+inline size_t spg_fold_slot_words(int C) { return (size_t)SPG_FOLD_SLOTS * 4 * C + 8; }
+struct SpgBnFold {
+  const unsigned long long* slots;   // null: nothing to do
+  int C, update_times;
+  float momentum, eps;
+  double count;                      // rows behind the statistics
+  const float *gamma, *beta;
+  float *rm, *rv;                    // running statistics (may be null)
+  float *mean, *rstd, *s, *t;        // outputs [C]
+};
 #define SPG_FC_ROWS 32   // rows per workgroup for the few-row GEMMs (FC layers over superpoints, filter net over edges)
 
 // Y[M,N] = prologue(A)[M,K] @ W[N,K]^T (+ bias), with a fused epilogue.
@@ -23,6 +50,8 @@ struct SpgGemmParams {
                       // of parts is decided by the launcher (one per tile and row-wave, or one per persistent workgroup and
                       // row-wave) and returned through spg_launch_gemm's stat_parts
   float* stat_cnt;    // forward: [parts] rows behind every partial (required with stat)
+  unsigned long long* stat_slots;   // forward, instead of stat / stat_cnt: fixed-point slots of this layer (SpgBnFold above)
+  SpgBnFold fold;     // forward: statistics of the layer that PRODUCED operand `a`, to be finished in this launch's prologue
   // max-pool over the rows of a tile (= the points of a superpoint), fused: BatchNorm is monotone per channel, so the
   // pooled normalised value is the raw MAX where the BatchNorm scale is >= 0 and the raw MIN otherwise, and the sign of
   // the scale gamma * rstd is the sign of gamma -- known before the statistics are.  pool_out [ntile, pool_ld] receives

@@ -182,6 +182,71 @@ __device__ __forceinline__ void spg_store_tile_vec(const f32x16 (&acc)[TI][TJ], 
   spg_store_tile_vec_impl<RW, CW, TI, TJ>(acc, st, ybase, ldy, lane);
 }
 
+// ---- fixed-point statistics slots (SpgBnFold, spg_gemm.h) ----
+__device__ __forceinline__ void spg_fx_split(double v, long long& hi, long long& lo) {
+  v = fmin(fmax(v, -0x1p36), 0x1p36);
+  const double t = v * 256.0, f = floor(t);
+  hi = (long long)f;                        // |hi| <= 2^44
+  lo = (long long)((t - f) * 0x1p44);       // [0, 2^44): 2^19 contributions fit one int64 slot
+}
+__device__ __forceinline__ double spg_fx_join(long long hi, long long lo) { return ((double)hi + (double)lo * 0x1p-44) * (1.0 / 256.0); }
+
+// one contribution (rows n, mean, M2 of those rows) of column `col` into the layer's slots
+__device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int C, int col, float n, float mean, float m2) {
+  const double sx = (double)n * (double)mean, sxx = (double)m2 + (double)n * (double)mean * (double)mean;
+  unsigned long long* s = slots + (size_t)(blockIdx.x & (SPG_FOLD_SLOTS - 1)) * 4 * C + col;
+  if (!(fabs(sx) <= 0x1p36 && sxx <= 0x1p36)) atomicOr(slots + (size_t)SPG_FOLD_SLOTS * 4 * C, 1ull);      // NaN / inf / out of range
+  long long hi, lo;
+  spg_fx_split(sx, hi, lo);
+  __hip_atomic_fetch_add(s, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(s + C, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  spg_fx_split(sxx, hi, lo);
+  __hip_atomic_fetch_add(s + 2 * (size_t)C, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(s + 3 * (size_t)C, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// consumer prologue: all threads of the workgroup; ends with a workgroup barrier behind which s / t / mean / rstd are readable
+__device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f) {
+  const int C = f.C;
+  const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    // every slot is an exact integer sum; the 8 slots are decoded and added in float64 in slot order (deterministic) -- adding
+    // the integers of all slots first could overflow (each slot may hold up to 2^19 contributions of up to 2^44)
+    double sx = 0.0, sxx = 0.0;
+#pragma unroll
+    for (int k = 0; k < SPG_FOLD_SLOTS; ++k) {
+      const unsigned long long* s = f.slots + (size_t)k * 4 * C + c;
+      sx += spg_fx_join((long long)s[0], (long long)s[C]);
+      sxx += spg_fx_join((long long)s[2 * (size_t)C], (long long)s[3 * (size_t)C]);
+    }
+    const double M = f.count;
+    if (bad) sx = __builtin_nan("");
+    const double mean = sx / M;
+    double m2 = sxx - M * mean * mean;
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = m2 / M;
+    const double rstd = 1.0 / sqrt(var + (double)f.eps);
+    const double g = f.gamma ? (double)f.gamma[c] : 1.0, be = f.beta ? (double)f.beta[c] : 0.0;
+    f.mean[c] = (float)mean;
+    f.rstd[c] = (float)rstd;
+    f.s[c] = (float)(g * rstd);
+    f.t[c] = (float)(be - mean * g * rstd);
+    if (first && f.rm != nullptr && f.update_times > 0) {
+      const double uvar = M > 1.0 ? m2 / (M - 1.0) : var;
+      float rm = f.rm[c], rv = f.rv[c];
+      for (int u = 0; u < f.update_times; ++u) {
+        rm = (1.f - f.momentum) * rm + f.momentum * (float)mean;
+        rv = (1.f - f.momentum) * rv + f.momentum * (float)uvar;
+      }
+      f.rm[c] = rm;
+      f.rv[c] = rv;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's copies of s / t have left for L2 ...
+  __syncthreads();                                         // ... before any of its waves loads them
+}
+
 // Statistics of a persistent workgroup: every wave keeps (rows, mean, M2) of ITS columns over the tiles it has seen
 // (merged tile by tile with Chan's formula) and writes ONE partial when the stream ends -- 4x fewer partials for the
 // finalize kernel, which then needs no slicing / last-arrival ticket.  Backward: plain running sums.
@@ -238,7 +303,7 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
   //      spg_bn_finalize_kernel combines the ntile*WI partials with Chan's formula ----
   const int nvw = min(max(mvalid - roww, 0), IT / WI);      // valid rows of this wave
   const long part = (long)tile * WI + wi;
-  if (p.stat != nullptr) {
+  if (p.stat != nullptr || p.stat_slots != nullptr) {
     const float inv = nvw > 0 ? 1.f / (float)nvw : 0.f;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -267,12 +332,16 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
         sacc->a[j] += delta * f;
         sacc->b[j] += m2 + delta * delta * (na * f);
       } else if (h == 0 && (FULL || col < p.N)) {
-        p.stat[(part * 2 + 0) * p.N + col] = mean;
-        p.stat[(part * 2 + 1) * p.N + col] = m2;
+        if (p.stat_slots != nullptr) {
+          if (nvw > 0) spg_slots_add_fwd(p.stat_slots, p.N, col, (float)nvw, mean, m2);
+        } else {
+          p.stat[(part * 2 + 0) * p.N + col] = mean;
+          p.stat[(part * 2 + 1) * p.N + col] = m2;
+        }
       }
     }
     if (sacc != nullptr) sacc->n += (float)nvw;
-    else if (lane == 0 && wj == 0 && n0 == 0) p.stat_cnt[part] = (float)nvw;
+    else if (lane == 0 && wj == 0 && n0 == 0 && p.stat_slots == nullptr) p.stat_cnt[part] = (float)nvw;
   }
   // ---- max-pool over the rows of the tile, fused (see SpgGemmParams): every lane keeps ONE extremum of its column --
   //      the maximum of key = v * sign, sign = -1 where the BatchNorm scale is negative -- with the first row that
@@ -521,6 +590,12 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
   constexpr int B_F4 = (WRED && PREC == 0) ? SPG_KC * (JT + 4) / 4 : (SPG_KC / 4) * (JT + 1);   // float4 slots of one weight buffer
   f32x16 acc[TI][TJ];
 
+  // BatchNorm of the layer that produced operand `a`: its statistics arrive as fixed-point slots and are finished here (every
+  // workgroup; spg_gemm.h) -- behind the barrier at its end the scale / shift arrays the staging pipes read exist
+  if constexpr (!WRED) {
+    if (p.fold.slots != nullptr) spg_bn_fold_fwd(p.fold);
+  }
+
   if constexpr (AMODE >= 0 && FULL) {
     static_assert(4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) + 2 * WI * JT <= 4 * (A_F4 + B_F4), "epilogue staging + pooling exchange must fit one LDS buffer");
     int tile = blockIdx.x, ct = blockIdx.y;
@@ -591,7 +666,7 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
     for (int j = 0; j < TJ; ++j) { sacc.a[j] = 0.f; sacc.b[j] = 0.f; }
     sacc.s1 = f32x4{0.f, 0.f, 0.f, 0.f}; sacc.s2 = sacc.s1;
     const int tile0 = tile;                      // < rstride: index of this workgroup among those of its column tile
-    const bool accum = STREAM && p.stat != nullptr && p.stat_accum;
+    const bool accum = STREAM && (p.stat != nullptr || p.stat_slots != nullptr) && p.stat_accum;
     // backward kernels (two operand streams + four constant arrays per register set): the loads of the next tile's SECOND
     // chunk are issued after the epilogue instead of under the last chunk -- nothing but the accumulators and the
     // loop-invariant offsets is then live across the epilogue (no spills)
@@ -735,11 +810,15 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
               na = nn;
             }
             if (col < p.N) {
-              p.stat[(part * 2 + 0) * p.N + col] = mean;
-              p.stat[(part * 2 + 1) * p.N + col] = m2;
+              if (p.stat_slots != nullptr) {
+                spg_slots_add_fwd(p.stat_slots, p.N, col, na, mean, m2);
+              } else {
+                p.stat[(part * 2 + 0) * p.N + col] = mean;
+                p.stat[(part * 2 + 1) * p.N + col] = m2;
+              }
             }
           }
-          if (lane == 0 && wj == 0 && n0 == 0) p.stat_cnt[part] = sacc.n * (float)WI;
+          if (lane == 0 && wj == 0 && n0 == 0 && p.stat_slots == nullptr) p.stat_cnt[part] = sacc.n * (float)WI;
         }
       } else {
         constexpr int CW = JT / WJ, LPR = CW / 4;
@@ -970,7 +1049,7 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
 #else
         const int no_stat_accum = g_tune[SPG_TUNE_NO_STAT_ACCUM];
 #endif
-        q.stat_accum = !no_stat_accum && p.stat != nullptr && (!WRED || (q.vec_store && p.N <= p.n_mask));
+        q.stat_accum = !no_stat_accum && (p.stat != nullptr || p.stat_slots != nullptr) && (!WRED || (q.vec_store && p.N <= p.n_mask));
         if (q.stat_accum && stat_parts != nullptr) *stat_parts = (int)(q.rstride < q.ntile ? q.rstride : q.ntile);      // one per workgroup
         grid = dim3((unsigned)slots, 1);
         if constexpr (IT == 128 && !(WRED && JT == 128)) {
@@ -1014,6 +1093,8 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts)
   SPG_CHECK_ARG(p.epi == SPG_EPI_FWD || p.Y != nullptr, "backward epilogue needs an output");
   SPG_CHECK_ARG((p.epi == SPG_EPI_BWD) == (p.w_red != 0), "forward epilogue <-> [N,K] weights, backward epilogue <-> [K,N] weights");
   SPG_CHECK_ARG(p.epi != SPG_EPI_FWD || p.stat == nullptr || p.stat_cnt != nullptr, "forward statistics need stat_cnt");
+  SPG_CHECK_ARG(p.stat_slots == nullptr || (p.epi == SPG_EPI_FWD && p.stat == nullptr), "statistics slots replace the partials of a forward launch");
+  SPG_CHECK_ARG(p.fold.slots == nullptr || (p.epi == SPG_EPI_FWD && !p.w_red), "a statistics fold belongs to a forward launch");
   // vector path: 16-byte aligned rows, and every row addressable up to the next multiple of 4 of its logical width
   // (padded leading dimensions; partial quads are masked through the A operand / the store mask)
   const bool walign = (p.ldw & 3) == 0 && (((uintptr_t)p.W) & 15) == 0 && p.ldw >= (((p.w_red ? p.N : p.K) + 3) & ~3);

@@ -34,6 +34,7 @@ struct Layer {
   float* Wpad = nullptr;        // FC layers whose input width is not a multiple of 4: zero-padded copy of W
   long ldw = 0;                 // leading dimension of the weight actually fed to the kernels
   float *mean = nullptr, *rstd = nullptr, *s = nullptr, *t = nullptr;   // BN batch constants
+  unsigned long long* slots = nullptr;      // train mode: fixed-point statistics slots of this layer (SpgBnFold, spg_gemm.h)
   float *dW = nullptr, *db = nullptr, *dgamma = nullptr, *dbeta = nullptr;
 };
 
@@ -58,6 +59,9 @@ struct Plan {
   float *stat = nullptr, *stat_cnt = nullptr, *pmax = nullptr, *pmin = nullptr;
   double* fin = nullptr;    // scratch of the sliced BatchNorm finalize
   int *imax = nullptr, *imin = nullptr;
+  unsigned long long* slots_all = nullptr;  // all layers' statistics slots, one region (cleared by one memset per forward)
+  size_t slots_words = 0;
+  bool fold = false;        // train mode: BatchNorm statistics are finished by the consuming GEMM instead of a finalize launch
   size_t bytes = 0;
 };
 
@@ -136,6 +140,14 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
       l.Wb_t = cv.take<char>(spg_split_bytes(l.cin, l.cout));
     }
   }
+  if (pl.training) {
+    size_t words = 0;
+    for (const Layer& l : pl.L) if (l.bn) words += spg_fold_slot_words(l.cout);
+    pl.slots_all = cv.take<unsigned long long>(words); pl.slots_words = words;
+    size_t off = 0;
+    for (Layer& l : pl.L)
+      if (l.bn) { l.slots = pl.slots_all ? pl.slots_all + off : nullptr; off += spg_fold_slot_words(l.cout); }
+  }
   auto carve_segment = [&](Segment& sg, float* final_out) {
     for (size_t k = 0; k < sg.convs.size(); ++k) {
       Layer& l = pl.L[sg.convs[k]];
@@ -197,7 +209,18 @@ SpgOperand input_operand(const Plan& pl, const Segment& sg, bool is_fc, size_t k
   return op_affine(p, p.y, p.ldy, p.cout);
 }
 
+// the statistics of `prod` (rows = `count`) finished in the prologue of the launch that consumes its output
+SpgBnFold fold_of(const Plan& pl, const Layer& prod, long count, int update_times) {
+  SpgBnFold f; memset(&f, 0, sizeof(f));
+  if (!pl.fold || !prod.bn) return f;
+  f.slots = prod.slots; f.C = prod.cout; f.update_times = update_times; f.momentum = pl.cfg.bn_momentum; f.eps = pl.cfg.bn_eps;
+  f.count = (double)count; f.gamma = prod.gamma; f.beta = prod.beta; f.rm = prod.rm; f.rv = prod.rv;
+  f.mean = prod.mean; f.rstd = prod.rstd; f.s = prod.s; f.t = prod.t;
+  return f;
+}
+
 int bn_stats(const Plan& pl, Layer& l, int nparts, long M, int update_times, hipStream_t st) {
+  if (pl.training && pl.fold) return 0;      // finished by the consumer (fold_of)
   if (pl.training)
     return spg_launch_bn_finalize(pl.stat, pl.stat_cnt, nparts, M, l.cout, l.gamma, l.beta, l.rm, l.rv,
                                   pl.cfg.bn_momentum, pl.cfg.bn_eps, update_times, l.mean, l.rstd, l.s, l.t, pl.fin, st);
@@ -233,11 +256,13 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     const bool last = k + 1 == sg.convs.size();
     SpgGemmParams g; memset(&g, 0, sizeof(g));
     g.a = input_operand(pl, sg, false, k, clouds, stnT);
+    if (k > 0) g.fold = fold_of(pl, pl.L[sg.convs[k - 1]], pl.M, update_times);
     g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = (int)pl.M; g.N = l.cout; g.K = l.cin;
     g.rows_per_tile = pl.P; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
     if (l.Wb_f != nullptr) { g.Wb = l.Wb_f; g.ldwb = spg_split_ld(l.cin); g.wb_part_bytes = (long)l.cout * g.ldwb * 2; }
     if (last && !pl.training) g.Y = nullptr;     // inference: only the pooled values of the last conv are consumed
     g.stat = pl.training ? pl.stat : nullptr; g.stat_cnt = pl.stat_cnt;
+    if (pl.fold) { g.stat = nullptr; g.stat_slots = l.slots; }
     int nparts = 0;
     if (last) {      // max-pool fused into the epilogue: the sign of the BatchNorm scale is the sign of gamma
       g.pool_out = sg.pooled; g.pool_idx = sg.aidx; g.pool_ld = sg.ldpool; g.pool_sign = l.gamma;
@@ -250,10 +275,13 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     Layer& l = pl.L[sg.fcs[k]];
     SpgGemmParams g; memset(&g, 0, sizeof(g));
     g.a = input_operand(pl, sg, true, k, clouds, stnT);
+    // the producer's statistics: the last convolution (over all points) for the first fc layer, else the previous fc layer
+    g.fold = k == 0 ? fold_of(pl, pl.L[sg.convs.back()], pl.M, update_times) : fold_of(pl, pl.L[sg.fcs[k - 1]], pl.B, update_times);
     if (l.Wpad) SPG_TRY(spg_launch_pad_rows(l.W, l.cin, l.Wpad, l.ldw, l.cout, l.cin, st));
     g.W = l.Wpad ? l.Wpad : l.W; g.ldw = l.ldw; g.bias = l.b; g.M = pl.B; g.N = l.cout; g.K = l.cin;
     g.rows_per_tile = SPG_FC_ROWS; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
     g.stat = (pl.training && l.bn) ? pl.stat : nullptr; g.stat_cnt = pl.stat_cnt;
+    if (pl.fold && l.bn) { g.stat = nullptr; g.stat_slots = l.slots; }
     int nparts = 0;
     SPG_TRY(spg_launch_gemm(g, st, &nparts));
     if (l.bn) SPG_TRY(bn_stats(pl, l, nparts, pl.B, update_times, st));
@@ -449,6 +477,14 @@ extern "C" int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, cons
         sb.jobs[sb.njobs++] = SpgSplitJob{l.W, l.cin, l.cout, l.cin, l.Wb_f, l.Wb_t};
       }
     SPG_TRY(spg_launch_split_weights(sb, st));
+  }
+  // train mode: BatchNorm statistics travel as fixed-point slots from each producer GEMM to its consumer (spg_gemm.h) -- no
+  // finalize launches; not with synchronised BatchNorm (the ranks' all-reduce sits between producer and consumer)
+  // (every tile contributes at most 4 wave partials per channel: far below the slots' capacity up to ~500 k superpoints)
+  pl.fold = pl.training && !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && 4L * B <= SPG_FOLD_MAX_CONTRIBUTIONS;
+  if (pl.fold) {
+    hipError_t me = hipMemsetAsync(pl.slots_all, 0, pl.slots_words * sizeof(unsigned long long), st);
+    if (me != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(me)); return (int)me; }
   }
   const float* stnT = ext_transform;      // [B, 4] = T - I of an externally evaluated STN (LocalCloudEmbedder), or null
   if (pl.has_stn) {
