@@ -31,6 +31,16 @@ struct SpgBnFold {
   float *rm, *rv;                    // running statistics (may be null)
   float *mean, *rstd, *s, *t;        // outputs [C]
 };
+// backward: (sum dz, sum dz * xhat) of a layer -> the constants of the BatchNorm-backward prologue, finished by the first
+// launch that applies them (the layer's weight gradient); same slots layout
+struct SpgBnFoldBwd {
+  const unsigned long long* slots;   // null: nothing to do
+  int C;
+  double count;
+  const float *s, *mean, *rstd;      // forward constants of the layer [C]
+  float* consts;                     // out [4][C] = {s, c1, mean, s * c2 * rstd}
+  float *dgamma, *dbeta;             // out [C] (may be null)
+};
 #define SPG_FC_ROWS 32   // rows per workgroup for the few-row GEMMs (FC layers over superpoints, filter net over edges)
 
 // Y[M,N] = prologue(A)[M,K] @ W[N,K]^T (+ bias), with a fused epilogue.
@@ -94,6 +104,7 @@ struct SpgWgradParams {
   float* colsum;      // [nsplit][N] or null: column sums of the (finished) `a` operand over each split's rows -- the bias
                       // gradient of a layer without BatchNorm comes with the weight gradient instead of from its own launch
                       // (identity `a` operands only)
+  SpgBnFoldBwd fold;  // BatchNorm-backward sums of the `a` operand's layer, to be finished in this launch's prologue (or slots == null)
   int allow_lowp;     // 1: this launch may use the opt-in bf16 / split-bf16 MFMA mode (spg_tune key 7).  Set by the PointNet
                       // convolutions only; 0 (memset default) keeps fp32 MFMA whatever the shape (filter net, RNN cell, dense layer)
 };

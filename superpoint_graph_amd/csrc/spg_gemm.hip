@@ -191,11 +191,10 @@ __device__ __forceinline__ void spg_fx_split(double v, long long& hi, long long&
 }
 __device__ __forceinline__ double spg_fx_join(long long hi, long long lo) { return ((double)hi + (double)lo * 0x1p-44) * (1.0 / 256.0); }
 
-// one contribution (rows n, mean, M2 of those rows) of column `col` into the layer's slots
-__device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int C, int col, float n, float mean, float m2) {
-  const double sx = (double)n * (double)mean, sxx = (double)m2 + (double)n * (double)mean * (double)mean;
+// one contribution (two sums) of column `col` into the layer's slots
+__device__ __forceinline__ void spg_slots_add(unsigned long long* slots, int C, int col, double sx, double sxx) {
   unsigned long long* s = slots + (size_t)(blockIdx.x & (SPG_FOLD_SLOTS - 1)) * 4 * C + col;
-  if (!(fabs(sx) <= 0x1p36 && sxx <= 0x1p36)) atomicOr(slots + (size_t)SPG_FOLD_SLOTS * 4 * C, 1ull);      // NaN / inf / out of range
+  if (!(fabs(sx) <= 0x1p36 && fabs(sxx) <= 0x1p36)) atomicOr(slots + (size_t)SPG_FOLD_SLOTS * 4 * C, 1ull);      // NaN / inf / out of range
   long long hi, lo;
   spg_fx_split(sx, hi, lo);
   __hip_atomic_fetch_add(s, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -203,6 +202,41 @@ __device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int
   spg_fx_split(sxx, hi, lo);
   __hip_atomic_fetch_add(s + 2 * (size_t)C, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_fetch_add(s + 3 * (size_t)C, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// forward: (rows n, mean, M2 of those rows) -> (sum x, sum x^2)
+__device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int C, int col, float n, float mean, float m2) {
+  spg_slots_add(slots, C, col, (double)n * (double)mean, (double)m2 + (double)n * (double)mean * (double)mean);
+}
+
+// backward consumer prologue (weight-gradient kernels): sums (sum dz, sum dz * xhat) of the layer whose BatchNorm-backward
+// formula this launch's `a` operand applies -> consts [4][C] = {s, c1, mean, s * c2 * rstd}; workgroup 0 also writes the
+// BatchNorm parameter gradients.  All threads of the workgroup; ends with a workgroup barrier.
+__device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f) {
+  const int C = f.C;
+  const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < SPG_FOLD_SLOTS; ++k) {
+      const unsigned long long* s = f.slots + (size_t)k * 4 * C + c;
+      a += spg_fx_join((long long)s[0], (long long)s[C]);
+      b += spg_fx_join((long long)s[2 * (size_t)C], (long long)s[3 * (size_t)C]);
+    }
+    if (bad) a = __builtin_nan("");
+    const float ps = f.s[c], pmean = f.mean[c], prstd = f.rstd[c];
+    const double c1 = a / f.count, c2 = b / f.count;
+    f.consts[0 * C + c] = ps;
+    f.consts[1 * C + c] = (float)c1;
+    f.consts[2 * C + c] = pmean;
+    f.consts[3 * C + c] = (float)((double)ps * c2 * (double)prstd);
+    if (first) {
+      if (f.dbeta) f.dbeta[c] = (float)a;
+      if (f.dgamma) f.dgamma[c] = (float)b;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 // consumer prologue: all threads of the workgroup; ends with a workgroup barrier behind which s / t / mean / rstd are readable
@@ -407,8 +441,14 @@ __device__ __forceinline__ void spg_bwd_stat_store(const SpgGemmParams& p, f32x4
     for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
   }
   if (lane < LPR) {
-    *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 0) * p.N + col) = s1;
-    *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 1) * p.N + col) = s2;
+    if (p.stat_slots != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < p.n_mask) spg_slots_add(p.stat_slots, p.n_mask, col + e, (double)s1[e], (double)s2[e]);
+    } else {
+      *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 0) * p.N + col) = s1;
+      *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 1) * p.N + col) = s2;
+    }
   }
 }
 
@@ -428,7 +468,7 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32
   const int wi = wave / WJ, wj = wave % WJ;
   const int colw = wj * CW, roww = wi * RW;
   float* st = red + wave * SPG_EPI_WAVE_FLOATS(RW, CW);
-  const bool do_stats = p.stat != nullptr && p.mmean != nullptr;           // uniform
+  const bool do_stats = (p.stat != nullptr || p.stat_slots != nullptr) && p.mmean != nullptr;           // uniform
   const bool do_mask = p.mask_relu != 0 && p.Yp != nullptr;                // uniform
   const bool use_y = p.Yp != nullptr && (do_stats || do_mask);
   const int lr = lane / LPR, lc = 4 * (lane % LPR);
@@ -472,7 +512,7 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32
     }
   if (sacc != nullptr) {               // persistent stream: running sums, written once when the stream ends
     sacc->s1 += s1; sacc->s2 += s2;
-  } else if (p.stat != nullptr) {
+  } else if (p.stat != nullptr || p.stat_slots != nullptr) {
     spg_bwd_stat_store<IT, JT, WI, WJ>(p, s1, s2, (long)tile * WI + wi, n0);
   }
 }
@@ -486,7 +526,7 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
   const int colw = wj * (JT / WJ), roww = wi * (IT / WI);
-  const bool do_stats = p.stat != nullptr && p.mmean != nullptr;           // uniform
+  const bool do_stats = (p.stat != nullptr || p.stat_slots != nullptr) && p.mmean != nullptr;           // uniform
   const bool do_mask = p.mask_relu != 0 && p.Yp != nullptr;                // uniform
   const bool use_y = p.Yp != nullptr && (do_stats || do_mask);
 #pragma unroll
@@ -533,13 +573,17 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the 16-load batches of different sub-tiles apart (register pressure)
     }
-    if (p.stat != nullptr) {     // per-wave partial sums, no LDS / barrier; spg_bn_bwd_finalize_kernel adds them up
+    if (p.stat != nullptr || p.stat_slots != nullptr) {     // per-wave partial sums, no LDS / barrier
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (h == 0 && (FULL || col < p.N)) {
         const long part = (long)tile * WI + wi;
-        p.stat[(part * 2 + 0) * p.N + col] = s1;
-        p.stat[(part * 2 + 1) * p.N + col] = s2;
+        if (p.stat_slots != nullptr) {
+          if (col < p.n_mask) spg_slots_add(p.stat_slots, p.n_mask, col, (double)s1, (double)s2);
+        } else {
+          p.stat[(part * 2 + 0) * p.N + col] = s1;
+          p.stat[(part * 2 + 1) * p.N + col] = s2;
+        }
       }
     }
   }
@@ -555,7 +599,7 @@ __device__ __forceinline__ void spg_tile_epilogue(const SpgGemmParams& p, f32x16
     if (mvalid == IT && n0 + JT <= p.N) spg_epilogue_fwd<IT, JT, WI, WJ, true, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0, sacc);
     else spg_epilogue_fwd<IT, JT, WI, WJ, false, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0);
   } else {
-    const bool full = mvalid == IT && n0 + JT <= p.N && (n0 + JT <= p.n_mask || (p.stat == nullptr && !p.mask_relu));
+    const bool full = mvalid == IT && n0 + JT <= p.N && (n0 + JT <= p.n_mask || (p.stat == nullptr && p.stat_slots == nullptr && !p.mask_relu));
     if (FULL && full && p.vec_store) spg_epilogue_bwd_vec<IT, JT, WI, WJ>(p, acc, red, tile, m0, n0, sacc);
     else if (full) spg_epilogue_bwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
     else spg_epilogue_bwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
@@ -840,8 +884,14 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
             s1 += *reinterpret_cast<const f32x4*>(xch + (w * JT + cl) * 2);
             s2 += *reinterpret_cast<const f32x4*>(xch + (w * JT + cl) * 2 + 4);
           }
-          *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 0) * p.N + n0 + cl) = s1;
-          *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 1) * p.N + n0 + cl) = s2;
+          if (p.stat_slots != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + cl + e < p.n_mask) spg_slots_add(p.stat_slots, p.n_mask, n0 + cl + e, (double)s1[e], (double)s2[e]);
+          } else {
+            *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 0) * p.N + n0 + cl) = s1;
+            *reinterpret_cast<f32x4*>(p.stat + (part * 2 + 1) * p.N + n0 + cl) = s2;
+          }
         }
       }
     }
@@ -1093,7 +1143,7 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts)
   SPG_CHECK_ARG(p.epi == SPG_EPI_FWD || p.Y != nullptr, "backward epilogue needs an output");
   SPG_CHECK_ARG((p.epi == SPG_EPI_BWD) == (p.w_red != 0), "forward epilogue <-> [N,K] weights, backward epilogue <-> [K,N] weights");
   SPG_CHECK_ARG(p.epi != SPG_EPI_FWD || p.stat == nullptr || p.stat_cnt != nullptr, "forward statistics need stat_cnt");
-  SPG_CHECK_ARG(p.stat_slots == nullptr || (p.epi == SPG_EPI_FWD && p.stat == nullptr), "statistics slots replace the partials of a forward launch");
+  SPG_CHECK_ARG(p.stat_slots == nullptr || p.stat == nullptr, "statistics slots replace the partials");
   SPG_CHECK_ARG(p.fold.slots == nullptr || (p.epi == SPG_EPI_FWD && !p.w_red), "a statistics fold belongs to a forward launch");
   // vector path: 16-byte aligned rows, and every row addressable up to the next multiple of 4 of its logical width
   // (padded leading dimensions; partial quads are masked through the A operand / the store mask)
@@ -1138,6 +1188,9 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   const int i0 = blockIdx.y * IT, j0 = blockIdx.z * JT;
   const long ms = (long)split * p.rows_per_split;
   const long me = min((long)p.M, ms + p.rows_per_split);
+  // BatchNorm backward of the `a` operand's layer: its sums arrive as fixed-point slots and become the constants of the
+  // BNBWD / POOLBWD prologue here (every workgroup; spg_gemm.h) -- readable behind the barrier at its end
+  if (p.fold.slots != nullptr) spg_bn_fold_bwd(p.fold);
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)

@@ -35,6 +35,7 @@ struct Layer {
   long ldw = 0;                 // leading dimension of the weight actually fed to the kernels
   float *mean = nullptr, *rstd = nullptr, *s = nullptr, *t = nullptr;   // BN batch constants
   unsigned long long* slots = nullptr;      // train mode: fixed-point statistics slots of this layer (SpgBnFold, spg_gemm.h)
+  unsigned long long* slots_bwd = nullptr;  // the same for the backward sums (sum dz, sum dz * xhat)
   float *dW = nullptr, *db = nullptr, *dgamma = nullptr, *dbeta = nullptr;
 };
 
@@ -142,11 +143,14 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
   }
   if (pl.training) {
     size_t words = 0;
-    for (const Layer& l : pl.L) if (l.bn) words += spg_fold_slot_words(l.cout);
+    for (const Layer& l : pl.L) if (l.bn) words += 2 * spg_fold_slot_words(l.cout);
     pl.slots_all = cv.take<unsigned long long>(words); pl.slots_words = words;
     size_t off = 0;
     for (Layer& l : pl.L)
-      if (l.bn) { l.slots = pl.slots_all ? pl.slots_all + off : nullptr; off += spg_fold_slot_words(l.cout); }
+      if (l.bn) {
+        l.slots = pl.slots_all ? pl.slots_all + off : nullptr; off += spg_fold_slot_words(l.cout);
+        l.slots_bwd = pl.slots_all ? pl.slots_all + off : nullptr; off += spg_fold_slot_words(l.cout);
+      }
   }
   auto carve_segment = [&](Segment& sg, float* final_out) {
     for (size_t k = 0; k < sg.convs.size(); ++k) {
@@ -344,9 +348,18 @@ int zero_async(float* p, size_t n, hipStream_t st) {
 
 // Backward of one segment.  `cur` is the gradient wrt the raw output of the segment's last fc layer
 // (IDENT operand).  If want_dxy, the gradient wrt the first two input channels of conv 0 is left in s.dxy.
+// the BatchNorm-backward sums of `prod` (rows = count), to be finished by the next weight-gradient launch (spg_gemm.h)
+SpgBnFoldBwd fold_bwd_of(const Plan& pl, const Layer& prod, long count, float* consts) {
+  SpgBnFoldBwd f; memset(&f, 0, sizeof(f));
+  f.slots = prod.slots_bwd; f.C = prod.cout; f.count = (double)count; f.s = prod.s; f.mean = prod.mean; f.rstd = prod.rstd;
+  f.consts = consts; f.dgamma = prod.dgamma; f.dbeta = prod.dbeta;
+  return f;
+}
+
 int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, SpgOperand cur, const float* clouds,
                      const float* stnT, bool want_dxy, hipStream_t st) {
   const int B = pl.B;
+  SpgBnFoldBwd pending; memset(&pending, 0, sizeof(pending));     // set by a data-gradient launch, consumed by the next weight gradient
   // ---- fc head ----
   float* fz[2] = {s.fzA, s.fzB};
   int flip = 0;
@@ -354,6 +367,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     Layer& l = pl.L[sg.fcs[k]];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, true, k, clouds, stnT); w.M = B; w.N = l.cout; w.K = l.cin;
+    w.fold = pending; memset(&pending, 0, sizeof(pending));
     // a bias without BatchNorm behind it: its gradient (column sums of `cur`, an IDENT operand here) rides along with the
     // weight gradient; a bias in front of train-mode BatchNorm has zero gradient
     const bool bias_rides = l.db != nullptr && !l.bn && cur.mode == SPG_PRO_IDENT;
@@ -373,12 +387,15 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     g.Yp = first ? sg.pooled : prod.y; g.ldyp = first ? sg.ldpool : prod.ldy;
     g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
     g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
+    if (pl.fold) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; }
     int nparts = 0;
     SPG_TRY(spg_launch_gemm(g, st, &nparts));
     // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
     const int C = prod.cout;
     if (first && s.grad_global != nullptr && sg.nextra > 0)     // columns >= C pass through: gradient wrt the global features
       SPG_TRY(spg_launch_copy2d(out + C, sg.ldpool, s.grad_global, sg.nextra, B, sg.nextra, st));
+    if (pl.fold) pending = fold_bwd_of(pl, prod, first ? pl.M : (long)B, s.consts);      // finished by the next weight gradient
+    else
     SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, first ? pl.M : (long)B, C, prod.s, prod.mean,
                                        prod.rstd, s.consts, prod.dgamma, prod.dbeta, s.fin, st));
     if (!first) {
@@ -397,6 +414,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     Layer& l = pl.L[sg.convs[k]];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, false, k, clouds, stnT); w.M = (int)pl.M; w.N = l.cout; w.K = l.cin;
+    w.fold = pending; memset(&pending, 0, sizeof(pending));
     w.allow_lowp = 1;      // the opt-in precision modes act on the PointNet convolutions only
     SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
     if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
@@ -410,8 +428,11 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.ldy;
       g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
       g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
+      if (pl.fold) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; }
       int nparts = 0;
       SPG_TRY(spg_launch_gemm(g, st, &nparts));
+      if (pl.fold) pending = fold_bwd_of(pl, prod, pl.M, s.consts);
+      else
       SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, pl.M, prod.cout, prod.s, prod.mean, prod.rstd, s.consts,
                                          prod.dgamma, prod.dbeta, s.fin, st));
       cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, prod.cout);
@@ -482,7 +503,7 @@ extern "C" int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, cons
   // finalize launches; not with synchronised BatchNorm (the ranks' all-reduce sits between producer and consumer)
   // (every tile contributes at most 4 wave partials per channel: far below the slots' capacity up to ~500 k superpoints)
   pl.fold = pl.training && !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && 4L * B <= SPG_FOLD_MAX_CONTRIBUTIONS;
-  if (pl.fold) {
+  if (pl.training) {      // always in train mode: the backward decides about its own slots independently (they are cleared here too)
     hipError_t me = hipMemsetAsync(pl.slots_all, 0, pl.slots_words * sizeof(unsigned long long), st);
     if (me != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(me)); return (int)me; }
   }
@@ -546,6 +567,7 @@ extern "C" int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, con
   // the forward wrote the last fc output to `emb`; it is not needed by the backward, so pass a dummy
   SPG_TRY(make_plan(cfg, B, 1, workspace, params, (float*)grad_emb /*unused as y*/, pl));
   pl.main.extra = clouds_global;
+  pl.fold = !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && 4L * B <= SPG_FOLD_MAX_CONTRIBUTIONS;
   bind_grads(pl, grads);
   BwdScratch s;
   carve_bwd(pl, bwd_workspace, s);

@@ -282,6 +282,12 @@ def pointnet_backward(state: PointNetState, groups, grad_emb, out_grads=None, wa
     destination is a pre-zeroed flat gradient buffer)."""
     cfg, B = state.cfg, state.B
     _require_training_state(state, 'PointNet')
+    if getattr(state, 'backward_done', False):
+        # the BatchNorm-backward sums are accumulated into slots of the forward workspace that the forward cleared (spg_gemm.h):
+        # a second backward pass over the same forward would add to them again
+        raise RuntimeError('PointNet: a second backward() through the same forward is not supported by the HIP path '
+                           '(run the forward again)')
+    state.backward_done = True
     grad_emb = _req(grad_emb.contiguous(), torch.float32, 'grad_emb')
     nbytes = lib().spg_pointnet_bwd_workspace_bytes(ctypes.byref(cfg), B)
     bws = torch.empty(nbytes, dtype=torch.uint8, device=grad_emb.device)
