@@ -121,6 +121,10 @@ int spg_launch_split_weights(const SpgSplitBatch& b, hipStream_t stream);
 int spg_gemm_precision();      // spg_tune key 7: 0 fp32 MFMA, 1 bf16, 3 split-bf16
 
 int spg_gemm_ntiles(const SpgGemmParams& p);
+// Data-gradient launches with 128-column tiles keep one workgroup per tile (no persistent stream: registers), i.e. one
+// statistics contribution per tile and row-wave -- 2000 per channel on the unit scene.  That many atomics cost more on the
+// kernel's tail (+11 us measured) than the finalize launch they would save (6 us): such launches keep the partials path.
+inline bool spg_gemm_bwd_stats_want_partials(const SpgGemmParams& g) { return g.w_red && g.N > 64 && g.rows_per_tile > SPG_FC_ROWS; }
 // number of statistics / pooling partials per row tile (= waves along the rows of the tile shape used for this problem)
 int spg_gemm_row_waves(int rows_per_tile, int N);
 int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts = nullptr);

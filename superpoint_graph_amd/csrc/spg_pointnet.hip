@@ -428,10 +428,11 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.ldy;
       g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
       g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
-      if (pl.fold) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; }
+      const bool foldk = pl.fold && !spg_gemm_bwd_stats_want_partials(g);
+      if (foldk) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; }
       int nparts = 0;
       SPG_TRY(spg_launch_gemm(g, st, &nparts));
-      if (pl.fold) pending = fold_bwd_of(pl, prod, pl.M, s.consts);
+      if (foldk) pending = fold_bwd_of(pl, prod, pl.M, s.consts);
       else
       SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, pl.M, prod.cout, prod.s, prod.mean, prod.rstd, s.consts,
                                          prod.dgamma, prod.dbeta, s.fin, st));
