@@ -366,7 +366,8 @@ class CloudEmbedder():
             idx_valid = torch.nonzero(valid).reshape(-1)
             slot = torch.cumsum(valid.to(torch.int64), 0) - 1          # row of the embedding matrix, -1 for too-small superpoints
             slot[~valid] = -1
-            self._flag_cache = (clouds_flag, idx_valid.to(dev), slot.to(dev))
+            # (pinned staging + non-blocking copies: a pageable H2D would stall the host until the stream has drained)
+            self._flag_cache = (clouds_flag, idx_valid.pin_memory().to(dev, non_blocking=True), slot.pin_memory().to(dev, non_blocking=True))
         self._slot_of_row = self._flag_cache[2]
         return self._flag_cache[1], clouds.to(dev, non_blocking=True), clouds_global.to(dev, non_blocking=True)
 

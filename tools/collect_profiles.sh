@@ -1,11 +1,11 @@
 #!/bin/bash
 # Everything the round's measurement deliverables need, in one GPU-box call (run from the repo root):
-#   tools/collect_profiles.sh <tag>            e.g. r02  ->  gpurun_out/<tag>_{bench.json,kernel_stats.txt,pmc_*.txt,gemm_traffic.json}
+#   tools/collect_profiles.sh <tag>            e.g. r03  ->  gpurun_out/<tag>_{bench.json,kernel_stats.txt,pmc_*.txt,gemm_traffic.json}
 # Passes: (1) bench.py (default flags: the driver's command), (2) rocprofv3 --kernel-trace of the train steps, summarised
 # over the steady-state window (tools/prof_summary.py), (3)+(4) --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes
 # (never with other trace domains), each followed by the known-byte-count calibration of tools/pmc_calib.py.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
