@@ -70,15 +70,15 @@ class GraphConvInfo(object):
         if edges_h.size and (int(edges_h.min()) < 0 or int(edges_h.max()) >= p):
             raise IndexError('GraphConvInfo.set_batch_device: an edge endpoint is outside [0, number of nodes)')
         self._degrees = torch.from_numpy(np.bincount(edges_h[:, 1], minlength=p).astype(np.int64))
-        # pinned staging: a copy from pageable memory blocks the host until the stream reaches it, i.e. until the PREVIOUS step
-        # has drained -- host and GPU would take turns instead of overlapping
-        edges_d = torch.from_numpy(edges_h).pin_memory().to(dev, non_blocking=True)
+        # through the pinned staging ring: a copy from pageable memory blocks the host until the stream reaches it, i.e. until
+        # the PREVIOUS step has drained -- host and GPU would take turns instead of overlapping
+        edges_d = ops.upload(torch.from_numpy(edges_h), dev)
         feats, self._idxe = edge_feat_func(edgeattrs)
         if self._idxe is not None:
             raise NotImplementedError('filter sharing (idxe) is not supported by set_batch_device')
         idxn, degs_gpu, perm, _err = ops.set_batch(edges_d, p)      # the device flag duplicates the host check above
         self._idxn, self._degrees_gpu = idxn, degs_gpu
-        feats_d = feats.float().contiguous().pin_memory().to(dev, non_blocking=True)
+        feats_d = ops.upload(feats.float(), dev)
         self._edgefeats = ops.gather_rows(feats_d, perm) if idxn.numel() else feats_d
         self._edge_indexes = None                                   # built on demand (get_pyg_buffers): only the pyg path reads it
         self._graph = ops.DeviceGraph(self._idxn, self._degrees_gpu)

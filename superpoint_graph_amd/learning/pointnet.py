@@ -366,8 +366,8 @@ class CloudEmbedder():
             idx_valid = torch.nonzero(valid).reshape(-1)
             slot = torch.cumsum(valid.to(torch.int64), 0) - 1          # row of the embedding matrix, -1 for too-small superpoints
             slot[~valid] = -1
-            # (pinned staging + non-blocking copies: a pageable H2D would stall the host until the stream has drained)
-            self._flag_cache = (clouds_flag, idx_valid.pin_memory().to(dev, non_blocking=True), slot.pin_memory().to(dev, non_blocking=True))
+            # (pinned staging ring, non-blocking: a pageable H2D would stall the host until the stream has drained)
+            self._flag_cache = (clouds_flag, ops.upload(idx_valid, dev), ops.upload(slot, dev))
         self._slot_of_row = self._flag_cache[2]
         return self._flag_cache[1], clouds.to(dev, non_blocking=True), clouds_global.to(dev, non_blocking=True)
 
