@@ -60,11 +60,12 @@ class _PinnedRing:
         if host.numel() == 0:
             return host.to(device)
         key = (host.dtype, max(1024, 1 << (host.numel() - 1).bit_length()))
-        ring = self.slots.setdefault(key, [])
+        ring = self.slots.get(key)
+        if ring is None:      # ONE pinned allocation per (dtype, size class), cut into the ring's slots (pinning costs ~30 ms a call)
+            block = torch.empty(self.depth * key[1], dtype=key[0]).pin_memory()
+            ring = self.slots[key] = [[block[k * key[1]:(k + 1) * key[1]], None] for k in range(self.depth)]
         i = self.next.get(key, 0)
         self.next[key] = (i + 1) % self.depth
-        if len(ring) <= i:
-            ring.append([torch.empty(key[1], dtype=key[0]).pin_memory(), None])
         buf, ev = ring[i]
         if ev is not None:
             ev.synchronize()
