@@ -242,6 +242,14 @@ typedef struct {
 int spg_edge_features(const spg_edge_feature_specs* specs, const int64_t* edges, long E, const double* mean,
                       const double* scale, float* out, void* stream);
 
+/* Host -> device upload of a small per-batch buffer (the reference's `.cuda()` of idxn / degs / edgefeats,
+ * learning/ecc/GraphConvInfo.py:71-79, and of the clouds, learning/pointnet.py:150-152) WITHOUT a host stall: the bytes
+ * are copied into a slot of a library-owned ring of page-locked staging buffers and sent from there with an asynchronous
+ * copy on `stream`; the call returns as soon as the copy is enqueued and `host` may be re-used at once.  A copy from
+ * pageable memory would block the host until the stream reaches it (= until the previous step has drained).  A slot is
+ * re-used only after the event recorded behind its last copy has completed.  Thread-safe.  bytes == 0 is a no-op. */
+int spg_upload(const void* host, size_t bytes, void* device, void* stream);
+
 /* Random streams of the loader generated on the device (optional; the default keeps numpy's streams on the host so
  * that seeded runs reproduce the reference's clouds): Philox4x32-10 keyed by (seed, superpoint id, step).  counts /
  * ids int64 [S], slot int32 [S] (row of the cloud tensor or -1) -> sample_idx int32 [S, npts] (spg.py:207-214), M

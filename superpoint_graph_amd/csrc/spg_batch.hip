@@ -176,3 +176,63 @@ extern "C" int spg_edge_features(const spg_edge_feature_specs* specs, const int6
   SPG_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// spg_upload: page-locked staging ring for the small per-batch host -> device copies
+// ------------------------------------------------------------------------------------------------------------------
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+struct StagingSlot {
+  void* buf = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+constexpr int kStagingSlots = 32;
+struct StagingRing {
+  std::mutex mu;
+  StagingSlot slot[SPG_MAX_DEVICES][kStagingSlots];
+  int next[SPG_MAX_DEVICES] = {};
+};
+StagingRing g_staging;
+
+}  // namespace
+
+extern "C" int spg_upload(const void* host, size_t bytes, void* device, void* stream) {
+  if (bytes == 0) return 0;
+  SPG_CHECK_ARG(host && device, "bad argument");
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) { spg_set_error("spg_upload: hipGetDevice failed"); return rc ? (int)rc : 1; }
+  std::lock_guard<std::mutex> lock(g_staging.mu);
+  StagingSlot& s = g_staging.slot[dev][g_staging.next[dev]];
+  g_staging.next[dev] = (g_staging.next[dev] + 1) % kStagingSlots;
+  if (s.done == nullptr) {
+    rc = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    if (rc != hipSuccess) { spg_set_error("hipEventCreate: %s", hipGetErrorString(rc)); return (int)rc; }
+  }
+  if (s.pending) {      // the copy that last used this slot must have left the staging buffer
+    rc = hipEventSynchronize(s.done);
+    if (rc != hipSuccess) { spg_set_error("hipEventSynchronize: %s", hipGetErrorString(rc)); return (int)rc; }
+    s.pending = false;
+  }
+  if (s.cap < bytes) {
+    if (s.buf != nullptr) (void)hipHostFree(s.buf);
+    s.buf = nullptr; s.cap = 0;
+    size_t cap = 64 * 1024;
+    while (cap < bytes) cap *= 2;
+    rc = hipHostMalloc(&s.buf, cap, hipHostMallocDefault);
+    if (rc != hipSuccess) { s.buf = nullptr; spg_set_error("hipHostMalloc(%zu): %s", cap, hipGetErrorString(rc)); return (int)rc; }
+    s.cap = cap;
+  }
+  std::memcpy(s.buf, host, bytes);
+  rc = hipMemcpyAsync(device, s.buf, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (rc != hipSuccess) { spg_set_error("hipMemcpyAsync: %s", hipGetErrorString(rc)); return (int)rc; }
+  rc = hipEventRecord(s.done, (hipStream_t)stream);
+  if (rc != hipSuccess) { spg_set_error("hipEventRecord: %s", hipGetErrorString(rc)); return (int)rc; }
+  s.pending = true;
+  return 0;
+}

@@ -46,45 +46,20 @@ def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
 # --------------------------------------------------------------------------------------------------
 # host -> device staging
 # --------------------------------------------------------------------------------------------------
-class _PinnedRing:
-    """Re-used pinned staging buffers for the small per-batch uploads (edge lists, index vectors).  A copy from PAGEABLE
-    memory blocks the host until the stream reaches it -- i.e. until the previous step has drained, so host and GPU take
-    turns --, and allocating pinned memory per batch costs tens of milliseconds; a ring of long-lived pinned buffers costs a
-    memcpy.  Every slot remembers the event of its last upload and waits for it before it is overwritten."""
-
-    def __init__(self, depth=8):
-        self.depth, self.slots, self.next = depth, {}, {}
-
-    def upload(self, host: torch.Tensor, device) -> torch.Tensor:
-        host = host.contiguous()
-        if host.numel() == 0:
-            return host.to(device)
-        key = (host.dtype, max(1024, 1 << (host.numel() - 1).bit_length()))
-        ring = self.slots.get(key)
-        if ring is None:      # ONE pinned allocation per (dtype, size class), cut into the ring's slots (pinning costs ~30 ms a call)
-            block = torch.empty(self.depth * key[1], dtype=key[0]).pin_memory()
-            ring = self.slots[key] = [[block[k * key[1]:(k + 1) * key[1]], None] for k in range(self.depth)]
-        i = self.next.get(key, 0)
-        self.next[key] = (i + 1) % self.depth
-        buf, ev = ring[i]
-        if ev is not None:
-            ev.synchronize()
-        view = buf[:host.numel()].view(host.shape)
-        view.copy_(host)
-        out = view.to(device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        ring[i][1] = ev
-        return out
-
-
-_pinned = _PinnedRing()
-
-
 def upload(host: torch.Tensor, device=None) -> torch.Tensor:
-    """Asynchronous host-to-device copy of a small tensor through the pinned staging ring."""
-    device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
-    return _pinned.upload(host, device)
+    """Asynchronous host-to-device copy of a small per-batch tensor (edge lists, index vectors, edge features) through the
+    library's page-locked staging ring (spg_upload): a copy from PAGEABLE memory blocks the host until the stream reaches it
+    -- i.e. until the previous step has drained, so host and GPU would take turns -- and pinning per batch costs tens of
+    milliseconds.  The call returns once the copy is enqueued on the current stream; `host` may be re-used at once."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if host.is_cuda:
+        return host.to(device)
+    if device.index is not None and device.index != torch.cuda.current_device():
+        raise RuntimeError(f'upload: target cuda:{device.index} is not the current device cuda:{torch.cuda.current_device()}')
+    host = host.contiguous()
+    out = torch.empty(host.shape, dtype=host.dtype, device=device)
+    check(lib().spg_upload(host.data_ptr(), host.numel() * host.element_size(), out.data_ptr(), _stream()), 'spg_upload')
+    return out
 
 
 # --------------------------------------------------------------------------------------------------
