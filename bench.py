@@ -131,7 +131,7 @@ def gemm_traffic(args):
     return t['hbm_mb_per_launch'] * 1e6, os.path.relpath(files[-1], ROOT)
 
 
-def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, iters=20):
+def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, iters=40):
     """The reference's own "trainer time" window (learning/main.py:192-215): every step gets a FRESH batch -- the clouds
     come from pinned host memory (H2D on a side stream, overlapped with the previous step) and the batched graph is built
     anew on the GPU (GraphConvInfo.set_batch_device, as the CLI's collate does: ordering by target, edge-feature reordering,
@@ -147,26 +147,19 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
         samples = [spg.sample_from_scene(s, f'w{b}_{i}') for i, s in enumerate(scenes)]
         targets, _, (meta, flag, clouds, diam) = spg.eccpc_collate(samples)
         batches.append((targets, [s[1] for s in samples], flag, clouds.pin_memory(), diam.pin_memory()))
-    side = torch.cuda.Stream()
-    cur = torch.cuda.current_stream()
+    from superpoint_graph_amd.learning.prefetch import SideStreamBatches
 
-    def upload(b):
-        targets, GIs, flag, clouds, diam = batches[b % nb]
-        with torch.cuda.stream(side):
-            c, d, lab = clouds.to(dev, non_blocking=True), diam.to(dev, non_blocking=True), targets[:, 0].contiguous().to(dev, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(side)
-        return c, d, lab, done
-
-    def run(n):
-        nxt = upload(0)
+    def fresh_batches(n):
+        """what the CLI's collate does for every batch (eccpc_collate(device_batch=True) + the trainer's uploads): issued on the
+        side stream by SideStreamBatches, so it overlaps the step in flight"""
         for it in range(n):
-            targets, graphs, flag, _, _ = batches[it % nb]
-            c, d, lab, done = nxt
-            nxt = upload(it + 1)                      # H2D of the next batch overlaps this step
-            cur.wait_event(done)
+            targets, graphs, flag, clouds, diam = batches[it % nb]
             gi = ecc.GraphConvInfo()
             gi.set_batch_device(graphs, spg.cloud_edge_feats)      # edge list / features H2D + ordering + CSR on the device
+            yield gi, flag, ops.upload(clouds, dev), ops.upload(diam, dev), ops.upload(targets[:, 0].contiguous(), dev)
+
+    def run(n):
+        for gi, flag, c, d, lab in SideStreamBatches(fresh_batches(n)):
             model.ecc.set_info([gi], 1)
             arena.zero_grad()
             emb = embedder.run(model, None, flag, c, d)
@@ -174,7 +167,7 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
             loss.backward(arena.one)
             embedder.bw_hook()
             arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)
-    run(4)
+    run(12)               # the side stream's allocator pool and the staging ring fill during the first batches
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(iters)
@@ -183,8 +176,9 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
     n = int(batches[0][2].numel())
     log(f'trainer window: {dt * 1e3:.3f} ms/step')
     return {'ms_per_step': dt * 1e3, 'superpoints_per_s': n / dt,
-            'what': 'fresh batch every step: pinned H2D of clouds/labels on a side stream + GraphConvInfo.set_batch_device (edge list / features H2D, '
-                    'ordering by target + CSR / reverse CSR as kernels) + zero_grad..Adam (learning/main.py:192-215)'}
+            'what': 'fresh batch every step: pinned H2D of clouds/labels + GraphConvInfo.set_batch_device (edge list / features H2D, ordering by '
+                    'target + CSR / reverse CSR as kernels), both on a side stream (SideStreamBatches, as the CLI does) + zero_grad..Adam '
+                    '(learning/main.py:192-215)'}
 
 
 def forward_only(dev, flag, clouds_d, diam_d, GIs, n_feat, iters=40):

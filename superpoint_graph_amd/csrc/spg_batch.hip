@@ -190,12 +190,20 @@ struct StagingSlot {
   size_t cap = 0;
   hipEvent_t done = nullptr;
   bool pending = false;
+  bool own = false;          // buf is this slot's own allocation (not a piece of the device's shared block)
 };
-constexpr int kStagingSlots = 32;
+// two rings per device: 32 slots for the small per-batch vectors (<= 1 MiB: edge lists, index vectors, edge features) and 4
+// slots for large buffers (clouds of a host-side loader), so that page-locked memory stays bounded by 4 x the largest upload
+constexpr int kSmallSlots = 32, kLargeSlots = 4;
+constexpr size_t kSmallBytes = 1u << 20;
+// the small slots start as 512 KiB pieces of ONE page-locked block per device (a hipHostMalloc costs ~0.5 ms: 32 of them would
+// spread over the first steps of a run); a slot that meets a larger buffer gets its own allocation
+constexpr size_t kSmallInitial = 512u << 10;
 struct StagingRing {
   std::mutex mu;
-  StagingSlot slot[SPG_MAX_DEVICES][kStagingSlots];
-  int next[SPG_MAX_DEVICES] = {};
+  StagingSlot slot[SPG_MAX_DEVICES][kSmallSlots + kLargeSlots];
+  int next_small[SPG_MAX_DEVICES] = {}, next_large[SPG_MAX_DEVICES] = {};
+  void* block[SPG_MAX_DEVICES] = {};
 };
 StagingRing g_staging;
 
@@ -208,8 +216,23 @@ extern "C" int spg_upload(const void* host, size_t bytes, void* device, void* st
   hipError_t rc = hipGetDevice(&dev);
   if (rc != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) { spg_set_error("spg_upload: hipGetDevice failed"); return rc ? (int)rc : 1; }
   std::lock_guard<std::mutex> lock(g_staging.mu);
-  StagingSlot& s = g_staging.slot[dev][g_staging.next[dev]];
-  g_staging.next[dev] = (g_staging.next[dev] + 1) % kStagingSlots;
+  int idx;
+  if (bytes <= kSmallBytes) {
+    idx = g_staging.next_small[dev];
+    g_staging.next_small[dev] = (idx + 1) % kSmallSlots;
+  } else {
+    idx = kSmallSlots + g_staging.next_large[dev];
+    g_staging.next_large[dev] = (g_staging.next_large[dev] + 1) % kLargeSlots;
+  }
+  if (g_staging.block[dev] == nullptr) {
+    rc = hipHostMalloc(&g_staging.block[dev], kSmallSlots * kSmallInitial, hipHostMallocDefault);
+    if (rc != hipSuccess) { g_staging.block[dev] = nullptr; spg_set_error("hipHostMalloc: %s", hipGetErrorString(rc)); return (int)rc; }
+    for (int k = 0; k < kSmallSlots; ++k) {
+      g_staging.slot[dev][k].buf = (char*)g_staging.block[dev] + (size_t)k * kSmallInitial;
+      g_staging.slot[dev][k].cap = kSmallInitial;
+    }
+  }
+  StagingSlot& s = g_staging.slot[dev][idx];
   if (s.done == nullptr) {
     rc = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
     if (rc != hipSuccess) { spg_set_error("hipEventCreate: %s", hipGetErrorString(rc)); return (int)rc; }
@@ -220,13 +243,13 @@ extern "C" int spg_upload(const void* host, size_t bytes, void* device, void* st
     s.pending = false;
   }
   if (s.cap < bytes) {
-    if (s.buf != nullptr) (void)hipHostFree(s.buf);
-    s.buf = nullptr; s.cap = 0;
+    if (s.buf != nullptr && s.own) (void)hipHostFree(s.buf);
+    s.buf = nullptr; s.cap = 0; s.own = false;
     size_t cap = 64 * 1024;
     while (cap < bytes) cap *= 2;
     rc = hipHostMalloc(&s.buf, cap, hipHostMallocDefault);
     if (rc != hipSuccess) { s.buf = nullptr; spg_set_error("hipHostMalloc(%zu): %s", cap, hipGetErrorString(rc)); return (int)rc; }
-    s.cap = cap;
+    s.cap = cap; s.own = true;
   }
   std::memcpy(s.buf, host, bytes);
   rc = hipMemcpyAsync(device, s.buf, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);

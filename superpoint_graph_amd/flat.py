@@ -47,9 +47,12 @@ class FlatParameters:
         self.flat = torch.nn.Parameter(data)             # hand THIS to the optimizer
         self.flat.grad = self._gbuf[:self.numel]
         self._modules = list(model.modules())
+        self._written_log = []                           # modules whose backward has written since the last _clear_written()
+        self._uncovered = {}                             # frozenset(written module ids) -> parameters no kernel has written
         for m in self._modules:
             m._spg_direct_grads = True                   # the HIP autograd Functions then write into p.grad directly
             m._spg_grad_written = False
+            m._spg_written_log = self._written_log
         # for every parameter: the modules on its path (a kernel-backed module writes the gradients of all its descendants)
         named = dict(model.named_modules())
         self._cover = []
@@ -161,13 +164,18 @@ class FlatParameters:
         if not self._stale:
             return
         self._stale = False
-        for p, chain in zip(self.params, self._cover):
-            if not any(getattr(m, '_spg_grad_written', False) for m in chain):
-                p.grad.zero_()
+        key = frozenset(id(m) for m in self._written_log)       # the same few modules every step: one dictionary lookup
+        todo = self._uncovered.get(key)
+        if todo is None:
+            todo = self._uncovered[key] = [p for p, chain in zip(self.params, self._cover)
+                                           if not any(getattr(m, '_spg_grad_written', False) for m in chain)]
+        for p in todo:
+            p.grad.zero_()
 
     def _clear_written(self):
-        for m in self._modules:
+        for m in self._written_log:
             m._spg_grad_written = False
+        del self._written_log[:]
 
     def clamp_grad_(self, clip: float):
         self._resolve_stale()
@@ -205,3 +213,6 @@ def mark_direct_write(module):
                            'FlatParameters.zero_grad() in between; the HIP kernels overwrite (do not accumulate) the '
                            'gradient views -- gradient accumulation is not supported in FlatParameters mode')
     module._spg_grad_written = True
+    log = getattr(module, '_spg_written_log', None)
+    if log is not None:
+        log.append(module)

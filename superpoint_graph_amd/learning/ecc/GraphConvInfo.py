@@ -109,13 +109,14 @@ class GraphConvInfo(object):
         if self._graph is not None and self._idxn.is_cuda:
             return            # built by set_batch_device: already resident
         self._validate()
-        self._idxn = self._idxn.cuda()
+        # reference GraphConvInfo.py:71-79; through the staging ring: pageable `.cuda()` copies stall the host until the stream has drained
+        self._idxn = ops.upload(self._idxn)
         if self._idxe is not None:
-            self._idxe = self._idxe.cuda()
-        self._degrees_gpu = self._degrees.cuda()
-        self._edgefeats = self._edgefeats.cuda()
+            self._idxe = ops.upload(self._idxe)
+        self._degrees_gpu = ops.upload(self._degrees)
+        self._edgefeats = ops.upload(self._edgefeats)
         if self._edge_indexes is not None:
-            self._edge_indexes = self._edge_indexes.cuda()
+            self._edge_indexes = ops.upload(self._edge_indexes)
         self._graph = ops.DeviceGraph(self._idxn, self._degrees_gpu)
 
     def device_graph(self):

@@ -104,6 +104,9 @@ def build_parser():
     a('--batch_device', default=1, type=int,
       help='Bool, build the batched graph (edge ordering by target, edge-feature reordering, CSR) on the GPU in eccpc_collate; '
            'needs collation in the main process, i.e. it is only active together with --loader_device 1')
+    a('--batch_stream', default=1, type=int,
+      help='Bool, run the device half of the loader (cloud kernels, graph construction, uploads) on a second HIP stream so that it '
+           'overlaps the training step in flight (superpoint_graph_amd/learning/prefetch.py); active with --batch_device 1')
     a('--gemm_precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
       help="Arithmetic of the wide PointNet GEMMs: f32 = fp32 MFMA (the reference's arithmetic, default); bf16x3 = split-bf16 "
            "products (~2^-16 per product, fp32 accumulate); bf16 = bf16 operands.  Tolerances: tests/test_gpu_precision.py")
@@ -299,6 +302,14 @@ class Session:
         return spg.eccpc_collate
 
     def _loader(self, dataset, train):
+        loader = self._host_loader(dataset, train)
+        a = self.args
+        if a.cuda and getattr(a, 'batch_stream', 1) and self._collate() is not spg.eccpc_collate:
+            from .prefetch import SideStreamBatches
+            return SideStreamBatches(loader)        # the collate's kernels / copies overlap the step in flight
+        return loader
+
+    def _host_loader(self, dataset, train):
         a = self.args
         collate, nw = self._collate(), self._nworkers()
         if self.dp and a.dp_replicate_loader:
@@ -330,8 +341,9 @@ class Session:
 
     def _forward(self, targets, GIs, clouds_data):
         self.model.ecc.set_info(GIs, self.args.cuda)
-        label_mode = targets[:, 0].contiguous().cuda(non_blocking=True)
-        label_vec = targets[:, 2:].contiguous().cuda(non_blocking=True)
+        # through the staging ring (ops.upload): a pageable `.cuda()` would stall the host until the previous step has drained
+        label_mode = ops.upload(targets[:, 0].contiguous()) if self.args.cuda else targets[:, 0].contiguous()
+        label_vec = ops.upload(targets[:, 2:].contiguous()) if self.args.cuda else targets[:, 2:].contiguous()
         embeddings = self.embedder.run(self.model, *clouds_data)
         outputs = self.model.ecc(embeddings)
         return outputs, label_mode, label_vec

@@ -369,7 +369,7 @@ class CloudEmbedder():
             # (pinned staging ring, non-blocking: a pageable H2D would stall the host until the stream has drained)
             self._flag_cache = (clouds_flag, ops.upload(idx_valid, dev), ops.upload(slot, dev))
         self._slot_of_row = self._flag_cache[2]
-        return self._flag_cache[1], clouds.to(dev, non_blocking=True), clouds_global.to(dev, non_blocking=True)
+        return self._flag_cache[1], ops.upload(clouds, dev), ops.upload(clouds_global, dev)
 
     def _scatter(self, out, idx_valid, n_rows):
         if out.shape[0] == 0:                          # no embeddable superpoint in the batch

@@ -246,16 +246,16 @@ def load_superpoints_device(args, points, offsets, ids, train, test_seed_offset=
     rng = rng or getattr(args, 'loader_rng', 'host')
     if rng == 'device':
         dev = points.device
-        slot_d = torch.from_numpy(slot).to(dev)
+        slot_d = ops.upload(torch.from_numpy(slot), dev)
         if train:
             _device_rng_step[0] += 1
         sidx_d, M_d, noise_d = ops.loader_random(
-            torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)).to(dev),
-            torch.from_numpy(np.asarray(ids, dtype=np.int64)).to(dev), slot_d, npts, F, nv,
+            ops.upload(torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)), dev),
+            ops.upload(torch.from_numpy(np.asarray(ids, dtype=np.int64)), dev), slot_d, npts, F, nv,
             int(getattr(args, 'seed', 0)) + (0 if train else int(test_seed_offset)), _device_rng_step[0] if train else 0, augment,
             float(args.pc_augm_scale), args.pc_augm_rot == 1, float(args.pc_augm_mirror_prob),
             bool(getattr(args, 'pc_augm_jitter', 0)))
-        clouds, diam = ops.load_superpoints(points, torch.from_numpy(off_h.astype(np.int64)).to(dev), slot_d, sidx_d, cols,
+        clouds, diam = ops.load_superpoints(points, ops.upload(torch.from_numpy(off_h.astype(np.int64)), dev), slot_d, sidx_d, cols,
                                             bool(args.pc_xyznormalize), nv, M_d, noise_d)
         return torch.from_numpy(flag), clouds, diam
     if rng != 'host':
@@ -294,9 +294,9 @@ def load_superpoints_device(args, points, offsets, ids, train, test_seed_offset=
                 noise[slot[s]] = np.clip(0.01 * np.random.randn(npts, F), -0.05, 0.05).astype(np.float32)
     dev = points.device
     clouds, diam = ops.load_superpoints(
-        points, torch.from_numpy(off_h.astype(np.int64)).to(dev), torch.from_numpy(slot).to(dev),
-        torch.from_numpy(sidx).to(dev), cols, bool(args.pc_xyznormalize), nv,
-        None if Ms is None else torch.from_numpy(Ms).to(dev), None if noise is None else torch.from_numpy(noise).to(dev))
+        points, ops.upload(torch.from_numpy(off_h.astype(np.int64)), dev), ops.upload(torch.from_numpy(slot), dev),
+        ops.upload(torch.from_numpy(sidx), dev), cols, bool(args.pc_xyznormalize), nv,
+        None if Ms is None else ops.upload(torch.from_numpy(Ms), dev), None if noise is None else ops.upload(torch.from_numpy(noise), dev))
     return torch.from_numpy(flag), clouds, diam
 
 
@@ -364,8 +364,8 @@ def spg_edge_features_device(edges, node_att, edge_att, args, scaler=None, devic
     e = torch.from_numpy(np.ascontiguousarray(np.asarray(edges, dtype=np.int64))).to(dev)
     mean = scale = None
     if scaler is not None:
-        mean = torch.from_numpy(np.asarray(scaler.mean_, dtype=np.float64)).to(dev)
-        scale = torch.from_numpy(np.asarray(scaler.scale_, dtype=np.float64)).to(dev)
+        mean = ops.upload(torch.from_numpy(np.asarray(scaler.mean_, dtype=np.float64)), dev)
+        scale = ops.upload(torch.from_numpy(np.asarray(scaler.scale_, dtype=np.float64)), dev)
     return ops.edge_features(cols, e, mean, scale)
 
 

@@ -54,6 +54,8 @@ def upload(host: torch.Tensor, device=None) -> torch.Tensor:
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     if host.is_cuda:
         return host.to(device)
+    if host.is_pinned():                      # page-locked already (DataLoader pin_memory, pre-pinned buffers): a true asynchronous copy
+        return host.to(device, non_blocking=True)
     if device.index is not None and device.index != torch.cuda.current_device():
         raise RuntimeError(f'upload: target cuda:{device.index} is not the current device cuda:{torch.cuda.current_device()}')
     host = host.contiguous()

@@ -8,20 +8,16 @@ import bench
 from superpoint_graph_amd.flat import FlatParameters
 from superpoint_graph_amd.learning import pointnet
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device('cuda', 0)
 args = types.SimpleNamespace(scenes=1, n_sp=1000, n_edges=5000, n_feat=14)
 model = bench.build_model('gru_10_0,f_13', dev).train()
 embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
 arena = FlatParameters(model, lazy_zero=True, host_counters=True)
 log = lambda s: print(s, flush=True)
-bench.trainer_window(args, dev, model, embedder, arena, [0], 13, log, iters=iters)      # warm (allocations, pinned ring)
-pr = cProfile.Profile()
-pr.enable()
+bench.trainer_window(args, dev, model, embedder, arena, [0], 13, log, iters=iters)      # warm (allocations, staging ring)
 out = bench.trainer_window(args, dev, model, embedder, arena, [0], 13, log, iters=iters)
-pr.disable()
-print(out['ms_per_step'], 'ms/step')
-pstats.Stats(pr).sort_stats('tottime').print_stats(25)
+print(out['ms_per_step'], 'ms/step (bench.trainer_window, side-stream batches)')
 
 # ---- per-phase host time of the same loop (perf_counter around each call; no synchronisation inside the loop) ----
 import time
@@ -113,3 +109,32 @@ t0 = time.perf_counter()
 for _ in range(200):
     pg[:65000].view(5000, 13).copy_(f)
 print(f'copy_ into a pageable buffer 260 KB: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us; torch threads {torch.get_num_threads()}')
+
+# ---- cProfile of the resident step loop: which host functions cost what ----
+targets, graphs, flag, clouds, diam, lab_h = batches[0]
+c, d, lab = clouds.to(dev), diam.to(dev), lab_h.to(dev)
+gi = ecc.GraphConvInfo()
+gi.set_batch_device(graphs, spg.cloud_edge_feats)
+model.ecc.set_info([gi], 1)
+
+
+def step():
+    arena.zero_grad()
+    emb = embedder.run(model, None, flag, c, d)
+    loss = ops.cross_entropy(model.ecc(emb), lab)
+    loss.backward(arena.one)
+    embedder.bw_hook()
+    arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)
+
+
+for _ in range(10):
+    step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(40):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats('tottime').print_stats(40)
