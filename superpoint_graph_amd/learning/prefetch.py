@@ -16,6 +16,18 @@ from __future__ import annotations
 import torch
 
 
+_side_streams = {}      # device index -> the ONE side stream of that device
+
+
+def side_stream() -> 'torch.cuda.Stream':
+    """The batch-construction stream of the current device.  One long-lived stream: the caching allocator keeps a pool per
+    stream, so a fresh stream per epoch would start every epoch with cold (hipMalloc-ed) buffers."""
+    dev = torch.cuda.current_device()
+    if dev not in _side_streams:
+        _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return _side_streams[dev]
+
+
 class SideStreamBatches:
     """for batch in SideStreamBatches(loader): ...  -- `loader` is any iterable whose `__next__` enqueues the batch's device work
     on the CURRENT stream (a `DataLoader` with `num_workers == 0` and a device collate, or a generator)."""
@@ -31,7 +43,7 @@ class SideStreamBatches:
         if not torch.cuda.is_available():
             raise RuntimeError('SideStreamBatches needs a GPU: the superpoint_graph_amd batch construction has no CPU path')
         main = torch.cuda.current_stream()
-        side = self.side if self.side is not None else torch.cuda.Stream()
+        side = self.side if self.side is not None else side_stream()
         it = iter(self.loader)
         fence_prev = None                     # recorded on `main` at the previous request
         while True:
