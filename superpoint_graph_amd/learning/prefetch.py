@@ -49,8 +49,10 @@ class SideStreamBatches:
         while True:
             fence = torch.cuda.Event()
             fence.record(main)                # everything the consumer has enqueued so far (steps <= j-1)
-            if fence_prev is not None:
-                side.wait_event(fence_prev)   # steps <= j-2 are complete before batch j's buffers may be (re)written
+            # steps <= j-2 are complete before batch j's buffers may be (re)written; the first batch of an iteration waits for
+            # everything enqueued so far (the side stream and its pool outlive the iteration: the previous epoch's last steps
+            # may still be reading what they freed)
+            side.wait_event(fence_prev if fence_prev is not None else fence)
             with torch.cuda.stream(side):
                 try:
                     batch = next(it)
