@@ -138,7 +138,7 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
     CSR / reverse CSR; the host concatenates and counts degrees) -- then zero_grad ... optimizer step as in the headline
     measurement.  Reported next to `value` (which keeps its inputs resident, as the metric definition says)."""
     from superpoint_graph_amd import ops, synth
-    from superpoint_graph_amd.learning import ecc, spg
+    from superpoint_graph_amd.learning import ecc, pointnet, spg
     nb = 4
     batches = []
     for b in range(nb):
@@ -156,6 +156,8 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
             targets, graphs, flag, clouds, diam = batches[it % nb]
             gi = ecc.GraphConvInfo()
             gi.set_batch_device(graphs, spg.cloud_edge_feats)      # edge list / features H2D + ordering + CSR on the device
+            flag = flag.clone()                                    # a fresh batch object, as a collate produces it
+            pointnet.stage_flags(flag)                             # (eccpc_collate(device_batch=True) does this)
             yield gi, flag, ops.upload(clouds, dev), ops.upload(diam, dev), ops.upload(targets[:, 0].contiguous(), dev)
 
     def run(n):
@@ -171,11 +173,12 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(iters)
+    t_host = (time.perf_counter() - t0) / iters          # the host has enqueued everything: if this is close to dt the loop is host-bound
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     n = int(batches[0][2].numel())
-    log(f'trainer window: {dt * 1e3:.3f} ms/step')
-    return {'ms_per_step': dt * 1e3, 'superpoints_per_s': n / dt,
+    log(f'trainer window: {dt * 1e3:.3f} ms/step (host enqueue {t_host * 1e3:.3f} ms/step)')
+    return {'ms_per_step': dt * 1e3, 'superpoints_per_s': n / dt, 'host_enqueue_ms_per_step': t_host * 1e3,
             'what': 'fresh batch every step: pinned H2D of clouds/labels + GraphConvInfo.set_batch_device (edge list / features H2D, ordering by '
                     'target + CSR / reverse CSR as kernels), both on a side stream (SideStreamBatches, as the CLI does) + zero_grad..Adam '
                     '(learning/main.py:192-215)'}

@@ -250,6 +250,43 @@ int spg_edge_features(const spg_edge_feature_specs* specs, const int64_t* edges,
  * re-used only after the event recorded behind its last copy has completed.  Thread-safe.  bytes == 0 is a no-op. */
 int spg_upload(const void* host, size_t bytes, void* device, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Superpoint-graph construction on the device (SURVEY.md section 8, row f4 tail): partition/graphs.py:75-210
+ * compute_sp_graph AFTER scipy's Delaunay triangulation (which stays on the host), and compute_geof of
+ * partition/ply_c/ply_c.cpp:384-462.  Host mirror: superpoint_graph_amd/partition/graphs.py.
+ *   spg_spg_tet_edges      tets int32 [T,4] (Delaunay.simplices), comp int32 [n] (in_component) -> both directions of every
+ *                          vertex pair that joins two components (graphs.py:85-107) as keys (source << 32 | target), in
+ *                          arbitrary order; count (device uint64) = number of keys found (keys may be NULL: count only);
+ *   spg_spg_unique_edges   np.unique(edges, axis=1) + the d_max filter (:108-113; float32 distance in the reference's
+ *                          operation order, d_max <= 0: no filter) -> edge_keys [count] in (source, target) order and their
+ *                          component-pair index comp[s] * n_com + comp[t] (:120);
+ *   spg_spg_group_edges    stable order by component pair (:121-125) and the superedge segments (:127-128): seg_cc [n_seg],
+ *                          seg_off [n_seg + 1] (capacity n + 1), n_seg (device int64);
+ *   spg_spg_superpoints    :141-172 for all components: centroids [n_com,3], length / surface / volume [n_com], point_count
+ *                          uint64 [n_com], sp_labels uint32 [n_com, n_labels + 1] from labels int32 [n] (histogram) or
+ *                          label_rows uint32 [n, n_labels + 1] (column sums), or neither;
+ *   spg_spg_superedges     :174-208 for all superedges.
+ * workspace: spg_spg_workspace_bytes(which = 0 unique_edges / 1 group_edges / 2 superpoints, n = number of keys / edges / points).
+ * Integer results are bit-exact; float features are accumulated in float64 and rounded once.
+ * ---------------------------------------------------------------------------------------------- */
+size_t spg_spg_workspace_bytes(int which, long n);
+int spg_spg_tet_edges(const int32_t* tets, long T, const int32_t* comp, uint64_t* keys, long capacity, uint64_t* count, void* stream);
+int spg_spg_unique_edges(const uint64_t* keys, long n, const float* xyz, const int32_t* comp, long n_com, float d_max,
+                         uint64_t* edge_keys, uint64_t* cc_keys, uint64_t* count, void* workspace, size_t workspace_bytes, void* stream);
+int spg_spg_group_edges(const uint64_t* cc_keys, const uint64_t* edge_keys, long n, uint64_t* cc_sorted, uint64_t* edges_sorted,
+                        uint64_t* seg_cc, int64_t* seg_off, int64_t* n_seg, void* workspace, size_t workspace_bytes, void* stream);
+int spg_spg_superpoints(const float* xyz, long n, const int32_t* comp, int n_com, const int32_t* labels, const uint32_t* label_rows,
+                        int n_labels, float* centroids, float* length, float* surface, float* volume, uint64_t* point_count,
+                        uint32_t* sp_labels, void* workspace, size_t workspace_bytes, void* stream);
+int spg_spg_superedges(const uint64_t* edges_sorted, const uint64_t* seg_cc, const int64_t* seg_off, long n_sedg, long n_com,
+                       const float* xyz, const float* centroids, const float* length, const float* surface, const float* volume,
+                       const uint64_t* point_count, uint32_t* source, uint32_t* target, float* delta_mean, float* delta_std,
+                       float* delta_norm, float* delta_centroid, float* length_ratio, float* surface_ratio, float* volume_ratio,
+                       float* point_count_ratio, void* stream);
+/* compute_geof (ply_c.cpp:384-462): xyz float32 [n,3], target uint32 [n, k_nn] (the k_nn nearest neighbours of every point)
+ * -> geof float32 [n,4] = linearity, planarity, scattering, verticality.  Covariance and eigen-decomposition in float64. */
+int spg_compute_geof(const float* xyz, const uint32_t* target, long n, int k_nn, float* geof, void* stream);
+
 /* Random streams of the loader generated on the device (optional; the default keeps numpy's streams on the host so
  * that seeded runs reproduce the reference's clouds): Philox4x32-10 keyed by (seed, superpoint id, step).  counts /
  * ids int64 [S], slot int32 [S] (row of the cloud tensor or -1) -> sample_idx int32 [S, npts] (spg.py:207-214), M

@@ -631,6 +631,58 @@ def check_baseline_size(refmods, write):
         print(f'  wrote {out} ({os.path.getsize(out) / 1e6:.2f} MB)')
 
 
+def check_sp_graph(write):
+    """partition/graphs.py:75-210 compute_sp_graph: the IMPORTED reference function (scipy's `Delaunay.vertices` is today's
+    `.simplices`: the attribute is supplied, nothing else is touched) against oracle/spg_partition_oracle.py on a synthetic
+    labelled cloud that exercises every branch (1-, 2- and many-point components, duplicated points, with / without labels and
+    d_max); writes tests/golden/sp_graph.npz (inputs incl. the tetrahedra, reference outputs)."""
+    import importlib
+    import warnings
+    import scipy.spatial
+    from oracle import spg_partition_oracle as P
+    sys.path.insert(0, os.path.join(REF, 'partition'))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        graphs = importlib.import_module('graphs')
+
+    class _Delaunay(scipy.spatial.Delaunay):
+        @property
+        def vertices(self):
+            return self.simplices
+    graphs.Delaunay = _Delaunay
+    blob = {}
+    for tag, seed, d_max, with_labels in (('a', 0, 1.5, True), ('b', 1, 0.0, True), ('c', 2, 0.8, False)):
+        xyz, comp, components, labels = P.synthetic_cloud(seed)
+        n_labels = 5 if with_labels else 0
+        lab = labels if with_labels else np.zeros(0, dtype=np.int64)
+        ref = graphs.compute_sp_graph(xyz, d_max, comp, components, lab, n_labels)
+        tets = scipy.spatial.Delaunay(xyz).simplices
+        mine = P.sp_graph_after_triangulation(xyz, d_max, comp, components, lab, n_labels, tets)
+        worst = 0.0
+        for k, a in ref.items():
+            b = mine[k]
+            if isinstance(a, (bool, list)):
+                assert (a == b) if isinstance(a, bool) else len(b) == 0, k
+                continue
+            assert a.shape == b.shape and a.dtype == b.dtype, (k, a.shape, b.shape)
+            if a.dtype.kind in 'ui' or k.startswith('sp_') or 'ratio' in k or k == 'se_delta_centroid':
+                assert np.array_equal(a, b), f'sp_graph {tag}: {k} differs'      # integers and everything order-independent: bit-equal
+            else:                                                                # sums over a group whose edge order the reference leaves open
+                worst = max(worst, float(np.abs(a.astype(np.float64) - b).max() / np.abs(a).max()))
+        assert worst < 1e-6, worst
+        print(f'  sp_graph {tag}: {len(xyz)} points, {len(components)} components, {len(ref["source"])} superedges: integers / superpoint '
+              f'features bit-equal, offset statistics {worst:.1e}')
+        blob.update({f'{tag}/xyz': xyz, f'{tag}/comp': comp, f'{tag}/labels': lab, f'{tag}/tets': tets.astype(np.int32),
+                     f'{tag}/d_max': np.float64(d_max), f'{tag}/n_labels': np.int64(n_labels)})
+        for k, a in ref.items():
+            if not isinstance(a, (bool, list)):
+                blob[f'{tag}/ref/{k}'] = a
+    if write:
+        out = os.path.join(ROOT, 'tests', 'golden', 'sp_graph.npz')
+        np.savez_compressed(out, **blob)
+        print('  wrote', out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--write', action='store_true', help='write tests/golden/*.npz')
@@ -646,6 +698,8 @@ def main():
         check_metrics(a.write)
     if a.only in ('', 'baseline_size'):
         check_baseline_size(refmods, a.write)
+    if a.only in ('', 'sp_graph'):
+        check_sp_graph(a.write)
     if a.only in ('', 'local_embedder'):
         check_local_embedder(refmods, a.write)
     cw = torch.linspace(0.5, 1.5, 13)

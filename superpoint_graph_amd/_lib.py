@@ -94,6 +94,13 @@ SIGNATURES = {
     'spg_set_batch': (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),
     'spg_gather_rows': (_i, [_p, _l, _p, _l, _i, _p, _l, _p]),
     'spg_upload': (_i, [_p, _sz, _p, _p]),
+    'spg_spg_workspace_bytes': (_sz, [_i, _l]),
+    'spg_spg_tet_edges': (_i, [_p, _l, _p, _p, _l, _p, _p]),
+    'spg_spg_unique_edges': (_i, [_p, _l, _p, _p, _l, ctypes.c_float, _p, _p, _p, _p, _sz, _p]),
+    'spg_spg_group_edges': (_i, [_p, _p, _l, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'spg_spg_superpoints': (_i, [_p, _l, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'spg_spg_superedges': (_i, [_p, _p, _p, _l, _l] + [_p] * 16 + [_p]),
+    'spg_compute_geof': (_i, [_p, _p, _l, _i, _p, _p]),
     'spg_edge_features': (_i, [ctypes.POINTER(EdgeFeatureSpecs), _p, _l, _p, _p, _p, _p]),
     'spg_loader_random': (_i, [_p, _p, _p, _i, _i, _i, ctypes.c_uint64, ctypes.c_uint32, _i, ctypes.c_float, _i, ctypes.c_float, _i, _p, _p, _p, _p]),
     'spg_cross_entropy_fwd': (_i, [_p, _p, _p, _i, _i, ctypes.c_int64, _i, _p, _p, _p, _p]),

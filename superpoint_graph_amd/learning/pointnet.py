@@ -347,6 +347,23 @@ class _ScatterEmbeddings(torch.autograd.Function):
         return ops.gather_rows(grad.contiguous(), ctx.idx_valid), None, None
 
 
+def stage_flags(clouds_flag):
+    """Index vectors CloudEmbedder derives from `clouds_flag` (rows of the valid superpoints, embedding row of every
+    superpoint), computed and uploaded on the CURRENT stream and attached to the flag tensor: a device collate calls this
+    while it builds the batch (on the side stream of learning/prefetch.py), so the training stream starts a step without the
+    two small uploads.  -> (idx_valid, slot_of_row) on the device."""
+    staged = getattr(clouds_flag, '_spg_staged', None)
+    if staged is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+        valid = clouds_flag.eq(0)
+        idx_valid = torch.nonzero(valid).reshape(-1)
+        slot = torch.cumsum(valid.to(torch.int64), 0) - 1          # row of the embedding matrix, -1 for too-small superpoints
+        slot[~valid] = -1
+        # (staging ring, non-blocking: a pageable H2D would stall the host until the stream has drained)
+        staged = clouds_flag._spg_staged = (ops.upload(idx_valid, dev), ops.upload(slot, dev))
+    return staged
+
+
 class CloudEmbedder():
     """Evaluates PointNet on superpoints; too small superpoints get zero embeddings (reference
     learning/pointnet.py:138-180).  `ptn_mem_monger` keeps its observable semantics (autograd is cut after
@@ -362,12 +379,7 @@ class CloudEmbedder():
     def _to_device(self, clouds_flag, clouds, clouds_global):
         dev = torch.device('cuda', torch.cuda.current_device())
         if self._flag_cache[0] is not clouds_flag:       # (same batch object again: benchmarks, multi-pass evaluation)
-            valid = clouds_flag.eq(0)
-            idx_valid = torch.nonzero(valid).reshape(-1)
-            slot = torch.cumsum(valid.to(torch.int64), 0) - 1          # row of the embedding matrix, -1 for too-small superpoints
-            slot[~valid] = -1
-            # (pinned staging ring, non-blocking: a pageable H2D would stall the host until the stream has drained)
-            self._flag_cache = (clouds_flag, ops.upload(idx_valid, dev), ops.upload(slot, dev))
+            self._flag_cache = (clouds_flag,) + tuple(stage_flags(clouds_flag))      # staged by the device collate, or now
         self._slot_of_row = self._flag_cache[2]
         return self._flag_cache[1], ops.upload(clouds, dev), ops.upload(clouds_global, dev)
 

@@ -6,11 +6,14 @@ they queue BEHIND the previous step and delay the next one; `SideStreamBatches` 
 stream instead, so this device work overlaps the training step that is still executing, and hands every batch over with one
 event (the training stream waits for it; the host never does).
 
-Memory discipline (no `record_stream` bookkeeping needed): tensors of batch j are allocated in the side stream's pool and are
-dropped by the consumer at the earliest when it asks for batch j+1, i.e. after step j has been enqueued.  A later build may get
-the same blocks again; before building batch j the side stream therefore waits for the event that was recorded on the training
-stream when batch j-1 was requested (all of step j-2 and everything before it) -- the last possible reader of anything that can
-have been freed -- while step j-1 is the one it overlaps with."""
+The construction runs ONE batch ahead: batch j+1 is built (host work + side-stream launches) right after batch j has been
+handed over and before the consumer enqueues step j, so its chain of small dependent launches has the whole of step j to finish.
+
+Memory discipline (no `record_stream` bookkeeping needed): tensors of a batch are allocated in the side stream's pool and are
+dropped by the consumer at the earliest when it receives the next batch.  When batch j is built the consumer still holds batch
+j-2 (it receives j-1 only after this build), so the newest blocks that can have been freed -- and that this build may get again --
+belong to batch j-3, last read by step j-3.  Before building batch j the side stream therefore waits for the event recorded on
+the training stream at the PREVIOUS build (when steps <= j-3 had been enqueued), and overlaps with steps j-2 and j-1."""
 from __future__ import annotations
 
 import torch
@@ -45,21 +48,31 @@ class SideStreamBatches:
         main = torch.cuda.current_stream()
         side = self.side if self.side is not None else side_stream()
         it = iter(self.loader)
-        fence_prev = None                     # recorded on `main` at the previous request
-        while True:
+        fence_prev = [None]                   # recorded on `main` at the previous build
+
+        def build():
+            """-> (batch, event) or None.  Called BEFORE the consumer enqueues the step of the batch handed out last, so the
+            construction chain (a dozen dependent small launches, ~0.2 ms of latency) starts next to the step still in flight and
+            has a whole step of slack -- independent of how far the host runs ahead of the GPU."""
             fence = torch.cuda.Event()
-            fence.record(main)                # everything the consumer has enqueued so far (steps <= j-1)
-            # steps <= j-2 are complete before batch j's buffers may be (re)written; the first batch of an iteration waits for
-            # everything enqueued so far (the side stream and its pool outlive the iteration: the previous epoch's last steps
-            # may still be reading what they freed)
-            side.wait_event(fence_prev if fence_prev is not None else fence)
+            fence.record(main)                # everything the consumer has enqueued so far (steps <= j-2 when batch j is built)
+            # ... of which steps <= j-3 = everything up to the PREVIOUS build are the last readers of whatever batch j's buffers may
+            # reuse (see the module docstring); the first build of an iteration waits for everything enqueued so far (the side
+            # stream and its pool outlive the iteration: the previous epoch's last steps may still be reading what they freed)
+            side.wait_event(fence_prev[0] if fence_prev[0] is not None else fence)
+            fence_prev[0] = fence
             with torch.cuda.stream(side):
                 try:
                     batch = next(it)
                 except StopIteration:
-                    return
+                    return None
                 built = torch.cuda.Event()
                 built.record(side)
+            return batch, built
+
+        pending = build()
+        while pending is not None:
+            batch, built = pending
+            pending = build()                 # batch j+1 is under construction before step j is enqueued
             main.wait_event(built)
-            fence_prev = fence
             yield batch

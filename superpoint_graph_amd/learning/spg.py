@@ -179,6 +179,9 @@ def eccpc_collate(batch, device_batch=False):
         clouds = torch.cat([_as_tensor(f) for f in clouds if f is not None], 0)
         clouds_global = torch.cat([_as_tensor(f) for f in clouds_global if f is not None], 0)
         clouds_flag = torch.cat([_as_tensor(f) for f in clouds_flag if f is not None], 0)
+        if device_batch:              # CloudEmbedder's index vectors travel with the batch (uploaded here, on the collate's stream)
+            from .pointnet import stage_flags
+            stage_flags(clouds_flag)
         clouds_meta = [item for sublist in clouds_meta if sublist is not None for item in sublist]
     return targets, GIs, (clouds_meta, clouds_flag, clouds, clouds_global)
 

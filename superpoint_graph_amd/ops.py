@@ -564,3 +564,84 @@ def eval_accumulate(logits, label_mode, label_vec, confusion, counters):
     check(lib().spg_eval_accumulate(_ptr(logits), S, N * C, N, C, _ptr(label_mode), _ptr(label_vec), _ptr(pred),
                                     _ptr(confusion), _ptr(counters), _stream()), 'spg_eval_accumulate')
     return pred
+
+
+# --------------------------------------------------------------------------------------------------
+# superpoint-graph construction (partition/graphs.py compute_sp_graph after the triangulation, ply_c compute_geof)
+# --------------------------------------------------------------------------------------------------
+def _u8_workspace(nbytes, dev):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def sp_graph(xyz, comp, n_com: int, tets, d_max: float, labels=None, label_rows=None, n_labels: int = 0):
+    """xyz f32 [n,3], comp i32 [n], tets i32 [T,4] (Delaunay simplices), all on the device -> dict of device tensors with the
+    keys of the reference's compute_sp_graph (partition/graphs.py:75-210).  Three host synchronisations (the numbers of raw
+    interface pairs, unique edges and superedges size the next stage's buffers)."""
+    _req(xyz, torch.float32, 'xyz'); _req(comp, torch.int32, 'comp'); _req(tets, torch.int32, 'tets')
+    L, dev, st = lib(), xyz.device, _stream()
+    n, T = int(xyz.shape[0]), int(tets.shape[0])
+    if xyz.dim() != 2 or xyz.shape[1] != 3 or comp.numel() != n or (T and tets.shape[1] != 4):
+        raise ValueError('sp_graph: xyz [n,3], comp [n], tets [T,4] expected')
+    u64, f32 = torch.int64, torch.float32                 # (torch has no uint64 arithmetic: int64 storage, the library reads it unsigned)
+    cnt = torch.zeros(1, dtype=u64, device=dev)
+    # ---- superpoints (graphs.py:141-172) ----
+    out = {'sp_centroids': torch.empty(n_com, 3, dtype=f32, device=dev), 'sp_length': torch.empty(n_com, 1, dtype=f32, device=dev),
+           'sp_surface': torch.empty(n_com, 1, dtype=f32, device=dev), 'sp_volume': torch.empty(n_com, 1, dtype=f32, device=dev),
+           'sp_point_count': torch.empty(n_com, 1, dtype=u64, device=dev)}
+    sp_labels = None
+    if labels is not None or label_rows is not None:
+        sp_labels = torch.empty(n_com, n_labels + 1, dtype=torch.int32, device=dev)
+        if labels is not None:
+            _req(labels, torch.int32, 'labels')
+        else:
+            _req(label_rows, torch.int32, 'label_rows')
+    ws = _u8_workspace(L.spg_spg_workspace_bytes(2, n), dev)
+    check(L.spg_spg_superpoints(_ptr(xyz), n, _ptr(comp), n_com, _ptr(labels), _ptr(label_rows), n_labels, _ptr(out['sp_centroids']),
+                                _ptr(out['sp_length']), _ptr(out['sp_surface']), _ptr(out['sp_volume']), _ptr(out['sp_point_count']),
+                                _ptr(sp_labels), _ptr(ws), ws.numel(), st), 'spg_spg_superpoints')
+    out['sp_labels'] = sp_labels
+    # ---- interface edges of the tetrahedra, unique, shorter than d_max (:85-113) ----
+    keys = torch.empty(max(12 * T, 1), dtype=u64, device=dev)
+    check(L.spg_spg_tet_edges(_ptr(tets) if T else None, T, _ptr(comp), _ptr(keys), 12 * T, _ptr(cnt), st), 'spg_spg_tet_edges')
+    n_raw = int(cnt.item())
+    edge_keys = torch.empty(max(n_raw, 1), dtype=u64, device=dev)
+    cc_keys = torch.empty(max(n_raw, 1), dtype=u64, device=dev)
+    ws = _u8_workspace(L.spg_spg_workspace_bytes(0, n_raw), dev)
+    check(L.spg_spg_unique_edges(_ptr(keys), n_raw, _ptr(xyz), _ptr(comp), n_com, float(d_max), _ptr(edge_keys), _ptr(cc_keys), _ptr(cnt),
+                                 _ptr(ws), ws.numel(), st), 'spg_spg_unique_edges')
+    n_edg = int(cnt.item())
+    # ---- ordered by component pair, superedge segments (:117-128) ----
+    cc_sorted = torch.empty(max(n_edg, 1), dtype=u64, device=dev)
+    edges_sorted = torch.empty(max(n_edg, 1), dtype=u64, device=dev)
+    seg_cc = torch.empty(max(n_edg, 1), dtype=u64, device=dev)
+    seg_off = torch.empty(n_edg + 1, dtype=u64, device=dev)
+    ws = _u8_workspace(L.spg_spg_workspace_bytes(1, n_edg), dev)
+    check(L.spg_spg_group_edges(_ptr(cc_keys), _ptr(edge_keys), n_edg, _ptr(cc_sorted), _ptr(edges_sorted), _ptr(seg_cc), _ptr(seg_off),
+                                _ptr(cnt), _ptr(ws), ws.numel(), st), 'spg_spg_group_edges')
+    n_sedg = int(cnt.item())
+    # ---- superedge features (:174-208) ----
+    se = {'source': torch.empty(n_sedg, 1, dtype=torch.int32, device=dev), 'target': torch.empty(n_sedg, 1, dtype=torch.int32, device=dev)}
+    for k, w in (('se_delta_mean', 3), ('se_delta_std', 3), ('se_delta_norm', 1), ('se_delta_centroid', 3), ('se_length_ratio', 1),
+                 ('se_surface_ratio', 1), ('se_volume_ratio', 1), ('se_point_count_ratio', 1)):
+        se[k] = torch.empty(n_sedg, w, dtype=f32, device=dev)
+    check(L.spg_spg_superedges(_ptr(edges_sorted), _ptr(seg_cc), _ptr(seg_off), n_sedg, n_com, _ptr(xyz), _ptr(out['sp_centroids']),
+                               _ptr(out['sp_length']), _ptr(out['sp_surface']), _ptr(out['sp_volume']), _ptr(out['sp_point_count']),
+                               _ptr(se['source']), _ptr(se['target']), _ptr(se['se_delta_mean']), _ptr(se['se_delta_std']),
+                               _ptr(se['se_delta_norm']), _ptr(se['se_delta_centroid']), _ptr(se['se_length_ratio']),
+                               _ptr(se['se_surface_ratio']), _ptr(se['se_volume_ratio']), _ptr(se['se_point_count_ratio']), st),
+          'spg_spg_superedges')
+    out.update(se)
+    out['edges'] = edges_sorted[:n_edg]                    # (source << 32 | target) of every Delaunay edge behind the superedges
+    out['seg_off'] = seg_off[:n_sedg + 1]
+    return out
+
+
+def compute_geof(xyz, target, k_nn: int):
+    """xyz f32 [n,3], target (u)int32 [n * k_nn] neighbour indices on the device -> geof f32 [n,4] (ply_c.cpp:384-462)."""
+    _req(xyz, torch.float32, 'xyz'); _req(target, torch.int32, 'target')
+    n = int(xyz.shape[0])
+    if target.numel() != n * k_nn:
+        raise ValueError(f'compute_geof: {n} points x {k_nn} neighbours need {n * k_nn} targets, got {target.numel()}')
+    geof = torch.empty(n, 4, dtype=torch.float32, device=xyz.device)
+    check(lib().spg_compute_geof(_ptr(xyz), _ptr(target), n, int(k_nn), _ptr(geof), _stream()), 'spg_compute_geof')
+    return geof
