@@ -21,6 +21,15 @@ graphs = {
     'ring': ((np.arange(n) - 1) % n, np.ones(n, np.int64)),
     'scene': (e[order, 0], np.bincount(e[:, 1], minlength=n)),
 }
+# where does a hop go?  node i lives in workgroup i // 4, workgroup b on XCD b % 8
+graphs['ring4'] = ((np.arange(n) - 4) % n, np.ones(n, np.int64))        # source in the NEXT workgroup: another XCD, always
+graphs['ring32'] = ((np.arange(n) - 32) % n, np.ones(n, np.int64))      # source 8 workgroups away: the SAME XCD, another CU
+rs = np.random.default_rng(0)
+anyw = rs.integers(0, n, (n, 5))
+xcd = (np.arange(n) // 4) % 8
+same = np.stack([rs.choice(np.flatnonzero(xcd == xcd[i]), 5) for i in range(n)])
+graphs['rand5'] = (anyw.reshape(-1), np.full(n, 5, np.int64))           # 5 in-neighbours anywhere
+graphs['rand5x'] = (same.reshape(-1), np.full(n, 5, np.int64))          # 5 in-neighbours on the node's own XCD
 x = torch.randn(n, 32).cuda()
 for name, (idxn, degs) in graphs.items():
     E = len(idxn)

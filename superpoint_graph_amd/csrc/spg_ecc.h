@@ -96,6 +96,8 @@ int spg_launch_ecc_edge_wgrad(const SpgGraph& g, int matrix, const float* states
 int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream);
 
 // ---- persistent (one launch for all iterations) forms of the GRU recurrence, spg_ecc.hip ----
+#define SPG_PX_MAX_NODES 1024      // nodes per persistent launch (one wavefront each, all co-resident)
+#define SPG_PX_SAVE_F 12           // floats per lane and (node, iteration) of forward internals kept for the backward (3 quads)
 struct SpgEccPersistFwd {
   SpgGraph g;
   const float* W;
@@ -108,6 +110,8 @@ struct SpgEccPersistFwd {
   SpgGruParams gru;
   unsigned long long* gran; // [SPG_PX_MAX_ITERS][SPG_PX_MAX_NODES][32] granules
   unsigned* ctl;            // {epoch base, workgroups done, error count, -}
+  float* fsave;             // [N][R][3 quads][64 lanes][4] forward internals kept for the backward (training), or null
+  unsigned* fsave_tag;      // set to a magic word by the persistent forward when fsave was written
 };
 
 struct SpgEccPersistBwd {
@@ -124,6 +128,8 @@ struct SpgEccPersistBwd {
   SpgGruParams gru;
   unsigned long long* gran;
   unsigned* ctl;
+  const float* fsave;       // forward internals (see SpgEccPersistFwd) -- used when *fsave_tag carries the magic word
+  const unsigned* fsave_tag;
 };
 
 // return false when the persistent form is not applicable (too many nodes / iterations, switched off, another stream owns

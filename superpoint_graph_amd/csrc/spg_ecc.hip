@@ -282,6 +282,32 @@ struct GruRowsLds {
   __device__ __forceinline__ float dot_ig(const float* v) const { return dot(ig, v); }
 };
 
+// The same rows held in REGISTERS (persistent forward kernel: one wave per SIMD has 512 VGPRs to itself; 160 of them take the
+// five rows of this lane, so an iteration's dot products read only the broadcast operand from LDS -- 40 instead of 200 LDS
+// reads per lane and iteration).  Same accumulation order as GruRowsLds::dot: the results are bit-identical.
+struct GruRowsReg {
+  float ih1[32], hh1[32], ih2[32], hh2[32], ig[32];
+  __device__ __forceinline__ void load(const GruRowsLds& l) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { ih1[k] = l.ih1[k]; hh1[k] = l.hh1[k]; ih2[k] = l.ih2[k]; hh2[k] = l.hh2[k]; ig[k] = l.ig[k]; }
+  }
+  static __device__ __forceinline__ float dot(const float (&row)[32], const float* __restrict__ v) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(v + 4 * q);   // LDS broadcast read
+      a0 = fmaf(row[4 * q + 0], x[0], a0); a1 = fmaf(row[4 * q + 1], x[1], a1);
+      a0 = fmaf(row[4 * q + 2], x[2], a0); a1 = fmaf(row[4 * q + 3], x[3], a1);
+    }
+    return a0 + a1;
+  }
+  __device__ __forceinline__ float dot_ih1(const float* v) const { return dot(ih1, v); }
+  __device__ __forceinline__ float dot_hh1(const float* v) const { return dot(hh1, v); }
+  __device__ __forceinline__ float dot_ih2(const float* v) const { return dot(ih2, v); }
+  __device__ __forceinline__ float dot_hh2(const float* v) const { return dot(hh2, v); }
+  __device__ __forceinline__ float dot_ig(const float* v) const { return dot(ig, v); }
+};
+
 // block-wide: global [GW][32] x2 + [32][32] -> LDS rows of SPG_WLD floats (w_ih | w_hh | w_ig); caller synchronises
 template <int GW>
 __device__ __forceinline__ void spg_stage_cell_weights(const SpgGruParams& G, float* __restrict__ sw) {
@@ -309,6 +335,9 @@ template <class Rows, bool WAVE = false>
 __device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, const Rows& w, const float* __restrict__ sa,
                                                      const float* __restrict__ sh, float* __restrict__ sx, int lane,
                                                      GruFwdState& st) {
+  // No fused multiply-add contraction in here: this function, its two halves below (persistent forward kernel) and the
+  // recompute inside the backward kernels must round identically whatever code surrounds them after inlining.
+#pragma clang fp contract(off)
   // input gate: x = sigmoid(W_ig h + b_ig) * a      (learning/modules.py:225-226)
   float gin = 1.f, x = 0.f;
   if (lane < 32) {
@@ -341,6 +370,74 @@ __device__ __forceinline__ void spg_gru_forward_node(const SpgGruParams& G, cons
   if (lane < 32) st.n = tanhf((gi2 + G.b_ih[64 + lane]) + g1 * (gh2 + G.b_hh[64 + lane]));
 }
 
+
+// spg_gru_forward_node in two halves (persistent forward kernel): everything that depends on the node's OWN state only -- the
+// input gate, W_hh h and its row normalisation -- is evaluated before the wave starts to wait for its neighbours' states, the
+// rest once the aggregate is there.  Same expressions, same order per value as spg_gru_forward_node: bit-identical results
+// (tests/test_gpu_ecc_persistent.py compares the two kernels).
+template <class Rows>
+__device__ __forceinline__ void spg_gru_hidden_part(const SpgGruParams& G, const Rows& w, const float* __restrict__ sh, int lane,
+                                                    GruFwdState& st) {
+#pragma clang fp contract(off)
+  float gin = 1.f;
+  if (lane < 32 && G.ingate) gin = spg_sigmoid(w.dot_ig(sh) + G.b_ig[lane]);
+  st.gin = gin;
+  float gh1 = w.dot_hh1(sh), gh2 = 0.f;
+  if (lane < 32) gh2 = w.dot_hh2(sh);
+  st.rstd_h = 1.f;
+  if (G.layernorm) {
+    const float mh = spg_wave_sum(gh1 + (lane < 32 ? gh2 : 0.f)) * (1.f / 96.f);
+    const float dh1 = gh1 - mh, dh2 = gh2 - mh;
+    const float vh = spg_wave_sum(dh1 * dh1 + (lane < 32 ? dh2 * dh2 : 0.f)) * (1.f / 96.f);
+    st.rstd_h = 1.0f / sqrtf(vh + SPG_IN_EPS);
+    gh1 = dh1 * st.rstd_h; gh2 = dh2 * st.rstd_h;
+  }
+  st.uh1 = gh1; st.uh2 = gh2;
+}
+
+template <class Rows, bool WAVE>
+__device__ __forceinline__ void spg_gru_input_part(const SpgGruParams& G, const Rows& w, const float* __restrict__ sa,
+                                                   float* __restrict__ sx, int lane, GruFwdState& st) {
+#pragma clang fp contract(off)
+  float x = 0.f;
+  if (lane < 32) {
+    x = st.gin * sa[lane];
+    sx[lane] = x;
+  }
+  st.x = x;
+  spg_node_sync<WAVE>();
+  float gi1 = w.dot_ih1(sx), gi2 = 0.f;
+  if (lane < 32) gi2 = w.dot_ih2(sx);
+  st.rstd_i = 1.f;
+  if (G.layernorm) {
+    const float mi = spg_wave_sum(gi1 + (lane < 32 ? gi2 : 0.f)) * (1.f / 96.f);
+    const float di1 = gi1 - mi, di2 = gi2 - mi;
+    const float vi = spg_wave_sum(di1 * di1 + (lane < 32 ? di2 * di2 : 0.f)) * (1.f / 96.f);
+    st.rstd_i = 1.0f / sqrtf(vi + SPG_IN_EPS);
+    gi1 = di1 * st.rstd_i; gi2 = di2 * st.rstd_i;
+  }
+  st.ui1 = gi1; st.ui2 = gi2;
+  const float gh1 = st.uh1, gh2 = st.uh2;
+  const float g1 = spg_sigmoid(((gi1 + G.b_ih[lane]) + gh1) + G.b_hh[lane]);
+  st.r = g1;
+  st.z = __shfl(g1, (lane & 31) + 32, 64);
+  st.n = 0.f;
+  if (lane < 32) st.n = tanhf((gi2 + G.b_ih[64 + lane]) + g1 * (gh2 + G.b_hh[64 + lane]));
+}
+
+// forward internals of one (node, iteration) kept for the backward (persistent kernels, training): SPG_PX_SAVE_F values per lane
+#define SPG_PX_SAVE_MAGIC 0x53504721u
+// three 16-byte stores / loads per lane (1 KiB per wave instruction): `s` points at this lane's first quad, quads 64 apart
+__device__ __forceinline__ void spg_px_save_state(f32x4* __restrict__ s, const GruFwdState& st) {
+  const f32x4 a = {st.gin, st.x, st.ui1, st.ui2}, b = {st.uh1, st.uh2, st.rstd_i, st.rstd_h}, c = {st.r, st.z, st.n, 0.f};
+  s[0] = a; s[64] = b; s[128] = c;
+}
+__device__ __forceinline__ void spg_px_load_state(const f32x4* __restrict__ s, GruFwdState& st) {
+  const f32x4 a = s[0], b = s[64], c = s[128];
+  st.gin = a[0]; st.x = a[1]; st.ui1 = a[2]; st.ui2 = a[3];
+  st.uh1 = b[0]; st.uh2 = b[1]; st.rstd_i = b[2]; st.rstd_h = b[3];
+  st.r = c[0]; st.z = c[1]; st.n = c[2];
+}
 
 // LSTMCellEx forward internals for one node (learning/modules.py:280-309).  The 128 gate pre-activations
 // (chunks i | f | g | o of 32) are two values per lane: index `lane` (i on lanes 0..31, f on 32..63) and index
@@ -469,14 +566,17 @@ struct SpgGruBwdOut { float *dgi, *dgh, *dui, *duh, *dpre, *xg; long ld96, ld32;
 template <bool WAVE>
 __device__ __forceinline__ void spg_gru_backward_node(const SpgGruParams& G, const float* __restrict__ sw, float* sa, float* sh,
                                                       float* sx, float* sd, int lane, bool active, long j, float dH,
-                                                      const SpgGruBwdOut& o, float& dh_acc, float& da) {
+                                                      const SpgGruBwdOut& o, float& dh_acc, float& da,
+                                                      const GruFwdState* saved = nullptr) {
   constexpr int GW = 96;
   const float* sw_ih = sw;
   const float* sw_hh = sw_ih + GW * SPG_WLD;
   const float* sw_ig = sw_hh + GW * SPG_WLD;
   {
     GruFwdState st;
-    {
+    if (saved != nullptr) {      // the forward kernel kept its internals (persistent kernels): nothing to recompute
+      st = *saved;
+    } else {
       GruRowsLds wr;
       spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane, wr);
       spg_gru_forward_node<GruRowsLds, WAVE>(G, wr, sa, sh, sx, lane, st);
@@ -862,7 +962,6 @@ int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long row
 // time (launches of one stream serialise; a second stream falls back to the per-iteration kernels).  Spins are bounded: a
 // wave that waits longer than SPG_PX_SPIN_LIMIT sweeps raises the error word of the control block (spg_ecc_persistent_errors)
 // and carries on, so a logic error can never hang the GPU.
-#define SPG_PX_MAX_NODES 1024
 #define SPG_PX_MAX_ITERS 16
 #define SPG_PX_KMAX 8          // edges per node whose filters stay in registers (16 VGPRs each in matrix mode)
 #define SPG_PX_CH 32           // edges gathered per pass (wave-private LDS staging)
@@ -994,8 +1093,16 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEc
     if (p.cat_all) p.out[(long)i * p.ldo + lane] = hcur;
   }
   __syncthreads();            // the cell weights are in LDS; from here on the waves run on their own
+  if (p.fsave_tag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *p.fsave_tag = SPG_PX_SAVE_MAGIC;
   if (!active) return;
+  GruRowsReg wq;              // this lane's gate rows, in registers for all iterations
+  wq.load(wr);
   for (int r = 0; r < p.R; ++r) {
+    // ---- what depends on the node's own state only (input gate, W_hh h, its normalisation): BEFORE waiting for the neighbours ----
+    if (lane < 32) sh[lane] = hcur;
+    spg_node_sync<true>();
+    GruFwdState st;
+    spg_gru_hidden_part(p.gru, wq, sh, lane, st);
     // ---- aggregate over the in-edges: mean of h_src (.) W_e ----
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < deg; c0 += SPG_PX_CH) {
@@ -1057,19 +1164,19 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEc
     } else if (lane < 32) {
       sa[lane] = a4[0] * invdeg;
     }
-    if (lane < 32) sh[lane] = hcur;
     spg_node_sync<true>();
-    if (p.agg != nullptr && lane < 32) p.agg[(long)i * p.ldS + (long)r * 32 + lane] = sa[lane];
-    // ---- GRU ----
-    GruFwdState st;
-    spg_gru_forward_node<GruRowsLds, true>(p.gru, wr, sa, sh, sx, lane, st);
+    // ---- the input half of the GRU ----
+    spg_gru_input_part<GruRowsReg, true>(p.gru, wq, sa, sx, lane, st);
     if (lane < 32) {
       hcur = st.n + st.z * (hcur - st.n);      // hy = newgate + inputgate * (hidden - newgate), learning/modules.py:250
+      // publish FIRST: the neighbours wait for this; everything the later kernels need follows behind it in the memory pipeline
       if (r + 1 < p.R) spg_px_store_granule(p.gran + ((long)(r + 1) * SPG_PX_MAX_NODES + i) * 32 + lane, base + (unsigned)r + 2u, hcur);
       p.states[(long)i * p.ldS + (long)(r + 1) * 32 + lane] = hcur;
       if (p.cat_all) p.out[(long)i * p.ldo + (long)(r + 1) * 32 + lane] = hcur;
       else if (r + 1 == p.R) p.out[(long)i * p.ldo + lane] = hcur;
+      if (p.agg != nullptr) p.agg[(long)i * p.ldS + (long)r * 32 + lane] = sa[lane];
     }
+    if (p.fsave != nullptr) spg_px_save_state(reinterpret_cast<f32x4*>(p.fsave) + ((long)i * p.R + r) * (SPG_PX_SAVE_F / 4) * 64 + lane, st);
     spg_node_sync<true>();      // sa / sh / sx are rewritten by the next iteration
   }
   spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
@@ -1134,8 +1241,13 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
     }
   }
   float dhdir = 0.f;          // direct GRU-path gradient wrt this node's state, carried from iteration to iteration (lanes 0..31)
+  // did the forward keep its internals for this workspace?  (the per-iteration forward clears the tag)
+  const bool saved = p.fsave != nullptr && p.fsave_tag != nullptr &&
+                     __hip_atomic_load((const spg_gu32*)p.fsave_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == SPG_PX_SAVE_MAGIC;
   // iterations R-1 .. 0 produce G^r; the extra pass r = -1 only forms the gradient wrt h^0
   for (int r = p.R - 1; r >= -1; --r) {
+    GruFwdState stf;            // issued before the wait for the neighbours' gradients: the loads are in flight while the wave polls
+    if (saved && r >= 0) spg_px_load_state(reinterpret_cast<const f32x4*>(p.fsave) + ((long)j * p.R + r) * (SPG_PX_SAVE_F / 4) * 64 + lane, stf);
     // ---- phase 1: dH = d(out)/d(h^{r+1}) + dhdir + sum over the out-edges of W_e . G^{r+1}[dst] ----
     float dH = 0.f;
     if (lane < 32) {
@@ -1217,7 +1329,7 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
     o.dgi = p.dgi + (long)r * GW; o.dgh = p.dgh + (long)r * GW; o.dui = p.dui + (long)r * GW; o.duh = p.duh + (long)r * GW;
     o.dpre = p.dpre + (long)r * 32; o.xg = p.xg + (long)r * 32; o.ld96 = p.ld96; o.ld32 = p.ld32;
     float dh_acc, da;
-    spg_gru_backward_node<true>(p.gru, sw, sa, sh, sx, sd, lane, true, j, dH, o, dh_acc, da);
+    spg_gru_backward_node<true>(p.gru, sw, sa, sh, sx, sd, lane, true, j, dH, o, dh_acc, da, saved ? &stf : nullptr);
     if (lane < 32) {
       dhdir = dh_acc;
       const float gc = da * invdeg;

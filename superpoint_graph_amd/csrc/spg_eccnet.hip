@@ -47,6 +47,8 @@ struct Plan {
   SpgGruParams gru;
   float *states = nullptr, *agg = nullptr, *stat = nullptr, *stat_cnt = nullptr;
   float* cells = nullptr;       // LSTM cell states c^r, laid out like `states`
+  float* fsave = nullptr;       // persistent GRU recurrence, training: forward internals kept for the backward
+  unsigned* fsave_tag = nullptr;
   float* cell_grads[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t bytes = 0;
 };
@@ -98,6 +100,13 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
   pl.states = cv.take<float>((size_t)N * pl.ldS);
   pl.agg = cv.take<float>((size_t)N * pl.ldS);
   if (pl.lstm) pl.cells = cv.take<float>((size_t)N * pl.ldS);
+  // persistent GRU recurrence in training: the forward keeps the cell's internals of every (node, iteration) for the backward
+  // (12 x 64 floats each: 31 MB per 1000 nodes x 10 iterations) instead of the backward recomputing them on its critical path
+  pl.fsave = nullptr; pl.fsave_tag = nullptr;
+  if (!pl.lstm && pl.training && N <= SPG_PX_MAX_NODES) {
+    pl.fsave_tag = cv.take<unsigned>(64);
+    pl.fsave = cv.take<float>((size_t)N * pl.R * SPG_PX_SAVE_F * 64);
+  }
   pl.stat = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, SPG_FC_ROWS) * 2 * cmax);
   pl.stat_cnt = cv.take<float>((size_t)spg_cdiv(E > 0 ? E : 1, SPG_FC_ROWS) + 64);
   pl.bytes = cv.off + 256;
@@ -223,9 +232,11 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
     q.g = gr; q.W = pl.F.back().y; q.matrix = pl.cfg.matrix; q.R = pl.R; q.h0 = h0;
     q.states = pl.states; q.ldS = pl.ldS; q.agg = pl.training ? pl.agg : nullptr;
     q.out = out; q.cat_all = pl.cfg.cat_all; q.ldo = pl.cfg.cat_all ? pl.ldS : 32; q.gru = pl.gru;
+    q.fsave = pl.fsave; q.fsave_tag = pl.fsave_tag;
     int err = 0;
     if (spg_launch_ecc_persist_fwd(q, st, &err)) return err;
   }
+  if (pl.fsave_tag != nullptr) SPG_TRY(zero_async(pl.fsave_tag, sizeof(unsigned), st));      // per-iteration path: nothing was kept
   SPG_TRY(spg_launch_copy2d(h0, 32, pl.states, pl.ldS, N, 32, st));
   for (int r = 0; r < pl.R; ++r) {
     SpgEccStepFwd p; memset(&p, 0, sizeof(p));
@@ -287,6 +298,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     q.states = pl.states; q.ldS = ldS; q.agg = pl.agg; q.G = s.G;
     q.dgi = s.dgi; q.dgh = s.dgh; q.dui = s.dui; q.duh = s.duh; q.ld96 = ld96;
     q.dpre = s.dpre; q.xg = s.xg; q.ld32 = ldS; q.gx = grad_h0; q.gru = pl.gru;
+    q.fsave = pl.fsave; q.fsave_tag = pl.fsave_tag;
     int err = 0;
     persistent = spg_launch_ecc_persist_bwd(q, st, &err);      // writes every row of [G .. xg] itself (slot R: zeros)
     if (err != 0) return err;
