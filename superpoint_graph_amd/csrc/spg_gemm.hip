@@ -1133,9 +1133,7 @@ template <bool WRED, int AMODE>
 static int launch_gemm_shape(const SpgGemmParams& p, hipStream_t stream, int* sp) {
   if (p.rows_per_tile <= 32) return launch_gemm_t<32, 128, 1, 4, WRED, AMODE>(p, stream, sp);   // few rows (FC layers, filter net)
   if (p.N <= 32) return launch_gemm_t<128, 32, 4, 1, WRED, AMODE>(p, stream, sp);
-  // forward 64 -> 128 layers: two 128x64 column tiles instead of one 128x128 tile -- with only two reduction chunks per tile the
-  // epilogue dominates, and the narrower kernel (168 instead of 234 VGPRs) gets through it faster (measured: -7 us per step)
-  if (p.N <= 64 || (!WRED && p.N == 128 && p.K <= 64)) return launch_gemm_t<128, 64, 2, 2, WRED, AMODE>(p, stream, sp);
+  if (p.N <= 64) return launch_gemm_t<128, 64, 2, 2, WRED, AMODE>(p, stream, sp);
   return launch_gemm_t<128, 128, 2, 2, WRED, AMODE>(p, stream, sp);                                // wider outputs: grid.y column tiles
 }
 
