@@ -242,6 +242,16 @@ typedef struct {
 int spg_edge_features(const spg_edge_feature_specs* specs, const int64_t* edges, long E, const double* mean,
                       const double* scale, float* out, void* stream);
 
+/* The whole construction of a SMALL batch (N <= 4096 nodes, E <= 32768 edges) in two launches: spg_set_batch +
+ * spg_gather_rows of the edge features + spg_graph_build, from HOST pointers (edges int64 [E][2] with the batch node offsets
+ * applied, feats float32 [E][F]; uploaded through the staging ring of spg_upload) -> idxn [E], degs [N], feats_sorted [E][F]
+ * (GraphConvInfo.get_buffers(), learning/ecc/GraphConvInfo.py:33-79) and the device graph in graph_ws
+ * (spg_graph_workspace_bytes(N, N, E)).  Same results as the three calls it replaces (stable order by target).
+ * spg_batch_graph_scratch_bytes returns 0 when the batch is too large for it: use the three calls then. */
+size_t spg_batch_graph_scratch_bytes(int N, int E, int F);
+int spg_batch_graph_build(const int64_t* edges_host, const float* feats_host, int N, int E, int F, int64_t* idxn, int64_t* degs,
+                          float* feats_sorted, void* graph_ws, void* scratch, int32_t* error_flag, void* stream);
+
 /* Host -> device upload of a small per-batch buffer (the reference's `.cuda()` of idxn / degs / edgefeats,
  * learning/ecc/GraphConvInfo.py:71-79, and of the clouds, learning/pointnet.py:150-152) WITHOUT a host stall: the bytes
  * are copied into a slot of a library-owned ring of page-locked staging buffers and sent from there with an asynchronous

@@ -209,7 +209,7 @@ StagingRing g_staging;
 
 }  // namespace
 
-extern "C" int spg_upload(const void* host, size_t bytes, void* device, void* stream) {
+static int upload_impl(const void* host, size_t bytes, void* device, void* stream) {
   if (bytes == 0) return 0;
   SPG_CHECK_ARG(host && device, "bad argument");
   int dev = 0;
@@ -257,5 +257,173 @@ extern "C" int spg_upload(const void* host, size_t bytes, void* device, void* st
   rc = hipEventRecord(s.done, (hipStream_t)stream);
   if (rc != hipSuccess) { spg_set_error("hipEventRecord: %s", hipGetErrorString(rc)); return (int)rc; }
   s.pending = true;
+  return 0;
+}
+
+extern "C" int spg_upload(const void* host, size_t bytes, void* device, void* stream) { return upload_impl(host, bytes, device, stream); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// spg_batch_graph_build: the whole batch construction of a SMALL batch in ONE launch
+// ------------------------------------------------------------------------------------------------------------------
+// GraphConvInfo.set_batch (learning/ecc/GraphConvInfo.py:33-69) + `.cuda()` (:71-79) + the CSR / reverse CSR of spg_graph_build
+// for a batch of a few scenes (N <= 4096 nodes, E <= 32768 edges): the multi-launch path is ~20 launches of 3-10 us and 5
+// copies per batch -- all latency, and on the side stream every one of them takes a workgroup slot next to the persistent
+// GEMMs of the step in flight.  Here ONE workgroup of 1024 threads walks the phases (count -> scan -> bucket fill -> per-node
+// order -> outputs; the per-node counters and cursors in LDS) with workgroup barriers in between, a second small launch
+// reorders the edge features; the edge list and the edge features come from HOST pointers through
+// the staging ring.  Same results as spg_set_batch + spg_gather_rows + spg_graph_build: the order by target is the stable one
+// (ties by edge index), integer atomics only, deterministic.
+#include "spg_ecc.h"
+
+namespace {
+
+constexpr int kBgMaxNodes = 4096, kBgMaxEdges = 32768;
+
+struct BatchGraphArgs {
+  const int64_t* edges;      // [E][2] device
+  const float* feats;        // [E][F] device or null
+  int N, E, F;
+  int64_t* idxn;             // [E]
+  int64_t* degs;             // [N]
+  float* feats_sorted;       // [E][F]
+  int *hdr, *rowptr, *src, *dst, *rev_rowptr, *rev_eid;
+  float* invdeg;
+  int *bucket_in, *bucket_out, *inv;      // scratch: [E] each
+  int32_t* error_flag;       // may be null
+};
+
+// exclusive scan of cnt[0..n) (LDS) -> out[0..n] (global), and cnt[i] := out[i] (the bucket cursors start at the segment starts)
+__device__ __forceinline__ void block_exscan_lds(int* __restrict__ cnt, int n, int* __restrict__ out, int* part) {
+  const int t = threadIdx.x, chunk = (n + 1023) / 1024;
+  const int b = min(n, t * chunk), e = min(n, b + chunk);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += cnt[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int base = part[t] - s;
+  for (int i = b; i < e; ++i) { const int c = cnt[i]; out[i] = base; cnt[i] = base; base += c; }
+  if (t == 1023) out[n] = part[1023];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void insertion_sort(int* __restrict__ a, int b, int e) {
+  for (int i = b + 1; i < e; ++i) {
+    const int v = a[i];
+    int k = i - 1;
+    while (k >= b && a[k] > v) { a[k + 1] = a[k]; --k; }
+    a[k + 1] = v;
+  }
+}
+
+// one workgroup: the counters / cursors of all nodes live in LDS (integer LDS atomics: order-independent results)
+__global__ __launch_bounds__(1024) void batch_graph_kernel(const BatchGraphArgs a) {
+  __shared__ int s_in[kBgMaxNodes], s_out[kBgMaxNodes];
+  __shared__ int part[1024];
+  __shared__ int bad;
+  const int t = threadIdx.x, N = a.N, E = a.E;
+  if (t == 0) bad = 0;
+  for (int i = t; i < N; i += 1024) { s_in[i] = 0; s_out[i] = 0; }
+  __syncthreads();
+  for (int e = t; e < E; e += 1024) {
+    const int64_t s = a.edges[2 * (long)e], d = a.edges[2 * (long)e + 1];
+    if (s < 0 || s >= N || d < 0 || d >= N) { bad = 1; continue; }
+    atomicAdd(&s_in[(int)d], 1);
+    atomicAdd(&s_out[(int)s], 1);
+  }
+  __syncthreads();
+  if (t == 0) {
+    a.hdr[0] = N; a.hdr[1] = N; a.hdr[2] = E; a.hdr[3] = bad;
+    if (a.error_flag != nullptr) *a.error_flag = bad;
+  }
+  if (bad) return;                       // malformed edge list: flagged, nothing else is written (the host checked it before)
+  for (int i = t; i < N; i += 1024) {
+    const int d = s_in[i];
+    a.degs[i] = d;
+    a.invdeg[i] = d > 0 ? 1.0f / (float)d : 0.f;
+  }
+  __syncthreads();
+  block_exscan_lds(s_in, N, a.rowptr, part);
+  block_exscan_lds(s_out, N, a.rev_rowptr, part);
+  for (int e = t; e < E; e += 1024) {
+    const int s = (int)a.edges[2 * (long)e], d = (int)a.edges[2 * (long)e + 1];
+    a.bucket_in[atomicAdd(&s_in[d], 1)] = e;
+    a.bucket_out[atomicAdd(&s_out[s], 1)] = e;
+  }
+  __syncthreads();                       // s_in[i] / s_out[i] are now the segment ENDS
+  // order every target's bucket by edge index (= the stable order by target), emit the edge arrays
+  for (int i = t; i < N; i += 1024) {
+    const int e = s_in[i], b = e - (int)a.degs[i];
+    insertion_sort(a.bucket_in, b, e);
+    for (int p = b; p < e; ++p) {
+      const int eo = a.bucket_in[p];
+      const int64_t s = a.edges[2 * (long)eo];
+      a.idxn[p] = s;
+      a.src[p] = (int)s;
+      a.dst[p] = i;
+      a.inv[eo] = p;
+    }
+  }
+  __syncthreads();
+  // reverse CSR: for every source the NEW ids of its out-edges, ascending
+  for (int j = t; j < N; j += 1024) {
+    const int e = s_out[j], b = a.rev_rowptr[j];
+    for (int p = b; p < e; ++p) a.bucket_out[p] = a.inv[a.bucket_out[p]];
+    insertion_sort(a.bucket_out, b, e);
+    for (int p = b; p < e; ++p) a.rev_eid[p] = a.bucket_out[p];
+  }
+}
+
+// edge features in the new order: feats_sorted[p, :] = feats[perm[p], :]
+__global__ void gather_rows_i32_kernel(const float* __restrict__ src, const int* __restrict__ perm, long rows, int cols, float* __restrict__ dst) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= rows * cols) return;
+  const long p = u / cols;
+  dst[u] = src[(long)perm[p] * cols + (u - p * cols)];
+}
+
+size_t bg_al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t spg_batch_graph_scratch_bytes(int N, int E, int F) {
+  if (N < 1 || E < 0 || N > kBgMaxNodes || E > kBgMaxEdges) return 0;      // 0: not applicable, use the multi-launch path
+  const size_t e = (size_t)(E > 0 ? E : 1);
+  return bg_al(e * 16) + bg_al(e * (size_t)(F > 0 ? F : 1) * 4) + 3 * bg_al(e * 4) + 256;
+}
+
+extern "C" int spg_batch_graph_build(const int64_t* edges_host, const float* feats_host, int N, int E, int F, int64_t* idxn, int64_t* degs,
+                                     float* feats_sorted, void* graph_ws, void* scratch, int32_t* error_flag, void* stream) {
+  SPG_CHECK_ARG(N >= 1 && N <= kBgMaxNodes && E >= 0 && E <= kBgMaxEdges && F >= 0, "batch too large for the single-launch builder");
+  SPG_CHECK_ARG(degs && graph_ws && scratch && (E == 0 || (edges_host && idxn)) && (F == 0 || E == 0 || (feats_host && feats_sorted)), "null pointer");
+  const size_t e = (size_t)(E > 0 ? E : 1);
+  char* w = (char*)scratch;
+  BatchGraphArgs a;
+  a.edges = (const int64_t*)w; w += bg_al(e * 16);
+  a.feats = F > 0 ? (const float*)w : nullptr; w += bg_al(e * (size_t)(F > 0 ? F : 1) * 4);
+  a.bucket_in = (int*)w; w += bg_al(e * 4);
+  a.bucket_out = (int*)w; w += bg_al(e * 4);
+  a.inv = (int*)w;
+  if (E > 0) {
+    SPG_TRY(upload_impl(edges_host, (size_t)E * 16, (void*)a.edges, stream));
+    if (F > 0) SPG_TRY(upload_impl(feats_host, (size_t)E * F * 4, (void*)a.feats, stream));
+  }
+  SpgGraph g = spg_graph_view(graph_ws, N, E);
+  a.N = N; a.E = E; a.F = F; a.idxn = idxn; a.degs = degs; a.feats_sorted = feats_sorted;
+  a.hdr = (int*)g.hdr; a.rowptr = (int*)g.rowptr; a.src = (int*)g.src; a.dst = (int*)g.dst;
+  a.rev_rowptr = (int*)g.rev_rowptr; a.rev_eid = (int*)g.rev_eid; a.invdeg = (float*)g.invdeg;
+  a.error_flag = error_flag;
+  hipLaunchKernelGGL(batch_graph_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  SPG_LAUNCH_CHECK();
+  if (E > 0 && F > 0) {      // (a malformed edge list leaves bucket_in unwritten: the gather then reads scratch, never out of bounds)
+    hipLaunchKernelGGL(gather_rows_i32_kernel, dim3(spg_cdiv((long)E * F, 256)), dim3(256), 0, (hipStream_t)stream, a.feats,
+                       (const int*)a.bucket_in, (long)E, F, feats_sorted);
+    SPG_LAUNCH_CHECK();
+  }
   return 0;
 }

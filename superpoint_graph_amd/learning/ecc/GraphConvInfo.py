@@ -70,17 +70,24 @@ class GraphConvInfo(object):
         if edges_h.size and (int(edges_h.min()) < 0 or int(edges_h.max()) >= p):
             raise IndexError('GraphConvInfo.set_batch_device: an edge endpoint is outside [0, number of nodes)')
         self._degrees = torch.from_numpy(np.bincount(edges_h[:, 1], minlength=p).astype(np.int64))
-        # through the pinned staging ring: a copy from pageable memory blocks the host until the stream reaches it, i.e. until
-        # the PREVIOUS step has drained -- host and GPU would take turns instead of overlapping
-        edges_d = ops.upload(torch.from_numpy(edges_h), dev)
         feats, self._idxe = edge_feat_func(edgeattrs)
         if self._idxe is not None:
             raise NotImplementedError('filter sharing (idxe) is not supported by set_batch_device')
+        feats = feats.float()
+        self._edge_indexes = None                                   # built on demand (get_pyg_buffers): only the pyg path reads it
+        # a batch of a few scenes: ONE launch does the ordering by target, the edge-feature reordering and the CSR / reverse CSR,
+        # fed from the host arrays through the staging ring (ops.batch_graph_build)
+        built = ops.batch_graph_build(torch.from_numpy(edges_h), feats if feats.dim() == 2 else None, p, dev) if feats.dim() == 2 else None
+        if built is not None:
+            self._idxn, self._degrees_gpu, self._edgefeats, self._graph, _err = built
+            return
+        # larger batches: the multi-launch path.  Uploads go through the staging ring: a copy from pageable memory blocks the host
+        # until the stream reaches it, i.e. until the PREVIOUS step has drained -- host and GPU would take turns
+        edges_d = ops.upload(torch.from_numpy(edges_h), dev)
         idxn, degs_gpu, perm, _err = ops.set_batch(edges_d, p)      # the device flag duplicates the host check above
         self._idxn, self._degrees_gpu = idxn, degs_gpu
-        feats_d = ops.upload(feats.float(), dev)
+        feats_d = ops.upload(feats, dev)
         self._edgefeats = ops.gather_rows(feats_d, perm) if idxn.numel() else feats_d
-        self._edge_indexes = None                                   # built on demand (get_pyg_buffers): only the pyg path reads it
         self._graph = ops.DeviceGraph(self._idxn, self._degrees_gpu)
 
     @classmethod

@@ -81,6 +81,15 @@ class DeviceGraph:
         check(lib().spg_graph_build(_ptr(idxn) if self.E else None, _ptr(degs), self.N, self.n_src, self.E, _ptr(self.ws),
                                     _stream()), 'spg_graph_build')
 
+    @classmethod
+    def from_workspace(cls, ws: torch.Tensor, idxn: torch.Tensor, degs: torch.Tensor):
+        """A graph whose workspace was already filled on the device (ops.batch_graph_build)."""
+        g = cls.__new__(cls)
+        g.N, g.E = int(degs.numel()), int(idxn.numel())
+        g.n_src = g.N
+        g.ws, g.idxn, g.degs = ws, idxn, degs
+        return g
+
     def export(self):
         dev = self.ws.device
         rowptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
@@ -422,6 +431,36 @@ def set_batch(edges, n_nodes: int):
     check(lib().spg_set_batch(_ptr(edges) if E else None, n_nodes, E, _ptr(idxn) if E else None, _ptr(degs), _ptr(perm) if E else None,
                               _ptr(ws), _ptr(err), _stream()), 'spg_set_batch')
     return idxn, degs, perm, err
+
+
+def batch_graph_build(edges_h: torch.Tensor, feats_h: Optional[torch.Tensor], n_nodes: int, device=None):
+    """The whole construction of a small batch in one launch (include/spg_hip.h: spg_batch_graph_build): HOST edges i64 [E, 2]
+    (batch node offsets applied) and HOST edge features f32 [E, F] -> (idxn, degs, feats_sorted, DeviceGraph, error flag) on the
+    device, or None when the batch is too large for the single-workgroup builder (use set_batch + gather_rows + DeviceGraph)."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    E = int(edges_h.shape[0])
+    F = 0 if feats_h is None else int(feats_h.shape[1])
+    L = lib()
+    nscratch = L.spg_batch_graph_scratch_bytes(n_nodes, E, F)
+    if nscratch == 0 or edges_h.is_cuda or (feats_h is not None and feats_h.is_cuda):
+        return None
+    edges_h = edges_h.contiguous()
+    if edges_h.dtype != torch.int64:
+        raise TypeError('edges must be int64')
+    if feats_h is not None:
+        feats_h = feats_h.contiguous()
+        if feats_h.dtype != torch.float32 or feats_h.shape[0] != E:
+            raise TypeError(f'edge features must be float32 [{E}, F]')
+    idxn = torch.empty(E, dtype=torch.int64, device=device)
+    degs = torch.empty(n_nodes, dtype=torch.int64, device=device)
+    feats = torch.empty(E, F, dtype=torch.float32, device=device) if feats_h is not None else None
+    ws = torch.empty(L.spg_graph_workspace_bytes(n_nodes, n_nodes, E), dtype=torch.uint8, device=device)
+    scratch = torch.empty(nscratch, dtype=torch.uint8, device=device)
+    err = torch.empty(1, dtype=torch.int32, device=device)
+    check(L.spg_batch_graph_build(edges_h.data_ptr() if E else None, feats_h.data_ptr() if (feats_h is not None and E) else None, n_nodes, E, F,
+                                  _ptr(idxn) if E else None, _ptr(degs), _ptr(feats) if (feats is not None and E) else None, _ptr(ws),
+                                  _ptr(scratch), _ptr(err), _stream()), 'spg_batch_graph_build')
+    return idxn, degs, feats, DeviceGraph.from_workspace(ws, idxn, degs), err
 
 
 def gather_rows(src, perm):

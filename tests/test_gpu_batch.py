@@ -135,3 +135,37 @@ def test_collate_device_batch_matches_host_collate(hip):
             emb = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1)).run(model, *rest)
             outs.append(model.ecc(emb))
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * float(outs[0].abs().max())
+
+
+@pytest.mark.parametrize('n,e,f', [(1000, 5000, 13), (37, 0, 13), (1, 0, 5), (4000, 20000, 13), (513, 3001, 1), (4096, 32768, 13)])
+def test_single_launch_builder_equals_the_multi_launch_path(hip, n, e, f):
+    """spg_batch_graph_build (one workgroup: ordering by target, edge-feature reordering, CSR / reverse CSR, fed from host
+    pointers) against spg_set_batch + spg_gather_rows + spg_graph_build: every buffer bit-identical; hubs and isolated nodes."""
+    from superpoint_graph_amd import ops
+    rng = np.random.default_rng(n + e)
+    edges = rng.integers(0, n, size=(e, 2)).astype(np.int64)
+    if e > 200:
+        edges[:90, 1] = 3          # in-degree 90
+        edges[90:170, 0] = 5       # out-degree 80
+    feats = torch.from_numpy(rng.standard_normal((e, f)).astype(np.float32))
+    built = ops.batch_graph_build(torch.from_numpy(edges), feats, n)
+    assert built is not None
+    idxn, degs, fs, graph, err = built
+    edges_d = torch.from_numpy(edges).cuda()
+    idxn2, degs2, perm, err2 = ops.set_batch(edges_d, n)
+    fs2 = ops.gather_rows(feats.cuda(), perm) if e else feats.cuda()
+    graph2 = ops.DeviceGraph(idxn2, degs2)
+    assert int(err) == 0 and int(err2) == 0
+    assert torch.equal(idxn, idxn2) and torch.equal(degs, degs2) and torch.equal(fs, fs2)
+    for a, b in zip(graph.export(), graph2.export()):
+        assert torch.equal(a, b)
+    assert torch.equal(graph.hdr, graph2.hdr)
+
+
+def test_single_launch_builder_limits_and_malformed_edges(hip):
+    from superpoint_graph_amd import ops
+    assert ops.batch_graph_build(torch.zeros(40000, 2, dtype=torch.int64), torch.zeros(40000, 3), 100) is None      # too many edges
+    assert ops.batch_graph_build(torch.zeros(10, 2, dtype=torch.int64), torch.zeros(10, 3), 5000) is None          # too many nodes
+    bad = torch.tensor([[0, 1], [2, 7], [1, 0]], dtype=torch.int64)
+    out = ops.batch_graph_build(bad, torch.zeros(3, 2), 4)
+    assert int(out[4]) == 1                                                                                        # flagged, no out-of-bounds write
