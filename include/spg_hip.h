@@ -297,6 +297,19 @@ int spg_spg_superedges(const uint64_t* edges_sorted, const uint64_t* seg_cc, con
  * -> geof float32 [n,4] = linearity, planarity, scattering, verticality.  Covariance and eigen-decomposition in float64. */
 int spg_compute_geof(const float* xyz, const uint32_t* target, long n, int k_nn, float* geof, void* stream);
 
+/* prune (partition/ply_c/ply_c.cpp:288-382, libply_c.prune(xyz, voxel_size, rgb, labels, objects, n_labels, n_objects)):
+ * regular voxel grid -> per non-empty voxel the mean position, the mean colour and the label / object histograms; voxels are
+ * numbered in the order of their first point.  Two phases because the number of voxels sizes the outputs: spg_prune_voxels
+ * (bins, ordering; *n_voxels on the device) then spg_prune_reduce on the SAME workspace.  error flag: 1 = more than 2^21 bins
+ * along an axis, 2 = a label / object id beyond n_labels / n_objects.  Float results use the reference's float32 operations in
+ * the reference's order (bit-exact restatement; the reference itself cannot be built here: Boost). */
+size_t spg_prune_workspace_bytes(long n);
+int spg_prune_voxels(const float* xyz, long n, float voxel_size, int64_t* n_voxels, int32_t* error_flag, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int spg_prune_reduce(const float* xyz, const uint8_t* rgb, const uint8_t* labels, const uint32_t* objects, long n, long n_voxels,
+                     int n_labels, int n_objects, float* out_xyz, uint8_t* out_rgb, uint32_t* out_labels, uint32_t* out_objects,
+                     int32_t* error_flag, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Random streams of the loader generated on the device (optional; the default keeps numpy's streams on the host so
  * that seeded runs reproduce the reference's clouds): Philox4x32-10 keyed by (seed, superpoint id, step).  counts /
  * ids int64 [S], slot int32 [S] (row of the cloud tensor or -1) -> sample_idx int32 [S, npts] (spg.py:207-214), M

@@ -7,6 +7,7 @@ CPU restatements for the superpoint-graph construction row (SURVEY.md section 8,
   eigenvalues).  PINNED: oracle/validate_against_reference.py runs the imported reference function on the same inputs and
   requires every array equal (integers) / equal to float32 round-off given the unspecified edge order (floats); the same run
   writes tests/golden/sp_graph.npz.
+* `prune`: partition/ply_c/ply_c.cpp:288-382 in numpy, float32 in the reference's operation order.  PARITY UNPINNED (see `geof`).
 * `geof`: partition/ply_c/ply_c.cpp:384-462 `compute_geof` in float64 numpy.  PARITY UNPINNED: the reference is a C++
   extension that needs Eigen and Boost.Python, neither of which is in this image, so it cannot be compiled (oracle/_ref) or
   imported; the restatement follows the published formulas (covariance of the k_nn + 1 neighbourhood, sorted eigenvalues,
@@ -116,6 +117,34 @@ def geof(xyz, target, k_nn):
         u = np.einsum('nk,ndk->nd', lam, np.abs(v))                        # :441-444
         ver = u[:, 2] / np.sqrt((u ** 2).sum(1))
     return np.stack((lin, pla, sca, ver), 1).astype(np.float32)
+
+
+def prune(xyz, voxel_size, rgb, labels, objects, n_labels, n_objects):
+    """ply_c.cpp:288-382 in numpy with the reference's float32 operations in the reference's order (np.add.at is unbuffered: the
+    additions of one voxel happen in input order, like the serial loop).  PARITY UNPINNED like `geof` (Boost.Python extension)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    vs = np.float32(voxel_size)
+    bins = np.floor((xyz - xyz.min(0)) / vs).astype(np.uint32)                       # :326-328
+    _, first, inv = np.unique(bins, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    rank = np.empty(len(first), dtype=np.int64)
+    rank[np.argsort(first, kind='stable')] = np.arange(len(first))                    # voxel index = order of first occurrence (:166-176)
+    vox = rank[inv]
+    V = len(first)
+    acc = np.zeros((V, 3), np.float32)
+    np.add.at(acc, vox, xyz)                                                          # :259-261, float32, input order
+    col = np.zeros((V, 3), np.uint32)
+    np.add.at(col, vox, np.asarray(rgb, dtype=np.uint32).reshape(-1, 3))
+    count = np.bincount(vox, minlength=V).astype(np.float32)
+    out_xyz = acc / count[:, None]                                                    # :365-368
+    out_rgb = (col.astype(np.float32) / count[:, None]).astype(np.uint8)              # :371-374 (truncation)
+    lab = np.zeros((V, n_labels + 1), np.uint32)
+    obj = np.zeros((V, n_objects + 1), np.uint32)
+    if n_labels > 0:
+        np.add.at(lab, (vox, np.asarray(labels, dtype=np.int64).reshape(-1)), 1)
+        if n_objects > 0:
+            np.add.at(obj, (vox, np.asarray(objects, dtype=np.int64).reshape(-1)), 1)
+    return out_xyz, out_rgb, lab, obj
 
 
 def synthetic_cloud(seed, n=3000, n_blobs=24, duplicates=20):

@@ -103,6 +103,9 @@ SIGNATURES = {
     'spg_spg_superpoints': (_i, [_p, _l, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'spg_spg_superedges': (_i, [_p, _p, _p, _l, _l] + [_p] * 16 + [_p]),
     'spg_compute_geof': (_i, [_p, _p, _l, _i, _p, _p]),
+    'spg_prune_workspace_bytes': (_sz, [_l]),
+    'spg_prune_voxels': (_i, [_p, _l, ctypes.c_float, _p, _p, _p, _sz, _p]),
+    'spg_prune_reduce': (_i, [_p, _p, _p, _p, _l, _l, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'spg_edge_features': (_i, [ctypes.POINTER(EdgeFeatureSpecs), _p, _l, _p, _p, _p, _p]),
     'spg_loader_random': (_i, [_p, _p, _p, _i, _i, _i, ctypes.c_uint64, ctypes.c_uint32, _i, ctypes.c_float, _i, ctypes.c_float, _i, _p, _p, _p, _p]),
     'spg_cross_entropy_fwd': (_i, [_p, _p, _p, _i, _i, ctypes.c_int64, _i, _p, _p, _p, _p]),

@@ -442,6 +442,115 @@ size_t scan_tmp(long n) {
 }
 size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
+// -------------------------------------------------------------------------------------------------------------------
+// prune (partition/ply_c/ply_c.cpp:288-382): voxel-grid subsampling -- mean position / mean colour / label and object
+// histograms per non-empty voxel, voxels numbered in the order of their FIRST point (the reference's std::map insertion counter).
+// Bit-exact by construction: the bin of a point is floor((x - x_min) / voxel_size) in float32 exactly as the reference writes
+// it; a stable radix sort by (bin_x, bin_y, bin_z) keeps the points of a voxel in input order, so ONE thread per voxel adds its
+// positions in the reference's order with float32 additions (no reassociation, no fma) -- the same rounding as the serial loop.
+// -------------------------------------------------------------------------------------------------------------------
+__global__ void minmax_kernel(const float* __restrict__ xyz, long n, unsigned* __restrict__ mm) {      // mm[0..2] = min, mm[3..5] = max (ordered bits)
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    for (int d = 0; d < 3; ++d) { const float v = xyz[3 * i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+  for (int d = 0; d < 3; ++d) {
+    for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[d], ordered_bits(lo[d])); atomicMax(&mm[3 + d], ordered_bits(hi[d])); }
+  }
+}
+__device__ __forceinline__ float from_ordered(unsigned b) { return __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b); }
+
+__global__ void voxel_keys_kernel(const float* __restrict__ xyz, long n, const unsigned* __restrict__ mm, float voxel, u64* __restrict__ keys,
+                                  unsigned* __restrict__ idx, unsigned* __restrict__ flag) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 k = 0;
+  for (int d = 0; d < 3; ++d) {
+    const float b = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i + d], from_ordered(mm[d])), voxel));      // ply_c.cpp:326-328 / 338-340
+    const unsigned u = (unsigned)b;
+    if (!(b >= 0.f) || u >= (1u << 21)) atomicOr(flag, 1u);                                          // grid wider than 2^21 bins per axis
+    k = (k << 21) | (u64)(u & 0x1fffffu);
+  }
+  keys[i] = k;
+  idx[i] = (unsigned)i;
+}
+
+// key of segment v = index of its first point (the stable sort keeps input order inside a voxel: the first entry of a segment is
+// the voxel's first occurrence); the slots behind the last segment (their number is only known on the device) get keys >= 2^32
+__global__ void segment_first_kernel(const unsigned* __restrict__ idx_sorted, const int64_t* __restrict__ seg_off, const unsigned* __restrict__ nseg,
+                                     long n, u64* __restrict__ first, unsigned* __restrict__ seg_id, int64_t* __restrict__ n_voxels,
+                                     const unsigned* __restrict__ flag, int32_t* __restrict__ error_flag) {
+  const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v == 0) { *n_voxels = (int64_t)*nseg; if (error_flag != nullptr) *error_flag = (int32_t)*flag; }
+  if (v >= n) return;
+  first[v] = v < (long)*nseg ? (u64)idx_sorted[seg_off[v]] : ((1ull << 32) | (u64)v);
+  seg_id[v] = (unsigned)v;
+}
+
+struct PruneOut { float* xyz; uint8_t* rgb; uint32_t* labels; uint32_t* objects; int n_labels, n_objects; };
+
+__global__ void prune_reduce_kernel(const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ labels,
+                                    const uint32_t* __restrict__ objects, const unsigned* __restrict__ idx_sorted,
+                                    const int64_t* __restrict__ seg_off, const unsigned* __restrict__ order, long n_vox, PruneOut o,
+                                    unsigned* __restrict__ flag) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_vox) return;
+  const unsigned seg = order[r];
+  const long b = seg_off[seg], e = seg_off[seg + 1];
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  unsigned cr = 0, cg = 0, cb = 0;
+  uint32_t* hl = o.labels + r * (o.n_labels + 1);
+  uint32_t* ho = o.objects + r * (o.n_objects + 1);
+  for (int k = 0; k <= o.n_labels; ++k) hl[k] = 0;
+  for (int k = 0; k <= o.n_objects; ++k) ho[k] = 0;
+  for (long j = b; j < e; ++j) {                                    // input order (ply_c.cpp:336-354)
+    const long p = idx_sorted[j];
+    ax = __fadd_rn(ax, xyz[3 * p]); ay = __fadd_rn(ay, xyz[3 * p + 1]); az = __fadd_rn(az, xyz[3 * p + 2]);
+    if (rgb != nullptr) { cr += rgb[3 * p]; cg += rgb[3 * p + 1]; cb += rgb[3 * p + 2]; }
+    if (labels != nullptr) {
+      const int l = labels[p];
+      if (l <= o.n_labels) hl[l] += 1; else atomicOr(flag, 2u);     // the reference's vector::at would throw
+    }
+    if (objects != nullptr) {
+      const uint32_t q = objects[p];
+      if (q <= (uint32_t)o.n_objects) ho[q] += 1; else atomicOr(flag, 2u);
+    }
+  }
+  const float count = (float)(unsigned)(e - b);
+  o.xyz[3 * r] = __fdiv_rn(ax, count); o.xyz[3 * r + 1] = __fdiv_rn(ay, count); o.xyz[3 * r + 2] = __fdiv_rn(az, count);      // :365-368
+  o.rgb[3 * r] = (uint8_t)__fdiv_rn((float)cr, count); o.rgb[3 * r + 1] = (uint8_t)__fdiv_rn((float)cg, count);               // :371-374
+  o.rgb[3 * r + 2] = (uint8_t)__fdiv_rn((float)cb, count);
+}
+
+size_t prune_rle_tmp(long n) {
+  size_t b = 0;
+  (void)rocprim::run_length_encode(nullptr, b, (u64*)nullptr, (unsigned)n, (u64*)nullptr, (int64_t*)nullptr, (unsigned*)nullptr, (hipStream_t)0);
+  return b;
+}
+
+struct PruneWs {
+  unsigned *mm, *nseg, *flag, *idx0, *idx_sorted, *seg_id, *order;
+  u64 *keys0, *keys1, *uniq, *first0, *first1;
+  int64_t *counts, *seg_off;
+  void* tmp; size_t tmp_bytes;
+  bool ok;
+};
+PruneWs prune_carve(void* ws, size_t bytes, long n) {
+  Carve w{(char*)ws, bytes};
+  PruneWs p;
+  p.mm = (unsigned*)w.take(256); p.nseg = p.mm + 8; p.flag = p.mm + 9;
+  p.keys0 = (u64*)w.take((size_t)n * 8); p.keys1 = (u64*)w.take((size_t)n * 8);
+  p.idx0 = (unsigned*)w.take((size_t)n * 4); p.idx_sorted = (unsigned*)w.take((size_t)n * 4);
+  p.uniq = (u64*)w.take((size_t)n * 8);
+  p.counts = (int64_t*)w.take((size_t)(n + 1) * 8); p.seg_off = (int64_t*)w.take((size_t)(n + 1) * 8);
+  p.first0 = (u64*)w.take((size_t)n * 8); p.first1 = (u64*)w.take((size_t)n * 8);
+  p.seg_id = (unsigned*)w.take((size_t)n * 4); p.order = (unsigned*)w.take((size_t)n * 4);
+  p.tmp_bytes = max2(max2(sort_pairs_u32_tmp(n), prune_rle_tmp(n)), scan_tmp(n + 1));
+  p.tmp = w.take(p.tmp_bytes);
+  p.ok = w.ok;
+  return p;
+}
+
 }  // namespace
 
 extern "C" int spg_spg_tet_edges(const int32_t* tets, long T, const int32_t* comp, uint64_t* keys, long capacity, uint64_t* count,
@@ -583,5 +692,63 @@ extern "C" int spg_compute_geof(const float* xyz, const uint32_t* target, long n
   if (n == 0) return 0;
   hipLaunchKernelGGL(geof_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, xyz, target, n, k_nn, geof);
   SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t spg_prune_workspace_bytes(long n) {
+  if (n < 1) n = 1;
+  return 256 + 5 * align256((size_t)n * 8) + 4 * align256((size_t)n * 4) + 2 * align256((size_t)(n + 1) * 8) +
+         align256(max2(max2(sort_pairs_u32_tmp(n), prune_rle_tmp(n)), scan_tmp(n + 1))) + 4096;
+}
+
+// phase 1: voxel of every point, points ordered by voxel, voxels in first-occurrence order; *n_voxels (device int64) for the caller
+extern "C" int spg_prune_voxels(const float* xyz, long n, float voxel_size, int64_t* n_voxels, int32_t* error_flag, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  SPG_CHECK_ARG(xyz && n > 0 && n < (1L << 32) && voxel_size > 0.f && n_voxels && workspace, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  PruneWs p = prune_carve(workspace, workspace_bytes, n);
+  SPG_CHECK_ARG(p.ok, "workspace too small (spg_prune_workspace_bytes(n))");
+  SPG_RP(hipMemsetAsync(p.mm, 0xff, 3 * sizeof(unsigned), st));          // running minima (ordered bits): all ones
+  SPG_RP(hipMemsetAsync(p.mm + 3, 0, 7 * sizeof(unsigned), st));          // running maxima, segment count, flag: zero
+  const dim3 block(256);
+  hipLaunchKernelGGL(minmax_kernel, dim3(n < 262144 ? spg_cdiv(n, 256) : 1024), block, 0, st, xyz, n, p.mm);
+  SPG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(voxel_keys_kernel, dim3(spg_cdiv(n, 256)), block, 0, st, xyz, n, (const unsigned*)p.mm, voxel_size, p.keys0, p.idx0, p.flag);
+  SPG_LAUNCH_CHECK();
+  size_t b = p.tmp_bytes;
+  SPG_RP(rocprim::radix_sort_pairs(p.tmp, b, (const u64*)p.keys0, p.keys1, (const unsigned*)p.idx0, p.idx_sorted, (size_t)n, 0, 63, st));
+  SPG_RP(hipMemsetAsync(p.counts, 0, (size_t)(n + 1) * 8, st));
+  b = p.tmp_bytes;
+  SPG_RP(rocprim::run_length_encode(p.tmp, b, (const u64*)p.keys1, (unsigned)n, p.uniq, p.counts, p.nseg, st));
+  b = p.tmp_bytes;
+  SPG_RP(rocprim::exclusive_scan(p.tmp, b, p.counts, p.seg_off, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), st));
+  // voxels in the order of their first point: sort the segments by the index of their first entry
+  hipLaunchKernelGGL(segment_first_kernel, dim3(spg_cdiv(n, 256)), block, 0, st, (const unsigned*)p.idx_sorted, (const int64_t*)p.seg_off,
+                     (const unsigned*)p.nseg, n, p.first0, p.seg_id, n_voxels, (const unsigned*)p.flag, error_flag);
+  SPG_LAUNCH_CHECK();
+  b = p.tmp_bytes;
+  SPG_RP(rocprim::radix_sort_pairs(p.tmp, b, (const u64*)p.first0, p.first1, (const unsigned*)p.seg_id, p.order, (size_t)n, 0, 34, st));
+  return 0;
+}
+
+// phase 2 (same workspace, untouched since phase 1): per-voxel means and histograms into arrays of n_voxels rows.
+// rgb uint8 [n,3] or NULL (zeros), labels uint8 [n] or NULL, objects uint32 [n] or NULL; error_flag |= 2 for a label / object id
+// beyond n_labels / n_objects (the reference's vector::at would throw).
+extern "C" int spg_prune_reduce(const float* xyz, const uint8_t* rgb, const uint8_t* labels, const uint32_t* objects, long n, long n_voxels,
+                                int n_labels, int n_objects, float* out_xyz, uint8_t* out_rgb, uint32_t* out_labels, uint32_t* out_objects,
+                                int32_t* error_flag, void* workspace, size_t workspace_bytes, void* stream) {
+  SPG_CHECK_ARG(xyz && n > 0 && n_voxels >= 0 && n_voxels <= n && n_labels >= 0 && n_objects >= 0 && workspace, "bad argument");
+  if (n_voxels == 0) return 0;
+  SPG_CHECK_ARG(out_xyz && out_rgb && out_labels && out_objects, "null output");
+  hipStream_t st = (hipStream_t)stream;
+  PruneWs p = prune_carve(workspace, workspace_bytes, n);
+  SPG_CHECK_ARG(p.ok, "workspace too small (spg_prune_workspace_bytes(n))");
+  PruneOut o{out_xyz, out_rgb, out_labels, out_objects, n_labels, n_objects};
+  hipLaunchKernelGGL(prune_reduce_kernel, dim3(spg_cdiv(n_voxels, 256)), dim3(256), 0, st, xyz, rgb, labels, objects,
+                     (const unsigned*)p.idx_sorted, (const int64_t*)p.seg_off, (const unsigned*)p.order, n_voxels, o, p.flag);
+  SPG_LAUNCH_CHECK();
+  if (error_flag != nullptr) {
+    SPG_RP(hipMemcpyAsync(error_flag, p.flag, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  }
   return 0;
 }

@@ -684,3 +684,34 @@ def compute_geof(xyz, target, k_nn: int):
     geof = torch.empty(n, 4, dtype=torch.float32, device=xyz.device)
     check(lib().spg_compute_geof(_ptr(xyz), _ptr(target), n, int(k_nn), _ptr(geof), _stream()), 'spg_compute_geof')
     return geof
+
+
+def prune(xyz, voxel_size: float, rgb=None, labels=None, objects=None, n_labels: int = 0, n_objects: int = 0):
+    """Voxel-grid subsampling (ply_c.cpp:288-382) of device tensors: xyz f32 [n,3], rgb u8 [n,3] or None, labels u8 [n] or None,
+    objects i32 [n] (read as uint32) or None -> (xyz f32 [V,3], rgb u8 [V,3], labels i32 [V, n_labels+1], objects i32 [V, n_objects+1]);
+    voxels in the order of their first point.  One host synchronisation (the number of voxels)."""
+    _req(xyz, torch.float32, 'xyz')
+    L, dev, st = lib(), xyz.device, _stream()
+    n = int(xyz.shape[0])
+    if rgb is not None:
+        _req(rgb, torch.uint8, 'rgb')
+    if labels is not None:
+        _req(labels, torch.uint8, 'labels')
+    if objects is not None:
+        _req(objects, torch.int32, 'objects')
+    ws = _u8_workspace(L.spg_prune_workspace_bytes(n), dev)
+    nv = torch.zeros(1, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(L.spg_prune_voxels(_ptr(xyz), n, float(voxel_size), _ptr(nv), _ptr(err), _ptr(ws), ws.numel(), st), 'spg_prune_voxels')
+    V = int(nv.item())
+    if int(err.item()) & 1:
+        raise ValueError('prune: more than 2^21 voxels along an axis (voxel_size too small for the extent of the cloud)')
+    out_xyz = torch.empty(V, 3, dtype=torch.float32, device=dev)
+    out_rgb = torch.empty(V, 3, dtype=torch.uint8, device=dev)
+    out_lab = torch.empty(V, n_labels + 1, dtype=torch.int32, device=dev)
+    out_obj = torch.empty(V, n_objects + 1, dtype=torch.int32, device=dev)
+    check(L.spg_prune_reduce(_ptr(xyz), _ptr(rgb), _ptr(labels), _ptr(objects), n, V, int(n_labels), int(n_objects), _ptr(out_xyz),
+                             _ptr(out_rgb), _ptr(out_lab), _ptr(out_obj), _ptr(err), _ptr(ws), ws.numel(), st), 'spg_prune_reduce')
+    if int(err.item()) & 2:
+        raise IndexError('prune: a label / object id exceeds n_labels / n_objects')
+    return out_xyz, out_rgb, out_lab, out_obj

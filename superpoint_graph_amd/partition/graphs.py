@@ -77,3 +77,19 @@ def compute_geof(xyz, target, k_nn):
     xyz_d = ops.upload(torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32)), dev)
     tgt = np.ascontiguousarray(target).reshape(-1).astype(np.uint32).view(np.int32)
     return ops.compute_geof(xyz_d, ops.upload(torch.from_numpy(tgt), dev), int(k_nn)).cpu().numpy()
+
+
+def prune(xyz, voxel_size, rgb, labels, objects, n_labels, n_objects):
+    """prune the point cloud xyz with a regular voxel grid (reference partition/ply_c/ply_c.cpp:288-382, called as
+    libply_c.prune(xyz, voxel_width, rgb, labels, objects, n_labels, n_objects)) -> (xyz float32 [V,3], rgb uint8 [V,3],
+    labels uint32 [V, n_labels+1], objects uint32 [V, n_objects+1]).  Like the reference, labels are read only when
+    n_labels > 0 and objects only when n_objects > 0 (callers pass dummy arrays otherwise)."""
+    dev = _dev()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    n = len(xyz)
+    up = lambda a: ops.upload(torch.from_numpy(a), dev)
+    rgb_d = up(np.ascontiguousarray(rgb, dtype=np.uint8).reshape(n, 3))
+    lab_d = up(np.ascontiguousarray(labels, dtype=np.uint8).reshape(n)) if n_labels > 0 else None
+    obj_d = up(np.ascontiguousarray(objects, dtype=np.uint32).reshape(n).view(np.int32)) if (n_labels > 0 and n_objects > 0) else None
+    x, c, l, o = ops.prune(up(xyz), float(np.float32(voxel_size)), rgb_d, lab_d, obj_d, int(n_labels), int(n_objects))
+    return x.cpu().numpy(), c.cpu().numpy(), l.cpu().numpy().view(np.uint32), o.cpu().numpy().view(np.uint32)

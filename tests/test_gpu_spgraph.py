@@ -142,3 +142,44 @@ def test_compute_geof_vs_restatement(hip):
     assert np.abs(mine - ref).max() < 2e-5                      # both float64 inside; float32 results
     assert (mine[: n // 2, 3] < 0.2).mean() > 0.95              # horizontal slab: low verticality
     assert (mine[n // 2:, 3] > 0.3).mean() > 0.9                # vertical slab
+
+
+def _cloud(n, seed):
+    rng = np.random.default_rng(seed)
+    xyz = (rng.normal(size=(n, 3)) * [8, 6, 1.5] + [100, -50, 3]).astype(np.float32)
+    xyz[rng.integers(0, n, n // 50)] = xyz[rng.integers(0, n, n // 50)]              # exact duplicates
+    rgb = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    labels = rng.integers(0, 9, n).astype(np.uint8)
+    objects = rng.integers(0, 41, n).astype(np.uint32)
+    return xyz, rgb, labels, objects
+
+
+@pytest.mark.parametrize('n,voxel', [(200_000, 0.05), (50_000, 0.5), (3_000, 100.0)])
+def test_prune_is_bit_exact_vs_restatement(hip, n, voxel):
+    """Every output of the voxel-grid subsampling equal to the float32 restatement of ply_c.cpp:288-382, bit for bit: voxel
+    order (first occurrence), positions (float32 sums in input order), truncated colour means, label / object histograms."""
+    from superpoint_graph_amd.partition import libply_c
+    xyz, rgb, labels, objects = _cloud(n, n)
+    for n_labels, n_objects in ((8, 40), (8, 0), (0, 0)):
+        got = libply_c.prune(xyz, voxel, rgb, labels, objects, n_labels, n_objects)
+        ref = P.prune(xyz, voxel, rgb, labels, objects, n_labels, n_objects)
+        for a, b, what in zip(got, ref, ('xyz', 'rgb', 'labels', 'objects')):
+            assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+            assert np.array_equal(a, b), f'{what} differs (n_labels {n_labels}, n_objects {n_objects})'
+        assert got[2].sum() == (n if n_labels else 0) and got[3].sum() == (n if n_objects and n_labels else 0)
+    if voxel == 100.0:
+        assert len(got[0]) == 1                                                        # one voxel: the mean of the whole cloud, serial float32 sum
+
+
+def test_prune_known_answer_and_errors(hip):
+    from superpoint_graph_amd.partition import libply_c
+    xyz = np.array([[0, 0, 0], [0.9, 0.1, 0.2], [1.5, 0, 0], [0.2, 0.2, 0.2], [1.6, 0.1, 0.1]], np.float32)
+    rgb = np.array([[10, 20, 30], [20, 30, 40], [100, 100, 100], [30, 40, 50], [101, 103, 105]], np.uint8)
+    lab = np.array([1, 2, 0, 1, 2], np.uint8)
+    x, c, l, o = libply_c.prune(xyz, 1.0, rgb, lab, np.zeros(1, dtype=np.uint8), 2, 0)
+    assert c.tolist() == [[20, 30, 40], [100, 101, 102]] and l.tolist() == [[0, 2, 1], [1, 0, 1]] and o.tolist() == [[0], [0]]
+    assert np.allclose(x, [[1.1 / 3, 0.1, 0.4 / 3], [1.55, 0.05, 0.05]], atol=1e-7)
+    with pytest.raises(IndexError):
+        libply_c.prune(xyz, 1.0, rgb, lab, np.zeros(1, dtype=np.uint8), 1, 0)         # label 2 with n_labels = 1 (vector::at throws in the reference)
+    with pytest.raises(ValueError):
+        libply_c.prune(xyz * 1e6, 1e-3, rgb, lab, np.zeros(1, dtype=np.uint8), 2, 0)  # > 2^21 bins along an axis

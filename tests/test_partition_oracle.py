@@ -64,3 +64,15 @@ def test_geof_known_answers():
     f = P.geof(ball.astype(np.float32), np.concatenate([nb, np.zeros((4000 - 16, 300), dtype=np.int64)]), 300)[:16]
     assert (f[:, 2] > 0.75).all()                                                                   # isotropic: scattering near 1
     assert np.allclose(f[:, 0] + f[:, 1] + f[:, 2], 1.0, atol=1e-6)
+
+
+def test_prune_known_answer():
+    """Five points, two voxels: hand-computed means, truncated colour means, label histograms, voxel order = first occurrence."""
+    xyz = np.array([[0, 0, 0], [0.9, 0.1, 0.2], [1.5, 0, 0], [0.2, 0.2, 0.2], [1.6, 0.1, 0.1]], np.float32)
+    rgb = np.array([[10, 20, 30], [20, 30, 40], [100, 100, 100], [30, 40, 50], [101, 103, 105]], np.uint8)
+    lab = np.array([1, 2, 0, 1, 2], np.uint8)
+    x, c, l, o = P.prune(xyz, 1.0, rgb, lab, np.zeros(1), 2, 0)
+    assert np.allclose(x, [[1.1 / 3, 0.1, 0.4 / 3], [1.55, 0.05, 0.05]], atol=1e-7)
+    assert c.tolist() == [[20, 30, 40], [100, 101, 102]] and l.tolist() == [[0, 2, 1], [1, 0, 1]] and o.tolist() == [[0], [0]]
+    x2, _, l2, _ = P.prune(xyz[::-1].copy(), 1.0, rgb[::-1].copy(), lab[::-1].copy(), np.zeros(1), 2, 0)      # reversed input: voxel order flips
+    assert np.allclose(x2, x[::-1], atol=1e-7) and l2.tolist() == l[::-1].tolist()
