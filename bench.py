@@ -115,6 +115,45 @@ def cpu_baseline(model_config, scenes, state, max_seconds=25.0, n_feat=14):
             'sample': f'{cnt} fwd+bwd steps of one {n}-superpoint scene (median {med * 1e3:.0f} ms/step), {what}{sweep}'}
 
 
+def gemm_traffic_live(args, log):
+    """HBM bytes per row-GEMM launch MEASURED in this run: two rocprofv3 passes of this very script (--pmc FETCH_SIZE and --pmc
+    WRITE_SIZE in separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes; 6 training steps each), summarised by
+    tools/pmc_traffic.py with the gfx950 unit corrections (FETCH_SIZE x2, WRITE_SIZE x1: calibrated on known byte counts,
+    profiles/r03_pmc_calib_*.txt).  -> (bytes per launch, all-kernel bytes per step, description) or None when rocprofv3 is not
+    there / a pass fails (the committed file is used then)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None or os.environ.get('SPG_BENCH_NO_LIVE_PMC'):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import pmc_traffic
+        dbs = []
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = tempfile.mkdtemp(prefix=f'spg_pmc_{counter}_', dir='/tmp')
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'rocpd', '-d', out, '--', sys.executable, os.path.abspath(__file__),
+                   '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-forward-only', '--no-trainer-window', '--no-roofline',
+                   '--precision', args.precision, '--scenes', str(args.scenes), '--n-sp', str(args.n_sp), '--n-edges', str(args.n_edges),
+                   '--n-feat', str(args.n_feat), '--model-config', args.model_config]
+            env = dict(os.environ, TMPDIR='/tmp', SPG_BENCH_NO_LIVE_PMC='1')
+            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            found = glob.glob(os.path.join(out, '**', '*.db'), recursive=True)
+            if not found:
+                return None
+            dbs.append(found[0])
+        t = pmc_traffic.summarise(dbs[0], dbs[1])
+        for d in dbs:
+            shutil.rmtree(os.path.dirname(os.path.dirname(d)), ignore_errors=True)
+        log(f'live PMC passes: {t["hbm_mb_per_launch"]:.1f} MB per GEMM launch, {t["all_kernels_hbm_mb_per_step"]:.0f} MB per step')
+        return t['hbm_mb_per_launch'] * 1e6, t['all_kernels_hbm_mb_per_step'] * 1e6, 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes of 6 steps of this script), FETCH_SIZE x2.000 / WRITE_SIZE x1.000 (gfx950 units, calibrated: profiles/r03_pmc_calib_*.txt)'
+    except Exception as e:      # a profiler problem must never take the bench line down
+        log(f'live PMC passes failed ({type(e).__name__}: {e}); using the committed traffic file')
+        return None
+
+
 def gemm_traffic(args):
     """HBM bytes per row-GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     runs, gfx950 correction applied; profiles/*_gemm_traffic.json) -- only for the workload they were collected on.
@@ -234,6 +273,7 @@ def main():
                          "bf16 MFMAs per operand pair, fp32 accumulate, ~2^-16 per product); bf16 = bf16 operands.  A SEPARATE line: never "
                          "replaces the f32 headline (tolerances: tests/test_gpu_precision.py)")
     ap.add_argument('--tune', default='', help='A/B switches of the library for experiments: comma-separated key:value pairs of spg_tune (include/spg_hip.h), e.g. 8:1 = per-iteration RNN-ECC launches, 9:1 = no side stream')
+    ap.add_argument('--no-live-pmc', action='store_true', help='do not run the two rocprofv3 PMC passes for roofline.traffic (use the committed file)')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
     args = ap.parse_args()
 
@@ -407,14 +447,21 @@ def main():
         L.spg_prof_enable(0)
         log('instrumented pass done')
         ach = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        traffic, traffic_src = gemm_traffic(args)
+        live = gemm_traffic_live(args, log) if (world == 1 and not args.no_live_pmc) else None
+        if live is not None:
+            traffic, traffic_all, traffic_src, traffic_note = live[0], live[1], 'live', live[2]
+        else:
+            traffic, traffic_src = gemm_traffic(args)
+            traffic_all = None
+            traffic_src = ('static:' + traffic_src) if traffic_src else None
+            traffic_note = 'HBM bytes per launch (rocprofv3 PMC passes of the same command, tools/collect_profiles.sh; read from the file, not measured in this run)'
         gflop_step = flops.value / nprof / 1e9
         # flat keys only (nested objects are dropped by the driver's parser): aggregate over every MFMA GEMM launch of a
         # step, the dominant instantiation, and the whole step (algorithmic GEMM FLOP / wall time per step)
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                              'traffic_source': ('static:' + traffic_src) if traffic_src else None,
-                              'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes of the same command, tools/collect_profiles.sh; read from the file, not measured in this run)',
+                              'traffic_source': traffic_src, 'traffic_unit': 'HBM bytes per GEMM launch; ' + traffic_note,
+                              'traffic_all_kernels_per_step': traffic_all,
                               'kernel': 'spg_rowgemm_kernel + spg_wgrad_kernel (fp32 MFMA 32x32x2)',
                               'launches_per_step': launches.value / nprof, 'gemm_ms_per_step': ms.value / nprof,
                               'algorithmic_gflop_per_step': gflop_step,

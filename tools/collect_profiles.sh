@@ -18,10 +18,10 @@ tail -c 2000 $OUT/${TAG}_bench.json
 
 # the opt-in precision modes: separate lines, same box, same session (they never replace the f32 headline)
 for P in bf16x3 bf16; do
-  timeout 300 python $ROOT/bench.py --precision $P --no-cpu-baseline --no-trainer-window --no-forward-only > $OUT/${TAG}_bench_$P.json 2>> $OUT/${TAG}_bench.err
+  timeout 300 python $ROOT/bench.py --precision $P --no-cpu-baseline --no-trainer-window --no-forward-only --no-live-pmc > $OUT/${TAG}_bench_$P.json 2>> $OUT/${TAG}_bench.err
 done
-timeout 300 python $ROOT/bench.py --precision bf16x3 --no-cpu-baseline --no-trainer-window --no-forward-only --n-sp 10000 --n-edges 50000 --n-feat 11 --model-config gru_10,f_8 > $OUT/${TAG}_bench_sema3d_bf16x3.json 2>> $OUT/${TAG}_bench.err
-timeout 300 python $ROOT/bench.py --precision f32 --no-cpu-baseline --no-trainer-window --no-forward-only --n-sp 10000 --n-edges 50000 --n-feat 11 --model-config gru_10,f_8 > $OUT/${TAG}_bench_sema3d_f32.json 2>> $OUT/${TAG}_bench.err
+timeout 300 python $ROOT/bench.py --precision bf16x3 --no-cpu-baseline --no-trainer-window --no-forward-only --no-live-pmc --n-sp 10000 --n-edges 50000 --n-feat 11 --model-config gru_10,f_8 > $OUT/${TAG}_bench_sema3d_bf16x3.json 2>> $OUT/${TAG}_bench.err
+timeout 300 python $ROOT/bench.py --precision f32 --no-cpu-baseline --no-trainer-window --no-forward-only --no-live-pmc --n-sp 10000 --n-edges 50000 --n-feat 11 --model-config gru_10,f_8 > $OUT/${TAG}_bench_sema3d_f32.json 2>> $OUT/${TAG}_bench.err
 timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_trace_x3 -- python $ROOT/bench.py --precision bf16x3 --steps 20 --warmup 5 $STEPS > /dev/null 2> $OUT/${TAG}_trace_x3.err
 python $ROOT/tools/prof_summary.py $(db /tmp/p_trace_x3) 70 > $OUT/${TAG}_kernel_stats_bf16x3.txt
 

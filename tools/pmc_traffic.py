@@ -21,13 +21,14 @@ def per_kernel(db, counter):
     return out
 
 
-def main():
-    fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+def summarise(fetch_db, write_db, calib_fetch_db=None, calib_write_db=None, calib_mib=None):
+    """-> dict (the content of profiles/rNN_gemm_traffic.json)"""
+    fetch, write = per_kernel(fetch_db, 'FETCH_SIZE'), per_kernel(write_db, 'WRITE_SIZE')
     kb = 1024.0
     fcorr, wcorr, calib = 2.0, 1.0, None
-    if len(sys.argv) >= 6:
-        mib = float(sys.argv[5])
-        cf, cw = per_kernel(sys.argv[3], 'FETCH_SIZE'), per_kernel(sys.argv[4], 'WRITE_SIZE')
+    if calib_fetch_db is not None:
+        mib = float(calib_mib)
+        cf, cw = per_kernel(calib_fetch_db, 'FETCH_SIZE'), per_kernel(calib_write_db, 'WRITE_SIZE')
         add = [k for k in cf if 'CUDAFunctorOnSelf_add' in k][0]
         fill = [k for k in cw if 'FillFunctor' in k][0]
         fcorr = mib * 1024 * 1024 / (cf[add][1] / cf[add][0] * kb)
@@ -48,7 +49,7 @@ def main():
         rows.append({'kernel': k, 'launches_per_step': n / steps, 'fetch_mb_per_launch': gf[k][1] / n * kb * fcorr / 1e6,
                      'write_mb_per_launch': gw.get(k, [1, 0.0])[1] / max(gw.get(k, [1, 0.0])[0], 1) * kb * wcorr / 1e6})
     allk = lambda d: sum(v[1] for v in d.values())
-    print(json.dumps({
+    return {
         'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py; FETCH_SIZE x%.3f, '
                   'WRITE_SIZE x%.3f (%s)' % (fcorr, wcorr, 'calibrated on tools/pmc_calib.py in the same session' if calib else
                                              'gfx950 rule of MI355X_MICROARCH.md; WRITE_SIZE uncalibrated'),
@@ -56,8 +57,8 @@ def main():
         'launches_per_step': launches / steps, 'fetch_mb_per_step': f_b / steps / 1e6, 'write_mb_per_step': w_b / steps / 1e6,
         'hbm_mb_per_step': (f_b + w_b) / steps / 1e6, 'hbm_mb_per_launch': (f_b + w_b) / launches / 1e6,
         'all_kernels_hbm_mb_per_step': (allk(fetch) * kb * fcorr + allk(write) * kb * wcorr) / steps / 1e6,
-        'per_kernel': rows[:24]}, indent=1))
+        'per_kernel': rows[:24]}
 
 
 if __name__ == '__main__':
-    main()
+    print(json.dumps(summarise(*sys.argv[1:6]), indent=1))
