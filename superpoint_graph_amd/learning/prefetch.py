@@ -7,14 +7,22 @@ stream instead, so this device work overlaps the training step that is still exe
 event (the training stream waits for it; the host never does).
 
 The construction runs ONE batch ahead: batch j+1 is built (host work + side-stream launches) right after batch j has been
-handed over and before the consumer enqueues step j, so its chain of small dependent launches has the whole of step j to finish.
+handed over and before the consumer enqueues step j, so its launches have the whole of step j to finish.
 
-Memory discipline (no `record_stream` bookkeeping needed): tensors of a batch are allocated in the side stream's pool and are
-dropped by the consumer at the earliest when it receives the next batch.  When batch j is built the consumer still holds batch
-j-2 (it receives j-1 only after this build), so the newest blocks that can have been freed -- and that this build may get again --
-belong to batch j-3, last read by step j-3.  Before building batch j the side stream therefore waits for the event recorded on
-the training stream at the PREVIOUS build (when steps <= j-3 had been enqueued), and overlaps with steps j-2 and j-1."""
+Cross-stream dependencies are NOT free on this stack (an event record is a marker packet that drains the queue's pipeline, a
+wait is a barrier packet: measured ~25 us each, tools/trainer_window_attrib.py), so the loop uses as few as it can:
+* training stream <- side stream: the batch was built a whole step ago; `built.query()` on the host is normally already true
+  and then nothing is enqueued at all (completion observed by the host orders everything enqueued afterwards);
+* side stream <- training stream (memory safety: buffers of a batch live in the side stream's allocator pool; once the
+  consumer drops them a later build may get the same blocks): this object KEEPS a reference to every batch it has handed out,
+  so none of their blocks can be freed, and only every `fence_every` builds records ONE event on the training stream (all
+  steps enqueued so far = the steps of every batch handed out), makes the side stream wait for it and only then lets go of
+  those batches.  Whenever their blocks are freed afterwards, every later side-stream operation is already ordered behind
+  their last reader.  Cost: `fence_every` + 2 batches stay allocated.
+"""
 from __future__ import annotations
+
+import collections
 
 import torch
 
@@ -35,9 +43,10 @@ class SideStreamBatches:
     """for batch in SideStreamBatches(loader): ...  -- `loader` is any iterable whose `__next__` enqueues the batch's device work
     on the CURRENT stream (a `DataLoader` with `num_workers == 0` and a device collate, or a generator)."""
 
-    def __init__(self, loader, stream: 'torch.cuda.Stream | None' = None):
+    def __init__(self, loader, stream: 'torch.cuda.Stream | None' = None, fence_every: int = 4):
         self.loader = loader
         self.side = stream
+        self.fence_every = max(1, int(fence_every))
 
     def __len__(self):
         return len(self.loader)
@@ -48,19 +57,25 @@ class SideStreamBatches:
         main = torch.cuda.current_stream()
         side = self.side if self.side is not None else side_stream()
         it = iter(self.loader)
-        fence_prev = [None]                   # recorded on `main` at the previous build
+        held = collections.deque()            # batches built and not yet released by this object
+        nbuilt = [0]
+        # the side stream and its pool outlive the iteration: the previous epoch's last steps may still be reading what they freed
+        start = torch.cuda.Event()
+        start.record(main)
+        side.wait_event(start)
 
         def build():
             """-> (batch, event) or None.  Called BEFORE the consumer enqueues the step of the batch handed out last, so the
-            construction chain (a dozen dependent small launches, ~0.2 ms of latency) starts next to the step still in flight and
-            has a whole step of slack -- independent of how far the host runs ahead of the GPU."""
-            fence = torch.cuda.Event()
-            fence.record(main)                # everything the consumer has enqueued so far (steps <= j-2 when batch j is built)
-            # ... of which steps <= j-3 = everything up to the PREVIOUS build are the last readers of whatever batch j's buffers may
-            # reuse (see the module docstring); the first build of an iteration waits for everything enqueued so far (the side
-            # stream and its pool outlive the iteration: the previous epoch's last steps may still be reading what they freed)
-            side.wait_event(fence_prev[0] if fence_prev[0] is not None else fence)
-            fence_prev[0] = fence
+            construction (launches + copies, ~0.2 ms of latency) starts next to the step still in flight and has a whole step of
+            slack -- independent of how far the host runs ahead of the GPU."""
+            if nbuilt[0] and nbuilt[0] % self.fence_every == 0:
+                # main has enqueued the steps of every batch handed out so far = everything in `held` but the newest (built, not
+                # yet handed out): order the side stream behind them, THEN let go of those batches
+                fence = torch.cuda.Event()
+                fence.record(main)
+                side.wait_event(fence)
+                while len(held) > 1:
+                    held.popleft()
             with torch.cuda.stream(side):
                 try:
                     batch = next(it)
@@ -68,11 +83,14 @@ class SideStreamBatches:
                     return None
                 built = torch.cuda.Event()
                 built.record(side)
+            held.append(batch)
+            nbuilt[0] += 1
             return batch, built
 
         pending = build()
         while pending is not None:
             batch, built = pending
             pending = build()                 # batch j+1 is under construction before step j is enqueued
-            main.wait_event(built)
+            if not built.query():             # built a whole step ago: normally complete already -- then the training stream needs
+                main.wait_event(built)        # no cross-stream dependency at all (one costs ~25 us of pipeline drain)
             yield batch
