@@ -963,7 +963,7 @@ int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long row
 // wave that waits longer than SPG_PX_SPIN_LIMIT sweeps raises the error word of the control block (spg_ecc_persistent_errors)
 // and carries on, so a logic error can never hang the GPU.
 #define SPG_PX_MAX_ITERS 16
-#define SPG_PX_KMAX 8          // edges per node whose filters stay in registers (16 VGPRs each in matrix mode)
+#define SPG_PX_KMAX 12         // edges per node whose filters stay in registers (16 VGPRs each in matrix mode)
 #define SPG_PX_CH 32           // edges gathered per pass (wave-private LDS staging)
 #define SPG_PX_SPIN_LIMIT 400000
 
@@ -995,35 +995,31 @@ __device__ __forceinline__ void spg_px_gather_plain(const float* __restrict__ X,
   }
 }
 
-__device__ __forceinline__ void spg_px_gather_granules(const unsigned long long* __restrict__ gran, unsigned tag, const int* ids,
-                                                       int n, int lane, float* hs, unsigned* ctl) {
+// PER entries per half wave and sweep (2 * PER peers per round): a node with more than 8 peers would otherwise need a second
+// round -- a second hop latency on the path of the nodes that gate their neighbourhood
+template <int PER>
+__device__ __forceinline__ void spg_px_gather_granules_t(const unsigned long long* __restrict__ gran, unsigned tag, const int* ids,
+                                                         int n, int lane, float* hs, unsigned* ctl) {
   const int half = lane >> 5, c = lane & 31;
-  for (int p = 0; p < n; p += 8) {
+  for (int p = 0; p < n; p += 2 * PER) {
     for (unsigned spins = 0;; ++spins) {
-      unsigned long long x[4];
+      unsigned long long x[PER];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < PER; ++k) {
         const int u = p + 2 * k + half;
         x[k] = __hip_atomic_load((spg_gu64*)(gran + (long)ids[u < n ? u : 0] * 32 + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       bool ok = true;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < PER; ++k) {
         const int u = p + 2 * k + half;
         if (u < n) ok = ok && (unsigned)(x[k] >> 32) == tag;
       }
-      if (__all(ok)) {
+      const bool done = __all(ok);
+      if (done || spins > SPG_PX_SPIN_LIMIT) {
+        if (!done && lane == 0) atomicAdd(ctl + 2, 1u);      // never hang: flag the error and go on with what is there
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int u = p + 2 * k + half;
-          if (u < n) hs[u * 32 + c] = __uint_as_float((unsigned)x[k]);
-        }
-        break;
-      }
-      if (spins > SPG_PX_SPIN_LIMIT) {      // never hang: flag the error and go on with what is there
-        if (lane == 0) atomicAdd(ctl + 2, 1u);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
           const int u = p + 2 * k + half;
           if (u < n) hs[u * 32 + c] = __uint_as_float((unsigned)x[k]);
         }
@@ -1032,6 +1028,12 @@ __device__ __forceinline__ void spg_px_gather_granules(const unsigned long long*
       __builtin_amdgcn_s_sleep(1);
     }
   }
+}
+
+__device__ __forceinline__ void spg_px_gather_granules(const unsigned long long* __restrict__ gran, unsigned tag, const int* ids,
+                                                       int n, int lane, float* hs, unsigned* ctl) {
+  if (n <= 8) spg_px_gather_granules_t<4>(gran, tag, ids, n, lane, hs, ctl);
+  else spg_px_gather_granules_t<8>(gran, tag, ids, n, lane, hs, ctl);
 }
 
 // the last workgroup to finish advances the epoch base past every tag this launch used and re-arms the counter
