@@ -139,7 +139,7 @@ def gemm_traffic_live(args, log):
                    '--precision', args.precision, '--scenes', str(args.scenes), '--n-sp', str(args.n_sp), '--n-edges', str(args.n_edges),
                    '--n-feat', str(args.n_feat), '--model-config', args.model_config]
             env = dict(os.environ, TMPDIR='/tmp', SPG_BENCH_NO_LIVE_PMC='1')
-            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
             found = glob.glob(os.path.join(out, '**', '*.db'), recursive=True)
             if not found:
                 return None
