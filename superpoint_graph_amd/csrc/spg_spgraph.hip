@@ -361,24 +361,36 @@ __device__ void jacobi_eigen3(double A[3][3], double V[3][3]) {
   }
 }
 
-__global__ void geof_kernel(const float* __restrict__ xyz, const uint32_t* __restrict__ target, long n, int k_nn, float* __restrict__ geof) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// 256 points per workgroup; their k_nn neighbour indices are staged through LDS with coalesced loads (a thread's own row is a
+// 4 k_nn-byte strided segment of `target`: read directly, every load instruction would touch 64 different cache lines).
+// One gather pass: moments of the offsets from the point itself (d = x_j - x_i, exact in float64), covariance = E[d d^T] - E[d] E[d]^T.
+__global__ __launch_bounds__(256) void geof_kernel(const float* __restrict__ xyz, const uint32_t* __restrict__ target, long n, int k_nn,
+                                                   float* __restrict__ geof) {
+  extern __shared__ uint32_t nb[];                       // [256][k_nn + 1] (row padded by one word: conflict-free per-thread rows)
+  const long base = (long)blockIdx.x * 256;
+  const int rows = (int)min(256L, n - base), ld = k_nn + 1;
+  for (long u = threadIdx.x; u < (long)rows * k_nn; u += 256) {
+    const int r = (int)(u / k_nn), c = (int)(u - (long)r * k_nn);
+    nb[r * ld + c] = target[base * k_nn + u];
+  }
+  __syncthreads();
+  const long i = base + threadIdx.x;
   if (i >= n) return;
-  // neighbourhood = the point and its k_nn neighbours (:398-412); mean, then centred second moments / (k_nn + 1) (:414-415)
-  double sx = xyz[3 * i], sy = xyz[3 * i + 1], sz = xyz[3 * i + 2];
+  // neighbourhood = the point and its k_nn neighbours (:398-412); centred second moments / (k_nn + 1) (:414-415)
+  const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+  double sx = 0, sy = 0, sz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+  const uint32_t* mine = nb + threadIdx.x * ld;
   for (int k = 0; k < k_nn; ++k) {
-    const long j = target[i * k_nn + k];
-    sx += xyz[3 * j]; sy += xyz[3 * j + 1]; sz += xyz[3 * j + 2];
+    const long j = mine[k];
+    const double dx = (double)xyz[3 * j] - px, dy = (double)xyz[3 * j + 1] - py, dz = (double)xyz[3 * j + 2] - pz;
+    sx += dx; sy += dy; sz += dz;
+    xx += dx * dx; xy += dx * dy; xz += dx * dz; yy += dy * dy; yz += dy * dz; zz += dz * dz;
   }
   const double inv = 1.0 / (double)(k_nn + 1);
-  const double mx = sx * inv, my = sy * inv, mz = sz * inv;
-  double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int k = -1; k < k_nn; ++k) {
-    const long j = k < 0 ? i : (long)target[i * k_nn + k];
-    const double dx = xyz[3 * j] - mx, dy = xyz[3 * j + 1] - my, dz = xyz[3 * j + 2] - mz;
-    A[0][0] += dx * dx; A[0][1] += dx * dy; A[0][2] += dx * dz; A[1][1] += dy * dy; A[1][2] += dy * dz; A[2][2] += dz * dz;
-  }
-  A[0][0] *= inv; A[0][1] *= inv; A[0][2] *= inv; A[1][1] *= inv; A[1][2] *= inv; A[2][2] *= inv;
+  const double mx = sx * inv, my = sy * inv, mz = sz * inv;      // (the point itself contributes d = 0)
+  double A[3][3];
+  A[0][0] = xx * inv - mx * mx; A[0][1] = xy * inv - mx * my; A[0][2] = xz * inv - mx * mz;
+  A[1][1] = yy * inv - my * my; A[1][2] = yz * inv - my * mz; A[2][2] = zz * inv - mz * mz;
   A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
   double V[3][3];
   jacobi_eigen3(A, V);
@@ -690,7 +702,9 @@ extern "C" int spg_spg_superedges(const uint64_t* edges_sorted, const uint64_t* 
 extern "C" int spg_compute_geof(const float* xyz, const uint32_t* target, long n, int k_nn, float* geof, void* stream) {
   SPG_CHECK_ARG(n >= 0 && k_nn >= 0 && (n == 0 || (xyz && geof && (k_nn == 0 || target))), "bad argument");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(geof_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, xyz, target, n, k_nn, geof);
+  SPG_CHECK_ARG(k_nn <= 150, "k_nn too large for the LDS staging of the neighbour lists (150)");
+  hipLaunchKernelGGL(geof_kernel, dim3(spg_cdiv(n, 256)), dim3(256), (size_t)256 * (k_nn + 1) * sizeof(uint32_t), (hipStream_t)stream, xyz,
+                     target, n, k_nn, geof);
   SPG_LAUNCH_CHECK();
   return 0;
 }
