@@ -28,6 +28,10 @@ def compute_sp_graph(xyz, d_max, in_component, components, labels, n_labels, tet
     dev = _dev()
     xyz = np.ascontiguousarray(xyz, dtype=np.float32)
     in_component = np.asarray(in_component)
+    if xyz.ndim != 2 or xyz.shape[1] != 3 or in_component.shape != (len(xyz),):
+        raise ValueError('compute_sp_graph: xyz [n,3] and in_component [n] expected')
+    if len(xyz) == 0 or int(in_component.min()) < 0:
+        raise ValueError('compute_sp_graph: empty cloud or negative component index')
     n_com = int(in_component.max()) + 1
     if components is not None and len(components) != n_com:
         raise ValueError(f'compute_sp_graph: {len(components)} components for max(in_component) + 1 = {n_com}')
@@ -37,7 +41,10 @@ def compute_sp_graph(xyz, d_max, in_component, components, labels, n_labels, tet
     if tetrahedra is None:
         from scipy.spatial import Delaunay
         tetrahedra = Delaunay(xyz).simplices          # (`tri.vertices` in the reference: the attribute's old name)
-    tets = ops.upload(torch.from_numpy(np.ascontiguousarray(tetrahedra, dtype=np.int32)), dev)
+    tetrahedra = np.ascontiguousarray(tetrahedra, dtype=np.int32).reshape(-1, 4)
+    if tetrahedra.size and (int(tetrahedra.min()) < 0 or int(tetrahedra.max()) >= len(xyz)):
+        raise IndexError('compute_sp_graph: a tetrahedron vertex is outside [0, number of points)')
+    tets = ops.upload(torch.from_numpy(tetrahedra), dev)
     xyz_d = ops.upload(torch.from_numpy(xyz), dev)
     comp_d = ops.upload(torch.from_numpy(np.ascontiguousarray(in_component, dtype=np.int32)), dev)
     lab_d = rows_d = None
@@ -75,7 +82,10 @@ def compute_geof(xyz, target, k_nn):
     partition/ply_c/ply_c.cpp:384-462, called as libply_c.compute_geof(xyz, graph_nn['target'], k_nn)) -> float32 [n,4]."""
     dev = _dev()
     xyz_d = ops.upload(torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32)), dev)
-    tgt = np.ascontiguousarray(target).reshape(-1).astype(np.uint32).view(np.int32)
+    tgt = np.ascontiguousarray(target).reshape(-1).astype(np.uint32)
+    if tgt.size and int(tgt.max()) >= len(xyz):
+        raise IndexError('compute_geof: a neighbour index is outside [0, number of points)')
+    tgt = tgt.view(np.int32)
     return ops.compute_geof(xyz_d, ops.upload(torch.from_numpy(tgt), dev), int(k_nn)).cpu().numpy()
 
 
