@@ -169,3 +169,34 @@ def test_single_launch_builder_limits_and_malformed_edges(hip):
     bad = torch.tensor([[0, 1], [2, 7], [1, 0]], dtype=torch.int64)
     out = ops.batch_graph_build(bad, torch.zeros(3, 2), 4)
     assert int(out[4]) == 1                                                                                        # flagged, no out-of-bounds write
+
+
+def test_side_stream_batches_hand_over_and_memory_discipline(hip):
+    """SideStreamBatches (learning/prefetch.py): batches are built on the side stream one step ahead and consumed on the training
+    stream with (normally) no cross-stream dependency at all, their buffers come from the side stream's allocator pool.  Stress:
+    every batch is a buffer filled with its index by a kernel on the side stream; the consumer first keeps the training stream busy
+    (so that the host runs far ahead), then reads the buffer.  A batch handed over too early, or a block recycled while its reader
+    is still queued, shows up as a wrong value."""
+    from superpoint_graph_amd.learning.prefetch import SideStreamBatches
+    dev = torch.device('cuda')
+    n_batches, size = 120, 1 << 18
+
+    def loader():
+        for i in range(n_batches):
+            buf = torch.empty(size, device=dev)            # allocated and written on the CURRENT (= side) stream
+            buf.fill_(float(i))
+            extra = torch.empty(size // 2 + 17 * (i % 5), device=dev).fill_(-1.0)      # varying sizes: blocks get split / recycled
+            yield i, buf, extra
+
+    busy = torch.randn(2048, 2048, device=dev)
+    sums = []
+    for i, buf, extra in SideStreamBatches(loader(), fence_every=3):
+        for _ in range(3):                                  # ~0.3 ms of queued work per step: the host gets ahead of the GPU
+            busy = (busy @ busy) * 1e-3
+        sums.append((i, buf.sum(), buf.min(), buf.max(), extra.max()))
+        del buf, extra
+    torch.cuda.synchronize()
+    assert len(sums) == n_batches
+    for i, s, lo, hi, ex in sums:
+        assert float(lo) == float(i) == float(hi) and float(s) == float(i) * size, (i, float(lo), float(hi))
+        assert float(ex) == -1.0
