@@ -12,7 +12,8 @@ loader touches), `transforms3d` -> its closed forms (oracle/spg_loader_oracle.py
 ECC backward raises on torch >= 1.5 (GraphConvModule.py:146): `GraphConvFunction` is replaced by the restated
 oracle.EccFunction exactly as in oracle/validate_against_reference.py, where that restatement is pinned.
 
-    python oracle/gen_main_golden.py            # writes tests/golden/main_cli.npz
+    python oracle/gen_main_golden.py                      # writes tests/golden/main_cli.npz
+    python oracle/gen_main_golden.py --variant frozen     # lr 1e-7: tests/golden/main_cli_frozen.npz
 """
 import json
 import os
@@ -151,7 +152,13 @@ def main():
     from learning import main as ref_main
     odir = tempfile.mkdtemp(prefix='spg_main_golden_')
     torch.set_num_threads(8)
-    argv = ['main.py', '--dataset', 'custom_dataset', '--cuda', '0', '--odir', odir] + main_fixture.CLI
+    # `--variant frozen`: the same run with lr = 1e-7 -- the parameters move by <= 4e-7 in four Adam steps, so EVERY loss of the run
+    # (not only the first) is comparable at fp32 round-off and the end-to-end test can be sharp (tests/golden/main_cli_frozen.npz)
+    frozen = len(sys.argv) > 2 and sys.argv[1] == '--variant' and sys.argv[2] == 'frozen'
+    cli = list(main_fixture.CLI)
+    if frozen:
+        cli[cli.index('--lr') + 1] = '1e-7'
+    argv = ['main.py', '--dataset', 'custom_dataset', '--cuda', '0', '--odir', odir] + cli
     old = sys.argv
     sys.argv = argv
     try:
@@ -172,7 +179,7 @@ def main():
     for k in ('ecc.1.weight', 'ecc.0._cell.weight_ih', 'ecc.0._fnet.7.weight', 'ptn.convs.12.weight', 'ptn.fcs.6.weight', 'ptn.stn.proj.weight',
               'ptn.convs.13.running_mean', 'ptn.convs.13.running_var', 'ecc.0._fnet.5.running_var'):
         out['param/' + k] = ckpt['state_dict'][k].numpy()
-    path = os.path.join(ROOT, 'tests', 'golden', 'main_cli.npz')
+    path = os.path.join(ROOT, 'tests', 'golden', 'main_cli_frozen.npz' if frozen else 'main_cli.npz')
     np.savez_compressed(path, **out)
     print('losses:', LOSSES)
     print('stats:', json.dumps(stats))
