@@ -200,3 +200,25 @@ def test_side_stream_batches_hand_over_and_memory_discipline(hip):
     for i, s, lo, hi, ex in sums:
         assert float(lo) == float(i) == float(hi) and float(s) == float(i) * size, (i, float(lo), float(hi))
         assert float(ex) == -1.0
+
+
+def test_staging_ring_wraps_without_corrupting_pending_uploads(hip):
+    """spg_upload: 32 small + 4 large page-locked slots per device, re-used round robin; a slot is rewritten only after the copy
+    that last used it has left it.  300 uploads of different content and size (crossing the small / large boundary, growing slots)
+    with the stream kept busy, all verified afterwards."""
+    from superpoint_graph_amd import ops
+    rng = np.random.default_rng(0)
+    busy = torch.randn(2048, 2048, device='cuda')
+    host, dev = [], []
+    for i in range(300):
+        n = int(rng.choice([7, 1000, 70_000, 300_000, 600_000]))          # 28 B .. 2.4 MB (large ring above 1 MiB)
+        a = torch.from_numpy(rng.standard_normal(n).astype(np.float32)) if i % 3 else torch.from_numpy(rng.integers(-9, 9, n))
+        if i % 10 == 0:
+            busy = (busy @ busy) * 1e-3                                      # copies queue up behind real work
+        host.append(a.clone())
+        dev.append(ops.upload(a))
+        a.zero_()                                                           # the host buffer may be re-used at once
+    torch.cuda.synchronize()
+    for h, d in zip(host, dev):
+        assert d.dtype == h.dtype and torch.equal(d.cpu(), h)
+    assert ops.upload(torch.zeros(0)).numel() == 0
