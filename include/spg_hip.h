@@ -418,6 +418,11 @@ int spg_tune(int key, int value);
 /* Number of bounded-spin time-outs the persistent RNN-ECC launches of the current device have raised so far (0 in a correct
  * run; a wave that waits too long for a neighbour's state gives up instead of hanging the GPU).  Synchronises the device. */
 int spg_ecc_persistent_errors(void);
+/* The same count, and the error word is cleared.  Production callers (learning/main.py: once per epoch and before every
+ * checkpoint, where the host synchronises anyway) raise when it is non-zero: the affected launches carried on with stale
+ * neighbour states, i.e. the ECC outputs / gradients of those steps are wrong (spg_tune key 8 = 1 selects the
+ * per-iteration kernels, which cannot time out). */
+int spg_ecc_persistent_errors_clear(void);
 int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops);
 
 #ifdef __cplusplus

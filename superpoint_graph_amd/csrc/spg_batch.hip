@@ -380,9 +380,11 @@ __global__ __launch_bounds__(1024) void batch_graph_kernel(const BatchGraphArgs 
 }
 
 // edge features in the new order: feats_sorted[p, :] = feats[perm[p], :]
-__global__ void gather_rows_i32_kernel(const float* __restrict__ src, const int* __restrict__ perm, long rows, int cols, float* __restrict__ dst) {
+// `bad` = the builder's header word 3: a malformed edge list left `perm` unwritten (scratch) -- nothing is gathered then
+__global__ void gather_rows_i32_kernel(const float* __restrict__ src, const int* __restrict__ perm, long rows, int cols, float* __restrict__ dst,
+                                       const int* __restrict__ bad) {
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= rows * cols) return;
+  if (u >= rows * cols || bad[3] != 0) return;
   const long p = u / cols;
   dst[u] = src[(long)perm[p] * cols + (u - p * cols)];
 }
@@ -420,9 +422,9 @@ extern "C" int spg_batch_graph_build(const int64_t* edges_host, const float* fea
   a.error_flag = error_flag;
   hipLaunchKernelGGL(batch_graph_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   SPG_LAUNCH_CHECK();
-  if (E > 0 && F > 0) {      // (a malformed edge list leaves bucket_in unwritten: the gather then reads scratch, never out of bounds)
+  if (E > 0 && F > 0) {      // (a malformed edge list leaves bucket_in unwritten: the gather reads the builder's flag and does nothing)
     hipLaunchKernelGGL(gather_rows_i32_kernel, dim3(spg_cdiv((long)E * F, 256)), dim3(256), 0, (hipStream_t)stream, a.feats,
-                       (const int*)a.bucket_in, (long)E, F, feats_sorted);
+                       (const int*)a.bucket_in, (long)E, F, feats_sorted, (const int*)a.hdr);
     SPG_LAUNCH_CHECK();
   }
   return 0;

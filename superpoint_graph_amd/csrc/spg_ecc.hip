@@ -1381,6 +1381,19 @@ extern "C" int spg_ecc_persistent_errors(void) {
   return (int)ctl[2];
 }
 
+// reads AND clears the error word (one blocking 16-byte copy each way: call it where the host synchronises anyway)
+extern "C" int spg_ecc_persistent_errors_clear(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES || g_px_buf[dev] == nullptr) return 0;
+  unsigned ctl[4] = {0, 0, 0, 0};
+  if (hipMemcpy(ctl, g_px_buf[dev], sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (ctl[2] != 0u) {
+    const unsigned zero = 0u;
+    if (hipMemcpy((char*)g_px_buf[dev] + 2 * sizeof(unsigned), &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  }
+  return (int)ctl[2];
+}
+
 bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err) {
   *err = 0;
   char* buf = px_acquire(p.g.N, p.R, stream);

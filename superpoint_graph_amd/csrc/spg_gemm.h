@@ -13,9 +13,10 @@ enum { SPG_EPI_FWD = 0, SPG_EPI_BWD = 1 };
 // shift anyway -- sums the 8 slots per channel in its prologue, computes mean / rstd / scale / shift in float64 and writes
 // them (every workgroup writes the same bits; workgroup 0 also advances the running statistics).  Integer addition is
 // order-independent, so the result is deterministic (bit-identical from run to run) although the arrival order is not.
-// Representation of a double v: hi = floor(v * 2^8), lo = frac(v * 2^8) * 2^44 (both int64): |v| <= 2^36 per contribution
-// (clamped), resolution 2^-52, up to 2^19 contributions per slot (4 M per layer) without overflow -- the launcher falls back to
-// the finalize path beyond that.  A non-finite contribution raises the flag word behind
+// Representation of a double v: hi = floor(v * 2^SH), lo = frac(v * 2^SH) * 2^44 (both int64), up to 2^19 contributions per
+// slot (4 M per layer) without overflow -- the launcher falls back to the finalize path beyond that.  Forward sums use
+// SH = -8 (|v| <= 2^52 per contribution, quantum 2^-36: a pre-BatchNorm rms of ~3e6 over a workgroup's 512 rows is still in
+// range), backward sums SH = +8 (|v| <= 2^36, quantum 2^-52: gradients are small numbers); spg_gemm.hip: spg_fx_split.  A non-finite contribution raises the flag word behind
 // the slots and the consumer then produces NaN statistics, as the arithmetic it replaces would.
 // Slot layout of one layer: int64 [8 slots][4 limbs: sum x hi, lo, sum x^2 hi, lo][C channels], then one flag word.
 // Measured (tools/probe/bn_atomic_probe.hip): +0.3..0.6 us on the producer's tail at C = 64..256, ~1 us of consumer prologue.

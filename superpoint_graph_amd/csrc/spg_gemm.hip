@@ -183,29 +183,48 @@ __device__ __forceinline__ void spg_store_tile_vec(const f32x16 (&acc)[TI][TJ], 
 }
 
 // ---- fixed-point statistics slots (SpgBnFold, spg_gemm.h) ----
+// A double v is split as v * 2^SH = hi + lo * 2^-44 (hi = floor, lo in [0, 2^44)); each limb is an exact int64 sum, 2^19
+// contributions per slot without overflow, |hi| <= 2^44 per contribution.  Two scalings:
+//   forward sums (sum x, sum x^2), SH = -8: |v| <= 2^52 per contribution, quantum 2^-36 -- a persistent workgroup's partial
+//     over 512 rows stays in range up to a pre-BatchNorm rms of ~3e6 (un-normalised metre coordinates with pc_xyznormalize 0;
+//     the 2^36 range of round 3 turned rms > 1e4 into NaN statistics where the reference's fp32 stays finite);
+//     a quantum of 1.5e-11 per contribution is invisible next to eps = 1e-5 in var + eps and to fp32 in the mean;
+//   backward sums (sum dz, sum dz * xhat), SH = +8: gradients are SMALL numbers -- quantum 2^-52, |v| <= 2^36.
+template <int SH>
 __device__ __forceinline__ void spg_fx_split(double v, long long& hi, long long& lo) {
-  v = fmin(fmax(v, -0x1p36), 0x1p36);
-  const double t = v * 256.0, f = floor(t);
+  constexpr double LIM = SH < 0 ? 0x1p52 : 0x1p36, SC = SH < 0 ? 0x1p-8 : 0x1p8;
+  v = fmin(fmax(v, -LIM), LIM);
+  const double t = v * SC, f = floor(t);
   hi = (long long)f;                        // |hi| <= 2^44
   lo = (long long)((t - f) * 0x1p44);       // [0, 2^44): 2^19 contributions fit one int64 slot
 }
-__device__ __forceinline__ double spg_fx_join(long long hi, long long lo) { return ((double)hi + (double)lo * 0x1p-44) * (1.0 / 256.0); }
+template <int SH>
+__device__ __forceinline__ double spg_fx_join(long long hi, long long lo) {
+  constexpr double ISC = SH < 0 ? 0x1p8 : 0x1p-8;
+  return ((double)hi + (double)lo * 0x1p-44) * ISC;
+}
 
 // one contribution (two sums) of column `col` into the layer's slots
-__device__ __forceinline__ void spg_slots_add(unsigned long long* slots, int C, int col, double sx, double sxx) {
+template <int SH>
+__device__ __forceinline__ void spg_slots_add_t(unsigned long long* slots, int C, int col, double sx, double sxx) {
+  constexpr double LIM = SH < 0 ? 0x1p52 : 0x1p36;
   unsigned long long* s = slots + (size_t)(blockIdx.x & (SPG_FOLD_SLOTS - 1)) * 4 * C + col;
-  if (!(fabs(sx) <= 0x1p36 && fabs(sxx) <= 0x1p36)) atomicOr(slots + (size_t)SPG_FOLD_SLOTS * 4 * C, 1ull);      // NaN / inf / out of range
+  if (!(fabs(sx) <= LIM && fabs(sxx) <= LIM)) atomicOr(slots + (size_t)SPG_FOLD_SLOTS * 4 * C, 1ull);      // NaN / inf / out of range
   long long hi, lo;
-  spg_fx_split(sx, hi, lo);
+  spg_fx_split<SH>(sx, hi, lo);
   __hip_atomic_fetch_add(s, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_fetch_add(s + C, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  spg_fx_split(sxx, hi, lo);
+  spg_fx_split<SH>(sxx, hi, lo);
   __hip_atomic_fetch_add(s + 2 * (size_t)C, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_fetch_add(s + 3 * (size_t)C, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// backward: (sum dz, sum dz * xhat)
+__device__ __forceinline__ void spg_slots_add(unsigned long long* slots, int C, int col, double sx, double sxx) {
+  spg_slots_add_t<8>(slots, C, col, sx, sxx);
+}
 // forward: (rows n, mean, M2 of those rows) -> (sum x, sum x^2)
 __device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int C, int col, float n, float mean, float m2) {
-  spg_slots_add(slots, C, col, (double)n * (double)mean, (double)m2 + (double)n * (double)mean * (double)mean);
+  spg_slots_add_t<-8>(slots, C, col, (double)n * (double)mean, (double)m2 + (double)n * (double)mean * (double)mean);
 }
 
 // backward consumer prologue (weight-gradient kernels): sums (sum dz, sum dz * xhat) of the layer whose BatchNorm-backward
@@ -220,8 +239,8 @@ __device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f) {
 #pragma unroll
     for (int k = 0; k < SPG_FOLD_SLOTS; ++k) {
       const unsigned long long* s = f.slots + (size_t)k * 4 * C + c;
-      a += spg_fx_join((long long)s[0], (long long)s[C]);
-      b += spg_fx_join((long long)s[2 * (size_t)C], (long long)s[3 * (size_t)C]);
+      a += spg_fx_join<8>((long long)s[0], (long long)s[C]);
+      b += spg_fx_join<8>((long long)s[2 * (size_t)C], (long long)s[3 * (size_t)C]);
     }
     if (bad) a = __builtin_nan("");
     const float ps = f.s[c], pmean = f.mean[c], prstd = f.rstd[c];
@@ -251,8 +270,8 @@ __device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f) {
 #pragma unroll
     for (int k = 0; k < SPG_FOLD_SLOTS; ++k) {
       const unsigned long long* s = f.slots + (size_t)k * 4 * C + c;
-      sx += spg_fx_join((long long)s[0], (long long)s[C]);
-      sxx += spg_fx_join((long long)s[2 * (size_t)C], (long long)s[3 * (size_t)C]);
+      sx += spg_fx_join<-8>((long long)s[0], (long long)s[C]);
+      sxx += spg_fx_join<-8>((long long)s[2 * (size_t)C], (long long)s[3 * (size_t)C]);
     }
     const double M = f.count;
     if (bad) sx = __builtin_nan("");

@@ -61,6 +61,15 @@ class FlatParameters:
                 continue
             parts = name.split('.')[:-1]
             self._cover.append([named['.'.join(parts[:k])] for k in range(len(parts) + 1)])
+        # Parameters NO kernel-backed module covers (an affine `b` BatchNorm token of GraphNetwork, a HipLinear whose input
+        # width is no multiple of 4 and therefore runs torch's F.linear, any stock torch layer a user adds) receive their
+        # gradients from autograd's AccumulateGrad, which ADDS to `.grad`: these views are zeroed eagerly by zero_grad()
+        # -- one multi-tensor fill, and only when such parameters exist -- and are never touched by _resolve_stale().
+        self._autograd_grads = [p.grad for p, chain in zip(self.params, self._cover)
+                                if not any(_direct_writer(m) for m in chain)]
+        self._covered = [(p, chain) for p, chain in zip(self.params, self._cover) if any(_direct_writer(m) for m in chain)]
+        for m in self._modules:
+            m._spg_lazy_zero = self.lazy_zero
         self._stale = False
         self.one = torch.ones((), dtype=dt, device=dev)      # seed of loss.backward(arena.one): autograd otherwise launches a fill for it
         if host_counters:
@@ -154,6 +163,8 @@ class FlatParameters:
     def zero_grad(self):
         if self.lazy_zero:
             self._stale = True          # resolved by _resolve_stale() before the gradients are consumed
+            if self._autograd_grads:
+                torch._foreach_zero_(self._autograd_grads)
         else:
             self._gbuf.zero_()
         self._clear_written()
@@ -167,7 +178,7 @@ class FlatParameters:
         key = frozenset(id(m) for m in self._written_log)       # the same few modules every step: one dictionary lookup
         todo = self._uncovered.get(key)
         if todo is None:
-            todo = self._uncovered[key] = [p for p, chain in zip(self.params, self._cover)
+            todo = self._uncovered[key] = [p for p, chain in self._covered
                                            if not any(getattr(m, '_spg_grad_written', False) for m in chain)]
         for p in todo:
             p.grad.zero_()
@@ -201,6 +212,31 @@ class FlatParameters:
         else:
             dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=group)
         self.flat.grad.div_(self._gbuf[self.numel])
+
+
+def _direct_writer(m):
+    """Module classes whose HIP backward WRITES the gradient views of all parameters below them (PointNet incl. its STN,
+    a stand-alone STNkD, the RNN-ECC module incl. filter network and cell, HipLinear on the kernel path)."""
+    from .learning.modules import HipLinear, RNNGraphConvModule
+    from .learning.pointnet import PointNet, STNkD
+    if isinstance(m, HipLinear):
+        return m._kernel_shape_ok()
+    return isinstance(m, (PointNet, STNkD, RNNGraphConvModule))
+
+
+def prepare_autograd_fallback(module):
+    """A kernel-covered module that takes torch's path for ONE call (HipLinear on an input the kernels do not serve):
+    autograd will ACCUMULATE into the arena views, so under lazy zeroing they must be cleared before that backward -- now,
+    at forward time, once per zero_grad() interval -- and the module counts as written so _resolve_stale() leaves them."""
+    if not getattr(module, '_spg_lazy_zero', False) or getattr(module, '_spg_grad_written', False):
+        return
+    for p in module.parameters(recurse=False):
+        if p.grad is not None:
+            p.grad.zero_()
+    module._spg_grad_written = True
+    log = getattr(module, '_spg_written_log', None)
+    if log is not None:
+        log.append(module)
 
 
 def mark_direct_write(module):

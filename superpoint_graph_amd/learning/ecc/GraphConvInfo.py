@@ -8,6 +8,17 @@ import numpy as np
 import torch
 
 
+def _concat_edge_attribute(per_graph):
+    """Per-graph edge-attribute arrays -> one array in batch order.  A graph WITHOUT edges (an isolated superpoint, a tiny
+    scene) contributes an empty array whose trailing shape is unknown ((0, 0) from SuperpointGraph, (0,) from igraph's empty
+    value list): it is skipped instead of being concatenated -- the reference and `set_batch` extend a Python list, for
+    which an empty graph is harmless (GraphConvInfo.py:55-57).  All graphs empty: (0, 0)."""
+    full = [np.asarray(a) for a in per_graph if np.asarray(a).shape[0] > 0]
+    if not full:
+        return np.zeros((0, 0), dtype=np.float32)
+    return np.concatenate(full) if len(full) > 1 else full[0]
+
+
 class GraphConvInfo(object):
     def __init__(self, *args, **kwargs):
         self._idxn = None
@@ -65,7 +76,7 @@ class GraphConvInfo(object):
                 # per-graph [E_g, width] arrays when the graph offers them (SuperpointGraph), else igraph's value lists
                 edgeattrs[a].append(fast(a) if fast is not None else np.asarray(G.es.get_attribute_values(a)))
             p += G.vcount()
-        edgeattrs = {a: (np.concatenate(v) if len(v) > 1 else v[0]) for a, v in edgeattrs.items()}
+        edgeattrs = {a: _concat_edge_attribute(v) for a, v in edgeattrs.items()}
         edges_h = np.concatenate(edges) if edges else np.zeros((0, 2), dtype=np.int64)
         if edges_h.size and (int(edges_h.min()) < 0 or int(edges_h.max()) >= p):
             raise IndexError('GraphConvInfo.set_batch_device: an edge endpoint is outside [0, number of nodes)')

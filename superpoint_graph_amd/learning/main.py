@@ -402,6 +402,8 @@ class Session:
                 break
         cm.allreduce()
         acc_meter.add_counts(*cm.accuracy_counts())
+        if a.cuda:
+            ops.check_persistent_ecc('this training epoch')      # (the meters above already synchronised the device)
         return acc_meter.value()[0], loss_meter.value()[0], cm.get_overall_accuracy(), cm.get_average_intersection_union()
 
     # ---- learning/main.py:229-264 ----
@@ -469,6 +471,8 @@ class Session:
                 cm.get_mean_class_accuracy(), cm.confusion_matrix)
 
     def checkpoint(self, epoch, with_scaler=True):
+        if self.args.cuda:
+            ops.check_persistent_ecc('the steps behind this checkpoint')       # never persist parameters trained on corrupted ECC outputs
         if self.rank != 0:                  # replicas are identical after every step: rank 0 writes
             return
         state = {'epoch': epoch + 1, 'args': self.args, 'state_dict': self.model.state_dict(), 'optimizer': self.optimizer.state_dict()}

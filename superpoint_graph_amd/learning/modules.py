@@ -131,6 +131,12 @@ class _LinearFunction(torch.autograd.Function):
             else:
                 ops.linear_wgrad(gy, x, out=weight.grad)
             return None, gx, None, None
+        if getattr(m, '_spg_direct_grads', False):
+            if any(p is not None and p.requires_grad and (p.grad is None or not p.grad.is_contiguous()) for p in (weight, m.bias)):
+                raise RuntimeError('FlatParameters mode: a parameter has no contiguous .grad view into the gradient arena '
+                                   '(optimizer.zero_grad(set_to_none=True)?); use FlatParameters.zero_grad()')
+            from ..flat import prepare_autograd_fallback       # partly frozen layer: autograd accumulates what is returned
+            prepare_autograd_fallback(m)
         if m.bias is not None:
             gw, gb = ops.linear_wgrad_bias(gy, x)
         else:
@@ -143,11 +149,16 @@ class HipLinear(nn.Linear):
     for 2-d float32 CUDA inputs -- the classifier of the graph network (reference learning/graphnet.py:47-49).  torch's
     path costs three hipBLASLt launches with host-side argument uploads, a reduction and two accumulations per step."""
 
-    def forward(self, input):
+    def _kernel_shape_ok(self):
         w = self.weight
-        if (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and w.is_contiguous() and w.shape[1] % 4 == 0
-                and w.data_ptr() % 16 == 0):
-            return _LinearFunction.apply(self, input.contiguous(), w, self.bias)
+        return w.is_contiguous() and w.shape[1] % 4 == 0 and w.data_ptr() % 16 == 0
+
+    def forward(self, input):
+        if input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and self._kernel_shape_ok():
+            return _LinearFunction.apply(self, input.contiguous(), self.weight, self.bias)
+        if getattr(self, '_spg_direct_grads', False) and torch.is_grad_enabled():
+            from ..flat import prepare_autograd_fallback       # torch's path accumulates: see FlatParameters(lazy_zero=True)
+            prepare_autograd_fallback(self)
         return super(HipLinear, self).forward(input)
 
 

@@ -417,6 +417,21 @@ def eccrnn_backward(state: EccRnnState, groups, grad_out, out_grads=None):
 # --------------------------------------------------------------------------------------------------
 # batch construction on the device
 # --------------------------------------------------------------------------------------------------
+def check_persistent_ecc(what='training'):
+    """Health check of the dataflow-synchronised RNN-ECC launches (include/spg_hip.h: spg_ecc_persistent_errors_clear): a
+    wave whose bounded spin ran out (a peer workgroup was not resident in time: shared GPU, profiler, another stream holding
+    CUs) carried on with stale neighbour states.  Synchronises the device; call it where the host synchronises anyway (epoch
+    end, before a checkpoint).  Raises after clearing the counter and switching this process to the per-iteration kernels
+    (spg_tune key 8), so a caller that catches the error can repeat the affected work safely."""
+    n = lib().spg_ecc_persistent_errors_clear()
+    if n == 0:
+        return
+    lib().spg_tune(8, 1)
+    raise RuntimeError(f'{n} persistent RNN-ECC spin time-out(s) during {what}: the ECC outputs / gradients of the affected steps '
+                       'are wrong (a workgroup of the dataflow-synchronised launch was not resident in time).  The process now '
+                       'uses the per-iteration kernels (spg_tune key 8); repeat the work since the last check')
+
+
 def set_batch(edges, n_nodes: int):
     """edges i64 [E, 2] (source, target; batch node offsets applied) on the device -> (idxn i64 [E], degs i64 [N],
     perm i64 [E]): edges ordered by target (stable), see include/spg_hip.h."""

@@ -222,3 +222,30 @@ def test_staging_ring_wraps_without_corrupting_pending_uploads(hip):
     for h, d in zip(host, dev):
         assert d.dtype == h.dtype and torch.equal(d.cpu(), h)
     assert ops.upload(torch.zeros(0)).numel() == 0
+
+
+@pytest.mark.parametrize('sizes,empty', [([300, 1, 120], [1]), ([200, 50], [0]), ([1], [0]), ([40, 30], [0, 1])])
+def test_set_batch_device_with_edgeless_graphs(sizes, empty):
+    """A graph WITHOUT edges in the batch (an isolated superpoint, a tiny scene): the reference / host `set_batch` extend Python
+    lists, for which it is harmless (GraphConvInfo.py:55-57); the device path concatenates per-graph arrays and must skip the
+    empty ones (numpy refuses to concatenate (0, 0) with (E, 13)).  Incl. the all-empty batch."""
+    from superpoint_graph_amd.learning import ecc, spg
+    graphs = _graphs(7, sizes)
+    for i in empty:
+        graphs[i] = spg.SuperpointGraph(sizes[i], np.zeros((0, 2), dtype=np.int64), True, {'f': []})
+    dev = ecc.GraphConvInfo()
+    dev.set_batch_device(graphs, spg.cloud_edge_feats)
+    idxn_d, _, degs_d, degs_gpu, ef_d = dev.get_buffers()
+    off = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    E = [np.asarray(g.get_edgelist()).reshape(-1, 2) + p for g, p in zip(graphs, off)]
+    E = np.concatenate(E) if E else np.zeros((0, 2), dtype=np.int64)
+    assert np.array_equal(degs_d.numpy(), np.bincount(E[:, 1].astype(np.int64), minlength=sum(sizes)))
+    assert torch.equal(degs_gpu.cpu(), degs_d)
+    stable = np.argsort(E[:, 1], kind='stable')
+    assert np.array_equal(idxn_d.cpu().numpy(), E[stable, 0])
+    if len(E):
+        F = np.concatenate([np.asarray(g.es.get_attribute_values('f')) for g in graphs if g.ecount()])
+        assert np.array_equal(ef_d.cpu().numpy(), F[stable])
+    else:
+        assert ef_d.shape[0] == 0
+    dev.device_graph()          # the CSR exists (an edge-less batch is a valid graph: every node aggregates nothing)

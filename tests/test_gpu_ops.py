@@ -220,6 +220,45 @@ def test_fused_clamp_adam_matches_torch(hip):
             assert maxrel(a.grad, b.grad) < 2e-5 and maxrel(a, b) < 2e-5, step   # fp32 trajectories drift by rounding
 
 
+def test_lazy_zero_arena_with_autograd_parameters(hip):
+    """FlatParameters(lazy_zero=True) -- the CLI default -- with parameters NO HIP kernel writes: the affine BatchNorm of a
+    `b` token and an `f_K` layer whose input width is no multiple of 4 (torch's F.linear) get their gradients from autograd's
+    AccumulateGrad, which ADDS.  They must be zeroed every step (they were accumulated onto stale values and then
+    cleared right before Adam, i.e. never trained).  Trajectory against torch.optim.Adam on an un-flattened twin."""
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.learning import graphnet
+    def make():
+        torch.manual_seed(5)
+        return graphnet.GraphNetwork('f_30,b,r,f_8', 32, [13, 32], use_pyg=0).to(DEV).train()
+    ref, mod = make(), make()
+    assert not dict(mod.named_children())['3']._kernel_shape_ok() and dict(mod.named_children())['0']._kernel_shape_ok()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    arena = FlatParameters(mod, lazy_zero=True, host_counters=True)
+    assert len(arena._autograd_grads) == 4          # BatchNorm weight / bias, second Linear weight / bias
+    x = torch.randn(64, 32, device=DEV)
+    y = torch.randint(0, 8, (64,), device=DEV)
+    for step in range(4):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(ref(x), y).backward()
+        opt.step()
+        arena.zero_grad()
+        torch.nn.functional.cross_entropy(mod(x), y).backward()
+        g_before = {k: p.grad.clone() for k, p in mod.named_parameters()}
+        arena.adam_step(lr=1e-2)
+        for (k, a), b in zip(mod.named_parameters(), ref.parameters()):
+            assert float(g_before[k].abs().max()) > 0, (k, step)
+            assert maxrel(a.grad, b.grad) < 1e-4 and maxrel(a, b) < 1e-4, (k, step)
+    # a kernel-covered HipLinear that takes torch's path for one call (3-d input): cleared at forward time, then accumulated once
+    arena.zero_grad()
+    fc0 = dict(mod.named_children())['0']
+    xx = torch.randn(2, 5, 32, device=DEV)
+    stale = fc0.weight.grad.clone()
+    fc0(xx).sum().backward()
+    expect = xx.reshape(-1, 32).sum(0).expand(30, 32)
+    arena.adam_step(lr=0.0)
+    assert maxrel(fc0.weight.grad, expect) < 1e-5 and float(stale.abs().max()) > 0
+
+
 @pytest.mark.parametrize('n,c,weighted,reduction', [(1000, 13, False, 'mean'), (1000, 13, True, 'mean'), (7, 8, True, 'sum'), (4099, 13, True, 'mean')])
 def test_cross_entropy_matches_torch(hip, n, c, weighted, reduction):
     """ops.cross_entropy (one launch each way) against torch.nn.functional.cross_entropy: loss, gradient, ignore_index."""

@@ -158,3 +158,14 @@ def test_superpoint_graph_igraph_semantics():
     assert R.vcount() in (2, 3, 4) and set(R.vs['v']) <= set('abcdef')
     K = k_big_enough(G, 40, 2)             # sizes 50, 5, 60, 70, ...: the prefix holding 2 superpoints of >= 40 points = ids 0..2
     assert K.vs['v'] == ['a', 'b', 'c'] and K.get_edgelist() == [(0, 1), (1, 2)]
+
+
+def test_concat_edge_attribute_skips_edgeless_graphs():
+    """GraphConvInfo.set_batch_device's concatenation of per-graph edge attributes: graphs without edges contribute arrays of
+    unknown trailing shape -- (0, 0) from SuperpointGraph, (0,) from an igraph value list -- and are skipped."""
+    from superpoint_graph_amd.learning.ecc.GraphConvInfo import _concat_edge_attribute
+    a, b = np.arange(6, dtype=np.float32).reshape(2, 3), np.arange(9, dtype=np.float32).reshape(3, 3)
+    out = _concat_edge_attribute([a, np.zeros((0, 0), dtype=np.float32), b, np.asarray([])])
+    assert out.shape == (5, 3) and np.array_equal(out[:2], a) and np.array_equal(out[2:], b)
+    assert _concat_edge_attribute([np.zeros((0, 0)), a]) is a
+    assert _concat_edge_attribute([np.asarray([]), np.zeros((0, 0))]).shape == (0, 0)
