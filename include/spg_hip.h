@@ -110,6 +110,11 @@ int spg_linear_wgrad(const float* dY, long lddy, const float* X, long ldx, int M
 size_t spg_linear_wgrad_bias_work_floats(int M, int N, int K);
 int spg_linear_wgrad_bias(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K, const float* in_scale,
                           const float* in_shift, int in_relu, float* dW, float* dbias, float* work, void* stream);
+/* The whole backward of Y = X W^T + b in ONE grouped launch + one batched reduction (round 4): dX [M, lddx] (may be null),
+ * dW [N, K], dbias [N] (may be null) -- the three are mutually independent, so they run as jobs of a single kernel
+ * (autograd of nn.Linear, the classifier of learning/graphnet.py:47-49).  work as for spg_linear_wgrad_bias. */
+int spg_linear_backward(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K, float* dX,
+                        long lddx, float* dW, float* dbias, float* work, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PointNet (learning/pointnet.py:16-133): STNkD + per-point MLP + max-pool + FC head, train-mode
@@ -413,7 +418,9 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * library-owned side stream next to the filter network's backward chain (experiment; measured slower, off by default).
  * key 10: 1 = train-mode BatchNorm statistics of spg_pointnet_forward go through per-workgroup partials and a finalize launch
  * per layer (the pre-round-3 path, still used with synchronised BatchNorm) instead of fixed-point slots finished by the
- * consuming GEMM.  Returns the previous value, -1 for an unknown key. */
+ * consuming GEMM.  key 11: 1 = no grouped launches (round 4: mutually independent few-row GEMMs / small reductions leave as
+ * jobs of ONE kernel; the bodies are unchanged, results bit-identical -- A/B timing and the equality test).
+ * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* Number of bounded-spin time-outs the persistent RNN-ECC launches of the current device have raised so far (0 in a correct
  * run; a wave that waits too long for a neighbour's state gives up instead of hanging the GPU).  Synchronises the device. */

@@ -71,6 +71,7 @@ SIGNATURES = {
     'spg_linear_wgrad': (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     'spg_linear_wgrad_bias_work_floats': (ctypes.c_size_t, [_i, _i, _i]),
     'spg_linear_wgrad_bias': (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
+    'spg_linear_backward': (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _p, _l, _p, _p, _p, _p]),
     'spg_pointnet_num_layers': (_i, [ctypes.POINTER(PointNetCfg)]),
     'spg_pointnet_workspace_bytes': (_sz, [ctypes.POINTER(PointNetCfg), _i, _i]),
     'spg_pointnet_forward': (_i, [ctypes.POINTER(PointNetCfg), _i, _p, _p, c_void_pp, _p, _p, _i, _i, _p]),

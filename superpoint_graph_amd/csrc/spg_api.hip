@@ -510,6 +510,28 @@ extern "C" int spg_linear_wgrad_bias(const float* dY, long lddy, const float* X,
   return spg_flush_reduce(rq, (hipStream_t)stream);
 }
 
+// the whole backward of a dense layer Y = X W^T + b: data gradient, weight gradient and bias gradient are mutually
+// independent -- ONE grouped launch (spg_gemm.h) + the batched reduction of the split partials, instead of three launches.
+// dX may be null (the input needs no gradient); dbias may be null.  work: >= spg_linear_wgrad_bias_work_floats floats.
+extern "C" int spg_linear_backward(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K,
+                                   float* dX, long lddx, float* dW, float* dbias, float* work, void* stream) {
+  SPG_CHECK_ARG(dY && X && W && dW && work, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SpgReduceQueue rq;
+  rq.arena = work; rq.arena_floats = spg_linear_wgrad_bias_work_floats(M, N, K);
+  {
+    SpgGroupScope grp(st);
+    SpgWgradParams w; memset(&w, 0, sizeof(w));
+    w.a = affine_operand(dY, lddy, N, nullptr, nullptr, 0);
+    w.b = affine_operand(X, ldx, K, nullptr, nullptr, 0);
+    w.M = M; w.N = N; w.K = K;
+    SPG_TRY(spg_queue_wgrad(rq, w, dW, st, dbias));
+    if (dX != nullptr) SPG_TRY(spg_linear_dgrad(dY, lddy, M, N, W, K, dX, lddx, stream));
+    SPG_TRY(grp.flush());
+  }
+  return spg_flush_reduce(rq, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 // element-wise gradient clamp + Adam on one flat buffer (learning/main.py:210-213, torch.optim.Adam semantics:
 // weight decay added to the clamped gradient, bias-corrected moments, denom = sqrt(v)/sqrt(1-b2^t) + eps)

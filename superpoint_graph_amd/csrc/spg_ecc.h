@@ -90,7 +90,48 @@ struct SpgEccStepBwd {
 };
 int spg_launch_ecc_step_bwd(const SpgEccStepBwd& p, hipStream_t stream);
 
-// dW_e = sum_r h^r_src (x) g^r_dst  (matrix) / h^r_src * g^r_dst (vector), r = 0..R-1
+// dW_e = sum_r h^r_src (x) g^r_dst  (matrix) / h^r_src * g^r_dst (vector), r = 0..R-1: one wavefront per edge, the sum over the
+// iterations in registers, written once.  The body lives here so that the grouped-launch kernel (spg_gemm.hip) can run it as
+// one of its jobs; bx = the workgroup's index inside the job.
+struct SpgEdgeWgrad {
+  SpgGraph g;
+  int matrix, R;
+  const float* states; long lds;
+  const float* G; long ldg;
+  float* dW;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void spg_ecc_edge_wgrad_body(const SpgEdgeWgrad& p, const int bx) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = bx * 4 + wave;
+  if (e >= p.g.E) return;
+  const float* hs = p.states + (long)p.g.src[e] * p.lds;
+  const float* gd = p.G + (long)p.g.dst[e] * p.ldg;
+  if (p.matrix) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < p.R; ++r) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gd + r * 32 + 4 * (lane & 7));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float hk = hs[r * 32 + (lane >> 3) + 8 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(hk, g4[c], acc[q][c]);
+      }
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(p.dW + (long)e * 1024);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[lane + 64 * q] = acc[q];
+  } else if (lane < 32) {
+    float a = 0.f;
+    for (int r = 0; r < p.R; ++r) a = fmaf(hs[r * 32 + lane], gd[r * 32 + lane], a);
+    p.dW[(long)e * 32 + lane] = a;
+  }
+}
+#endif
+// spg_gemm.hip: true when the job was taken by the grouped launch that is open on this thread (nothing to launch then)
+bool spg_group_add_edge_wgrad(const SpgEdgeWgrad& p, hipStream_t stream);
 int spg_launch_ecc_edge_wgrad(const SpgGraph& g, int matrix, const float* states, long lds, const float* G, long ldg,
                               int R, float* dW, hipStream_t stream);
 int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream);

@@ -882,43 +882,17 @@ int spg_launch_ecc_step_bwd(const SpgEccStepBwd& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // per-edge filter gradient, summed over the R iterations in registers (written once)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spg_ecc_edge_wgrad_kernel(const SpgGraph g, int matrix,
-                                                                 const float* __restrict__ states, long lds_,
-                                                                 const float* __restrict__ G, long ldg, int R,
-                                                                 float* __restrict__ dW) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int e = blockIdx.x * 4 + wave;
-  if (e >= g.E) return;
-  const float* hs = states + (long)g.src[e] * lds_;
-  const float* gd = G + (long)g.dst[e] * ldg;
-  if (matrix) {
-    f32x4 acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < R; ++r) {
-      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gd + r * 32 + 4 * (lane & 7));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float hk = hs[r * 32 + (lane >> 3) + 8 * q];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(hk, g4[c], acc[q][c]);
-      }
-    }
-    f32x4* o = reinterpret_cast<f32x4*>(dW + (long)e * 1024);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[lane + 64 * q] = acc[q];
-  } else if (lane < 32) {
-    float a = 0.f;
-    for (int r = 0; r < R; ++r) a = fmaf(hs[r * 32 + lane], gd[r * 32 + lane], a);
-    dW[(long)e * 32 + lane] = a;
-  }
+__global__ __launch_bounds__(256) void spg_ecc_edge_wgrad_kernel(const SpgEdgeWgrad p) {
+  spg_ecc_edge_wgrad_body(p, (int)blockIdx.x);
 }
 
 int spg_launch_ecc_edge_wgrad(const SpgGraph& g, int matrix, const float* states, long lds, const float* G, long ldg,
                               int R, float* dW, hipStream_t stream) {
   if (g.E == 0) return 0;
-  hipLaunchKernelGGL(spg_ecc_edge_wgrad_kernel, dim3(spg_cdiv(g.E, 4)), dim3(256), 0, stream, g, matrix, states, lds, G,
-                     ldg, R, dW);
+  SpgEdgeWgrad p;
+  p.g = g; p.matrix = matrix; p.states = states; p.lds = lds; p.G = G; p.ldg = ldg; p.R = R; p.dW = dW;
+  if (spg_group_add_edge_wgrad(p, stream)) return 0;      // inside a grouped launch (spg_gemm.h)
+  hipLaunchKernelGGL(spg_ecc_edge_wgrad_kernel, dim3(spg_cdiv(g.E, 4)), dim3(256), 0, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
 }

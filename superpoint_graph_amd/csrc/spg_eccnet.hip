@@ -336,6 +336,9 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
   SpgReduceQueue rq2;
   rq2.arena = s.work2; rq2.arena_floats = s.work2_floats;
   hipStream_t side = E > 0 ? spg_side_fork(st) : nullptr;
+  // Everything up to the per-edge filter gradient depends on the recurrence's outputs only: the cell's three weight gradients,
+  // its bias column sums and the per-edge filter gradient leave as ONE grouped launch (spg_gemm.h) instead of six
+  SpgGroupScope grp(st);
   {
     hipStream_t sg = side != nullptr ? side : st;
     SpgWgradParams w; memset(&w, 0, sizeof(w));
@@ -353,6 +356,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
   }
   // the deferred reductions of both queues leave in ONE launch at the end (after the join)
   auto flush_all = [&]() -> int {
+    SPG_TRY(grp.flush());
     if (side != nullptr) SPG_TRY(spg_side_join(st));
     for (int j = 0; j < rq2.njobs; ++j) {
       if (rq.njobs == SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(rq, st));
@@ -372,6 +376,9 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
   }
   // ---- per-edge filter gradients (sum over the iterations), then the filter network backward ----
   SPG_TRY(spg_launch_ecc_edge_wgrad(gr, pl.cfg.matrix, pl.states, ldS, s.G, ldS, R, s.dWts, st));
+  SPG_TRY(grp.flush());      // {cell weight gradients, bias column sums, per-edge filter gradient}
+  // the filter network's layers: weight gradient (+ bias column sums) and data gradient of a layer are independent of each
+  // other -- one grouped launch per layer
   SpgOperand cur = op_ident(s.dWts, pl.nout);
   float* dz[2] = {s.dzA, s.dzB};
   int flip = 0;
@@ -382,7 +389,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     const bool bias_rides = l.db != nullptr && !l.bn && cur.mode == SPG_PRO_IDENT;      // bias gradient = column sums of `cur`
     SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st, bias_rides ? l.db : nullptr));
     if (l.db && !bias_rides) {
-      if (l.bn) SPG_TRY(zero_async(l.db, (size_t)l.cout * 4, st));
+      if (l.bn) SPG_TRY(spg_group_zero(l.db, (size_t)l.cout, st));
       else SPG_TRY(spg_queue_colsum(rq, cur.X, cur.ld, E, l.cout, l.db, st));
     }
     if (i == 0) break;
@@ -396,6 +403,7 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     if (prod.bn) { g.ms = prod.s; g.mt = prod.t; g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat; }
     int nparts = 0;
     SPG_TRY(spg_launch_gemm(g, st, &nparts));
+    SPG_TRY(grp.flush());      // {weight gradient, bias column sums, data gradient} of layer i
     if (prod.bn) {
       SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
                                          s.consts, prod.dgamma, prod.dbeta, nullptr, st));

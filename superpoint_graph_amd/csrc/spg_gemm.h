@@ -63,6 +63,8 @@ struct SpgGemmParams {
   float* stat_cnt;    // forward: [parts] rows behind every partial (required with stat)
   unsigned long long* stat_slots;   // forward, instead of stat / stat_cnt: fixed-point slots of this layer (SpgBnFold above)
   SpgBnFold fold;     // forward: statistics of the layer that PRODUCED operand `a`, to be finished in this launch's prologue
+  SpgBnFoldBwd fold_bwd;   // data gradient: BatchNorm-backward sums of the `a` operand's layer, finished in this launch's prologue
+                           // too when the layer's weight gradient (which otherwise does it first) runs in the SAME grouped launch
   // max-pool over the rows of a tile (= the points of a superpoint), fused: BatchNorm is monotone per channel, so the
   // pooled normalised value is the raw MAX where the BatchNorm scale is >= 0 and the raw MIN otherwise, and the sign of
   // the scale gamma * rstd is the sign of gamma -- known before the statistics are.  pool_out [ntile, pool_ld] receives
@@ -120,6 +122,29 @@ inline long spg_split_ld(int k) { return (k + 7) & ~7; }
 inline size_t spg_split_bytes(int rows, int cols) { return (size_t)2 * rows * spg_split_ld(cols) * 2; }
 int spg_launch_split_weights(const SpgSplitBatch& b, hipStream_t stream);
 int spg_gemm_precision();      // spg_tune key 7: 0 fp32 MFMA, 1 bf16, 3 split-bf16
+
+// ---- grouped launches (round 4) ------------------------------------------------------------------------------------------
+// The step is a chain of ~80 dependent launches of which ~45 are few-row GEMMs / small reductions that take 5-15 us each
+// whatever they compute (dispatch, ramp, first loads, end-of-kernel release) on a fraction of the chip.  Wherever two or
+// more of them do NOT depend on each other -- a layer's data gradient and its weight gradient, the recurrent cell's three
+// parameter gradients and the per-edge filter gradient, ... -- they leave as ONE launch: spg_multi_kernel runs a list of
+// heterogeneous jobs, every workgroup executing the unchanged body of the kernel it replaces (same arithmetic, same
+// summation order: results are bit-identical to the separate launches).  No spin waits, no cross-workgroup dependencies.
+// Usage: open a scope on the stream, issue the launches (the launch functions below divert what the group can take and
+// launch everything else directly -- the caller asserts that ALL launches inside one scope are mutually independent), then
+// flush() (also at scope end).  One scope per thread at a time; spg_tune key 11 = 1 switches grouping off (A/B, tests).
+struct SpgGroupScope {
+  explicit SpgGroupScope(hipStream_t stream);
+  ~SpgGroupScope();
+  int flush();              // launches the collected jobs (if any) as one kernel; the scope stays open for the next group
+  bool active() const { return owner_; }      // false: nested scope or grouping switched off -- launches stay separate, in order
+  SpgGroupScope(const SpgGroupScope&) = delete;
+  SpgGroupScope& operator=(const SpgGroupScope&) = delete;
+ private:
+  bool owner_;
+};
+// zero `n` floats as a job of the open group (else hipMemsetAsync)
+int spg_group_zero(float* p, size_t n, hipStream_t stream);
 
 int spg_gemm_ntiles(const SpgGemmParams& p);
 // Data-gradient launches with 128-column tiles keep one workgroup per tile (no persistent stream: registers), i.e. one

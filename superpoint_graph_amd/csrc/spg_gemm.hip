@@ -42,7 +42,7 @@ std::vector<ProfRec> g_prof;
 std::mutex g_prof_mutex;      // host threads may launch on different streams while the instrumentation is on
 struct ProfScope {
   hipStream_t st; bool on; ProfRec r;
-  ProfScope(hipStream_t s, double flops, int tag = 0) : st(s), on(g_prof_on) {
+  ProfScope(hipStream_t s, double flops, int tag = 0, bool enable = true) : st(s), on(g_prof_on && enable) {
     if (on) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.flops = flops; r.tag = tag; r.M = r.N = r.K = 0; (void)hipEventRecord(r.a, st); }
   }
   ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); std::lock_guard<std::mutex> lock(g_prof_mutex); g_prof.push_back(r); } }
@@ -133,6 +133,59 @@ extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int rese
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// grouped launches (spg_gemm.h: SpgGroupScope): job table shared by the launchers and spg_multi_kernel (end of this file)
+// ---------------------------------------------------------------------------------------------
+#include "spg_ecc.h"
+enum { SPG_JOB_GEMM = 1, SPG_JOB_WGRAD = 2, SPG_JOB_COLSUM = 3, SPG_JOB_EDGE_WGRAD = 4, SPG_JOB_PAD_ROWS = 5, SPG_JOB_ZERO = 6 };
+struct SpgSmallJob {            // column sums: src [M, ld] -> dst [slices][N] (a = ld, b = M, c = rows per slice, i = N)
+  const float* src;             // pad rows:    src [rows, a] -> dst [rows, b] zero padded (c = rows, i = cols)
+  float* dst;                   // zero:        dst [b floats]
+  long a, b, c;
+  int i;
+};
+union SpgJobParams { SpgGemmParams g; SpgWgradParams w; SpgEdgeWgrad e; SpgSmallJob s; };
+struct SpgJobHdr { int kind, variant, first_block, gx, gy, gz, pad0, pad1; };
+#define SPG_GROUP_MAX_JOBS 7
+#define SPG_GROUP_MAX_WGRAD_ROWS 65536      // weight gradients over more rows than this are never grouped
+struct SpgMultiArgs {
+  int njobs, pad[3];
+  SpgJobHdr hdr[SPG_GROUP_MAX_JOBS];
+  SpgJobParams p[SPG_GROUP_MAX_JOBS];
+};
+static_assert(sizeof(SpgMultiArgs) <= 4096, "kernel arguments of a grouped launch must fit 4 KiB");
+// few-row row-GEMM bodies spg_rowgemm_body<32, 128, 1, 4, WRED, AMODE, FULL> the group can run: id, or -1
+constexpr int spg_gemm_variant(bool wred, int amode, bool full) {
+  const int m = amode == -1 ? (full ? -1 : 4)
+              : amode == SPG_PRO_IDENT ? (full ? 1 : 0)
+              : ((!wred && amode == SPG_PRO_AFFINE) || (wred && amode == SPG_PRO_BNBWD)) ? (full ? 3 : 2) : -1;
+  return m < 0 ? -1 : (wred ? 5 : 0) + m;
+}
+// weight-gradient bodies the group can run (the shapes the few-row layers of the S3DIS / Semantic3D configurations produce)
+//   X(id, IT, JT, WI, WJ, AMODE, BMODE, FULL, COLSUM)
+#define SPG_WGRAD_VARIANTS(X)                                                                      \
+  X(0, 128, 128, 2, 2, 3, 1, false, false)   X(1, 128, 128, 2, 2, 3, 1, true, false)               \
+  X(2, 64, 64, 2, 2, 0, 1, false, true)      X(3, 64, 64, 2, 2, 0, 1, true, true)                  \
+  X(4, 128, 64, 2, 2, 0, 1, false, false)    X(5, 128, 64, 2, 2, 0, 1, true, false)                \
+  X(6, 128, 128, 2, 2, -1, -1, false, true)                                                        \
+  X(7, 128, 32, 4, 1, 0, 0, false, false)    X(8, 128, 32, 4, 1, 0, 0, true, false)                \
+  X(9, 128, 32, 4, 1, -1, -1, false, true)                                                         \
+  X(10, 128, 32, 4, 1, 0, 0, false, true)    X(11, 128, 32, 4, 1, 0, 0, true, true)                \
+  X(12, 128, 32, 4, 1, 0, 1, false, true)    X(13, 128, 32, 4, 1, 0, 1, true, true)                \
+  X(14, 64, 64, 2, 2, 0, 1, false, false)    X(15, 64, 64, 2, 2, 0, 1, true, false)                \
+  X(16, 128, 128, 2, 2, 0, 1, false, true)   X(17, 128, 128, 2, 2, 0, 1, true, true)               \
+  X(18, 128, 64, 2, 2, 3, 1, false, false)   X(19, 128, 64, 2, 2, 3, 1, true, false)
+constexpr int spg_wgrad_variant(int it, int jt, int amode, int bmode, bool full, bool colsum) {
+#define SPG_X(id, IT_, JT_, WI_, WJ_, AM_, BM_, FU_, CS_) \
+  if (it == IT_ && jt == JT_ && amode == AM_ && bmode == BM_ && full == FU_ && colsum == CS_) return id;
+  SPG_WGRAD_VARIANTS(SPG_X)
+#undef SPG_X
+  return -1;
+}
+// host side (end of this file): true = the job was taken by the group that is open on this thread
+static bool spg_group_accepts(hipStream_t stream);
+static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
@@ -230,10 +283,10 @@ __device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int
 // backward consumer prologue (weight-gradient kernels): sums (sum dz, sum dz * xhat) of the layer whose BatchNorm-backward
 // formula this launch's `a` operand applies -> consts [4][C] = {s, c1, mean, s * c2 * rstd}; workgroup 0 also writes the
 // BatchNorm parameter gradients.  All threads of the workgroup; ends with a workgroup barrier.
-__device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f) {
+// `first`: exactly one workgroup of the step passes true (it writes dgamma / dbeta)
+__device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f, const bool first) {
   const int C = f.C;
   const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
-  const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double a = 0.0, b = 0.0;
 #pragma unroll
@@ -259,10 +312,10 @@ __device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f) {
 }
 
 // consumer prologue: all threads of the workgroup; ends with a workgroup barrier behind which s / t / mean / rstd are readable
-__device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f) {
+// `first`: exactly one workgroup of the launch passes true (it advances the running statistics)
+__device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f, const bool first) {
   const int C = f.C;
   const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
-  const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     // every slot is an exact integer sum; the 8 slots are decoded and added in float64 in slot order (deterministic) -- adding
     // the integers of all slots first could overflow (each slot may hold up to 2^19 contributions of up to 2^44)
@@ -637,8 +690,10 @@ __device__ __forceinline__ void spg_tile_epilogue(const SpgGemmParams& p, f32x16
 // STREAM: compiled with the multi-tile stream (persistent launches); without it has_next is a compile-time false
 // PREC: 0 = fp32 MFMA; 1 / 3 = bf16 / split-bf16 MFMA (FULL only; spg_common.h): operands are converted while staging,
 // the weights come pre-split (p.Wb, out-major for both the forward and -- pre-transposed -- the data gradient)
+// (bx, by): the workgroup's position in the launch grid -- blockIdx for a stand-alone launch, a virtual position inside its
+// job for a workgroup of a grouped launch (spg_multi_kernel below)
 template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false, bool STREAM = false, int PREC = 0>
-__global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGemmParams p) {
+__device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const int bx, const int by) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
   extern __shared__ f32x4 smem[];
@@ -656,16 +711,21 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
   // BatchNorm of the layer that produced operand `a`: its statistics arrive as fixed-point slots and are finished here (every
   // workgroup; spg_gemm.h) -- behind the barrier at its end the scale / shift arrays the staging pipes read exist
   if constexpr (!WRED) {
-    if (p.fold.slots != nullptr) spg_bn_fold_fwd(p.fold);
+    if (p.fold.slots != nullptr) spg_bn_fold_fwd(p.fold, bx == 0 && by == 0);
+  } else {
+    // data gradient launched NEXT TO the layer's weight gradient (grouped launch): it finishes the BatchNorm-backward
+    // constants its own staging reads itself -- the weight gradient's workgroups (which write the same bits, and dgamma /
+    // dbeta) are not ordered before it any more
+    if (p.fold_bwd.slots != nullptr) spg_bn_fold_bwd(p.fold_bwd, false);
   }
 
   if constexpr (AMODE >= 0 && FULL) {
     static_assert(4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) + 2 * WI * JT <= 4 * (A_F4 + B_F4), "epilogue staging + pooling exchange must fit one LDS buffer");
-    int tile = blockIdx.x, ct = blockIdx.y;
+    int tile = bx, ct = by;
     if (p.remap) {
       // XCD-aware item map (workgroup b runs on XCD b % 8): the column tiles of one row tile are consecutive workgroups
       // of ONE XCD (the second reader of an A tile finds it in that XCD's L2); a workgroup keeps its column tile
-      const int lin = blockIdx.x, j = lin >> 3;
+      const int lin = bx, j = lin >> 3;
       ct = j % p.ncol;
       tile = (j / p.ncol) * 8 + (lin & 7);
     }
@@ -917,10 +977,10 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
     return;
   }
 
-  const int tile = blockIdx.x;
+  const int tile = bx;
   const long m0 = (long)tile * p.rows_per_tile;
   const int mvalid = (int)min((long)p.rows_per_tile, (long)p.M - m0);
-  const int n0 = blockIdx.y * JT;
+  const int n0 = by * JT;
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -1014,6 +1074,11 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
   spg_tile_epilogue<IT, JT, WI, WJ, WRED, false, false>(p, acc, red, tile, m0, mvalid, n0);
 }
 
+template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false, bool STREAM = false, int PREC = 0>
+__global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGemmParams p) {
+  spg_rowgemm_body<IT, JT, WI, WJ, WRED, AMODE, FULL, STREAM, PREC>(p, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 
 // ---- weights for the bf16 MFMA modes: split (hi = bf16(w), lo = bf16(w - hi)) and, for the data gradient, transposed ----
 __global__ __launch_bounds__(256) void spg_split_weights_kernel(const SpgSplitBatch b) {
@@ -1076,7 +1141,10 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
   if (lds < epi) lds = epi;
   dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, JT));
   if (stat_parts != nullptr) *stat_parts = (int)grid.x * WI;      // one statistics partial per tile and row-wave, unless ...
-  ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
+  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  // few-row launches inside an open group (spg_gemm.h) become jobs of its one launch
+  const bool grouped = IT == 32 && spg_group_accepts(stream);
+  ProfScope prof(stream, flops, 0, !grouped);
   prof.r.M = p.M; prof.r.N = p.N; prof.r.K = p.K;
   if constexpr (AMODE >= 0) {
     // whole reduction chunks, no per-element prologue masks, every offset inside 32 bits: fast pipes (rows / output channels
@@ -1137,12 +1205,18 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
           return 0;
         }
       }
+      if constexpr (IT == 32 && spg_gemm_variant(WRED, AMODE, true) >= 0) {
+        if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, true), &q, sizeof(q), grid, lds, flops, stream)) return 0;
+      }
       hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false>), grid, dim3(SPG_THREADS), lds, stream, q);
       SPG_LAUNCH_CHECK();
       return 0;
     }
   }
   prof.r.tag = SPG_PROF_TAG(1, IT, JT, WRED ? 1 : 0, AMODE, 0);
+  if constexpr (IT == 32 && spg_gemm_variant(WRED, AMODE, false) >= 0) {
+    if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, false), &p, sizeof(p), grid, lds, flops, stream)) return 0;
+  }
   hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -1194,7 +1268,7 @@ int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts)
 // COLSUM: also the column sums of the `a` operand (bias gradient of a layer without BatchNorm); a compile-time switch so
 // that the main loop of every other instantiation (all wide BatchNorm layers) carries no predicate / accumulators for it
 template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE, bool FULL = false, int PREC = 0, bool COLSUM = false>
-__global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradParams p) {
+__device__ __forceinline__ void spg_wgrad_body(const SpgWgradParams& p, const int bx, const int by, const int bz) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   static_assert(WI * WJ == 4 && TI >= 1 && TJ >= 1, "4 waves per workgroup");
   extern __shared__ f32x4 smem[];
@@ -1203,13 +1277,13 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
-  const int split = blockIdx.x;
-  const int i0 = blockIdx.y * IT, j0 = blockIdx.z * JT;
+  const int split = bx;
+  const int i0 = by * IT, j0 = bz * JT;
   const long ms = (long)split * p.rows_per_split;
   const long me = min((long)p.M, ms + p.rows_per_split);
   // BatchNorm backward of the `a` operand's layer: its sums arrive as fixed-point slots and become the constants of the
   // BNBWD / POOLBWD prologue here (every workgroup; spg_gemm.h) -- readable behind the barrier at its end
-  if (p.fold.slots != nullptr) spg_bn_fold_bwd(p.fold);
+  if (p.fold.slots != nullptr) spg_bn_fold_bwd(p.fold, bx == 0 && by == 0 && bz == 0);
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -1223,7 +1297,7 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   // workgroups of the first column tile do it.  (Not available in the bf16 modes, whose tiles are not fp32.)
   static_assert(!COLSUM || PREC == 0, "column sums ride along with the fp32 tiles only");
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = COLSUM && blockIdx.z == 0 && tid < IT;
+  const bool do_colsum = COLSUM && bz == 0 && tid < IT;
   auto colsum_tile = [&](const float* __restrict__ At, int stride) __attribute__((always_inline)) {
     if constexpr (COLSUM) {
       if (do_colsum) {
@@ -1428,6 +1502,11 @@ __global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradPa
   }
 }
 
+template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE, bool FULL = false, int PREC = 0, bool COLSUM = false>
+__global__ __launch_bounds__(SPG_THREADS) void spg_wgrad_kernel(const SpgWgradParams p) {
+  spg_wgrad_body<IT, JT, WI, WJ, AMODE, BMODE, FULL, PREC, COLSUM>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 // out[i] = sum_k partial[k][i]: 64 elements x 16 split-groups per workgroup, fixed summation order (deterministic)
 __global__ __launch_bounds__(1024) void spg_reduce_partials_kernel(const float* __restrict__ partial, int nsplit, long n,
                                                                    float* __restrict__ out) {
@@ -1473,7 +1552,12 @@ template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE>
 static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t stream) {
   const size_t lds = (size_t)((AMODE >= 0 && BMODE >= 0) ? 2 : 1) * SPG_KC * (IT + 4 + JT + 4) * sizeof(float);
   dim3 grid(nsplit, spg_cdiv(p.N, IT), spg_cdiv(p.K, JT));
-  ProfScope prof(stream, 2.0 * (double)p.M * (double)p.N * (double)p.K);
+  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  // reductions over few rows (FC layers, filter net, recurrent cell) inside an open group become jobs of its one launch; the
+  // wide convolutions' weight gradients (performance-critical, own occupancy bounds) never do
+  const bool grouped = p.M <= SPG_GROUP_MAX_WGRAD_ROWS && spg_group_accepts(stream);
+  ProfScope prof(stream, flops, 0, !grouped);
+  auto try_group = [&](int variant) { return grouped && variant >= 0 && spg_group_add(SPG_JOB_WGRAD, variant, &p, sizeof(p), grid, lds, flops, stream); };
   if constexpr (AMODE >= 0 && BMODE >= 0 && AMODE != SPG_PRO_CLOUD && BMODE != SPG_PRO_CLOUD) {
     auto mode_ok = [](int mode, const SpgOperand& d, int nch) {
       if (mode == SPG_PRO_AFFINE) return d.c0 != nullptr && d.n_affine >= nch;
@@ -1490,11 +1574,13 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
       const int prec = ((IT == 128 || JT >= 64) && p.colsum == nullptr && p.allow_lowp) ? g_tune[SPG_TUNE_PRECISION] : 0;
       if constexpr (AMODE == SPG_PRO_IDENT) {
         if (p.colsum != nullptr) {
+          if (try_group(spg_wgrad_variant(IT, JT, AMODE, BMODE, true, true))) return 0;
           hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 0, true>), grid, dim3(SPG_THREADS), lds, stream, p);
           SPG_LAUNCH_CHECK();
           return 0;
         }
       }
+      if (prec == 0 && try_group(spg_wgrad_variant(IT, JT, AMODE, BMODE, true, false))) return 0;
       if (prec == 3) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 3>), grid, dim3(SPG_THREADS), lds, stream, p);
       else if (prec == 1) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 1>), grid, dim3(SPG_THREADS), lds, stream, p);
       else
@@ -1506,12 +1592,14 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
   prof.r.tag = SPG_PROF_TAG(2, IT, JT, AMODE, BMODE, 0);
   if constexpr (AMODE == SPG_PRO_IDENT || AMODE < 0) {
     if (p.colsum != nullptr) {
+      if (try_group(spg_wgrad_variant(IT, JT, AMODE, BMODE, false, true))) return 0;
       hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, false, 0, true>), grid, dim3(SPG_THREADS), lds, stream, p);
       SPG_LAUNCH_CHECK();
       return 0;
     }
   }
   SPG_CHECK_ARG(p.colsum == nullptr, "column sums ride along only with an identity `a` operand");
+  if (try_group(spg_wgrad_variant(IT, JT, AMODE, BMODE, false, false))) return 0;
   hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -2145,8 +2233,13 @@ int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, 
   const int slices = spg_cdiv(M, rps);
   float* part = out;
   if (slices > 1) SPG_TRY(queue_take(q, (size_t)slices * N, &part, stream));
-  hipLaunchKernelGGL(spg_colsum_kernel, dim3(spg_cdiv(N, 64), slices), dim3(1024), 0, stream, X, ld, M, N, rps, part);
-  SPG_LAUNCH_CHECK();
+  SpgSmallJob sj; memset(&sj, 0, sizeof(sj));
+  sj.src = X; sj.dst = part; sj.a = ld; sj.b = M; sj.c = rps; sj.i = N;
+  if (!(spg_group_accepts(stream) &&
+        spg_group_add(SPG_JOB_COLSUM, 0, &sj, sizeof(sj), dim3(spg_cdiv(N, 64), slices), 16 * 64 * sizeof(float), 0.0, stream))) {
+    hipLaunchKernelGGL(spg_colsum_kernel, dim3(spg_cdiv(N, 64), slices), dim3(1024), 0, stream, X, ld, M, N, rps, part);
+    SPG_LAUNCH_CHECK();
+  }
   if (slices > 1) {
     SpgReduceJob& j = q.jobs[q.njobs++];
     j.partial = part; j.out = out; j.nsplit = slices; j.n = N;
@@ -2181,6 +2274,9 @@ __global__ void spg_pad_rows_kernel(const float* __restrict__ src, long lds_, fl
 
 int spg_launch_pad_rows(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream) {
   const long n = rows * ldd;
+  SpgSmallJob sj; memset(&sj, 0, sizeof(sj));
+  sj.src = src; sj.dst = dst; sj.a = lds; sj.b = ldd; sj.c = rows; sj.i = cols;
+  if (spg_group_accepts(stream) && spg_group_add(SPG_JOB_PAD_ROWS, 0, &sj, sizeof(sj), dim3(spg_cdiv(n, 256)), 0, 0.0, stream)) return 0;
   hipLaunchKernelGGL(spg_pad_rows_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -2209,4 +2305,161 @@ int spg_launch_stn_dT(const float* clouds, int Ctot, int P, int G, const float* 
   hipLaunchKernelGGL(spg_stn_dT_kernel, dim3(spg_cdiv(G, 4)), dim3(256), 0, stream, clouds, Ctot, P, G, dxy, ldd, dT);
   SPG_LAUNCH_CHECK();
   return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// grouped launches: ONE kernel runs a list of mutually independent small jobs (spg_gemm.h: SpgGroupScope)
+// ---------------------------------------------------------------------------------------------
+// column sums with the summation order of spg_colsum_kernel (16 row groups per slice, combined in fixed order), 256 threads:
+// a thread carries the four row groups ty, ty + 4, ty + 8, ty + 12 in separate accumulators -- bit-identical results
+__device__ __forceinline__ void spg_colsum_body(const SpgSmallJob& j, const int bx, const int by, float* __restrict__ red) {
+  const int tx = threadIdx.x & 63, tq = threadIdx.x >> 6;
+  const int c = bx * 64 + tx;
+  const long m0 = (long)by * j.c, m1 = min(j.b, m0 + j.c);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < j.i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      for (long m = m0 + tq + 4 * u; m < m1; m += 16) s[u] += j.src[m * j.a + c];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) red[(tq + 4 * u) * 64 + tx] = s[u];
+  __syncthreads();
+  if (tq == 0 && c < j.i) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k * 64 + tx];
+    j.dst[(long)by * j.i + c] = t;
+  }
+}
+
+__global__ __launch_bounds__(SPG_THREADS, 2) void spg_multi_kernel(const SpgMultiArgs a_by_value) {
+  extern __shared__ f32x4 smem[];
+  // the job table is indexed dynamically: read it where it lies -- in the kernel-argument segment (constant address space,
+  // scalar loads) -- instead of through the by-value parameter, which the compiler would copy to scratch (3.9 KB per lane)
+  typedef __attribute__((address_space(4))) const SpgMultiArgs* spg_kernarg_ptr;
+  const SpgMultiArgs& a = *(const SpgMultiArgs*)(spg_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  int j = 0;
+  while (j + 1 < a.njobs && (int)blockIdx.x >= a.hdr[j + 1].first_block) ++j;      // wave-uniform scan (<= 7 entries)
+  j = __builtin_amdgcn_readfirstlane(j);
+  const SpgJobHdr h = a.hdr[j];
+  const int b = (int)blockIdx.x - h.first_block;
+  const int bx = b % h.gx, by = (b / h.gx) % h.gy, bz = b / (h.gx * h.gy);
+  const SpgJobParams& P = a.p[j];
+  if (h.kind == SPG_JOB_GEMM) {
+    switch (h.variant) {
+      case 0: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_IDENT, false>(P.g, bx, by); break;
+      case 1: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_IDENT, true>(P.g, bx, by); break;
+      case 2: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_AFFINE, false>(P.g, bx, by); break;
+      case 3: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_AFFINE, true>(P.g, bx, by); break;
+      case 4: spg_rowgemm_body<32, 128, 1, 4, false, -1, false>(P.g, bx, by); break;
+      case 5: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_IDENT, false>(P.g, bx, by); break;
+      case 6: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_IDENT, true>(P.g, bx, by); break;
+      case 7: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_BNBWD, false>(P.g, bx, by); break;
+      case 8: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_BNBWD, true>(P.g, bx, by); break;
+      case 9: spg_rowgemm_body<32, 128, 1, 4, true, -1, false>(P.g, bx, by); break;
+      default: break;
+    }
+  } else if (h.kind == SPG_JOB_WGRAD) {
+    switch (h.variant) {
+#define SPG_X(id, IT_, JT_, WI_, WJ_, AM_, BM_, FU_, CS_) \
+      case id: spg_wgrad_body<IT_, JT_, WI_, WJ_, AM_, BM_, FU_, 0, CS_>(P.w, bx, by, bz); break;
+      SPG_WGRAD_VARIANTS(SPG_X)
+#undef SPG_X
+      default: break;
+    }
+  } else if (h.kind == SPG_JOB_COLSUM) {
+    spg_colsum_body(P.s, bx, by, reinterpret_cast<float*>(smem));
+  } else if (h.kind == SPG_JOB_EDGE_WGRAD) {
+    spg_ecc_edge_wgrad_body(P.e, bx);
+  } else if (h.kind == SPG_JOB_PAD_ROWS) {
+    const long i = (long)bx * SPG_THREADS + threadIdx.x;
+    if (i < P.s.c * P.s.b) {
+      const long r = i / P.s.b;
+      const int c = (int)(i - r * P.s.b);
+      P.s.dst[i] = c < P.s.i ? P.s.src[r * P.s.a + c] : 0.f;
+    }
+  } else if (h.kind == SPG_JOB_ZERO) {
+    for (long i = (long)bx * 4 * SPG_THREADS + threadIdx.x; i < min(P.s.b, (long)(bx + 1) * 4 * SPG_THREADS); i += SPG_THREADS) P.s.dst[i] = 0.f;
+  }
+}
+
+namespace {
+struct SpgGroupState {
+  bool open = false;
+  hipStream_t st = nullptr;
+  int blocks = 0;
+  size_t lds = 0;
+  double flops = 0.0;
+  int rc = 0;                 // first launch error since the scope was opened
+  SpgMultiArgs a;
+};
+thread_local SpgGroupState g_grp;
+
+int group_flush() {
+  SpgGroupState& g = g_grp;
+  if (g.a.njobs == 0) return 0;
+  {
+    ProfScope prof(g.st, g.flops, SPG_PROF_TAG(3, 32, 32, 0, 0, 0));
+    hipLaunchKernelGGL(spg_multi_kernel, dim3((unsigned)g.blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
+  }
+  g.a.njobs = 0; g.blocks = 0; g.lds = 0; g.flops = 0.0;
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
+static bool spg_group_accepts(hipStream_t stream) { return g_grp.open && g_grp.st == stream && g_grp.rc == 0; }
+
+static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream) {
+  SpgGroupState& g = g_grp;
+  if (!spg_group_accepts(stream) || variant < 0 || bytes > sizeof(SpgJobParams)) return false;
+  const long nb = (long)grid.x * grid.y * grid.z;
+  if (nb <= 0 || nb > (1L << 24)) return false;
+  if (g.a.njobs == SPG_GROUP_MAX_JOBS || (long)g.blocks + nb > (1L << 30)) {
+    g.rc = group_flush();
+    if (g.rc != 0) return false;
+  }
+  SpgJobHdr& h = g.a.hdr[g.a.njobs];
+  h.kind = kind; h.variant = variant; h.first_block = g.blocks; h.gx = (int)grid.x; h.gy = (int)grid.y; h.gz = (int)grid.z; h.pad0 = h.pad1 = 0;
+  memcpy(&g.a.p[g.a.njobs], params, bytes);
+  ++g.a.njobs;
+  g.blocks += (int)nb;
+  if (lds > g.lds) g.lds = lds;
+  g.flops += flops;
+  return true;
+}
+
+bool spg_group_add_edge_wgrad(const SpgEdgeWgrad& p, hipStream_t stream) {
+  return spg_group_add(SPG_JOB_EDGE_WGRAD, 0, &p, sizeof(p), dim3(spg_cdiv(p.g.E, 4)), 0, 0.0, stream);
+}
+
+int spg_group_zero(float* p, size_t n, hipStream_t stream) {
+  if (p == nullptr || n == 0) return 0;
+  SpgSmallJob sj; memset(&sj, 0, sizeof(sj));
+  sj.dst = p; sj.b = (long)n;
+  if (spg_group_add(SPG_JOB_ZERO, 0, &sj, sizeof(sj), dim3(spg_cdiv((long)n, 4 * SPG_THREADS)), 0, 0.0, stream)) return 0;
+  hipError_t e = hipMemsetAsync(p, 0, n * sizeof(float), stream);
+  if (e != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+SpgGroupScope::SpgGroupScope(hipStream_t stream) : owner_(false) {
+  SpgGroupState& g = g_grp;
+  if (g.open || g_tune[SPG_TUNE_NO_GROUP]) return;      // nested scope / switched off: launches stay separate
+  g.open = true; g.st = stream; g.blocks = 0; g.lds = 0; g.flops = 0.0; g.rc = 0; g.a.njobs = 0;
+  owner_ = true;
+}
+int SpgGroupScope::flush() {
+  if (!owner_) return 0;
+  SpgGroupState& g = g_grp;
+  const int rc = g.rc != 0 ? g.rc : group_flush();
+  g.rc = 0;
+  return rc;
+}
+SpgGroupScope::~SpgGroupScope() {
+  if (!owner_) return;
+  (void)flush();
+  g_grp.open = false;
 }

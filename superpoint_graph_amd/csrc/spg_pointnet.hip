@@ -361,19 +361,26 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
   const int B = pl.B;
   SpgBnFoldBwd pending; memset(&pending, 0, sizeof(pending));     // set by a data-gradient launch, consumed by the next weight gradient
   // ---- fc head ----
+  // A layer's weight gradient and its data gradient depend on the same inputs and not on each other: both few-row launches
+  // leave as ONE grouped launch (spg_gemm.h) -- three launches per head instead of six.  The data gradient then finishes the
+  // BatchNorm-backward constants of its operand itself (fold_bwd), since the weight gradient is no longer ordered before it.
   float* fz[2] = {s.fzA, s.fzB};
   int flip = 0;
+  {
+  SpgGroupScope grp(st);
   for (int k = (int)sg.fcs.size() - 1; k >= 0; --k) {
     Layer& l = pl.L[sg.fcs[k]];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, true, k, clouds, stnT); w.M = B; w.N = l.cout; w.K = l.cin;
-    w.fold = pending; memset(&pending, 0, sizeof(pending));
+    w.fold = pending;
+    const SpgBnFoldBwd fold_k = pending;
+    memset(&pending, 0, sizeof(pending));
     // a bias without BatchNorm behind it: its gradient (column sums of `cur`, an IDENT operand here) rides along with the
     // weight gradient; a bias in front of train-mode BatchNorm has zero gradient
     const bool bias_rides = l.db != nullptr && !l.bn && cur.mode == SPG_PRO_IDENT;
     SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st, bias_rides ? l.db : nullptr));
     if (l.db && !bias_rides) {
-      if (l.bn) SPG_TRY(zero_async(l.db, l.cout, st));
+      if (l.bn) SPG_TRY(spg_group_zero(l.db, l.cout, st));
       else SPG_TRY(spg_queue_colsum(rq, cur.X, cur.ld, B, l.cout, l.db, st));
     }
     // data gradient -> producer of this layer's input
@@ -388,8 +395,10 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
     g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
     if (pl.fold) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; }
+    if (grp.active()) g.fold_bwd = fold_k;
     int nparts = 0;
     SPG_TRY(spg_launch_gemm(g, st, &nparts));
+    SPG_TRY(grp.flush());      // {weight gradient, bias column sums, data gradient} of this layer
     // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
     const int C = prod.cout;
     if (first && s.grad_global != nullptr && sg.nextra > 0)     // columns >= C pass through: gradient wrt the global features
@@ -407,6 +416,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       cur.c0 = s.consts; cur.c1 = s.consts + C; cur.c2 = s.consts + 2 * C; cur.c3 = s.consts + 3 * C;
     }
   }
+  }      // (the group scope ends with the head: the convolutions' launches are ordered, never grouped)
   // ---- conv stack ----
   float* dz[2] = {s.dzA, s.dzB};
   flip = 0;

@@ -120,16 +120,14 @@ class _LinearFunction(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         m = ctx.module
         gy = gy.contiguous()
-        gx = ops.linear_dgrad(gy, weight) if ctx.needs_input_grad[1] else None
+        need_dx = ctx.needs_input_grad[1]
         direct = getattr(m, '_spg_direct_grads', False) and weight.grad is not None and weight.grad.is_contiguous() and \
             (m.bias is None or (m.bias.grad is not None and m.bias.grad.is_contiguous()))
-        if direct:          # FlatParameters: write into the (zeroed) arena views, nothing for autograd to accumulate
+        if direct:          # FlatParameters: write into the arena views, nothing for autograd to accumulate
             from ..flat import mark_direct_write
             mark_direct_write(m)
-            if m.bias is not None:
-                ops.linear_wgrad_bias(gy, x, out_w=weight.grad, out_b=m.bias.grad)
-            else:
-                ops.linear_wgrad(gy, x, out=weight.grad)
+            gx, _, _ = ops.linear_backward(gy, x, weight, need_dx, m.bias is not None, out_w=weight.grad,
+                                           out_b=None if m.bias is None else m.bias.grad)
             return None, gx, None, None
         if getattr(m, '_spg_direct_grads', False):
             if any(p is not None and p.requires_grad and (p.grad is None or not p.grad.is_contiguous()) for p in (weight, m.bias)):
@@ -137,10 +135,7 @@ class _LinearFunction(torch.autograd.Function):
                                    '(optimizer.zero_grad(set_to_none=True)?); use FlatParameters.zero_grad()')
             from ..flat import prepare_autograd_fallback       # partly frozen layer: autograd accumulates what is returned
             prepare_autograd_fallback(m)
-        if m.bias is not None:
-            gw, gb = ops.linear_wgrad_bias(gy, x)
-        else:
-            gw, gb = ops.linear_wgrad(gy, x), None
+        gx, gw, gb = ops.linear_backward(gy, x, weight, need_dx, m.bias is not None)
         return None, gx, gw, gb
 
 

@@ -236,6 +236,21 @@ def linear_wgrad_bias(dy, x, out_w=None, out_b=None):
     return dw, db
 
 
+def linear_backward(dy, x, w, need_dx=True, has_bias=True, out_w=None, out_b=None):
+    """The whole backward of y = x w^T + b: (dx or None, dW, dbias or None) -- ONE grouped launch + one batched reduction
+    (spg_linear_backward) instead of three launches."""
+    _req(dy, torch.float32, 'dy'); _req(x, torch.float32, 'x'); _req(w, torch.float32, 'w')
+    M, N = dy.shape
+    K = x.shape[1]
+    dx = torch.empty(M, K, dtype=torch.float32, device=x.device) if need_dx else None
+    dw = torch.empty(N, K, dtype=torch.float32, device=x.device) if out_w is None else out_w
+    db = (torch.empty(N, dtype=torch.float32, device=x.device) if out_b is None else out_b) if has_bias else None
+    work = torch.empty(max(1, lib().spg_linear_wgrad_bias_work_floats(M, N, K)), dtype=torch.float32, device=x.device)
+    check(lib().spg_linear_backward(_ptr(dy), N, _ptr(x), K, _ptr(w), M, N, K, _ptr(dx), K, _ptr(dw), _ptr(db), _ptr(work), _stream()),
+          'spg_linear_backward')
+    return dx, dw, db
+
+
 # --------------------------------------------------------------------------------------------------
 # PointNet
 # --------------------------------------------------------------------------------------------------
