@@ -135,7 +135,8 @@ def gemm_traffic_live(args, log):
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             out = tempfile.mkdtemp(prefix=f'spg_pmc_{counter}_', dir='/tmp')
             cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'rocpd', '-d', out, '--', sys.executable, os.path.abspath(__file__),
-                   '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-forward-only', '--no-trainer-window', '--no-roofline',
+                   '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-forward-only', '--no-trainer-window', '--no-roofline', '--no-extras',
+                   '--fused-step', str(args.fused_step),
                    '--precision', args.precision, '--scenes', str(args.scenes), '--n-sp', str(args.n_sp), '--n-edges', str(args.n_edges),
                    '--n-feat', str(args.n_feat), '--model-config', args.model_config]
             env = dict(os.environ, TMPDIR='/tmp', SPG_BENCH_NO_LIVE_PMC='1')
@@ -148,7 +149,7 @@ def gemm_traffic_live(args, log):
         for d in dbs:
             shutil.rmtree(os.path.dirname(os.path.dirname(d)), ignore_errors=True)
         log(f'live PMC passes: {t["hbm_mb_per_launch"]:.1f} MB per GEMM launch, {t["all_kernels_hbm_mb_per_step"]:.0f} MB per step')
-        return t['hbm_mb_per_launch'] * 1e6, t['all_kernels_hbm_mb_per_step'] * 1e6, 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes of 6 steps of this script), FETCH_SIZE x2.000 / WRITE_SIZE x1.000 (gfx950 units, calibrated: profiles/r03_pmc_calib_*.txt)'
+        return t['hbm_mb_per_launch'] * 1e6, t['all_kernels_hbm_mb_per_step'] * 1e6, t.get('ecc'), 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes of 6 steps of this script), FETCH_SIZE x2.000 / WRITE_SIZE x1.000 (gfx950 units, calibrated: profiles/r03_pmc_calib_*.txt)'
     except Exception as e:      # a profiler problem must never take the bench line down
         log(f'live PMC passes failed ({type(e).__name__}: {e}); using the committed traffic file')
         return None
@@ -170,7 +171,7 @@ def gemm_traffic(args):
     return t['hbm_mb_per_launch'] * 1e6, os.path.relpath(files[-1], ROOT)
 
 
-def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, iters=40):
+def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, iters=40, fstep=None):
     """The reference's own "trainer time" window (learning/main.py:192-215): every step gets a FRESH batch -- the clouds
     come from pinned host memory (H2D on a side stream, overlapped with the previous step) and the batched graph is built
     anew on the GPU (GraphConvInfo.set_batch_device, as the CLI's collate does: ordering by target, edge-feature reordering,
@@ -203,6 +204,10 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
         for gi, flag, c, d, lab in SideStreamBatches(fresh_batches(n)):
             model.ecc.set_info([gi], 1)
             arena.zero_grad()
+            if fstep is not None:
+                fstep(flag, c, d, gi, lab)
+                arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)
+                continue
             emb = embedder.run(model, None, flag, c, d)
             loss = ops.cross_entropy(model.ecc(emb), lab)
             loss.backward(arena.one)
@@ -221,6 +226,35 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
             'what': 'fresh batch every step: pinned H2D of clouds/labels + GraphConvInfo.set_batch_device (edge list / features H2D, ordering by '
                     'target + CSR / reverse CSR as kernels), both on a side stream (SideStreamBatches, as the CLI does) + zero_grad..Adam '
                     '(learning/main.py:192-215)'}
+
+
+def other_workloads(args, log):
+    """Short runs (subprocesses of this script: fresh process, own spg_tune state) of the other BASELINE.json configurations
+    next to the headline: configs[2] = the reference's default --batch_size 2, configs[3] = 8 scenes per step, configs[4] =
+    Semantic3D scale (10 000 superpoints, 50 000 superedges, 11 point features, vector filters `gru_10,f_8`) in fp32 and with
+    the opt-in split-bf16 MFMA operands.  -> {name: {superpoints_per_s, ms_per_step, roofline fractions, ...}}"""
+    import subprocess
+    common = ['--steps', '12', '--warmup', '4', '--no-cpu-baseline', '--no-forward-only', '--no-trainer-window', '--no-live-pmc',
+              '--no-extras', '--fused-step', str(args.fused_step)]
+    sema = ['--n-sp', '10000', '--n-edges', '50000', '--n-feat', '11', '--model-config', 'gru_10,f_8']
+    runs = {'s3dis_2_scenes_per_step_f32': ['--scenes', '2'], 's3dis_8_scenes_per_step_f32': ['--scenes', '8'],
+            'semantic3d_scale_f32': sema, 'semantic3d_scale_bf16x3': sema + ['--precision', 'bf16x3']}
+    out = {}
+    for name, extra in runs.items():
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, capture_output=True, text=True, timeout=150)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+            d = json.loads(line)
+            rf = d.get('roofline', {})
+            out[name] = {'superpoints_per_s': d['value'], 'ms_per_step': d['ms_per_step'], 'dtype': d['dtype'].split(' ')[0],
+                         'workload': d['config']['workload'], 'roofline_bound': rf.get('bound'), 'roofline_frac': rf.get('frac'),
+                         'roofline_unit': rf.get('unit'), 'roofline_achieved': rf.get('achieved'), 'dominant_frac_of_fp32_mfma_peak': rf.get('dominant_frac'),
+                         'launches_per_step_gemm': rf.get('launches_per_step')}
+            log(f'{name}: {d["value"]:.0f} superpoints/s, {d["ms_per_step"]:.3f} ms/step, roofline {rf.get("bound")} {rf.get("frac")}')
+        except Exception as e:      # a side measurement must never take the headline down
+            out[name] = {'error': f'{type(e).__name__}: {e}'}
+            log(f'{name}: failed ({e})')
+    return out
 
 
 def forward_only(dev, flag, clouds_d, diam_d, GIs, n_feat, iters=40):
@@ -275,6 +309,8 @@ def main():
     ap.add_argument('--tune', default='', help='A/B switches of the library for experiments: comma-separated key:value pairs of spg_tune (include/spg_hip.h), e.g. 8:1 = per-iteration RNN-ECC launches, 9:1 = no side stream')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not run the two rocprofv3 PMC passes for roofline.traffic (use the committed file)')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
+    ap.add_argument('--fused-step', type=int, default=1, help='1 (default): forward + backward as ONE library call (superpoint_graph_amd/fused.py: spg_train_step; same kernels and results as the module path, tests/test_gpu_fused.py); 0: CloudEmbedder.run -> model.ecc -> cross_entropy -> backward -> bw_hook through the modules')
+    ap.add_argument('--no-extras', action='store_true', help='skip the short runs of the other BASELINE.json configurations (2 / 8 scenes per step, Semantic3D scale in f32 and split-bf16) and the sustained repeat')
     args = ap.parse_args()
 
     import faulthandler
@@ -331,9 +367,17 @@ def main():
 
     dp = world > 1 or bool(args.sync_bn)
     exchange = {}
+    from superpoint_graph_amd import fused as spg_fused
+    fstep = None
+    if args.fused_step and spg_fused.supports(model) and not args.sync_bn and not args.hipgraph:
+        fstep = spg_fused.FusedStep(model, arena, reduction='sum' if dp else 'mean', ptn_mem_monger=True)
 
     def fwd_bwd():
         arena.zero_grad()
+        if fstep is not None:      # the same step as ONE call into the library (include/spg_hip.h: spg_train_step)
+            fstep(flag, clouds_d, diam_d, GIs[0], label_mode)
+            exchange['w'] = fstep.normaliser
+            return
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
         out = model.ecc(emb)
         if dp:
@@ -416,7 +460,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'f32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 MFMA operands of the wide row-GEMMs, f32 accumulate and f32 everywhere else; NOT the headline arithmetic)', 'bf16': 'bf16 (MFMA operands of the wide row-GEMMs, f32 accumulate and f32 everywhere else; NOT the headline arithmetic)'}[args.precision], 'data': 'synthetic',
         'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x {args.n_feat} feats, '
                                f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config}' + (' (S3DIS production model, matrix filters, 10 GRU iterations)' if args.model_config == 'gru_10_0,f_13' else '') + ', train step fwd+bwd+Adam',
-                   'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'parallelism': (f'dp{world} (one scene shard per GPU, one flat-bucket RCCL all-reduce, ' + ('issued by libspg_hip' if native else 'torch.distributed') + ')') if world > 1 else 'single GPU',
+                   'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'step_call': 'spg_train_step (one library call: forward + backward)' if fstep is not None else 'module API (CloudEmbedder.run, model.ecc, cross_entropy, backward, bw_hook)', 'parallelism': (f'dp{world} (one scene shard per GPU, one flat-bucket RCCL all-reduce, ' + ('issued by libspg_hip' if native else 'torch.distributed') + ')') if world > 1 else 'single GPU',
                    'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics', 'precision': args.precision},
     }
 
@@ -449,7 +493,8 @@ def main():
         ach = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         live = gemm_traffic_live(args, log) if (world == 1 and not args.no_live_pmc) else None
         if live is not None:
-            traffic, traffic_all, traffic_src, traffic_note = live[0], live[1], 'live', live[2]
+            traffic, traffic_all, traffic_src, traffic_note = live[0], live[1], 'live', live[3]
+            live = (live[0], live[1], live[3], live[2])
         else:
             traffic, traffic_src = gemm_traffic(args)
             traffic_all = None
@@ -466,6 +511,25 @@ def main():
                               'launches_per_step': launches.value / nprof, 'gemm_ms_per_step': ms.value / nprof,
                               'algorithmic_gflop_per_step': gflop_step,
                               'step_achieved': gflop_step / ms_per_step, 'step_frac': gflop_step / ms_per_step / PEAK_FP32_MFMA_TFLOPS}
+        if traffic_all:
+            # the second roof of the step: HBM bytes of ALL kernels of a step / step time against 8 TB/s (6.29 TB/s achievable)
+            result['roofline'].update({'hbm_bytes_per_step': traffic_all, 'hbm_achieved_gbs': traffic_all / (ms_per_step * 1e-3) / 1e9,
+                                       'hbm_frac': traffic_all / (ms_per_step * 1e-3) / 8e12, 'hbm_peak_gbs': 8000.0})
+        if live is not None and len(live) > 3 and live[3]:
+            result['roofline']['ecc'] = live[3]      # the RNN-ECC kernels: duration, HBM bytes, what bounds them
+        if PREC != 0 and not traffic:
+            # no PMC pass for this workload: the algorithmic operand bytes of the instrumented GEMM launches (every operand and the
+            # output once, fp32 in memory) -- a LOWER bound of the traffic, hence of the achieved rate
+            alg = 0.0
+            for j in range(nshape):
+                n_, k_, cnt = keys[4 * j + 1], keys[4 * j + 2], keys[4 * j + 3]
+                if n_ > 0 and k_ > 0 and cnt > 0:
+                    m_ = vals[2 * j + 1] / (2.0 * n_ * k_ * cnt)
+                    alg += cnt * 4.0 * (m_ * k_ + n_ * k_ + m_ * n_)
+            if alg > 0:
+                traffic = alg / max(launches.value, 1)
+                result['roofline'].update({'traffic': traffic, 'traffic_source': 'algorithmic',
+                                           'traffic_unit': 'ALGORITHMIC bytes per GEMM launch (operands and output once, fp32 in memory): a lower bound of the HBM traffic'})
         if PREC != 0 and traffic:
             # the bf16 modes move the wide GEMMs under the HBM roof (activations stay fp32 in memory: same bytes, less matrix
             # time): report the GEMM launches against HBM -- static traffic of the same launches ÷ their measured time
@@ -486,8 +550,25 @@ def main():
                 'heaviest_shape_launches_per_step': tcnt / nprof, 'heaviest_shape_avg_us': tms / tcnt * 1e3,
                 'heaviest_shape_gflop_per_launch': tfl / tcnt / 1e9,
                 'heaviest_shape_frac': tfl / (tms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS})
+    if world == 1 and not args.no_extras:
+        # a sustained repeat of the very same step: >= 2 s of back-to-back steps (the timed region above is K steps = tens of ms)
+        torch.cuda.synchronize()
+        n_sus, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(100):
+                step()
+            n_sus += 100
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= 2.0:
+                break
+        sus = (time.perf_counter() - t0) / n_sus
+        result['sustained'] = {'seconds': time.perf_counter() - t0, 'steps': n_sus, 'ms_per_step': sus * 1e3, 'superpoints_per_s': n_sp_step / sus}
+        log(f'sustained: {n_sus} steps, {sus * 1e3:.3f} ms/step')
+        if 'roofline' in result:
+            result['roofline']['sustained_ms_per_step'] = sus * 1e3
+            result['roofline']['sustained_superpoints_per_s'] = n_sp_step / sus
     if world == 1 and not args.no_trainer_window:
-        result['trainer_window'] = trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log)
+        result['trainer_window'] = trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, fstep=fstep)
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -496,6 +577,11 @@ def main():
             result['forward_only'] = forward_only(dev, flag, clouds_d, diam_d, GIs, args.n_feat)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.model_config, scenes, state0, n_feat=args.n_feat)
+        if world == 1 and not args.no_extras:
+            ow = other_workloads(args, log)
+            result['other_workloads'] = ow
+            if 'roofline' in result:      # (the driver's parser keeps `roofline` / `config` / `cpu_baseline` and only the NAMES of other keys)
+                result['roofline']['other_workloads'] = ow
         print(json.dumps(result), flush=True)
     faulthandler.cancel_dump_traceback_later()
     if world > 1:

@@ -422,6 +422,65 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * jobs of ONE kernel; the bodies are unchanged, results bit-identical -- A/B timing and the equality test).
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
+/* ------------------------------------------------------------------------------------------------
+ * One training step's forward AND backward in ONE call (round 4): CloudEmbedder.run -> model.ecc (RNN-ECC module +
+ * classifier) -> weighted cross entropy -> backward -> bw_hook, i.e. learning/main.py:199-208 for the standard model
+ * (`gru_R.../lstm_R...` followed by `f_K`), with every gradient written to the caller's buffers (the flat gradient arena).
+ * Same kernels, same arithmetic and the same results as the module-level calls it replaces (spg_pointnet_forward_ext,
+ * spg_gather_rows, spg_eccrnn_forward, spg_linear_fwd, spg_cross_entropy_*, spg_linear_backward, spg_eccrnn_backward,
+ * spg_pointnet_backward_ext) -- what it adds is the ORDER of launches: inside one call the library knows the whole step, so
+ * the filter network's forward (needs only the superedge features) leaves next to PointNet's few-row launches and the tail of
+ * the RNN-ECC backward (cell and filter-network parameter gradients, needed by nobody before the optimiser) next to
+ * PointNet's backward, as jobs of the same grouped launches instead of ~12 latency-bound launches of their own; and the host
+ * enqueues a step with one ctypes call instead of ~15 autograd nodes.  The clamp + Adam update stays a separate call
+ * (spg_adam_clamp_step_scaled): the data-parallel all-reduce sits between the two.
+ * Buffers: everything is caller-allocated; workspace sizes from the *_workspace_bytes queries of the two networks. */
+typedef struct spg_step_args {
+  /* PointNet over the B embeddable superpoints (learning/pointnet.py:138-180) */
+  const spg_pointnet_cfg* ptn_cfg;
+  int B, bn_update_times;                 /* bn_update_times = 2 with ptn_mem_monger (the reference's forward + re-forward) */
+  const float* clouds;                    /* [B, nfeat, npts] */
+  const float* clouds_global;             /* [B, nfeat_global] */
+  const void* const* ptn_params;          /* 6 pointers per layer (spg_pointnet_forward) */
+  void* const* ptn_grads;                 /* 6 pointers per layer (spg_pointnet_backward) */
+  void* ptn_ws; void* ptn_bwd_ws;
+  float* emb;                             /* out [B, nf]: PointNet embeddings */
+  float* grad_emb;                        /* scratch [B, nf] */
+  /* scatter to all N superpoints: descriptors[i] = emb[slot_of_row[i]] (zero row where slot < 0, pointnet.py:177-179) */
+  int N, nf;
+  const int64_t* slot_of_row;             /* [N] */
+  const int64_t* idx_valid;               /* [B] rows of the valid superpoints */
+  float* desc;                            /* out [N, nf] */
+  float* grad_desc;                       /* scratch [N, nf] */
+  /* RNN-ECC module (learning/modules.py:152-183) */
+  const spg_eccrnn_cfg* ecc_cfg;
+  int E;
+  const void* graph_ws;
+  const float* edgefeats;                 /* [E, fnet_widths[0]] in the batch's edge order */
+  const void* const* ecc_params;
+  void* const* ecc_grads;
+  void* ecc_ws; void* ecc_bwd_ws;
+  float* ecc_out;                         /* out [N, nout] (nout = 32 or 32 * (R + 1) with cat_all) */
+  float* grad_ecc_out;                    /* scratch [N, nout] */
+  /* classifier Linear(nout -> n_classes) (learning/graphnet.py:47-49) */
+  int nout, n_classes;
+  const float* cls_W; const float* cls_b; /* [n_classes, nout], [n_classes] or null */
+  float* cls_dW; float* cls_db;
+  float* cls_work;                        /* >= spg_linear_wgrad_bias_work_floats(N, n_classes, nout) floats */
+  float* logits;                          /* out [N, n_classes] */
+  float* grad_logits;                     /* scratch [N, n_classes] */
+  /* weighted cross entropy (learning/main.py:205) */
+  const int64_t* target;                  /* [N] class index or ignore_index */
+  const float* class_weight;              /* [n_classes] or null */
+  int64_t ignore_index;
+  int reduction_mean;                     /* 1: mean over the labelled rows (single process); 0: sum (data parallel) */
+  float* loss_buf;                        /* out [N + 2]: log-sum-exp per row | loss | sum of the labelled rows' class weights */
+} spg_step_args;
+int spg_train_step(const spg_step_args* args, void* stream);
+/* loss, log-sum-exp, normaliser AND the gradient wrt the logits (for d loss = 1) in one single-workgroup launch */
+int spg_cross_entropy_fwd_bwd(const float* logits, const int64_t* target, const float* weight, int N, int C, int64_t ignore_index,
+                              int reduction_mean, float* loss, float* lse, float* wsum, float* grad_logits, void* stream);
+
 /* Number of bounded-spin time-outs the persistent RNN-ECC launches of the current device have raised so far (0 in a correct
  * run; a wave that waits too long for a neighbour's state gives up instead of hanging the GPU).  Synchronises the device. */
 int spg_ecc_persistent_errors(void);

@@ -45,6 +45,23 @@ class EdgeFeatureSpec(ctypes.Structure):
                 ('is_f64', ctypes.c_int), ('pad_', ctypes.c_int)]
 
 
+class StepArgs(ctypes.Structure):
+    """spg_step_args of include/spg_hip.h (spg_train_step)."""
+    _fields_ = [('ptn_cfg', ctypes.POINTER(PointNetCfg)), ('B', ctypes.c_int), ('bn_update_times', ctypes.c_int),
+                ('clouds', ctypes.c_void_p), ('clouds_global', ctypes.c_void_p), ('ptn_params', c_void_pp), ('ptn_grads', c_void_pp),
+                ('ptn_ws', ctypes.c_void_p), ('ptn_bwd_ws', ctypes.c_void_p), ('emb', ctypes.c_void_p), ('grad_emb', ctypes.c_void_p),
+                ('N', ctypes.c_int), ('nf', ctypes.c_int), ('slot_of_row', ctypes.c_void_p), ('idx_valid', ctypes.c_void_p),
+                ('desc', ctypes.c_void_p), ('grad_desc', ctypes.c_void_p),
+                ('ecc_cfg', ctypes.POINTER(EccRnnCfg)), ('E', ctypes.c_int), ('graph_ws', ctypes.c_void_p), ('edgefeats', ctypes.c_void_p),
+                ('ecc_params', c_void_pp), ('ecc_grads', c_void_pp), ('ecc_ws', ctypes.c_void_p), ('ecc_bwd_ws', ctypes.c_void_p),
+                ('ecc_out', ctypes.c_void_p), ('grad_ecc_out', ctypes.c_void_p),
+                ('nout', ctypes.c_int), ('n_classes', ctypes.c_int), ('cls_W', ctypes.c_void_p), ('cls_b', ctypes.c_void_p),
+                ('cls_dW', ctypes.c_void_p), ('cls_db', ctypes.c_void_p), ('cls_work', ctypes.c_void_p), ('logits', ctypes.c_void_p),
+                ('grad_logits', ctypes.c_void_p),
+                ('target', ctypes.c_void_p), ('class_weight', ctypes.c_void_p), ('ignore_index', ctypes.c_int64),
+                ('reduction_mean', ctypes.c_int), ('loss_buf', ctypes.c_void_p)]
+
+
 class EdgeFeatureSpecs(ctypes.Structure):
     _fields_ = [('ncols', ctypes.c_int), ('pad_', ctypes.c_int), ('col', EdgeFeatureSpec * SPG_EF_MAX_COLS)]
 
@@ -112,6 +129,8 @@ SIGNATURES = {
     'spg_loader_random': (_i, [_p, _p, _p, _i, _i, _i, ctypes.c_uint64, ctypes.c_uint32, _i, ctypes.c_float, _i, ctypes.c_float, _i, _p, _p, _p, _p]),
     'spg_cross_entropy_fwd': (_i, [_p, _p, _p, _i, _i, ctypes.c_int64, _i, _p, _p, _p, _p]),
     'spg_cross_entropy_bwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, ctypes.c_int64, _i, _p, _p]),
+    'spg_cross_entropy_fwd_bwd': (_i, [_p, _p, _p, _i, _i, ctypes.c_int64, _i, _p, _p, _p, _p, _p]),
+    'spg_train_step': (_i, [ctypes.POINTER(StepArgs), _p]),
     'spg_eval_accumulate': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
     'spg_set_bn_allreduce': (_i, [_p, _p, _p, _l]),
     'spg_rccl_unique_id': (_i, [_p]),

@@ -513,10 +513,9 @@ extern "C" int spg_linear_wgrad_bias(const float* dY, long lddy, const float* X,
 // the whole backward of a dense layer Y = X W^T + b: data gradient, weight gradient and bias gradient are mutually
 // independent -- ONE grouped launch (spg_gemm.h) + the batched reduction of the split partials, instead of three launches.
 // dX may be null (the input needs no gradient); dbias may be null.  work: >= spg_linear_wgrad_bias_work_floats floats.
-extern "C" int spg_linear_backward(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K,
-                                   float* dX, long lddx, float* dW, float* dbias, float* work, void* stream) {
+static int linear_backward_impl(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K, float* dX,
+                                long lddx, float* dW, float* dbias, float* work, hipStream_t st, bool defer) {
   SPG_CHECK_ARG(dY && X && W && dW && work, "null pointer");
-  hipStream_t st = (hipStream_t)stream;
   SpgReduceQueue rq;
   rq.arena = work; rq.arena_floats = spg_linear_wgrad_bias_work_floats(M, N, K);
   {
@@ -526,10 +525,25 @@ extern "C" int spg_linear_backward(const float* dY, long lddy, const float* X, l
     w.b = affine_operand(X, ldx, K, nullptr, nullptr, 0);
     w.M = M; w.N = N; w.K = K;
     SPG_TRY(spg_queue_wgrad(rq, w, dW, st, dbias));
-    if (dX != nullptr) SPG_TRY(spg_linear_dgrad(dY, lddy, M, N, W, K, dX, lddx, stream));
+    if (dX != nullptr) SPG_TRY(spg_linear_dgrad(dY, lddy, M, N, W, K, dX, lddx, (void*)st));
     SPG_TRY(grp.flush());
   }
+  if (defer) {      // the split partials are summed by the caller's next batched reduction (spg_gemm.h: spg_reduce_defer)
+    for (int j = 0; j < rq.njobs; ++j) spg_reduce_defer(rq.jobs[j]);
+    return 0;
+  }
   return spg_flush_reduce(rq, st);
+}
+
+extern "C" int spg_linear_backward(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K,
+                                   float* dX, long lddx, float* dW, float* dbias, float* work, void* stream) {
+  return linear_backward_impl(dY, lddy, X, ldx, W, M, N, K, dX, lddx, dW, dbias, work, (hipStream_t)stream, false);
+}
+
+// inside spg_train_step: the reduction of the partials waits for the step's final batched reduction
+int spg_linear_backward_deferred(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K, float* dX,
+                                 long lddx, float* dW, float* dbias, float* work, hipStream_t st) {
+  return linear_backward_impl(dY, lddy, X, ldx, W, M, N, K, dX, lddx, dW, dbias, work, st, true);
 }
 
 // ---------------------------------------------------------------------------------------------

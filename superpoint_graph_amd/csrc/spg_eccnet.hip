@@ -9,6 +9,7 @@
 #include "../../include/spg_hip.h"
 #include "spg_ecc.h"
 #include "spg_gemm.h"
+#include <memory>
 #include <vector>
 
 namespace {
@@ -20,6 +21,7 @@ struct FLayer {
   float *rm = nullptr, *rv = nullptr;
   float* y = nullptr;
   float *mean = nullptr, *rstd = nullptr, *s = nullptr, *t = nullptr;
+  unsigned long long *slots = nullptr, *slots_bwd = nullptr;   // train mode: fixed-point statistics slots (SpgBnFold, spg_gemm.h)
   float *dW = nullptr, *db = nullptr, *dgamma = nullptr, *dbeta = nullptr;
 };
 
@@ -44,6 +46,7 @@ struct Plan {
   bool lstm = false;
   bool training = false;
   std::vector<FLayer> F;
+  bool fold = false;            // train mode: the BatchNorm statistics travel as fixed-point slots from producer to consumer GEMM
   SpgGruParams gru;
   float *states = nullptr, *agg = nullptr, *stat = nullptr, *stat_cnt = nullptr;
   float* cells = nullptr;       // LSTM cell states c^r, laid out like `states`
@@ -85,6 +88,10 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
     if (l.bn) {
       l.mean = cv.take<float>(l.cout); l.rstd = cv.take<float>(l.cout);
       l.s = cv.take<float>(l.cout); l.t = cv.take<float>(l.cout);
+      if (pl.training) {
+        l.slots = cv.take<unsigned long long>(spg_fold_slot_words(l.cout));
+        l.slots_bwd = cv.take<unsigned long long>(spg_fold_slot_words(l.cout));
+      }
     }
   }
   memset(&pl.gru, 0, sizeof(pl.gru));
@@ -194,38 +201,60 @@ extern "C" size_t spg_eccrnn_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, i
   return pl.bytes;
 }
 
-extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0,
-                                  const float* edgefeats, const void* const* params, float* out, void* workspace,
-                                  int training, int bn_update_times, void* stream) {
-  SPG_CHECK_ARG(graph_ws && h0 && params && out && workspace, "null pointer");
-  SPG_CHECK_ARG(E == 0 || edgefeats != nullptr, "edgefeats");
-  hipStream_t st = (hipStream_t)stream;
-  Plan pl;
-  SPG_TRY(make_plan(cfg, N, E, training, workspace, params, pl));
-  if (E == 0 && pl.training && spg_sync_bn_active())
-    for (const FLayer& l : pl.F)      // the other ranks enter the layer's all-reduce: skipping it here would hang the job
-      SPG_CHECK_ARG(!l.bn, "synchronised BatchNorm: a rank with an edge-less batch cannot take part in the filter-network statistics");
-  // ---- filter-generating network (once per forward, shared by all iterations) ----
-  if (E > 0) {
-    for (int i = 0; i < (int)pl.F.size(); ++i) {
-      FLayer& l = pl.F[i];
+// train-mode BatchNorm of the filter network without finalize launches, like PointNet's (spg_gemm.h: SpgBnFold): not with
+// synchronised BatchNorm (the ranks' all-reduce sits between producer and consumer), not beyond the slots' capacity
+static bool fnet_fold(const Plan& pl) {
+  return pl.training && !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && (long)spg_cdiv(pl.E > 0 ? pl.E : 1, SPG_FC_ROWS) <= SPG_FOLD_MAX_CONTRIBUTIONS;
+}
+
+// ---- filter-generating network (once per forward, shared by all iterations): one stage per layer; each stage issues its
+//      launches into the group that is open when it runs (spg_gemm.h) ----
+static void fnet_forward_stages(const Plan& pl0, const float* edgefeats, int bn_update_times, std::vector<SpgStage>& out) {
+  auto plan = std::make_shared<Plan>(pl0);
+  for (int i = 0; i < (int)plan->F.size(); ++i) {
+    out.push_back([plan, i, edgefeats, bn_update_times](hipStream_t st) -> int {
+      const Plan& pl = *plan;
+      const FLayer& l = pl.F[i];
+      if (i == 0 && pl.fold)                 // the statistics slots of both directions: cleared launches before their first use
+        for (const FLayer& f : pl.F)
+          if (f.bn) {
+            SPG_TRY(spg_group_zero(reinterpret_cast<float*>(f.slots), 2 * spg_fold_slot_words(f.cout), st));
+            SPG_TRY(spg_group_zero(reinterpret_cast<float*>(f.slots_bwd), 2 * spg_fold_slot_words(f.cout), st));
+          }
       SpgGemmParams g; memset(&g, 0, sizeof(g));
       g.a = fnet_input(pl, i, edgefeats);
-      g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = E; g.N = l.cout; g.K = l.cin; g.rows_per_tile = SPG_FC_ROWS;
+      g.W = l.W; g.ldw = l.cin; g.bias = l.b; g.M = pl.E; g.N = l.cout; g.K = l.cin; g.rows_per_tile = SPG_FC_ROWS;
       g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.cout;
       g.stat = (l.bn && pl.training) ? pl.stat : nullptr; g.stat_cnt = pl.stat_cnt;
+      if (l.bn && pl.fold) { g.stat = nullptr; g.stat_slots = l.slots; }
+      if (i > 0 && pl.F[i - 1].bn && pl.fold) {      // the producer's statistics are finished in this launch's prologue
+        const FLayer& p = pl.F[i - 1];
+        SpgBnFold f; memset(&f, 0, sizeof(f));
+        f.slots = p.slots; f.C = p.cout; f.update_times = bn_update_times; f.momentum = pl.cfg.bn_momentum; f.eps = pl.cfg.bn_eps;
+        f.count = (double)pl.E; f.gamma = p.gamma; f.beta = p.beta; f.rm = p.rm; f.rv = p.rv;
+        f.mean = p.mean; f.rstd = p.rstd; f.s = p.s; f.t = p.t;
+        g.fold = f;
+      }
       int nparts = 0;
-      SPG_TRY(spg_launch_gemm(g, st, &nparts));
-      if (l.bn) {
+      {
+        // a finalize launch behind the GEMM (synchronised BatchNorm / fold switched off): the GEMM must not wait in a group
+        SpgGroupBypass direct(l.bn && !pl.fold && pl.training);
+        SPG_TRY(spg_launch_gemm(g, st, &nparts));
+      }
+      if (l.bn && !pl.fold) {
         if (pl.training)
-          SPG_TRY(spg_launch_bn_finalize(pl.stat, pl.stat_cnt, nparts, E, l.cout, l.gamma, l.beta, l.rm, l.rv,
+          SPG_TRY(spg_launch_bn_finalize(pl.stat, pl.stat_cnt, nparts, pl.E, l.cout, l.gamma, l.beta, l.rm, l.rv,
                                          pl.cfg.bn_momentum, pl.cfg.bn_eps, bn_update_times, l.mean, l.rstd, l.s, l.t, nullptr, st));
         else
           SPG_TRY(spg_launch_bn_eval(l.cout, l.gamma, l.beta, l.rm, l.rv, pl.cfg.bn_eps, l.s, l.t, st));
       }
-    }
+      return 0;
+    });
   }
-  // ---- recurrent part ----
+}
+
+static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float* h0, float* out, hipStream_t st) {
+  const int N = pl.N, E = pl.E;
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
   if (!pl.lstm) {      // GRU, <= 1024 nodes: all iterations in one dataflow-synchronised launch (spg_ecc.hip)
     SpgEccPersistFwd q; memset(&q, 0, sizeof(q));
@@ -252,6 +281,43 @@ extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const
   return 0;
 }
 
+// phase 0: the whole forward; phase 1: register the filter network's layers as riders (spg_gemm.h) and return -- they leave with
+// the caller's next grouped launches; phase 2: the recurrent part only (the caller has drained the riders)
+int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0, const float* edgefeats,
+                             const void* const* params, float* out, void* workspace, int training, int bn_update_times, void* stream,
+                             int phase) {
+  SPG_CHECK_ARG(graph_ws && params && workspace && (phase == 1 || (h0 && out)), "null pointer");
+  SPG_CHECK_ARG(E == 0 || edgefeats != nullptr, "edgefeats");
+  hipStream_t st = (hipStream_t)stream;
+  Plan pl;
+  SPG_TRY(make_plan(cfg, N, E, training, workspace, params, pl));
+  pl.fold = fnet_fold(pl);
+  if (E == 0 && pl.training && spg_sync_bn_active())
+    for (const FLayer& l : pl.F)      // the other ranks enter the layer's all-reduce: skipping it here would hang the job
+      SPG_CHECK_ARG(!l.bn, "synchronised BatchNorm: a rank with an edge-less batch cannot take part in the filter-network statistics");
+  if (phase != 2 && E > 0) {
+    std::vector<SpgStage> stages;
+    fnet_forward_stages(pl, edgefeats, bn_update_times, stages);
+    if (phase == 1) {
+      for (SpgStage& s : stages) spg_riders_push(std::move(s));
+      return 0;
+    }
+    for (SpgStage& s : stages) {      // on their own: every layer is a launch (a group of one, + the slot clearing)
+      SpgGroupScope grp(st);
+      SPG_TRY(s(st));
+      SPG_TRY(grp.flush());
+    }
+  }
+  if (phase == 1) return 0;
+  return eccrnn_recurrent_forward(pl, graph_ws, h0, out, st);
+}
+
+extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0,
+                                  const float* edgefeats, const void* const* params, float* out, void* workspace,
+                                  int training, int bn_update_times, void* stream) {
+  return spg_eccrnn_forward_phase(cfg, N, E, graph_ws, h0, edgefeats, params, out, workspace, training, bn_update_times, stream, 0);
+}
+
 extern "C" long spg_eccrnn_debug_offset(const spg_eccrnn_cfg* cfg, int N, int E, int training, int layer, int what) {
   Plan pl;
   char* fake = (char*)(uintptr_t)4096;
@@ -269,23 +335,148 @@ extern "C" size_t spg_eccrnn_bwd_workspace_bytes(const spg_eccrnn_cfg* cfg, int 
   return s.bytes;
 }
 
-extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
-                                   const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
-                                   void* workspace, void* bwd_workspace, void* stream) {
+// everything the backward's stages share (they may run after spg_eccrnn_backward_phase has returned: as riders)
+namespace {
+struct BwdCtx {
+  Plan pl;
+  BwdScratch s;
+  SpgReduceQueue rq, rq2;
+  SpgGraph gr;
+  const float* edgefeats = nullptr;
+  SpgOperand cur;
+  int flip = 0;
+  SpgBnFoldBwd pending;       // set by a data-gradient stage, finished by the next layer's launches (fold path)
+};
+
+// the tail of the backward: {cell parameter gradients + per-edge filter gradient}, then one stage per filter-network layer
+// ({weight gradient, bias column sums, data gradient}: mutually independent), then the hand-over of the split partials
+void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage>& out) {
+  out.push_back([c](hipStream_t st) -> int {
+    Plan& pl = c->pl; BwdScratch& s = c->s;
+    const int R = pl.R, GW = pl.GW, rows = pl.N * (R + 1);
+    const long ldS = pl.ldS;
+    SpgWgradParams w; memset(&w, 0, sizeof(w));
+    w.a = op_ident(s.dgi, GW); w.b = op_ident(s.xg, 32); w.M = rows; w.N = GW; w.K = 32;
+    SPG_TRY(spg_queue_wgrad(c->rq2, w, pl.cell_grads[0], st));
+    w.a = op_ident(s.dgh, GW); w.b = op_ident(pl.states, 32);
+    SPG_TRY(spg_queue_wgrad(c->rq2, w, pl.cell_grads[1], st));
+    // GRU: the biases are added behind the row normalisation; LSTM: in front of it
+    SPG_TRY(spg_queue_colsum(c->rq2, pl.lstm ? s.dgi : s.dui, GW, rows, GW, pl.cell_grads[2], st));
+    SPG_TRY(spg_queue_colsum(c->rq2, pl.lstm ? s.dgh : s.duh, GW, rows, GW, pl.cell_grads[3], st));
+    if (pl.cfg.ingate) {
+      w.a = op_ident(s.dpre, 32); w.b = op_ident(pl.states, 32); w.N = 32;
+      // the input gate's bias gradient = column sums of dpre: as their own small job, not riding along with the weight
+      // gradient -- the body that carries them needs more than 128 registers and would push the whole group (2700 small
+      // workgroups) to the 2-workgroups-per-CU build of the grouped kernel (spg_gemm.hip)
+      SPG_TRY(spg_queue_wgrad(c->rq2, w, pl.cell_grads[4], st));
+      SPG_TRY(spg_queue_colsum(c->rq2, s.dpre, 32, rows, 32, pl.cell_grads[5], st));
+    }
+    if (pl.E == 0) {   // no edges: the filter network received no gradient
+      for (FLayer& l : pl.F) {
+        SPG_TRY(spg_group_zero(l.dW, (size_t)l.cin * l.cout, st));
+        SPG_TRY(spg_group_zero(l.db, (size_t)l.cout, st));
+        SPG_TRY(spg_group_zero(l.dgamma, (size_t)l.cout, st));
+        SPG_TRY(spg_group_zero(l.dbeta, (size_t)l.cout, st));
+      }
+      return 0;
+    }
+    // per-edge filter gradients (sum over the iterations)
+    SPG_TRY(spg_launch_ecc_edge_wgrad(c->gr, pl.cfg.matrix, pl.states, ldS, s.G, ldS, R, s.dWts, st));
+    c->cur = op_ident(s.dWts, pl.nout);
+    return 0;
+  });
+  for (int i = (int)c->pl.F.size() - 1; i >= 0 && c->pl.E > 0; --i) {
+    out.push_back([c, i](hipStream_t st) -> int {
+      Plan& pl = c->pl; BwdScratch& s = c->s;
+      const int E = pl.E;
+      FLayer& l = pl.F[i];
+      const SpgOperand cur = c->cur;
+      const SpgBnFoldBwd fold_i = c->pending;
+      memset(&c->pending, 0, sizeof(c->pending));
+      SpgWgradParams w; memset(&w, 0, sizeof(w));
+      w.a = cur; w.b = fnet_input(pl, i, c->edgefeats); w.M = E; w.N = l.cout; w.K = l.cin;
+      w.fold = fold_i;
+      const bool bias_rides = l.db != nullptr && !l.bn && cur.mode == SPG_PRO_IDENT;      // bias gradient = column sums of `cur`
+      SPG_TRY(spg_queue_wgrad(c->rq, w, l.dW, st, bias_rides ? l.db : nullptr));
+      if (l.db && !bias_rides) {
+        if (l.bn) SPG_TRY(spg_group_zero(l.db, (size_t)l.cout, st));
+        else SPG_TRY(spg_queue_colsum(c->rq, cur.X, cur.ld, E, l.cout, l.db, st));
+      }
+      if (i == 0) return 0;
+      FLayer& prod = pl.F[i - 1];
+      float* dzb[2] = {s.dzA, s.dzB};
+      float* out = dzb[c->flip]; c->flip ^= 1;
+      SpgGemmParams g; memset(&g, 0, sizeof(g));
+      g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;
+      g.M = E; g.N = l.cin; g.K = l.cout; g.rows_per_tile = SPG_FC_ROWS;
+      g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.cout;
+      g.mask_relu = prod.relu ? 1 : 0; g.n_mask = prod.cout;
+      g.fold_bwd = fold_i;      // (the weight gradient of this layer may run in the same grouped launch: both finish the constants)
+      const bool fin = prod.bn && !pl.fold;      // finalize launch behind the data gradient: it must not wait in a group
+      if (prod.bn) {
+        g.ms = prod.s; g.mt = prod.t; g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
+        if (pl.fold) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; }
+      }
+      int nparts = 0;
+      {
+        SpgGroupBypass direct(fin);
+        SPG_TRY(spg_launch_gemm(g, st, &nparts));
+      }
+      if (prod.bn) {
+        if (fin) {
+          SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
+                                             s.consts, prod.dgamma, prod.dbeta, nullptr, st));
+        } else {
+          SpgBnFoldBwd f; memset(&f, 0, sizeof(f));
+          f.slots = prod.slots_bwd; f.C = prod.cout; f.count = (double)E; f.s = prod.s; f.mean = prod.mean; f.rstd = prod.rstd;
+          f.consts = s.consts; f.dgamma = prod.dgamma; f.dbeta = prod.dbeta;
+          c->pending = f;
+        }
+        c->cur = op_bnbwd(out, prod.y, prod.cout, s.consts, prod.cout);
+      } else {
+        c->cur = op_ident(out, l.cin);
+      }
+      return 0;
+    });
+  }
+  // the split partials of all weight / bias gradients: handed to the NEXT batched reduction of this thread (spg_gemm.h:
+  // spg_reduce_defer) -- PointNet's, when this chain rides next to its backward -- or summed by the caller's own flush
+  out.push_back([c](hipStream_t st) -> int {
+    for (int j = 0; j < c->rq2.njobs; ++j) spg_reduce_defer(c->rq2.jobs[j]);
+    for (int j = 0; j < c->rq.njobs; ++j) spg_reduce_defer(c->rq.jobs[j]);
+    c->rq.njobs = 0; c->rq2.njobs = 0;
+    return 0;
+  });
+}
+}  // namespace
+
+// phase 0: the whole backward; phase 1: back-propagation through the recurrence (-> grad_h0), the tail (cell and filter-network
+// parameter gradients) is registered as riders (spg_gemm.h): the caller lets them travel next to its next launches and MUST
+// call spg_riders_drain + spg_flush_deferred_reduce before the gradients are consumed or the workspaces released
+int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
+                              const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
+                              void* workspace, void* bwd_workspace, void* stream, int phase) {
   SPG_CHECK_ARG(graph_ws && params && grad_out && grad_h0 && grads && workspace && bwd_workspace, "null pointer");
   hipStream_t st = (hipStream_t)stream;
-  Plan pl;
+  if (phase == 0) spg_reduce_deferred_clear();      // (nothing may be left over from a call that failed half-way)
+  auto c = std::make_shared<BwdCtx>();
+  Plan& pl = c->pl;
   SPG_TRY(make_plan(cfg, N, E, 1, workspace, params, pl));
+  pl.fold = fnet_fold(pl);
   for (int i = 0; i < (int)pl.F.size(); ++i) {
     void* const* g = grads + 6 * i;
     pl.F[i].dW = (float*)g[0]; pl.F[i].db = (float*)g[1]; pl.F[i].dgamma = (float*)g[2]; pl.F[i].dbeta = (float*)g[3];
   }
   for (int k = 0; k < 6; ++k) pl.cell_grads[k] = (float*)grads[6 * pl.F.size() + k];
-  BwdScratch s;
+  BwdScratch& s = c->s;
   carve_bwd(pl, bwd_workspace, s);
-  SpgReduceQueue rq;
-  rq.arena = s.work; rq.arena_floats = s.work_floats;
-  SpgGraph gr = spg_graph_view(graph_ws, N, E);
+  c->rq.arena = s.work; c->rq.arena_floats = s.work_floats;
+  c->rq2.arena = s.work2; c->rq2.arena_floats = s.work2_floats;
+  c->gr = spg_graph_view(graph_ws, N, E);
+  c->edgefeats = edgefeats;
+  memset(&c->cur, 0, sizeof(c->cur));
+  memset(&c->pending, 0, sizeof(c->pending));
+  SpgGraph& gr = c->gr;
   const int R = pl.R;
   const int GW = pl.GW;
   const long ldS = pl.ldS, ld96 = (long)(R + 1) * GW;
@@ -329,88 +520,23 @@ extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, cons
     p.gru = pl.gru; p.cell = pl.cfg.cell;
     SPG_TRY(spg_launch_ecc_step_bwd(p, st));
   }
-  // ---- GRU parameter gradients: three weight-gradient GEMMs over all (node, iteration) rows.  They depend on nothing but the
-  //      recurrence's outputs and nothing below depends on them: with spg_tune key 9 they run on the library's side stream, next
-  //      to the filter network's backward chain (an experiment: measured 50 us per step slower than one stream, spg_common.h) ----
-  const int rows = N * (R + 1);
-  SpgReduceQueue rq2;
-  rq2.arena = s.work2; rq2.arena_floats = s.work2_floats;
-  hipStream_t side = E > 0 ? spg_side_fork(st) : nullptr;
-  // Everything up to the per-edge filter gradient depends on the recurrence's outputs only: the cell's three weight gradients,
-  // its bias column sums and the per-edge filter gradient leave as ONE grouped launch (spg_gemm.h) instead of six
-  SpgGroupScope grp(st);
-  {
-    hipStream_t sg = side != nullptr ? side : st;
-    SpgWgradParams w; memset(&w, 0, sizeof(w));
-    w.a = op_ident(s.dgi, GW); w.b = op_ident(s.xg, 32); w.M = rows; w.N = GW; w.K = 32;
-    SPG_TRY(spg_queue_wgrad(rq2, w, pl.cell_grads[0], sg));
-    w.a = op_ident(s.dgh, GW); w.b = op_ident(pl.states, 32);
-    SPG_TRY(spg_queue_wgrad(rq2, w, pl.cell_grads[1], sg));
-    // GRU: the biases are added behind the row normalisation; LSTM: in front of it
-    SPG_TRY(spg_queue_colsum(rq2, pl.lstm ? s.dgi : s.dui, GW, rows, GW, pl.cell_grads[2], sg));
-    SPG_TRY(spg_queue_colsum(rq2, pl.lstm ? s.dgh : s.duh, GW, rows, GW, pl.cell_grads[3], sg));
-    if (pl.cfg.ingate) {
-      w.a = op_ident(s.dpre, 32); w.b = op_ident(pl.states, 32); w.N = 32;
-      SPG_TRY(spg_queue_wgrad(rq2, w, pl.cell_grads[4], sg, pl.cell_grads[5]));      // + column sums = the input gate's bias gradient
-    }
+  // ---- the tail: nothing below depends on it, it depends on nothing but the recurrence's outputs ----
+  std::vector<SpgStage> stages;
+  eccrnn_backward_tail_stages(c, stages);
+  if (phase == 1) {
+    for (SpgStage& sg : stages) spg_riders_push(std::move(sg));
+    return 0;
   }
-  // the deferred reductions of both queues leave in ONE launch at the end (after the join)
-  auto flush_all = [&]() -> int {
+  for (SpgStage& sg : stages) {      // on their own: one grouped launch per stage
+    SpgGroupScope grp(st);
+    SPG_TRY(sg(st));
     SPG_TRY(grp.flush());
-    if (side != nullptr) SPG_TRY(spg_side_join(st));
-    for (int j = 0; j < rq2.njobs; ++j) {
-      if (rq.njobs == SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(rq, st));
-      rq.jobs[rq.njobs++] = rq2.jobs[j];
-    }
-    rq2.njobs = 0;
-    return spg_flush_reduce(rq, st);
-  };
-  if (E == 0) {   // no edges: the filter network received no gradient
-    for (FLayer& l : pl.F) {
-      SPG_TRY(zero_async(l.dW, (size_t)l.cin * l.cout * 4, st));
-      SPG_TRY(zero_async(l.db, (size_t)l.cout * 4, st));
-      SPG_TRY(zero_async(l.dgamma, (size_t)l.cout * 4, st));
-      SPG_TRY(zero_async(l.dbeta, (size_t)l.cout * 4, st));
-    }
-    return flush_all();
   }
-  // ---- per-edge filter gradients (sum over the iterations), then the filter network backward ----
-  SPG_TRY(spg_launch_ecc_edge_wgrad(gr, pl.cfg.matrix, pl.states, ldS, s.G, ldS, R, s.dWts, st));
-  SPG_TRY(grp.flush());      // {cell weight gradients, bias column sums, per-edge filter gradient}
-  // the filter network's layers: weight gradient (+ bias column sums) and data gradient of a layer are independent of each
-  // other -- one grouped launch per layer
-  SpgOperand cur = op_ident(s.dWts, pl.nout);
-  float* dz[2] = {s.dzA, s.dzB};
-  int flip = 0;
-  for (int i = (int)pl.F.size() - 1; i >= 0; --i) {
-    FLayer& l = pl.F[i];
-    SpgWgradParams w; memset(&w, 0, sizeof(w));
-    w.a = cur; w.b = fnet_input(pl, i, edgefeats); w.M = E; w.N = l.cout; w.K = l.cin;
-    const bool bias_rides = l.db != nullptr && !l.bn && cur.mode == SPG_PRO_IDENT;      // bias gradient = column sums of `cur`
-    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st, bias_rides ? l.db : nullptr));
-    if (l.db && !bias_rides) {
-      if (l.bn) SPG_TRY(spg_group_zero(l.db, (size_t)l.cout, st));
-      else SPG_TRY(spg_queue_colsum(rq, cur.X, cur.ld, E, l.cout, l.db, st));
-    }
-    if (i == 0) break;
-    FLayer& prod = pl.F[i - 1];
-    float* out = dz[flip]; flip ^= 1;
-    SpgGemmParams g; memset(&g, 0, sizeof(g));
-    g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;
-    g.M = E; g.N = l.cin; g.K = l.cout; g.rows_per_tile = SPG_FC_ROWS;
-    g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.cout;
-    g.mask_relu = prod.relu ? 1 : 0; g.n_mask = prod.cout;
-    if (prod.bn) { g.ms = prod.s; g.mt = prod.t; g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat; }
-    int nparts = 0;
-    SPG_TRY(spg_launch_gemm(g, st, &nparts));
-    SPG_TRY(grp.flush());      // {weight gradient, bias column sums, data gradient} of layer i
-    if (prod.bn) {
-      SPG_TRY(spg_launch_bn_bwd_finalize(s.stat, nparts, l.cin, E, prod.cout, prod.s, prod.mean, prod.rstd,
-                                         s.consts, prod.dgamma, prod.dbeta, nullptr, st));
-      cur = op_bnbwd(out, prod.y, prod.cout, s.consts, prod.cout);
-    } else {
-      cur = op_ident(out, l.cin);
-    }
-  }
-  return flush_all();     // join, then ONE launch sums the split partials of all weight / bias gradients
+  return spg_flush_deferred_reduce(st);     // ONE launch sums the split partials of all weight / bias gradients
+}
+
+extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
+                                   const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
+                                   void* workspace, void* bwd_workspace, void* stream) {
+  return spg_eccrnn_backward_phase(cfg, N, E, graph_ws, edgefeats, params, grad_out, grad_h0, grads, workspace, bwd_workspace, stream, 0);
 }

@@ -143,8 +143,33 @@ struct SpgGroupScope {
  private:
   bool owner_;
 };
+// while alive (and `on`): launches of this thread are NOT diverted into the open group -- for a launch that is followed by a
+// dependent plain launch inside the same stage (a BatchNorm finalize behind its GEMM)
+struct SpgGroupBypass {
+  explicit SpgGroupBypass(bool on = true);
+  ~SpgGroupBypass();
+ private:
+  bool on_;
+};
 // zero `n` floats as a job of the open group (else hipMemsetAsync)
 int spg_group_zero(float* p, size_t n, hipStream_t stream);
+
+// ---- riders: a dependent chain of small launches that travels NEXT TO the caller's launches ----------------------------------
+// The filter-generating network's forward (4 dependent few-row GEMMs) needs nothing from PointNet, and the tail of the RNN-ECC
+// backward (cell / filter-network parameter gradients: 6 dependent groups) is needed by nobody before the optimiser step --
+// yet both sit in the one stream, in front of resp. behind ~600 us of PointNet work, as ~45 + ~120 us of latency-bound
+// launches.  A stage is a closure that issues the launches of one link of such a chain; the chain is registered with
+// spg_riders_push and from then on EVERY grouped launch of this thread on that stream (SpgGroupScope::flush) first lets the
+// next stage add its jobs to the group that is about to leave: stage k+1 leaves with a later launch than stage k, so the
+// chain's own order is kept, and it costs no launch of its own.  spg_riders_drain runs what is left (one grouped launch per
+// stage) -- the owner of the chain MUST call it before anything consumes the chain's results and before its buffers go away.
+// The chain lives inside ONE C-ABI call (spg_train_step): nothing is deferred across calls.
+#include <functional>
+typedef std::function<int(hipStream_t)> SpgStage;
+void spg_riders_push(SpgStage stage);
+int spg_riders_pending();
+int spg_riders_drain(hipStream_t stream);
+void spg_riders_clear();
 
 int spg_gemm_ntiles(const SpgGemmParams& p);
 // Data-gradient launches with 128-column tiles keep one workgroup per tile (no persistent stream: registers), i.e. one
@@ -180,6 +205,11 @@ struct SpgReduceQueue {
 int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream, float* db = nullptr);
 int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, float* out, hipStream_t stream);
 int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream);
+// jobs whose partials are complete (in stream order) but whose summation may wait for the next batched reduction of this
+// thread: spg_flush_reduce takes them along; spg_flush_deferred_reduce sums what is still waiting (no-op when nothing is)
+void spg_reduce_defer(const SpgReduceJob& job);
+void spg_reduce_deferred_clear();
+int spg_flush_deferred_reduce(hipStream_t stream);
 
 // BatchNorm forward statistics: partials [nparts][2][N] (+ rows per partial, stat_cnt [nparts]) -> mean, rstd, scale s = gamma*rstd, shift t = beta - mean*s;
 // running stats updated `update_times` times (run_full_monger re-runs the forward, learning/pointnet.py:167,173)

@@ -145,16 +145,19 @@ struct SpgSmallJob {            // column sums: src [M, ld] -> dst [slices][N] (
   long a, b, c;
   int i;
 };
-union SpgJobParams { SpgGemmParams g; SpgWgradParams w; SpgEdgeWgrad e; SpgSmallJob s; };
-struct SpgJobHdr { int kind, variant, first_block, gx, gy, gz, pad0, pad1; };
-#define SPG_GROUP_MAX_JOBS 7
+// Kernel arguments of a grouped launch (<= 4 KiB): a table of job headers in launch order + the jobs' parameter structs packed
+// back to back (16-byte aligned) in one byte arena -- 12 small jobs or e.g. 2 row-GEMMs + 4 weight gradients + 4 small ones.
+struct SpgJobHdr { int kind, variant, first_block, gx, gy, gz, offset, weight; };
+#define SPG_GROUP_MAX_JOBS 12
+#define SPG_GROUP_ARENA_BYTES 3632
 #define SPG_GROUP_MAX_WGRAD_ROWS 65536      // weight gradients over more rows than this are never grouped
 struct SpgMultiArgs {
   int njobs, pad[3];
   SpgJobHdr hdr[SPG_GROUP_MAX_JOBS];
-  SpgJobParams p[SPG_GROUP_MAX_JOBS];
+  alignas(16) unsigned char arena[SPG_GROUP_ARENA_BYTES];
 };
 static_assert(sizeof(SpgMultiArgs) <= 4096, "kernel arguments of a grouped launch must fit 4 KiB");
+static_assert(sizeof(SpgGemmParams) % 8 == 0 && sizeof(SpgWgradParams) % 8 == 0, "parameter structs are packed back to back");
 // few-row row-GEMM bodies spg_rowgemm_body<32, 128, 1, 4, WRED, AMODE, FULL> the group can run: id, or -1
 constexpr int spg_gemm_variant(bool wred, int amode, bool full) {
   const int m = amode == -1 ? (full ? -1 : 4)
@@ -162,30 +165,41 @@ constexpr int spg_gemm_variant(bool wred, int amode, bool full) {
               : ((!wred && amode == SPG_PRO_AFFINE) || (wred && amode == SPG_PRO_BNBWD)) ? (full ? 3 : 2) : -1;
   return m < 0 ? -1 : (wred ? 5 : 0) + m;
 }
+// Two builds of the grouped kernel: LIGHT (bodies that fit 128 registers: 4 workgroups per CU -- what a group of MANY small
+// workgroups needs, e.g. the per-edge filter gradient next to the cell's weight gradients) and HEAVY (every body, 2 per CU).
+// A group is launched with the light build unless one of its jobs is a heavy variant (register counts of the stand-alone
+// instantiations, -Rpass-analysis=kernel-resource-usage).
+constexpr bool spg_gemm_variant_light(int v) { return v != 8; }      // 8 = data gradient, BNBWD prologue, full tiles: 144 VGPRs
 // weight-gradient bodies the group can run (the shapes the few-row layers of the S3DIS / Semantic3D configurations produce)
-//   X(id, IT, JT, WI, WJ, AMODE, BMODE, FULL, COLSUM)
-#define SPG_WGRAD_VARIANTS(X)                                                                      \
-  X(0, 128, 128, 2, 2, 3, 1, false, false)   X(1, 128, 128, 2, 2, 3, 1, true, false)               \
-  X(2, 64, 64, 2, 2, 0, 1, false, true)      X(3, 64, 64, 2, 2, 0, 1, true, true)                  \
-  X(4, 128, 64, 2, 2, 0, 1, false, false)    X(5, 128, 64, 2, 2, 0, 1, true, false)                \
-  X(6, 128, 128, 2, 2, -1, -1, false, true)                                                        \
-  X(7, 128, 32, 4, 1, 0, 0, false, false)    X(8, 128, 32, 4, 1, 0, 0, true, false)                \
-  X(9, 128, 32, 4, 1, -1, -1, false, true)                                                         \
-  X(10, 128, 32, 4, 1, 0, 0, false, true)    X(11, 128, 32, 4, 1, 0, 0, true, true)                \
-  X(12, 128, 32, 4, 1, 0, 1, false, true)    X(13, 128, 32, 4, 1, 0, 1, true, true)                \
-  X(14, 64, 64, 2, 2, 0, 1, false, false)    X(15, 64, 64, 2, 2, 0, 1, true, false)                \
-  X(16, 128, 128, 2, 2, 0, 1, false, true)   X(17, 128, 128, 2, 2, 0, 1, true, true)               \
-  X(18, 128, 64, 2, 2, 3, 1, false, false)   X(19, 128, 64, 2, 2, 3, 1, true, false)
+//   X(id, IT, JT, WI, WJ, AMODE, BMODE, FULL, COLSUM, LIGHT)
+#define SPG_WGRAD_VARIANTS(X)                                                                                    \
+  X(0, 128, 128, 2, 2, 3, 1, false, false, false)   X(1, 128, 128, 2, 2, 3, 1, true, false, false)               \
+  X(2, 64, 64, 2, 2, 0, 1, false, true, true)       X(3, 64, 64, 2, 2, 0, 1, true, true, true)                   \
+  X(4, 128, 64, 2, 2, 0, 1, false, false, false)    X(5, 128, 64, 2, 2, 0, 1, true, false, false)                \
+  X(6, 128, 128, 2, 2, -1, -1, false, true, false)                                                               \
+  X(7, 128, 32, 4, 1, 0, 0, false, false, true)     X(8, 128, 32, 4, 1, 0, 0, true, false, true)                 \
+  X(9, 128, 32, 4, 1, -1, -1, false, true, false)                                                                \
+  X(10, 128, 32, 4, 1, 0, 0, false, true, false)    X(11, 128, 32, 4, 1, 0, 0, true, true, true)                 \
+  X(12, 128, 32, 4, 1, 0, 1, false, true, false)    X(13, 128, 32, 4, 1, 0, 1, true, true, false)                \
+  X(14, 64, 64, 2, 2, 0, 1, false, false, true)     X(15, 64, 64, 2, 2, 0, 1, true, false, true)                 \
+  X(16, 128, 128, 2, 2, 0, 1, false, true, false)   X(17, 128, 128, 2, 2, 0, 1, true, true, false)               \
+  X(18, 128, 64, 2, 2, 3, 1, false, false, false)   X(19, 128, 64, 2, 2, 3, 1, true, false, false)
 constexpr int spg_wgrad_variant(int it, int jt, int amode, int bmode, bool full, bool colsum) {
-#define SPG_X(id, IT_, JT_, WI_, WJ_, AM_, BM_, FU_, CS_) \
+#define SPG_X(id, IT_, JT_, WI_, WJ_, AM_, BM_, FU_, CS_, LI_) \
   if (it == IT_ && jt == JT_ && amode == AM_ && bmode == BM_ && full == FU_ && colsum == CS_) return id;
   SPG_WGRAD_VARIANTS(SPG_X)
 #undef SPG_X
   return -1;
 }
+constexpr bool spg_wgrad_variant_light(int v) {
+#define SPG_X(id, IT_, JT_, WI_, WJ_, AM_, BM_, FU_, CS_, LI_) if (v == id) return LI_;
+  SPG_WGRAD_VARIANTS(SPG_X)
+#undef SPG_X
+  return false;
+}
 // host side (end of this file): true = the job was taken by the group that is open on this thread
 static bool spg_group_accepts(hipStream_t stream);
-static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream);
+static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight);
 
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
@@ -251,10 +265,25 @@ __device__ __forceinline__ void spg_fx_split(double v, long long& hi, long long&
   hi = (long long)f;                        // |hi| <= 2^44
   lo = (long long)((t - f) * 0x1p44);       // [0, 2^44): 2^19 contributions fit one int64 slot
 }
+// The consumer's side: the SPG_FOLD_SLOTS slots of one sum are added EXACTLY (128-bit integers: 8 x 2^63 * 2^44 fits) and
+// converted once -- the result does not depend on which workgroup used which slot, i.e. not on the launch geometry (a
+// grouped launch numbers its workgroups differently from the stand-alone launch of the same job; both give the same bits).
+// slots: first limb of slot 0 (hi); lo limb at +C; next slot at +stride
 template <int SH>
-__device__ __forceinline__ double spg_fx_join(long long hi, long long lo) {
+__device__ __forceinline__ double spg_fx_sum(const unsigned long long* __restrict__ s, size_t C, size_t stride) {
+  __int128 t = 0;
+#pragma unroll
+  for (int k = 0; k < SPG_FOLD_SLOTS; ++k) {
+    const long long hi = (long long)s[k * stride], lo = (long long)s[k * stride + C];
+    t += ((__int128)hi << 44) + (__int128)lo;
+  }
+  // sign and magnitude: both halves of |t| are non-negative, so the two conversions cannot cancel (two's-complement halves of a
+  // small negative total would: -2^64 + (2^64 - x rounded to 53 bits))
+  const bool neg = t < 0;
+  const unsigned __int128 u = neg ? (unsigned __int128)(-t) : (unsigned __int128)t;
+  const double mag = (double)(unsigned long long)(u >> 64) * 0x1p64 + (double)(unsigned long long)u;
   constexpr double ISC = SH < 0 ? 0x1p8 : 0x1p-8;
-  return ((double)hi + (double)lo * 0x1p-44) * ISC;
+  return (neg ? -mag : mag) * (0x1p-44 * ISC);
 }
 
 // one contribution (two sums) of column `col` into the layer's slots
@@ -288,13 +317,8 @@ __device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f, const boo
   const int C = f.C;
   const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int k = 0; k < SPG_FOLD_SLOTS; ++k) {
-      const unsigned long long* s = f.slots + (size_t)k * 4 * C + c;
-      a += spg_fx_join<8>((long long)s[0], (long long)s[C]);
-      b += spg_fx_join<8>((long long)s[2 * (size_t)C], (long long)s[3 * (size_t)C]);
-    }
+    double a = spg_fx_sum<8>(f.slots + c, (size_t)C, (size_t)4 * C);
+    const double b = spg_fx_sum<8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
     if (bad) a = __builtin_nan("");
     const float ps = f.s[c], pmean = f.mean[c], prstd = f.rstd[c];
     const double c1 = a / f.count, c2 = b / f.count;
@@ -317,15 +341,9 @@ __device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f, const bool f
   const int C = f.C;
   const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    // every slot is an exact integer sum; the 8 slots are decoded and added in float64 in slot order (deterministic) -- adding
-    // the integers of all slots first could overflow (each slot may hold up to 2^19 contributions of up to 2^44)
-    double sx = 0.0, sxx = 0.0;
-#pragma unroll
-    for (int k = 0; k < SPG_FOLD_SLOTS; ++k) {
-      const unsigned long long* s = f.slots + (size_t)k * 4 * C + c;
-      sx += spg_fx_join<-8>((long long)s[0], (long long)s[C]);
-      sxx += spg_fx_join<-8>((long long)s[2 * (size_t)C], (long long)s[3 * (size_t)C]);
-    }
+    // every slot is an exact integer sum; the 8 slots are added exactly too (spg_fx_sum)
+    double sx = spg_fx_sum<-8>(f.slots + c, (size_t)C, (size_t)4 * C);
+    const double sxx = spg_fx_sum<-8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
     const double M = f.count;
     if (bad) sx = __builtin_nan("");
     const double mean = sx / M;
@@ -1206,7 +1224,7 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
         }
       }
       if constexpr (IT == 32 && spg_gemm_variant(WRED, AMODE, true) >= 0) {
-        if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, true), &q, sizeof(q), grid, lds, flops, stream)) return 0;
+        if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, true), &q, sizeof(q), grid, lds, flops, stream, 2 + 2 * spg_cdiv(p.K, SPG_KC))) return 0;
       }
       hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false>), grid, dim3(SPG_THREADS), lds, stream, q);
       SPG_LAUNCH_CHECK();
@@ -1215,7 +1233,7 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
   }
   prof.r.tag = SPG_PROF_TAG(1, IT, JT, WRED ? 1 : 0, AMODE, 0);
   if constexpr (IT == 32 && spg_gemm_variant(WRED, AMODE, false) >= 0) {
-    if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, false), &p, sizeof(p), grid, lds, flops, stream)) return 0;
+    if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, false), &p, sizeof(p), grid, lds, flops, stream, 2 + 2 * spg_cdiv(p.K, SPG_KC))) return 0;
   }
   hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
@@ -1557,7 +1575,7 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
   // wide convolutions' weight gradients (performance-critical, own occupancy bounds) never do
   const bool grouped = p.M <= SPG_GROUP_MAX_WGRAD_ROWS && spg_group_accepts(stream);
   ProfScope prof(stream, flops, 0, !grouped);
-  auto try_group = [&](int variant) { return grouped && variant >= 0 && spg_group_add(SPG_JOB_WGRAD, variant, &p, sizeof(p), grid, lds, flops, stream); };
+  auto try_group = [&](int variant) { return grouped && variant >= 0 && spg_group_add(SPG_JOB_WGRAD, variant, &p, sizeof(p), grid, lds, flops, stream, 2 + 2 * (p.rows_per_split / SPG_KC)); };
   if constexpr (AMODE >= 0 && BMODE >= 0 && AMODE != SPG_PRO_CLOUD && BMODE != SPG_PRO_CLOUD) {
     auto mode_ok = [](int mode, const SpgOperand& d, int nch) {
       if (mode == SPG_PRO_AFFINE) return d.c0 != nullptr && d.n_affine >= nch;
@@ -1715,21 +1733,40 @@ __global__ __launch_bounds__(1024) void spg_reduce_batch_kernel(const SpgReduceB
   }
 }
 
-int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream) {
-  if (q.njobs == 0) return 0;
-  SpgReduceBatch b;
-  int blocks = 0;
-  for (int j = 0; j < q.njobs; ++j) {
-    b.jobs[j] = q.jobs[j];
-    b.first_block[j] = blocks;
-    blocks += spg_cdiv(q.jobs[j].n, SPG_REDUCE_ELEMS);
+namespace { thread_local std::vector<SpgReduceJob> g_deferred_reduce; }
+void spg_reduce_defer(const SpgReduceJob& job) { g_deferred_reduce.push_back(job); }
+void spg_reduce_deferred_clear() { g_deferred_reduce.clear(); }
+
+static int launch_reduce_jobs(const SpgReduceJob* jobs, int n, hipStream_t stream) {
+  for (int base = 0; base < n; base += SPG_MAX_REDUCE_JOBS) {
+    const int m = n - base < SPG_MAX_REDUCE_JOBS ? n - base : SPG_MAX_REDUCE_JOBS;
+    SpgReduceBatch b;
+    int blocks = 0;
+    for (int j = 0; j < m; ++j) {
+      b.jobs[j] = jobs[base + j];
+      b.first_block[j] = blocks;
+      blocks += spg_cdiv(jobs[base + j].n, SPG_REDUCE_ELEMS);
+    }
+    b.first_block[m] = blocks;
+    b.njobs = m;
+    hipLaunchKernelGGL(spg_reduce_batch_kernel, dim3(blocks), dim3(1024), 0, stream, b);
+    SPG_LAUNCH_CHECK();
   }
-  b.first_block[q.njobs] = blocks;
-  b.njobs = q.njobs;
-  hipLaunchKernelGGL(spg_reduce_batch_kernel, dim3(blocks), dim3(1024), 0, stream, b);
-  SPG_LAUNCH_CHECK();
-  q.njobs = 0;
   return 0;
+}
+
+int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream) {
+  if (q.njobs == 0 && g_deferred_reduce.empty()) return 0;
+  std::vector<SpgReduceJob> all(g_deferred_reduce);      // deferred jobs of this thread travel with this launch
+  g_deferred_reduce.clear();
+  all.insert(all.end(), q.jobs, q.jobs + q.njobs);
+  q.njobs = 0;
+  return launch_reduce_jobs(all.data(), (int)all.size(), stream);
+}
+
+int spg_flush_deferred_reduce(hipStream_t stream) {
+  SpgReduceQueue none;
+  return spg_flush_reduce(none, stream);
 }
 
 static int queue_take(SpgReduceQueue& q, size_t floats, float** out, hipStream_t stream) {
@@ -2236,7 +2273,7 @@ int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, 
   SpgSmallJob sj; memset(&sj, 0, sizeof(sj));
   sj.src = X; sj.dst = part; sj.a = ld; sj.b = M; sj.c = rps; sj.i = N;
   if (!(spg_group_accepts(stream) &&
-        spg_group_add(SPG_JOB_COLSUM, 0, &sj, sizeof(sj), dim3(spg_cdiv(N, 64), slices), 16 * 64 * sizeof(float), 0.0, stream))) {
+        spg_group_add(SPG_JOB_COLSUM, 0, &sj, sizeof(sj), dim3(spg_cdiv(N, 64), slices), 16 * 64 * sizeof(float), 0.0, stream, 2))) {
     hipLaunchKernelGGL(spg_colsum_kernel, dim3(spg_cdiv(N, 64), slices), dim3(1024), 0, stream, X, ld, M, N, rps, part);
     SPG_LAUNCH_CHECK();
   }
@@ -2276,7 +2313,7 @@ int spg_launch_pad_rows(const float* src, long lds, float* dst, long ldd, long r
   const long n = rows * ldd;
   SpgSmallJob sj; memset(&sj, 0, sizeof(sj));
   sj.src = src; sj.dst = dst; sj.a = lds; sj.b = ldd; sj.c = rows; sj.i = cols;
-  if (spg_group_accepts(stream) && spg_group_add(SPG_JOB_PAD_ROWS, 0, &sj, sizeof(sj), dim3(spg_cdiv(n, 256)), 0, 0.0, stream)) return 0;
+  if (spg_group_accepts(stream) && spg_group_add(SPG_JOB_PAD_ROWS, 0, &sj, sizeof(sj), dim3(spg_cdiv(n, 256)), 0, 0.0, stream, 0)) return 0;
   hipLaunchKernelGGL(spg_pad_rows_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -2334,7 +2371,8 @@ __device__ __forceinline__ void spg_colsum_body(const SpgSmallJob& j, const int 
   }
 }
 
-__global__ __launch_bounds__(SPG_THREADS, 2) void spg_multi_kernel(const SpgMultiArgs a_by_value) {
+template <bool HEAVY>
+__device__ __forceinline__ void spg_multi_body() {
   extern __shared__ f32x4 smem[];
   // the job table is indexed dynamically: read it where it lies -- in the kernel-argument segment (constant address space,
   // scalar loads) -- instead of through the by-value parameter, which the compiler would copy to scratch (3.9 KB per lane)
@@ -2346,52 +2384,58 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_multi_kernel(const SpgMult
   const SpgJobHdr h = a.hdr[j];
   const int b = (int)blockIdx.x - h.first_block;
   const int bx = b % h.gx, by = (b / h.gx) % h.gy, bz = b / (h.gx * h.gy);
-  const SpgJobParams& P = a.p[j];
+  const unsigned char* P = a.arena + h.offset;
+#define SPG_P(T) (*reinterpret_cast<const T*>(P))
   if (h.kind == SPG_JOB_GEMM) {
     switch (h.variant) {
-      case 0: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_IDENT, false>(P.g, bx, by); break;
-      case 1: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_IDENT, true>(P.g, bx, by); break;
-      case 2: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_AFFINE, false>(P.g, bx, by); break;
-      case 3: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_AFFINE, true>(P.g, bx, by); break;
-      case 4: spg_rowgemm_body<32, 128, 1, 4, false, -1, false>(P.g, bx, by); break;
-      case 5: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_IDENT, false>(P.g, bx, by); break;
-      case 6: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_IDENT, true>(P.g, bx, by); break;
-      case 7: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_BNBWD, false>(P.g, bx, by); break;
-      case 8: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_BNBWD, true>(P.g, bx, by); break;
-      case 9: spg_rowgemm_body<32, 128, 1, 4, true, -1, false>(P.g, bx, by); break;
+      case 0: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_IDENT, false>(SPG_P(SpgGemmParams), bx, by); break;
+      case 1: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_IDENT, true>(SPG_P(SpgGemmParams), bx, by); break;
+      case 2: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_AFFINE, false>(SPG_P(SpgGemmParams), bx, by); break;
+      case 3: spg_rowgemm_body<32, 128, 1, 4, false, SPG_PRO_AFFINE, true>(SPG_P(SpgGemmParams), bx, by); break;
+      case 4: spg_rowgemm_body<32, 128, 1, 4, false, -1, false>(SPG_P(SpgGemmParams), bx, by); break;
+      case 5: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_IDENT, false>(SPG_P(SpgGemmParams), bx, by); break;
+      case 6: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_IDENT, true>(SPG_P(SpgGemmParams), bx, by); break;
+      case 7: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_BNBWD, false>(SPG_P(SpgGemmParams), bx, by); break;
+      case 8: if constexpr (HEAVY) spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_BNBWD, true>(SPG_P(SpgGemmParams), bx, by); break;
+      case 9: spg_rowgemm_body<32, 128, 1, 4, true, -1, false>(SPG_P(SpgGemmParams), bx, by); break;
       default: break;
     }
   } else if (h.kind == SPG_JOB_WGRAD) {
     switch (h.variant) {
-#define SPG_X(id, IT_, JT_, WI_, WJ_, AM_, BM_, FU_, CS_) \
-      case id: spg_wgrad_body<IT_, JT_, WI_, WJ_, AM_, BM_, FU_, 0, CS_>(P.w, bx, by, bz); break;
+#define SPG_X(id, IT_, JT_, WI_, WJ_, AM_, BM_, FU_, CS_, LI_) \
+      case id: if constexpr (HEAVY || LI_) spg_wgrad_body<IT_, JT_, WI_, WJ_, AM_, BM_, FU_, 0, CS_>(SPG_P(SpgWgradParams), bx, by, bz); break;
       SPG_WGRAD_VARIANTS(SPG_X)
 #undef SPG_X
       default: break;
     }
   } else if (h.kind == SPG_JOB_COLSUM) {
-    spg_colsum_body(P.s, bx, by, reinterpret_cast<float*>(smem));
+    spg_colsum_body(SPG_P(SpgSmallJob), bx, by, reinterpret_cast<float*>(smem));
   } else if (h.kind == SPG_JOB_EDGE_WGRAD) {
-    spg_ecc_edge_wgrad_body(P.e, bx);
+    spg_ecc_edge_wgrad_body(SPG_P(SpgEdgeWgrad), bx);
   } else if (h.kind == SPG_JOB_PAD_ROWS) {
+    const SpgSmallJob& q = SPG_P(SpgSmallJob);
     const long i = (long)bx * SPG_THREADS + threadIdx.x;
-    if (i < P.s.c * P.s.b) {
-      const long r = i / P.s.b;
-      const int c = (int)(i - r * P.s.b);
-      P.s.dst[i] = c < P.s.i ? P.s.src[r * P.s.a + c] : 0.f;
+    if (i < q.c * q.b) {
+      const long r = i / q.b;
+      const int c = (int)(i - r * q.b);
+      q.dst[i] = c < q.i ? q.src[r * q.a + c] : 0.f;
     }
   } else if (h.kind == SPG_JOB_ZERO) {
-    for (long i = (long)bx * 4 * SPG_THREADS + threadIdx.x; i < min(P.s.b, (long)(bx + 1) * 4 * SPG_THREADS); i += SPG_THREADS) P.s.dst[i] = 0.f;
+    const SpgSmallJob& q = SPG_P(SpgSmallJob);
+    for (long i = (long)bx * 4 * SPG_THREADS + threadIdx.x; i < min(q.b, (long)(bx + 1) * 4 * SPG_THREADS); i += SPG_THREADS) q.dst[i] = 0.f;
   }
+#undef SPG_P
 }
+__global__ __launch_bounds__(SPG_THREADS, 2) void spg_multi_kernel(const SpgMultiArgs a_by_value) { spg_multi_body<true>(); }
+__global__ __launch_bounds__(SPG_THREADS, 4) void spg_multi_light_kernel(const SpgMultiArgs a_by_value) { spg_multi_body<false>(); }
 
 namespace {
 struct SpgGroupState {
   bool open = false;
   hipStream_t st = nullptr;
-  int blocks = 0;
-  size_t lds = 0;
+  size_t lds = 0, used = 0;   // dynamic LDS of the launch (max over the jobs); bytes of the parameter arena in use
   double flops = 0.0;
+  bool heavy = false;         // a job needs the 2-workgroups-per-CU build (spg_multi_kernel); else spg_multi_light_kernel
   int rc = 0;                 // first launch error since the scope was opened
   SpgMultiArgs a;
 };
@@ -2399,47 +2443,67 @@ thread_local SpgGroupState g_grp;
 
 int group_flush() {
   SpgGroupState& g = g_grp;
-  if (g.a.njobs == 0) return 0;
+  const int n = g.a.njobs;
+  if (n == 0) return 0;
+  // launch order = block order: the jobs whose workgroups run longest go first, so that the tail of the launch consists of
+  // short workgroups (measured: a 32-chunk data gradient behind 424 weight-gradient workgroups made its group slower than
+  // the two separate launches).  Stable insertion sort by weight, descending (<= 12 entries); then the block ranges.
+  for (int i = 1; i < n; ++i) {
+    const SpgJobHdr h = g.a.hdr[i];
+    int k = i - 1;
+    while (k >= 0 && g.a.hdr[k].weight < h.weight) { g.a.hdr[k + 1] = g.a.hdr[k]; --k; }
+    g.a.hdr[k + 1] = h;
+  }
+  long blocks = 0;
+  for (int i = 0; i < n; ++i) { g.a.hdr[i].first_block = (int)blocks; blocks += (long)g.a.hdr[i].gx * g.a.hdr[i].gy * g.a.hdr[i].gz; }
   {
     ProfScope prof(g.st, g.flops, SPG_PROF_TAG(3, 32, 32, 0, 0, 0));
-    hipLaunchKernelGGL(spg_multi_kernel, dim3((unsigned)g.blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
+    if (g.heavy) hipLaunchKernelGGL(spg_multi_kernel, dim3((unsigned)blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
+    else hipLaunchKernelGGL(spg_multi_light_kernel, dim3((unsigned)blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
   }
-  g.a.njobs = 0; g.blocks = 0; g.lds = 0; g.flops = 0.0;
+  g.a.njobs = 0; g.lds = 0; g.used = 0; g.flops = 0.0; g.heavy = false;
   SPG_LAUNCH_CHECK();
   return 0;
 }
 }  // namespace
 
-static bool spg_group_accepts(hipStream_t stream) { return g_grp.open && g_grp.st == stream && g_grp.rc == 0; }
+namespace { thread_local int g_bypass = 0; }
+SpgGroupBypass::SpgGroupBypass(bool on) : on_(on) { if (on_) ++g_bypass; }
+SpgGroupBypass::~SpgGroupBypass() { if (on_) --g_bypass; }
+static bool spg_group_accepts(hipStream_t stream) { return g_grp.open && g_grp.st == stream && g_grp.rc == 0 && g_bypass == 0; }
 
-static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream) {
+// weight: relative duration of ONE workgroup of the job (sequential reduction chunks); decides the launch order
+static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight) {
   SpgGroupState& g = g_grp;
-  if (!spg_group_accepts(stream) || variant < 0 || bytes > sizeof(SpgJobParams)) return false;
+  const size_t need = (bytes + 15) & ~(size_t)15;
+  if (!spg_group_accepts(stream) || variant < 0 || need > SPG_GROUP_ARENA_BYTES) return false;
   const long nb = (long)grid.x * grid.y * grid.z;
   if (nb <= 0 || nb > (1L << 24)) return false;
-  if (g.a.njobs == SPG_GROUP_MAX_JOBS || (long)g.blocks + nb > (1L << 30)) {
+  if (g.a.njobs == SPG_GROUP_MAX_JOBS || g.used + need > SPG_GROUP_ARENA_BYTES) {
     g.rc = group_flush();
     if (g.rc != 0) return false;
   }
   SpgJobHdr& h = g.a.hdr[g.a.njobs];
-  h.kind = kind; h.variant = variant; h.first_block = g.blocks; h.gx = (int)grid.x; h.gy = (int)grid.y; h.gz = (int)grid.z; h.pad0 = h.pad1 = 0;
-  memcpy(&g.a.p[g.a.njobs], params, bytes);
+  h.kind = kind; h.variant = variant; h.first_block = 0; h.gx = (int)grid.x; h.gy = (int)grid.y; h.gz = (int)grid.z;
+  h.offset = (int)g.used; h.weight = weight;
+  memcpy(g.a.arena + g.used, params, bytes);
+  g.used += need;
   ++g.a.njobs;
-  g.blocks += (int)nb;
+  if ((kind == SPG_JOB_GEMM && !spg_gemm_variant_light(variant)) || (kind == SPG_JOB_WGRAD && !spg_wgrad_variant_light(variant))) g.heavy = true;
   if (lds > g.lds) g.lds = lds;
   g.flops += flops;
   return true;
 }
 
 bool spg_group_add_edge_wgrad(const SpgEdgeWgrad& p, hipStream_t stream) {
-  return spg_group_add(SPG_JOB_EDGE_WGRAD, 0, &p, sizeof(p), dim3(spg_cdiv(p.g.E, 4)), 0, 0.0, stream);
+  return spg_group_add(SPG_JOB_EDGE_WGRAD, 0, &p, sizeof(p), dim3(spg_cdiv(p.g.E, 4)), 0, 0.0, stream, 1);
 }
 
 int spg_group_zero(float* p, size_t n, hipStream_t stream) {
   if (p == nullptr || n == 0) return 0;
   SpgSmallJob sj; memset(&sj, 0, sizeof(sj));
   sj.dst = p; sj.b = (long)n;
-  if (spg_group_add(SPG_JOB_ZERO, 0, &sj, sizeof(sj), dim3(spg_cdiv((long)n, 4 * SPG_THREADS)), 0, 0.0, stream)) return 0;
+  if (spg_group_add(SPG_JOB_ZERO, 0, &sj, sizeof(sj), dim3(spg_cdiv((long)n, 4 * SPG_THREADS)), 0, 0.0, stream, 0)) return 0;
   hipError_t e = hipMemsetAsync(p, 0, n * sizeof(float), stream);
   if (e != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
@@ -2448,13 +2512,49 @@ int spg_group_zero(float* p, size_t n, hipStream_t stream) {
 SpgGroupScope::SpgGroupScope(hipStream_t stream) : owner_(false) {
   SpgGroupState& g = g_grp;
   if (g.open || g_tune[SPG_TUNE_NO_GROUP]) return;      // nested scope / switched off: launches stay separate
-  g.open = true; g.st = stream; g.blocks = 0; g.lds = 0; g.flops = 0.0; g.rc = 0; g.a.njobs = 0;
+  g.open = true; g.st = stream; g.lds = 0; g.used = 0; g.flops = 0.0; g.rc = 0; g.a.njobs = 0; g.heavy = false;
   owner_ = true;
 }
+// ---- riders (spg_gemm.h) ----
+namespace {
+thread_local std::vector<SpgStage> g_riders;
+thread_local size_t g_rider_next = 0;
+thread_local bool g_rider_running = false;
+}  // namespace
+void spg_riders_push(SpgStage stage) { g_riders.push_back(std::move(stage)); }
+int spg_riders_pending() { return (int)(g_riders.size() - g_rider_next); }
+void spg_riders_clear() { g_riders.clear(); g_rider_next = 0; g_rider_running = false; }
+// the next stage issues its launches into the open group (what the group cannot take is launched directly: stream order keeps
+// it behind the previous stage, whose launch left earlier)
+static int riders_step(hipStream_t st) {
+  if (g_rider_running || g_rider_next >= g_riders.size()) return 0;
+  g_rider_running = true;
+  SpgStage stage = std::move(g_riders[g_rider_next++]);
+  const int rc = stage(st);
+  g_rider_running = false;
+  if (g_rider_next >= g_riders.size()) { g_riders.clear(); g_rider_next = 0; }
+  return rc;
+}
+int spg_riders_drain(hipStream_t stream) {
+  SPG_CHECK_ARG(!g_grp.open || spg_riders_pending() == 0, "spg_riders_drain inside an open group scope (the stages depend on each other)");
+  while (spg_riders_pending() > 0) {
+    SpgGroupScope grp(stream);          // (inside an open scope: the stages then simply join that group one after the other --
+    if (!grp.active()) {                //  NOT allowed: they depend on each other; run them ungrouped instead)
+      SPG_TRY(riders_step(stream));
+      continue;
+    }
+    SPG_TRY(grp.flush());               // flush() pulls exactly one stage
+  }
+  return 0;
+}
+
 int SpgGroupScope::flush() {
   if (!owner_) return 0;
   SpgGroupState& g = g_grp;
-  const int rc = g.rc != 0 ? g.rc : group_flush();
+  int rc = g.rc;
+  if (rc == 0 && !g_rider_running) rc = riders_step(g.st);      // one link of a rider chain leaves with this launch
+  if (rc == 0) rc = g.rc;
+  if (rc == 0) rc = group_flush();
   g.rc = 0;
   return rc;
 }

@@ -60,7 +60,71 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* _
   grad_logits[idx] = g;
 }
 
+// forward and backward in one single-workgroup launch (the gradient of the loss itself is 1): the same arithmetic as the two
+// kernels above, in the same order -- bit-identical loss and gradient
+__global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                          const float* __restrict__ weight, int N, int C, int64_t ignore_index,
+                                                          int reduction_mean, float* __restrict__ loss, float* __restrict__ lse,
+                                                          float* __restrict__ wsum_out, float* __restrict__ grad_logits) {
+  __shared__ double s_l[16], s_w[16];
+  __shared__ int s_bad;
+  __shared__ float s_wsum;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  double accl = 0.0, accw = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const float* x = logits + (long)i * C;
+    float m = -FLT_MAX;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+    const float l = m + logf(s);
+    lse[i] = l;
+    const int64_t t = target[i];
+    if (t != ignore_index && t >= 0 && t < C) {
+      const float w = weight ? weight[t] : 1.f;
+      accl += (double)(w * (l - x[t]));
+      accw += (double)w;
+    } else if (t != ignore_index) {
+      s_bad = 1;
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) { accl += __shfl_xor(accl, off, 64); accw += __shfl_xor(accw, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = accl; s_w[threadIdx.x >> 6] = accw; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < 16; ++k) { a += s_l[k]; b += s_w[k]; }
+    *wsum_out = (float)b;
+    s_wsum = (float)b;
+    *loss = s_bad ? __builtin_nanf("") : (float)(reduction_mean ? a / b : a);
+  }
+  __syncthreads();
+  const float wsum = s_wsum;
+  for (long idx = threadIdx.x; idx < (long)N * C; idx += 1024) {
+    const int i = (int)(idx / C), c = (int)(idx - (long)i * C);
+    const int64_t t = target[i];
+    float g = 0.f;
+    if (t != ignore_index && t >= 0 && t < C) {
+      const float w = weight ? weight[t] : 1.f;
+      const float scale = 1.f * w / (reduction_mean ? wsum : 1.f);
+      g = scale * (expf(logits[idx] - lse[i]) - (c == (int)t ? 1.f : 0.f));      // lse[i]: written by this workgroup above
+    }
+    grad_logits[idx] = g;
+  }
+}
+
 }  // namespace
+
+extern "C" int spg_cross_entropy_fwd_bwd(const float* logits, const int64_t* target, const float* weight, int N, int C,
+                                         int64_t ignore_index, int reduction_mean, float* loss, float* lse, float* wsum,
+                                         float* grad_logits, void* stream) {
+  SPG_CHECK_ARG(logits && target && loss && lse && wsum && grad_logits && N > 0 && C > 0, "bad argument");
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, target, weight, N, C, ignore_index,
+                     reduction_mean, loss, lse, wsum, grad_logits);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int spg_cross_entropy_fwd(const float* logits, const int64_t* target, const float* weight, int N, int C,
                                      int64_t ignore_index, int reduction_mean, float* loss, float* lse, float* wsum, void* stream) {

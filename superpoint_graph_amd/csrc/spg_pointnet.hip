@@ -63,6 +63,7 @@ struct Plan {
   unsigned long long* slots_all = nullptr;  // all layers' statistics slots, one region (cleared by one memset per forward)
   size_t slots_words = 0;
   bool fold = false;        // train mode: BatchNorm statistics are finished by the consuming GEMM instead of a finalize launch
+  bool pads_done = false;   // the zero-padded weight copies of this forward have been issued
   size_t bytes = 0;
 };
 
@@ -275,19 +276,38 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     SPG_TRY(spg_launch_gemm(g, st, &nparts));
     SPG_TRY(bn_stats(pl, l, nparts, pl.M, update_times, st));
   }
+  // every FC layer is a few-row launch: issued through a group scope (a group of one, or of two with the weight padding below),
+  // so that a rider chain of the caller -- the filter network's forward -- can leave with it (spg_gemm.h)
+  SpgGroupScope grp(st);
   for (size_t k = 0; k < sg.fcs.size(); ++k) {
     Layer& l = pl.L[sg.fcs[k]];
     SpgGemmParams g; memset(&g, 0, sizeof(g));
     g.a = input_operand(pl, sg, true, k, clouds, stnT);
     // the producer's statistics: the last convolution (over all points) for the first fc layer, else the previous fc layer
     g.fold = k == 0 ? fold_of(pl, pl.L[sg.convs.back()], pl.M, update_times) : fold_of(pl, pl.L[sg.fcs[k - 1]], pl.B, update_times);
-    if (l.Wpad) SPG_TRY(spg_launch_pad_rows(l.W, l.cin, l.Wpad, l.ldw, l.cout, l.cin, st));
+    // zero-padded weight copies (input widths that are no multiples of 4: 256 pooled channels + the diameter): they depend on
+    // the weights only -- all of them leave with the FIRST few-row launch of the forward that does not need one itself
+    if (!pl.pads_done) {
+      bool mine = false;
+      for (int idx : sg.fcs) mine = mine || pl.L[idx].Wpad != nullptr;
+      if (mine && k == 0) {      // this segment's own layers need them: a launch of their own, in front
+        for (Layer& q : pl.L) if (q.Wpad) SPG_TRY(spg_launch_pad_rows(q.W, q.cin, q.Wpad, q.ldw, q.cout, q.cin, st));
+        SPG_TRY(grp.flush());
+      } else if (!mine) {
+        for (Layer& q : pl.L) if (q.Wpad) SPG_TRY(spg_launch_pad_rows(q.W, q.cin, q.Wpad, q.ldw, q.cout, q.cin, st));
+      }
+      pl.pads_done = true;
+    }
     g.W = l.Wpad ? l.Wpad : l.W; g.ldw = l.ldw; g.bias = l.b; g.M = pl.B; g.N = l.cout; g.K = l.cin;
     g.rows_per_tile = SPG_FC_ROWS; g.epi = SPG_EPI_FWD; g.Y = l.y; g.ldy = l.ldy;
     g.stat = (pl.training && l.bn) ? pl.stat : nullptr; g.stat_cnt = pl.stat_cnt;
     if (pl.fold && l.bn) { g.stat = nullptr; g.stat_slots = l.slots; }
     int nparts = 0;
-    SPG_TRY(spg_launch_gemm(g, st, &nparts));
+    {
+      SpgGroupBypass direct(l.bn && pl.training && !pl.fold);      // a finalize launch follows: the GEMM must not wait in the group
+      SPG_TRY(spg_launch_gemm(g, st, &nparts));
+    }
+    SPG_TRY(grp.flush());
     if (l.bn) SPG_TRY(bn_stats(pl, l, nparts, pl.B, update_times, st));
   }
   return 0;

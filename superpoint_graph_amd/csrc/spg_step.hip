@@ -1,0 +1,69 @@
+// One training step's forward + backward in one C-ABI call (include/spg_hip.h: spg_train_step): the launch ORDER of a step
+// whose parts the library sees together.  reference: learning/main.py:199-208 (the trainer's loop body), CloudEmbedder.run_full
+// (learning/pointnet.py:155-180), GraphNetwork.forward (learning/graphnet.py:95-98).
+//
+// What is gained over the module-level calls (same kernels, same results):
+//   * the filter-generating network of the RNN-ECC module needs only the superedge features: its four dependent few-row
+//     GEMMs are registered as RIDERS (spg_gemm.h) and leave as extra jobs of PointNet's own few-row launches (the STN / FC
+//     heads) -- ~45 us of latency-bound launches vanish from the stream;
+//   * the tail of the RNN-ECC backward (the cell's and the filter network's parameter gradients: six dependent grouped
+//     launches, ~120 us) is needed by nobody before the optimiser step: it rides next to PointNet's backward the same way,
+//     and the split partials of all three modules are summed by ONE batched reduction at the very end;
+//   * cross entropy forward + backward are one launch;
+//   * the host enqueues the step with one call.
+#include "../../include/spg_hip.h"
+#include "spg_ecc.h"
+#include "spg_gemm.h"
+
+int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0, const float* edgefeats,
+                             const void* const* params, float* out, void* workspace, int training, int bn_update_times, void* stream,
+                             int phase);
+int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
+                              const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
+                              void* workspace, void* bwd_workspace, void* stream, int phase);
+int spg_linear_backward_deferred(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K, float* dX,
+                                 long lddx, float* dW, float* dbias, float* work, hipStream_t st);
+
+namespace {
+// whatever happens inside the step, no rider / deferred reduction survives the call (their buffers belong to the caller)
+struct StepGuard {
+  ~StepGuard() { spg_riders_clear(); spg_reduce_deferred_clear(); }
+};
+}  // namespace
+
+extern "C" int spg_train_step(const spg_step_args* a, void* stream) {
+  SPG_CHECK_ARG(a != nullptr, "null arguments");
+  SPG_CHECK_ARG(a->ptn_cfg && a->ecc_cfg && a->B > 0 && a->N > 0 && a->E >= 0, "cfg / sizes");
+  SPG_CHECK_ARG(a->clouds && a->ptn_params && a->ptn_grads && a->ptn_ws && a->ptn_bwd_ws && a->emb && a->grad_emb, "PointNet buffers");
+  SPG_CHECK_ARG(a->slot_of_row && a->idx_valid && a->desc && a->grad_desc && a->nf == a->ecc_cfg->nc, "scatter buffers / embedding width");
+  SPG_CHECK_ARG(a->graph_ws && a->ecc_params && a->ecc_grads && a->ecc_ws && a->ecc_bwd_ws && a->ecc_out && a->grad_ecc_out, "RNN-ECC buffers");
+  SPG_CHECK_ARG(a->cls_W && a->cls_dW && a->cls_work && a->logits && a->grad_logits && a->nout > 0 && (a->nout & 3) == 0 && a->n_classes > 0, "classifier buffers");
+  SPG_CHECK_ARG(a->target && a->loss_buf, "loss buffers");
+  SPG_CHECK_ARG(spg_riders_pending() == 0, "a rider chain is already registered on this thread");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = a->N, E = a->E, B = a->B;
+  StepGuard guard;
+  spg_reduce_deferred_clear();
+  // ---------------- forward ----------------
+  // the filter network's layers travel with PointNet's few-row launches
+  SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, N, E, a->graph_ws, nullptr, a->edgefeats, a->ecc_params, nullptr, a->ecc_ws, 1, 1, stream, 1));
+  SPG_TRY(spg_pointnet_forward_ext(a->ptn_cfg, B, a->clouds, a->clouds_global, nullptr, a->ptn_params, a->emb, a->ptn_ws, 1,
+                                   a->bn_update_times, stream));
+  SPG_TRY(spg_riders_drain(st));
+  SPG_TRY(spg_gather_rows(a->emb, a->nf, a->slot_of_row, N, a->nf, a->desc, a->nf, stream));
+  SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, N, E, a->graph_ws, a->desc, a->edgefeats, a->ecc_params, a->ecc_out, a->ecc_ws, 1, 1, stream, 2));
+  SPG_TRY(spg_linear_fwd(a->ecc_out, a->nout, N, a->nout, a->cls_W, a->cls_b, a->n_classes, nullptr, nullptr, 0, a->logits, a->n_classes, stream));
+  SPG_TRY(spg_cross_entropy_fwd_bwd(a->logits, a->target, a->class_weight, N, a->n_classes, a->ignore_index, a->reduction_mean,
+                                    a->loss_buf + N, a->loss_buf, a->loss_buf + N + 1, a->grad_logits, stream));
+  // ---------------- backward ----------------
+  SPG_TRY(spg_linear_backward_deferred(a->grad_logits, a->n_classes, a->ecc_out, a->nout, a->cls_W, N, a->n_classes, a->nout,
+                                       a->grad_ecc_out, a->nout, a->cls_dW, a->cls_db, a->cls_work, st));
+  // through the recurrence; its tail rides with PointNet's backward
+  SPG_TRY(spg_eccrnn_backward_phase(a->ecc_cfg, N, E, a->graph_ws, a->edgefeats, a->ecc_params, a->grad_ecc_out, a->grad_desc, a->ecc_grads,
+                                    a->ecc_ws, a->ecc_bwd_ws, stream, 1));
+  SPG_TRY(spg_gather_rows(a->grad_desc, a->nf, a->idx_valid, B, a->nf, a->grad_emb, a->nf, stream));
+  SPG_TRY(spg_pointnet_backward_ext(a->ptn_cfg, B, a->clouds, a->clouds_global, nullptr, a->ptn_params, a->grad_emb, a->ptn_grads, nullptr,
+                                    nullptr, a->ptn_ws, a->ptn_bwd_ws, stream));
+  SPG_TRY(spg_riders_drain(st));
+  return spg_flush_deferred_reduce(st);
+}

@@ -114,6 +114,10 @@ def build_parser():
       help="Random streams of the cloud loader: 'host' = numpy / python streams in the reference's order (seeded runs reproduce "
            "the reference's clouds), 'device' = counter-based generator on the GPU (no per-superpoint host loop)")
     a('--fused_optim', default=1, type=int, help='Bool, clamp + Adam as one launch over a flat parameter arena (adam only)')
+    a('--fused_step', default=1, type=int,
+      help='Bool, forward + backward of a training step as ONE call into the library (superpoint_graph_amd/fused.py: same kernels and '
+           'results as the module-level path; the filter network and the RNN-ECC parameter gradients travel next to PointNet\'s '
+           'launches).  Active with --fused_optim 1 for the standard model (gru_R / lstm_R followed by f_K); otherwise the modules run')
     a('--max_train_iters', default=0, type=int, help='Stop every training epoch after this many batches (0 = whole epoch)')
     # data parallel (one process per GPU: `python -m torch.distributed.run --nproc-per-node N -m superpoint_graph_amd.learning.main ...`)
     a('--sync_bn', default=0, type=int, help='Data parallel: BatchNorm statistics over the scenes of ALL ranks (= the single-process '
@@ -275,6 +279,12 @@ class Session:
             # overwrite every gradient) and the BatchNorm batch counters live on the host
             self.arena = FlatParameters(model, lazy_zero=True, host_counters=True)
             self.arena.attach_optimizer(optimizer)    # the Adam moments live in `optimizer.state` (checkpoint format kept)
+        self.fused = None
+        if self.arena is not None and getattr(args, 'fused_step', 1) and args.cuda:
+            from .. import fused
+            if fused.supports(model):
+                self.fused = fused.FusedStep(model, self.arena, class_weights=dbinfo['class_weights'],
+                                             reduction='sum' if self.dp else 'mean', ptn_mem_monger=bool(args.ptn_mem_monger))
         self.iter_log = []                            # (loss, trainer ms) per training batch, for tests and tools
         self.eval_log = []                            # loss per evaluation batch
 
@@ -363,6 +373,27 @@ class Session:
                 self.arena.zero_grad()
             else:
                 self.optimizer.zero_grad()
+            if self.fused is not None and len(clouds_data[2]) > 1:
+                # forward + backward + bw_hook as one library call (learning/main.py:199-208); gradients land in the arena
+                self.model.ecc.set_info(GIs, a.cuda)
+                label_mode = ops.upload(targets[:, 0].contiguous())
+                label_vec = ops.upload(targets[:, 2:].contiguous())
+                loss, outputs = self.fused(clouds_data[1], clouds_data[2], clouds_data[3], GIs[0], label_mode)
+                if self.dp:
+                    self.arena.allreduce_sums(self.fused.normaliser, loss)
+                    loss = (self.arena.loss_sum / self.arena.normaliser).reshape(())
+                    self.arena.optimizer_step(grad_clip=a.grad_clip, grad_div=self.arena.normaliser)
+                else:
+                    self.arena.optimizer_step(grad_clip=a.grad_clip)
+                t_trainer = 1000 * (time.time() - t0)
+                loss_meter.add(loss)
+                cm.count_predicted_batch_device(label_vec, outputs, label_mode)
+                _log_bounded(self.iter_log, (loss.clone(), t_trainer))
+                logging.debug('Batch loader time %f ms, trainer time %f ms.', t_loader, t_trainer)
+                t0 = time.time()
+                if a.max_train_iters and bidx + 1 >= a.max_train_iters:
+                    break
+                continue
             outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
             if self.dp:
                 # data parallel: back-propagate the SUM-reduced loss (gradients carry this rank's loss weight w_r), ONE all-reduce of

@@ -1,0 +1,122 @@
+"""spg_train_step (superpoint_graph_amd/fused.py: FusedStep; include/spg_hip.h): forward + backward of a training step as ONE
+C call, in which the filter network's forward and the tail of the RNN-ECC backward travel as riders next to PointNet's
+launches.  Same kernels and arithmetic as the module-level path (CloudEmbedder.run -> model.ecc -> cross_entropy -> backward
+-> bw_hook), so EVERYTHING must be bit-identical: loss, logits, descriptors, all gradients, the BatchNorm running statistics
+and batch counters -- over several optimiser steps, with class weights / sum reduction, with too-small superpoints, on the
+golden fixtures (matrix and vector filters, LSTM cell) and at BASELINE size."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_model, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _modular(model, arena, batch, cw, reduction, monger=True):
+    from superpoint_graph_amd import ops
+    from superpoint_graph_amd.learning import ecc, pointnet
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+    embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=int(monger)))
+    arena.zero_grad()
+    emb = embedder.run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])
+    logits = model.ecc(emb)
+    loss = ops.cross_entropy(logits, batch['label_mode'].to(DEV), weight=cw, reduction=reduction)
+    loss.backward(arena.one)
+    embedder.bw_hook()
+    return loss.detach().clone(), logits.detach().clone(), emb.detach().clone()
+
+
+def _fused(model, arena, step, batch):
+    from superpoint_graph_amd.learning import ecc
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+    arena.zero_grad()
+    loss, logits = step(batch['clouds_flag'], batch['clouds'], batch['clouds_global'], gi, batch['label_mode'].to(DEV))
+    return loss.clone(), logits.clone(), step.embeddings.clone()
+
+
+def _compare(spec, state0, batch, cw, reduction, nsteps=3, monger=True):
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep, supports
+    out = []
+    for fused in (False, True):
+        model = build_model(spec, state0).to(DEV).train()
+        arena = FlatParameters(model, lazy_zero=True, host_counters=True)
+        assert supports(model)
+        step = FusedStep(model, arena, class_weights=cw, reduction=reduction, ptn_mem_monger=monger) if fused else None
+        rec = []
+        for it in range(nsteps):
+            r = _fused(model, arena, step, batch) if fused else _modular(model, arena, batch, cw, reduction, monger)
+            torch.cuda.synchronize()
+            grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+            arena.adam_step(lr=1e-3, grad_clip=1.0)
+            rec.append((r, grads))
+        out.append((rec, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    (ra, sa), (rb, sb) = out
+    for it in range(nsteps):
+        (la, lga, ea), ga = ra[it]
+        (lb, lgb, eb), gb = rb[it]
+        assert torch.equal(la, lb), (it, float(la), float(lb))
+        assert torch.equal(lga, lgb) and torch.equal(ea, eb), it
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), (it, k)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert float(ra[0][0][0]) > 0 and np.isfinite(float(ra[-1][0][0]))
+
+
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small', 'lstm3_matrix_small'])
+@pytest.mark.parametrize('reduction', ['mean', 'sum'])
+def test_fused_step_bit_identical_to_modules_on_goldens(hip, tag, reduction):
+    spec, batch, state0, g = load_golden(tag)
+    cw = torch.from_numpy(g['class_weights']).to(DEV) if 'class_weights' in g.files else None
+    _compare(spec, state0, batch, cw, reduction)
+
+
+@pytest.mark.parametrize('n_sp,n_edges,small', [(1000, 5000, 0.0), (600, 2900, 0.1), (2000, 9000, 0.0)])
+def test_fused_step_bit_identical_at_scene_size(hip, n_sp, n_edges, small):
+    """BASELINE-size scene (persistent RNN-ECC), a scene with too-small superpoints (zero descriptors, B < N) and a 2000-node
+    batch (per-iteration RNN-ECC launches)."""
+    from oracle import spg_oracle as O
+    from superpoint_graph_amd import synth
+    spec = O.ModelSpec()
+    col = synth.collate_numpy([synth.scene(5, n_sp=n_sp, n_edges=n_edges, small_frac=small)])
+    idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    if small > 0:
+        assert int((batch['clouds_flag'] != 0).sum()) > 0
+    torch.manual_seed(1)
+    ref = build_model(spec)
+    with torch.no_grad():
+        ref.ptn.stn.proj.weight.normal_(0, 0.02)
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    _compare(spec, state0, batch, None, 'mean', nsteps=2, monger=(n_sp != 600))
+
+
+def test_fused_step_refuses_what_it_does_not_serve(hip):
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep, supports
+    from superpoint_graph_amd.learning import graphnet
+    spec, batch, state0, g = load_golden('s3dis_gru10_matrix')
+    model = build_model(spec, state0).to(DEV).train()
+    arena = FlatParameters(model, lazy_zero=True)
+    step = FusedStep(model, arena)
+    model.eval()
+    from superpoint_graph_amd.learning import ecc
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+    with pytest.raises(RuntimeError, match='TRAINING step'):
+        step(batch['clouds_flag'], batch['clouds'], batch['clouds_global'], gi, batch['label_mode'].to(DEV))
+    other = torch.nn.Module()
+    other.ptn = model.ptn
+    other.ecc = graphnet.GraphNetwork('gru_2,f_16,r,f_13', 32, [13, 32, 128, 64], 1, 0, 2, 30000, use_pyg=0, cuda=1).to(DEV)
+    assert not supports(other)
+    with pytest.raises(NotImplementedError):
+        FusedStep(other, arena)

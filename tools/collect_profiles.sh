@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-STEPS="--no-cpu-baseline --no-forward-only --no-trainer-window --no-roofline"
+STEPS="--no-cpu-baseline --no-forward-only --no-trainer-window --no-roofline --no-extras"
 db() { find $1 -name '*.db' | head -1; }
 
 timeout 600 python $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err

@@ -38,7 +38,8 @@ def summarise(fetch_db, write_db, calib_fetch_db=None, calib_write_db=None, cali
         calib = {'MiB': mib, 'fetch_true_over_reported': fcorr, 'write_true_over_reported_fill': wcorr,
                  'write_true_over_reported_add': mib * 1024 * 1024 / wadd}
     steps = sum(v[0] for k, v in fetch.items() if k.startswith('spg_adam_clamp_kernel'))
-    gemm = lambda d: {k: v for k, v in d.items() if k.startswith('spg_rowgemm_kernel') or k.startswith('spg_wgrad_kernel')}
+    # (spg_multi_*: grouped launches of few-row GEMMs / weight gradients, round 4 -- counted as one launch each, like bench.py's events)
+    gemm = lambda d: {k: v for k, v in d.items() if k.startswith('spg_rowgemm_kernel') or k.startswith('spg_wgrad_kernel') or k.startswith('spg_multi')}
     gf, gw = gemm(fetch), gemm(write)
     launches = sum(v[0] for v in gf.values())
     f_b = sum(v[1] for v in gf.values()) * kb * fcorr
@@ -49,7 +50,23 @@ def summarise(fetch_db, write_db, calib_fetch_db=None, calib_write_db=None, cali
         rows.append({'kernel': k, 'launches_per_step': n / steps, 'fetch_mb_per_launch': gf[k][1] / n * kb * fcorr / 1e6,
                      'write_mb_per_launch': gw.get(k, [1, 0.0])[1] / max(gw.get(k, [1, 0.0])[0], 1) * kb * wcorr / 1e6})
     allk = lambda d: sum(v[1] for v in d.values())
+    # the RNN-ECC kernels (latency-bound dataflow launches: no roof applies; reported with their HBM bytes and duration)
+    ecc = {}
+    try:
+        c = sqlite3.connect(fetch_db)
+        for name, n, avg_ns in c.execute("select name, count(*), avg(end - start) from kernels where name like '%spg_ecc_%' group by name"):
+            short = name.replace('void ', '').split('(')[0]
+            f, w = fetch.get(short, [0, 0.0]), write.get(short, [0, 0.0])
+            fb = f[1] / max(f[0], 1) * kb * fcorr
+            wb = w[1] / max(w[0], 1) * kb * wcorr
+            ecc[short] = {'launches_per_step': n / steps, 'avg_us': avg_ns / 1e3, 'hbm_fetch_mb': fb / 1e6, 'hbm_write_mb': wb / 1e6,
+                          'achieved_gbs': (fb + wb) / (avg_ns * 1e-9) / 1e9 if avg_ns else None,
+                          'bound': 'latency (dataflow-synchronised recurrence: one wavefront per node waits for its neighbours\' states each '
+                                   'iteration; HBM traffic = the filters once)' if 'persist' in short else 'hbm/l2'}
+    except Exception as e:
+        ecc = {'error': str(e)}
     return {
+        'ecc': ecc,
         'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py; FETCH_SIZE x%.3f, '
                   'WRITE_SIZE x%.3f (%s)' % (fcorr, wcorr, 'calibrated on tools/pmc_calib.py in the same session' if calib else
                                              'gfx950 rule of MI355X_MICROARCH.md; WRITE_SIZE uncalibrated'),

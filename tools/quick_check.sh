@@ -13,7 +13,7 @@ tail -5 $OUT/${TAG}_tests.log
 timeout 400 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 1500 $OUT/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
-STEPS="--no-cpu-baseline --no-forward-only --no-trainer-window --no-roofline"
+STEPS="--no-cpu-baseline --no-forward-only --no-trainer-window --no-roofline --no-extras"
 timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_trace -- python $ROOT/bench.py --steps 20 --warmup 5 $STEPS > /dev/null 2> $OUT/${TAG}_trace.err
 python $ROOT/tools/prof_summary.py $(find /tmp/p_trace -name '*.db' | head -1) 70 > $OUT/${TAG}_kernel_stats.txt
 head -12 $OUT/${TAG}_kernel_stats.txt
