@@ -94,6 +94,14 @@ struct SpgOperand {
   int ldg;            // POOLBWD: leading dimension of the per-group arrays X (=dpool) and aidx
 };
 
+// BatchNorm-backward prologue value a * (x - b) - (y - c) * d with ONE rounding sequence everywhere: the plain expression
+// leaves the compiler two ways to contract it into a fused multiply-add (either product can become the fma), and its choice
+// depends on the surrounding code -- the same body inlined into two kernels (stand-alone launch / grouped launch, scalar /
+// vector staging) then differs in the last bit.  sub, sub, mul (never contracted), fma: four VALU operations as before.
+__device__ __forceinline__ float spg_bnbwd_value(float a, float x, float b, float y, float c, float d) {
+  return fmaf(a, x - b, -__fmul_rn(y - c, d));
+}
+
 __device__ __forceinline__ float spg_fetch(const SpgOperand& d, long m, int c) {
   switch (d.mode) {
     case SPG_PRO_IDENT:
@@ -121,14 +129,14 @@ __device__ __forceinline__ float spg_fetch(const SpgOperand& d, long m, int c) {
     case SPG_PRO_BNBWD: {
       float dz = d.X[m * d.ld + c];
       float y = d.X2[m * d.ld + c];
-      return d.c0[c] * (dz - d.c1[c]) - (y - d.c2[c]) * d.c3[c];
+      return spg_bnbwd_value(d.c0[c], dz, d.c1[c], y, d.c2[c], d.c3[c]);
     }
     default: {  // SPG_PRO_POOLBWD
       long g = m / d.P;
       int p = (int)(m - g * d.P);
       float dz = (d.aidx[g * d.ldg + c] == p) ? d.X[g * d.ldg + c] : 0.f;
       float y = d.X2[m * d.ld + c];
-      return d.c0[c] * (dz - d.c1[c]) - (y - d.c2[c]) * d.c3[c];
+      return spg_bnbwd_value(d.c0[c], dz, d.c1[c], y, d.c2[c], d.c3[c]);
     }
   }
 }
@@ -271,13 +279,13 @@ __device__ __forceinline__ f32x4 spg_finish_raw(const SpgQuad& q, const SpgRaw& 
     // the gradient of the max-pool goes to the winning row of each (group, channel)
     const float g0 = r.ai.x == r.pp ? r.x[0] : 0.f, g1 = r.ai.y == r.pp ? r.x[1] : 0.f;
     const float g2 = r.ai.z == r.pp ? r.x[2] : 0.f, g3 = r.ai.w == r.pp ? r.x[3] : 0.f;
-    v[0] = q.a[0] * (g0 - q.b[0]) - (r.y[0] - q.c[0]) * q.d[0];
-    v[1] = q.a[1] * (g1 - q.b[1]) - (r.y[1] - q.c[1]) * q.d[1];
-    v[2] = q.a[2] * (g2 - q.b[2]) - (r.y[2] - q.c[2]) * q.d[2];
-    v[3] = q.a[3] * (g3 - q.b[3]) - (r.y[3] - q.c[3]) * q.d[3];
+    v[0] = spg_bnbwd_value(q.a[0], g0, q.b[0], r.y[0], q.c[0], q.d[0]);
+    v[1] = spg_bnbwd_value(q.a[1], g1, q.b[1], r.y[1], q.c[1], q.d[1]);
+    v[2] = spg_bnbwd_value(q.a[2], g2, q.b[2], r.y[2], q.c[2], q.d[2]);
+    v[3] = spg_bnbwd_value(q.a[3], g3, q.b[3], r.y[3], q.c[3], q.d[3]);
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = q.a[i] * (r.x[i] - q.b[i]) - (r.y[i] - q.c[i]) * q.d[i];
+    for (int i = 0; i < 4; ++i) v[i] = spg_bnbwd_value(q.a[i], r.x[i], q.b[i], r.y[i], q.c[i], q.d[i]);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = (valid && i < q.nvalid) ? v[i] : 0.f;
@@ -903,14 +911,14 @@ __device__ __forceinline__ f32x4 spg_finish_fast(const SpgQuad& q, const SpgRaw&
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(r.x[e], q.a[e], q.b[e]), lo);
   } else if (MODE == SPG_PRO_BNBWD) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = q.a[e] * (r.x[e] - q.b[e]) - (r.y[e] - q.c[e]) * q.d[e];
+    for (int e = 0; e < 4; ++e) v[e] = spg_bnbwd_value(q.a[e], r.x[e], q.b[e], r.y[e], q.c[e], q.d[e]);
   } else {   // POOLBWD: the pooled gradient goes to the arg-max point of each (group, channel)
     const float g0 = pai.x == pp ? px[0] : 0.f, g1 = pai.y == pp ? px[1] : 0.f;
     const float g2 = pai.z == pp ? px[2] : 0.f, g3 = pai.w == pp ? px[3] : 0.f;
-    v[0] = q.a[0] * (g0 - q.b[0]) - (r.y[0] - q.c[0]) * q.d[0];
-    v[1] = q.a[1] * (g1 - q.b[1]) - (r.y[1] - q.c[1]) * q.d[1];
-    v[2] = q.a[2] * (g2 - q.b[2]) - (r.y[2] - q.c[2]) * q.d[2];
-    v[3] = q.a[3] * (g3 - q.b[3]) - (r.y[3] - q.c[3]) * q.d[3];
+    v[0] = spg_bnbwd_value(q.a[0], g0, q.b[0], r.y[0], q.c[0], q.d[0]);
+    v[1] = spg_bnbwd_value(q.a[1], g1, q.b[1], r.y[1], q.c[1], q.d[1]);
+    v[2] = spg_bnbwd_value(q.a[2], g2, q.b[2], r.y[2], q.c[2], q.d[2]);
+    v[3] = spg_bnbwd_value(q.a[3], g3, q.b[3], r.y[3], q.c[3], q.d[3]);
   }
   return v;
 }

@@ -9,6 +9,11 @@
 //     epilogue.
 // One workgroup = 4 wavefronts (one per SIMD); tile = 128 rows x JT columns, reduction staged through
 // LDS in chunks of 32 in the [k/4][row][4] layout of spg_common.h.
+// No IMPLICIT fused multiply-add contraction in this translation unit (explicit fmaf only): whether a * b + c written as two
+// operations becomes one fma is the compiler's choice and depends on the surrounding code, so the same kernel body inlined
+// into two kernels -- its stand-alone launch and the grouped launch (spg_multi_kernel) -- could round differently.  The bodies
+// spell out the fmas they want; everything else rounds the same in every context (tests/test_gpu_grouped.py: bit-identical).
+#pragma clang fp contract(off)
 #include "../../include/spg_hip.h"
 #include "spg_gemm.h"
 #include <float.h>
@@ -147,12 +152,13 @@ struct SpgSmallJob {            // column sums: src [M, ld] -> dst [slices][N] (
 };
 // Kernel arguments of a grouped launch (<= 4 KiB): a table of job headers in launch order + the jobs' parameter structs packed
 // back to back (16-byte aligned) in one byte arena -- 12 small jobs or e.g. 2 row-GEMMs + 4 weight gradients + 4 small ones.
-struct SpgJobHdr { int kind, variant, first_block, gx, gy, gz, offset, weight; };
+struct SpgJobHdr { int kind, variant, gx, gy, gz, offset, weight, pad; };
 #define SPG_GROUP_MAX_JOBS 12
-#define SPG_GROUP_ARENA_BYTES 3632
+#define SPG_GROUP_ARENA_BYTES 3584
 #define SPG_GROUP_MAX_WGRAD_ROWS 65536      // weight gradients over more rows than this are never grouped
 struct SpgMultiArgs {
   int njobs, pad[3];
+  int first_block[SPG_GROUP_MAX_JOBS];      // first workgroup of every job: ONE batch of scalar loads finds a workgroup's job
   SpgJobHdr hdr[SPG_GROUP_MAX_JOBS];
   alignas(16) unsigned char arena[SPG_GROUP_ARENA_BYTES];
 };
@@ -199,7 +205,8 @@ constexpr bool spg_wgrad_variant_light(int v) {
 }
 // host side (end of this file): true = the job was taken by the group that is open on this thread
 static bool spg_group_accepts(hipStream_t stream);
-static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight);
+static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight,
+                          std::function<int()> direct = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
@@ -1224,7 +1231,12 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
         }
       }
       if constexpr (IT == 32 && spg_gemm_variant(WRED, AMODE, true) >= 0) {
-        if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, true), &q, sizeof(q), grid, lds, flops, stream, 2 + 2 * spg_cdiv(p.K, SPG_KC))) return 0;
+        if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, true), &q, sizeof(q), grid, lds, flops, stream, 2 + 2 * spg_cdiv(p.K, SPG_KC),
+                                     [q, grid, lds, stream]() -> int {
+                                       hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false>), grid, dim3(SPG_THREADS), lds, stream, q);
+                                       SPG_LAUNCH_CHECK();
+                                       return 0;
+                                     })) return 0;
       }
       hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE, true, false>), grid, dim3(SPG_THREADS), lds, stream, q);
       SPG_LAUNCH_CHECK();
@@ -1233,7 +1245,12 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
   }
   prof.r.tag = SPG_PROF_TAG(1, IT, JT, WRED ? 1 : 0, AMODE, 0);
   if constexpr (IT == 32 && spg_gemm_variant(WRED, AMODE, false) >= 0) {
-    if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, false), &p, sizeof(p), grid, lds, flops, stream, 2 + 2 * spg_cdiv(p.K, SPG_KC))) return 0;
+    if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, false), &p, sizeof(p), grid, lds, flops, stream, 2 + 2 * spg_cdiv(p.K, SPG_KC),
+                                 [p, grid, lds, stream]() -> int {
+                                   hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
+                                   SPG_LAUNCH_CHECK();
+                                   return 0;
+                                 })) return 0;
   }
   hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
@@ -2378,11 +2395,14 @@ __device__ __forceinline__ void spg_multi_body() {
   // scalar loads) -- instead of through the by-value parameter, which the compiler would copy to scratch (3.9 KB per lane)
   typedef __attribute__((address_space(4))) const SpgMultiArgs* spg_kernarg_ptr;
   const SpgMultiArgs& a = *(const SpgMultiArgs*)(spg_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  // (independent loads, issued together: a dependent scan would pay one scalar-memory round trip per entry)
   int j = 0;
-  while (j + 1 < a.njobs && (int)blockIdx.x >= a.hdr[j + 1].first_block) ++j;      // wave-uniform scan (<= 7 entries)
+  const int nj = a.njobs;
+#pragma unroll
+  for (int k = 1; k < SPG_GROUP_MAX_JOBS; ++k) j += (k < nj && (int)blockIdx.x >= a.first_block[k]) ? 1 : 0;
   j = __builtin_amdgcn_readfirstlane(j);
   const SpgJobHdr h = a.hdr[j];
-  const int b = (int)blockIdx.x - h.first_block;
+  const int b = (int)blockIdx.x - a.first_block[j];
   const int bx = b % h.gx, by = (b / h.gx) % h.gy, bz = b / (h.gx * h.gy);
   const unsigned char* P = a.arena + h.offset;
 #define SPG_P(T) (*reinterpret_cast<const T*>(P))
@@ -2437,6 +2457,7 @@ struct SpgGroupState {
   double flops = 0.0;
   bool heavy = false;         // a job needs the 2-workgroups-per-CU build (spg_multi_kernel); else spg_multi_light_kernel
   int rc = 0;                 // first launch error since the scope was opened
+  std::function<int()> direct;      // stand-alone launch of the group's FIRST job (a group of one leaves as the kernel it is)
   SpgMultiArgs a;
 };
 thread_local SpgGroupState g_grp;
@@ -2455,13 +2476,19 @@ int group_flush() {
     g.a.hdr[k + 1] = h;
   }
   long blocks = 0;
-  for (int i = 0; i < n; ++i) { g.a.hdr[i].first_block = (int)blocks; blocks += (long)g.a.hdr[i].gx * g.a.hdr[i].gy * g.a.hdr[i].gz; }
+  for (int i = 0; i < n; ++i) { g.a.first_block[i] = (int)blocks; blocks += (long)g.a.hdr[i].gx * g.a.hdr[i].gy * g.a.hdr[i].gz; }
+  for (int i = n; i < SPG_GROUP_MAX_JOBS; ++i) g.a.first_block[i] = 0x7fffffff;
+  int rc = 0;
   {
     ProfScope prof(g.st, g.flops, SPG_PROF_TAG(3, 32, 32, 0, 0, 0));
-    if (g.heavy) hipLaunchKernelGGL(spg_multi_kernel, dim3((unsigned)blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
+    // a group of ONE job gains nothing from the job table (its workgroups would pay the table's scalar loads on top of their
+    // own: +1.5 us measured on a 16 us launch): it leaves as the stand-alone kernel
+    if (n == 1 && g.direct) rc = g.direct();
+    else if (g.heavy) hipLaunchKernelGGL(spg_multi_kernel, dim3((unsigned)blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
     else hipLaunchKernelGGL(spg_multi_light_kernel, dim3((unsigned)blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
   }
-  g.a.njobs = 0; g.lds = 0; g.used = 0; g.flops = 0.0; g.heavy = false;
+  g.a.njobs = 0; g.lds = 0; g.used = 0; g.flops = 0.0; g.heavy = false; g.direct = nullptr;
+  if (rc != 0) return rc;
   SPG_LAUNCH_CHECK();
   return 0;
 }
@@ -2473,7 +2500,8 @@ SpgGroupBypass::~SpgGroupBypass() { if (on_) --g_bypass; }
 static bool spg_group_accepts(hipStream_t stream) { return g_grp.open && g_grp.st == stream && g_grp.rc == 0 && g_bypass == 0; }
 
 // weight: relative duration of ONE workgroup of the job (sequential reduction chunks); decides the launch order
-static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight) {
+static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight,
+                          std::function<int()> direct) {
   SpgGroupState& g = g_grp;
   const size_t need = (bytes + 15) & ~(size_t)15;
   if (!spg_group_accepts(stream) || variant < 0 || need > SPG_GROUP_ARENA_BYTES) return false;
@@ -2484,8 +2512,9 @@ static bool spg_group_add(int kind, int variant, const void* params, size_t byte
     if (g.rc != 0) return false;
   }
   SpgJobHdr& h = g.a.hdr[g.a.njobs];
-  h.kind = kind; h.variant = variant; h.first_block = 0; h.gx = (int)grid.x; h.gy = (int)grid.y; h.gz = (int)grid.z;
-  h.offset = (int)g.used; h.weight = weight;
+  h.kind = kind; h.variant = variant; h.gx = (int)grid.x; h.gy = (int)grid.y; h.gz = (int)grid.z;
+  h.offset = (int)g.used; h.weight = weight; h.pad = 0;
+  g.direct = g.a.njobs == 0 ? std::move(direct) : nullptr;
   memcpy(g.a.arena + g.used, params, bytes);
   g.used += need;
   ++g.a.njobs;
@@ -2560,6 +2589,9 @@ int SpgGroupScope::flush() {
 }
 SpgGroupScope::~SpgGroupScope() {
   if (!owner_) return;
-  (void)flush();
+  // what is still collected leaves; NO rider stage is pulled here (a scope that ends is not a launch site of its owner: a stage
+  // pulled now would leave alone, in front of the launches it was meant to travel with)
+  if (g_grp.rc == 0) (void)group_flush();
+  g_grp.rc = 0;
   g_grp.open = false;
 }

@@ -60,8 +60,12 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* _
   grad_logits[idx] = g;
 }
 
-// forward and backward in one single-workgroup launch (the gradient of the loss itself is 1): the same arithmetic as the two
-// kernels above, in the same order -- bit-identical loss and gradient
+// forward and backward in ONE launch (the gradient of the loss itself is 1): workgroup 0 is the forward kernel above (loss,
+// log-sum-exp per row, normaliser); every further workgroup takes CE_ROWS rows of the gradient -- it re-derives what it needs
+// from the forward with the forward's own arithmetic and summation order (the normaliser over all rows, the log-sum-exp of
+// its rows), so loss and gradient are bit-identical to the two separate launches.  (A single workgroup doing both took 20 us
+// against 8.5 + 4.7 for the pair: the 13 000 gradient elements behind the forward's critical path.)
+#define CE_ROWS 64
 __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                           const float* __restrict__ weight, int N, int C, int64_t ignore_index,
                                                           int reduction_mean, float* __restrict__ loss, float* __restrict__ lse,
@@ -69,46 +73,76 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(const float* __restric
   __shared__ double s_l[16], s_w[16];
   __shared__ int s_bad;
   __shared__ float s_wsum;
-  if (threadIdx.x == 0) s_bad = 0;
-  __syncthreads();
-  double accl = 0.0, accw = 0.0;
-  for (int i = threadIdx.x; i < N; i += 1024) {
-    const float* x = logits + (long)i * C;
+  __shared__ float s_lse[CE_ROWS];
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    double accl = 0.0, accw = 0.0;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+      const float* x = logits + (long)i * C;
+      float m = -FLT_MAX;
+      for (int c = 0; c < C; ++c) m = fmaxf(m, x[c]);
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+      const float l = m + logf(s);
+      lse[i] = l;
+      const int64_t t = target[i];
+      if (t != ignore_index && t >= 0 && t < C) {
+        const float w = weight ? weight[t] : 1.f;
+        accl += (double)(w * (l - x[t]));
+        accw += (double)w;
+      } else if (t != ignore_index) {
+        s_bad = 1;
+      }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { accl += __shfl_xor(accl, off, 64); accw += __shfl_xor(accw, off, 64); }
+    if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = accl; s_w[threadIdx.x >> 6] = accw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < 16; ++k) { a += s_l[k]; b += s_w[k]; }
+      *wsum_out = (float)b;
+      *loss = s_bad ? __builtin_nanf("") : (float)(reduction_mean ? a / b : a);
+    }
+    return;
+  }
+  // ---- gradient rows [r0, r1) ----
+  const int r0 = ((int)blockIdx.x - 1) * CE_ROWS, r1 = min(N, r0 + CE_ROWS);
+  float wsum = 1.f;
+  if (reduction_mean) {      // the normaliser, summed exactly like workgroup 0 sums it
+    double accw = 0.0;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+      const int64_t t = target[i];
+      if (t != ignore_index && t >= 0 && t < C) accw += (double)(weight ? weight[t] : 1.f);
+    }
+    for (int off = 32; off >= 1; off >>= 1) accw += __shfl_xor(accw, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = accw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double b = 0.0;
+      for (int k = 0; k < 16; ++k) b += s_w[k];
+      s_wsum = (float)b;
+    }
+  }
+  if ((int)threadIdx.x < r1 - r0) {
+    const float* x = logits + (long)(r0 + threadIdx.x) * C;
     float m = -FLT_MAX;
     for (int c = 0; c < C; ++c) m = fmaxf(m, x[c]);
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf(x[c] - m);
-    const float l = m + logf(s);
-    lse[i] = l;
-    const int64_t t = target[i];
-    if (t != ignore_index && t >= 0 && t < C) {
-      const float w = weight ? weight[t] : 1.f;
-      accl += (double)(w * (l - x[t]));
-      accw += (double)w;
-    } else if (t != ignore_index) {
-      s_bad = 1;
-    }
-  }
-  for (int off = 32; off >= 1; off >>= 1) { accl += __shfl_xor(accl, off, 64); accw += __shfl_xor(accw, off, 64); }
-  if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = accl; s_w[threadIdx.x >> 6] = accw; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < 16; ++k) { a += s_l[k]; b += s_w[k]; }
-    *wsum_out = (float)b;
-    s_wsum = (float)b;
-    *loss = s_bad ? __builtin_nanf("") : (float)(reduction_mean ? a / b : a);
+    s_lse[threadIdx.x] = m + logf(s);
   }
   __syncthreads();
-  const float wsum = s_wsum;
-  for (long idx = threadIdx.x; idx < (long)N * C; idx += 1024) {
-    const int i = (int)(idx / C), c = (int)(idx - (long)i * C);
-    const int64_t t = target[i];
+  if (reduction_mean) wsum = s_wsum;
+  for (int e = threadIdx.x; e < (r1 - r0) * C; e += 1024) {
+    const int il = e / C, c = e - il * C;
+    const long idx = (long)(r0 + il) * C + c;
+    const int64_t t = target[r0 + il];
     float g = 0.f;
     if (t != ignore_index && t >= 0 && t < C) {
       const float w = weight ? weight[t] : 1.f;
       const float scale = 1.f * w / (reduction_mean ? wsum : 1.f);
-      g = scale * (expf(logits[idx] - lse[i]) - (c == (int)t ? 1.f : 0.f));      // lse[i]: written by this workgroup above
+      g = scale * (expf(logits[idx] - s_lse[il]) - (c == (int)t ? 1.f : 0.f));
     }
     grad_logits[idx] = g;
   }
@@ -120,8 +154,8 @@ extern "C" int spg_cross_entropy_fwd_bwd(const float* logits, const int64_t* tar
                                          int64_t ignore_index, int reduction_mean, float* loss, float* lse, float* wsum,
                                          float* grad_logits, void* stream) {
   SPG_CHECK_ARG(logits && target && loss && lse && wsum && grad_logits && N > 0 && C > 0, "bad argument");
-  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, target, weight, N, C, ignore_index,
-                     reduction_mean, loss, lse, wsum, grad_logits);
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1 + spg_cdiv(N, CE_ROWS)), dim3(1024), 0, (hipStream_t)stream, logits, target, weight, N, C,
+                     ignore_index, reduction_mean, loss, lse, wsum, grad_logits);
   SPG_LAUNCH_CHECK();
   return 0;
 }
