@@ -246,6 +246,9 @@ def test_lazy_zero_arena_with_autograd_parameters(hip):
         g_before = {k: p.grad.clone() for k, p in mod.named_parameters()}
         arena.adam_step(lr=1e-2)
         for (k, a), b in zip(mod.named_parameters(), ref.parameters()):
+            if k == '0.bias':       # the bias in front of the train-mode BatchNorm: analytically zero gradient, round-off on both sides
+                assert float(a.grad.abs().max()) < 1e-6 and float(b.grad.abs().max()) < 1e-6
+                continue
             assert float(g_before[k].abs().max()) > 0, (k, step)
             assert maxrel(a.grad, b.grad) < 1e-4 and maxrel(a, b) < 1e-4, (k, step)
     # a kernel-covered HipLinear that takes torch's path for one call (3-d input): cleared at forward time, then accumulated once
