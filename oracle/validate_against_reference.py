@@ -631,6 +631,65 @@ def check_baseline_size(refmods, write):
         print(f'  wrote {out} ({os.path.getsize(out) / 1e6:.2f} MB)')
 
 
+def two_scene_batch(seeds=(0, 1)):
+    """The reference's default --batch_size 2 (learning/main.py:49): two BASELINE-shaped scenes in one batch (2000 superpoints,
+    10 000 superedges)."""
+    col = synth.collate_numpy([synth.scene(s, n_sp=1000, n_edges=5000) for s in seeds])
+    idxn, degs, ef, ei = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    return dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                edgefeats=torch.from_numpy(ef), edge_indexes=torch.from_numpy(ei),
+                label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+
+
+def check_two_scenes(refmods, write):
+    """The IMPORTED reference on a 2-scene batch -- its own default batch size, BASELINE.json configs[2] -- with the initial
+    state of the BASELINE-size golden (same seeds; only its digest is stored here): train forward, loss, all gradients,
+    running statistics.  Multi-scene batches take other launch paths than the unit scene (2000 nodes per RNN-ECC launch,
+    BatchNorm statistics over both scenes)."""
+    pointnet, graphnet, modules, ecc = refmods
+    print('== 2-scene batch (2 x 1000 superpoints, 10 000 superedges), gru_10_0,f_13, imported reference')
+    spec = O.ModelSpec()
+    batch = two_scene_batch()
+    model = make_reference_model(spec, 1, refmods)
+    randomize_bn_and_proj(model, 7)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    args = types.SimpleNamespace(cuda=0, ptn_mem_monger=1)
+    cw = torch.linspace(0.5, 1.5, 13)
+    model.train()
+    ecc.GraphConvFunction = O.EccFunction              # matrix-filter backward: restated (header)
+    model.ecc.set_info([ref_gci(ecc, batch)], 0)
+    embedder = pointnet.CloudEmbedder(args)
+    emb_t = embedder.run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])
+    logits_t = model.ecc(emb_t)
+    loss_t = torch.nn.functional.cross_entropy(logits_t, batch['label_mode'], weight=cw)
+    model.zero_grad()
+    loss_t.backward()
+    embedder.bw_hook()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    state1 = {k: v.clone() for k, v in model.state_dict().items()}
+    st = {k: v.clone() for k, v in state0.items()}
+    loss_o, logits_o, emb_o, grads_o = O.train_step(batch, spec, st, cw)
+    check('train embeddings (oracle vs reference)', emb_o, emb_t, 2e-5)
+    check('train logits (oracle vs reference)', logits_o, logits_t, 5e-5)
+    check('train loss (oracle vs reference)', loss_o, loss_t, 1e-5)
+    after_pool = [k for k in grads if (k.startswith('ecc.') or k.startswith('ptn.fcs.')) and float(grads[k].abs().max()) > 1e-6]
+    worst = max(maxrel(grads_o[k], grads[k]) for k in after_pool)
+    print(f'  gradients behind the max-pool (ECC, FC head): oracle vs reference worst {worst:.2e}')
+    assert worst < 2e-4
+    if write:
+        out = os.path.join(ROOT, 'tests', 'golden', 'two_scenes.npz')
+        blob = {'state0_sha256': np.array(state_digest(state0)), 'class_weights': cw.numpy(),
+                'train/emb': emb_t.detach().numpy(), 'train/logits': logits_t.detach().numpy(), 'train/loss': loss_t.detach().numpy()}
+        for k, v in grads.items():
+            blob['grad/' + k] = v.numpy()
+        for k, v in state1.items():
+            if 'running' in k:
+                blob['state1/' + k] = v.numpy()
+        np.savez_compressed(out, **blob)
+        print(f'  wrote {out} ({os.path.getsize(out) / 1e6:.2f} MB)')
+
+
 def check_sp_graph(write):
     """partition/graphs.py:75-210 compute_sp_graph: the IMPORTED reference function (scipy's `Delaunay.vertices` is today's
     `.simplices`: the attribute is supplied, nothing else is touched) against oracle/spg_partition_oracle.py on a synthetic
@@ -698,6 +757,8 @@ def main():
         check_metrics(a.write)
     if a.only in ('', 'baseline_size'):
         check_baseline_size(refmods, a.write)
+    if a.only in ('', 'two_scenes'):
+        check_two_scenes(refmods, a.write)
     if a.only in ('', 'sp_graph'):
         check_sp_graph(a.write)
     if a.only in ('', 'local_embedder'):

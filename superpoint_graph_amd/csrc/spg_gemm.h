@@ -210,6 +210,8 @@ int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream);
 void spg_reduce_defer(const SpgReduceJob& job);
 void spg_reduce_deferred_clear();
 int spg_flush_deferred_reduce(hipStream_t stream);
+// hands the queue's jobs to the open group of this thread (they leave with its launch, next to its other jobs)
+int spg_reduce_ride(SpgReduceQueue& q, hipStream_t stream, size_t max_bytes = (size_t)36 << 20);
 
 // BatchNorm forward statistics: partials [nparts][2][N] (+ rows per partial, stat_cnt [nparts]) -> mean, rstd, scale s = gamma*rstd, shift t = beta - mean*s;
 // running stats updated `update_times` times (run_full_monger re-runs the forward, learning/pointnet.py:167,173)

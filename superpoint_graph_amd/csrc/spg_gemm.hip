@@ -143,7 +143,7 @@ extern "C" int spg_prof_read(double* ms, long* launches, double* flops, int rese
 // grouped launches (spg_gemm.h: SpgGroupScope): job table shared by the launchers and spg_multi_kernel (end of this file)
 // ---------------------------------------------------------------------------------------------
 #include "spg_ecc.h"
-enum { SPG_JOB_GEMM = 1, SPG_JOB_WGRAD = 2, SPG_JOB_COLSUM = 3, SPG_JOB_EDGE_WGRAD = 4, SPG_JOB_PAD_ROWS = 5, SPG_JOB_ZERO = 6 };
+enum { SPG_JOB_GEMM = 1, SPG_JOB_WGRAD = 2, SPG_JOB_COLSUM = 3, SPG_JOB_EDGE_WGRAD = 4, SPG_JOB_PAD_ROWS = 5, SPG_JOB_ZERO = 6, SPG_JOB_REDUCE = 7 };
 struct SpgSmallJob {            // column sums: src [M, ld] -> dst [slices][N] (a = ld, b = M, c = rows per slice, i = N)
   const float* src;             // pad rows:    src [rows, a] -> dst [rows, b] zero padded (c = rows, i = cols)
   float* dst;                   // zero:        dst [b floats]
@@ -153,8 +153,8 @@ struct SpgSmallJob {            // column sums: src [M, ld] -> dst [slices][N] (
 // Kernel arguments of a grouped launch (<= 4 KiB): a table of job headers in launch order + the jobs' parameter structs packed
 // back to back (16-byte aligned) in one byte arena -- 12 small jobs or e.g. 2 row-GEMMs + 4 weight gradients + 4 small ones.
 struct SpgJobHdr { int kind, variant, gx, gy, gz, offset, weight, pad; };
-#define SPG_GROUP_MAX_JOBS 12
-#define SPG_GROUP_ARENA_BYTES 3584
+#define SPG_GROUP_MAX_JOBS 16
+#define SPG_GROUP_ARENA_BYTES 3440
 #define SPG_GROUP_MAX_WGRAD_ROWS 65536      // weight gradients over more rows than this are never grouped
 struct SpgMultiArgs {
   int njobs, pad[3];
@@ -1781,6 +1781,30 @@ int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream) {
   return launch_reduce_jobs(all.data(), (int)all.size(), stream);
 }
 
+// the queue's jobs become jobs of the group that is open on this thread (their partials are complete in stream order: the
+// launches that wrote them left earlier); the queue is emptied.  No open group: nothing happens, the jobs wait for the flush.
+// max_bytes: volume of partials taken per call (jobs in queue order, at least one) -- a reduction that rides should end in the
+// shadow of its group's other jobs (~3 TB/s measured: ~35 MB per 12 us group); the rest stays queued for the next call / the flush
+int spg_reduce_ride(SpgReduceQueue& q, hipStream_t stream, size_t max_bytes) {
+  if (!spg_group_accepts(stream)) return 0;
+  int kept = 0;
+  size_t taken = 0;
+  bool full = false;
+  for (int j = 0; j < q.njobs; ++j) {
+    const SpgReduceJob job = q.jobs[j];
+    const size_t bytes = (size_t)job.nsplit * job.n * sizeof(float);
+    if (!full && taken > 0 && taken + bytes > max_bytes) full = true;
+    if (full || !spg_group_add(SPG_JOB_REDUCE, 0, &job, sizeof(job), dim3(spg_cdiv(job.n, 64)), 16 * 16 * sizeof(f32x4), 0.0, stream,
+                               2 + job.nsplit / 32)) {
+      q.jobs[kept++] = job;
+      continue;
+    }
+    taken += bytes;
+  }
+  q.njobs = kept;
+  return 0;
+}
+
 int spg_flush_deferred_reduce(hipStream_t stream) {
   SpgReduceQueue none;
   return spg_flush_reduce(none, stream);
@@ -2388,6 +2412,46 @@ __device__ __forceinline__ void spg_colsum_body(const SpgSmallJob& j, const int 
   }
 }
 
+// out[i] = sum_k partial[k][i] with the summation order of spg_reduce_batch_kernel (16 split groups k = g, g + 16, ... each in
+// sequence, then the groups in order): bit-identical results; 64 elements per workgroup instead of 256, i.e. 4x the
+// workgroups -- as a job of a grouped launch the reduction should finish in the shadow of the launch's other jobs
+__device__ __forceinline__ void spg_reduce_body(const SpgReduceJob& job, const int bx, f32x4* __restrict__ red) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const long i = ((long)bx * 16 + tx) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = (job.n & 3) == 0 && ((((uintptr_t)job.out) | ((uintptr_t)job.partial)) & 15) == 0;   // wave-uniform
+  if (vec) {
+    if (i < job.n) {
+      int k = ty;
+      for (; k + 48 < job.nsplit; k += 64) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(job.partial + (long)k * job.n + i);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(job.partial + (long)(k + 16) * job.n + i);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(job.partial + (long)(k + 32) * job.n + i);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(job.partial + (long)(k + 48) * job.n + i);
+        s += v0; s += v1; s += v2; s += v3;
+      }
+      for (; k < job.nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(job.partial + (long)k * job.n + i);
+    }
+  } else {
+    for (int e = 0; e < 4; ++e)
+      if (i + e < job.n)
+        for (int k = ty; k < job.nsplit; k += 16) s[e] += job.partial[(long)k * job.n + i + e];
+  }
+  red[ty * 16 + tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < job.n) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k * 16 + tx];      // fixed order: deterministic
+    if (vec) {
+      *reinterpret_cast<f32x4*>(job.out + i) = t;
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (i + e < job.n) job.out[i + e] = t[e];
+    }
+  }
+}
+
 template <bool HEAVY>
 __device__ __forceinline__ void spg_multi_body() {
   extern __shared__ f32x4 smem[];
@@ -2440,6 +2504,8 @@ __device__ __forceinline__ void spg_multi_body() {
       const int c = (int)(i - r * q.b);
       q.dst[i] = c < q.i ? q.src[r * q.a + c] : 0.f;
     }
+  } else if (h.kind == SPG_JOB_REDUCE) {
+    spg_reduce_body(SPG_P(SpgReduceJob), bx, smem);
   } else if (h.kind == SPG_JOB_ZERO) {
     const SpgSmallJob& q = SPG_P(SpgSmallJob);
     for (long i = (long)bx * 4 * SPG_THREADS + threadIdx.x; i < min(q.b, (long)(bx + 1) * 4 * SPG_THREADS); i += SPG_THREADS) q.dst[i] = 0.f;

@@ -136,6 +136,12 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
       l.ldw = (l.cin + 3) & ~3;
       l.Wpad = cv.take<float>((size_t)l.cout * l.ldw);
     }
+    // training, first convolution of the main segment behind an STN: its data gradient wrt the transformed xy reads the weight
+    // untransposed [cout][cin]; with cin no multiple of 4 (14, 11) a zero-padded copy keeps it on the vector staging path
+    if (l.conv && pl.training && pl.has_stn && (int)i == (pl.has_stn ? c.n_stn_conv + c.n_stn_fc + 1 : 0) && (l.cin & 3) != 0) {
+      l.ldw = (l.cin + 3) & ~3;
+      l.Wpad = cv.take<float>((size_t)l.cout * l.ldw);
+    }
     if (l.conv && !pl.training) l.Wpack = cv.take<float>(spg_conv_stack_packed_floats(l.cin, l.cout));
     if (l.conv && pl.training && l.cin % SPG_KC == 0) {      // layers the full-tile GEMM path can take (whole reduction chunks)
       l.Wb_f = cv.take<char>(spg_split_bytes(l.cout, l.cin));
@@ -377,7 +383,7 @@ SpgBnFoldBwd fold_bwd_of(const Plan& pl, const Layer& prod, long count, float* c
 }
 
 int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, SpgOperand cur, const float* clouds,
-                     const float* stnT, bool want_dxy, hipStream_t st) {
+                     const float* stnT, bool want_dxy, hipStream_t st, bool ride_reduce = false) {
   const int B = pl.B;
   SpgBnFoldBwd pending; memset(&pending, 0, sizeof(pending));     // set by a data-gradient launch, consumed by the next weight gradient
   // ---- fc head ----
@@ -388,7 +394,11 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
   int flip = 0;
   {
   SpgGroupScope grp(st);
+  // the split partials the launches so far have queued (the other segment's weight gradients: ~100 MB, 2/3 of the step's final
+  // reduction) are summed as jobs of this segment's grouped launches -- a slice of ~35 MB each -- in the shadow of its
+  // latency-bound FC layers
   for (int k = (int)sg.fcs.size() - 1; k >= 0; --k) {
+    if (ride_reduce) SPG_TRY(spg_reduce_ride(rq, st));      // (a slice per group; before this layer queues its own partials)
     Layer& l = pl.L[sg.fcs[k]];
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, true, k, clouds, stnT); w.M = B; w.N = l.cout; w.K = l.cin;
@@ -470,7 +480,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     } else if (want_dxy) {
       // gradient wrt the transformed xy only (learning/pointnet.py:123-124): 2 output columns
       SpgGemmParams g; memset(&g, 0, sizeof(g));
-      g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;
+      g.a = cur; g.W = l.Wpad ? l.Wpad : l.W; g.ldw = l.Wpad ? l.ldw : l.cin; g.w_red = 1;
       g.M = (int)pl.M; g.N = 2; g.K = l.cout; g.rows_per_tile = pl.P;
       g.epi = SPG_EPI_BWD; g.Y = s.dxy; g.ldy = 2;
       SPG_TRY(spg_launch_gemm(g, st));
@@ -612,7 +622,7 @@ extern "C" int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, con
     SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, grad_transform, st));
   if (pl.has_stn) {
     SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, s.dT, st));
-    SPG_TRY(backward_segment(pl, pl.stn, s, rq, op_ident(s.dT, 4), clouds, nullptr, false, st));
+    SPG_TRY(backward_segment(pl, pl.stn, s, rq, op_ident(s.dT, 4), clouds, nullptr, false, st, true));
   }
   return spg_flush_reduce(rq, st);      // ONE launch sums the split partials of all weight / bias gradients
 }

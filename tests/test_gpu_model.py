@@ -371,14 +371,12 @@ def test_large_configs_train_step_vs_oracle(hip, name):
     err = {k: maxrel(p.grad, grads_o[k]) for k, p in model.named_parameters() if not noise_grad(k, grads_o)}
     ranked = sorted(err.values())
     print(name, 'gradient error vs the fp32 oracle: median', ranked[len(ranked) // 2], '90th percentile', ranked[int(0.9 * len(ranked))], 'max', ranked[-1])
-    # Gradients are compared in bulk.  At 8 000 - 10 000 superpoints (2.5 M ReLU inputs behind every FC layer, 256 k
-    # max-pool decisions) a handful of activations sit within fp32 round-off of a ReLU kink or of a max-pool tie; which
-    # side they fall on differs between two fp32 implementations and moves single entries of dbeta / dW by ~1e-2 of the
-    # tensor maximum.  Measured with a float64 oracle as referee (2 / 4 / 8 scenes): the HIP path and the fp32 CPU oracle
-    # deviate from float64 by the same 3e-3 ... 2e-2 on exactly those tensors and by < 1e-5 on all the others.
-    # (one flipped ReLU in the FC head changes its upstream gradient row, which reaches every layer in front of it: at
-    # 8 scenes the MEDIAN over the PointNet tensors is 2e-3 for both fp32 paths against float64)
-    assert ranked[-1] < 5e-2, err
+    # The PointNet gradients are bounded only coarsely here (5e-2): at 8 000 - 10 000 superpoints a few hundred of
+    # 1e8 ReLU / max-pool decisions sit within fp32 round-off of a tie; which side they fall on differs between two fp32
+    # implementations and moves single entries of dbeta / dW by ~1e-2 of the tensor maximum, so an unconditioned comparison
+    # cannot be sharp.  The sharp check at these very sizes -- HIP decisions held equal, fp64 oracle backward, EVERY gradient
+    # tensor within 1e-4 -- is tests/test_gpu_baseline_parity.py::test_decision_conditioned_gradients_at_large_configs.
+    assert ranked[-1] < 5e-2, err       # (coarse sanity only)
     ecc_only = {k: v for k, v in err.items() if k.startswith('ecc.')}       # behind the embeddings: only the filter net's ReLUs upstream
     assert max(ecc_only.values()) < 2e-4, ecc_only
     sd = model.state_dict()
