@@ -486,7 +486,9 @@ def main():
         # instantiation average above mixes the MFMA-bound 128->256 layer with HBM-bound 64->128 ones
         keys, vals = (ctypes.c_int * (4 * 256))(), (ctypes.c_double * (2 * 256))()
         nshape = L.spg_prof_read_shapes(keys, vals, 256)
-        top = max(range(nshape), key=lambda j: vals[2 * j]) if nshape > 0 else -1
+        # (tag kind 3 = grouped launches of several few-row GEMMs / weight gradients: not a shape)
+        shapes = [j for j in range(nshape) if keys[4 * j] // 1000000 != 3]
+        top = max(shapes, key=lambda j: vals[2 * j]) if shapes else -1
         L.spg_prof_read(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flops), 1)
         L.spg_prof_enable(0)
         log('instrumented pass done')
@@ -567,6 +569,19 @@ def main():
         if 'roofline' in result:
             result['roofline']['sustained_ms_per_step'] = sus * 1e3
             result['roofline']['sustained_superpoints_per_s'] = n_sp_step / sus
+    if world == 1 and not args.no_extras:
+        # how long the HOST needs to enqueue one step (GPU idle at the start: no back-pressure from a full queue)
+        hs = []
+        for _ in range(12):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            hs.append(time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        result['host_step_enqueue_ms'] = sorted(hs)[len(hs) // 2] * 1e3
+        if 'roofline' in result:
+            result['roofline']['host_step_enqueue_ms'] = result['host_step_enqueue_ms']
+        log(f'host enqueue of one step: {result["host_step_enqueue_ms"]:.3f} ms')
     if world == 1 and not args.no_trainer_window:
         result['trainer_window'] = trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, fstep=fstep)
     if world > 1:

@@ -46,3 +46,35 @@ for _ in range(10):
     torch.cuda.synchronize()
 print(f'{n} steps: host returned after {t_host / n * 1e3:.3f} ms/step, GPU done after {t_all / n * 1e3:.3f} ms/step; '
       f'enqueue of one step on an idle GPU: median {sorted(host_only)[5] * 1e3:.3f} ms')
+
+# ---- the same step as ONE library call (superpoint_graph_amd/fused.py: spg_train_step) ----
+import cProfile
+import pstats
+from superpoint_graph_amd.fused import FusedStep
+fstep = FusedStep(model, arena)
+
+
+def fused():
+    arena.zero_grad()
+    fstep(flag, clouds_d, diam_d, GIs[0], lab)
+    arena.adam_step(lr=1e-2, grad_clip=1.0)
+
+
+for _ in range(10):
+    fused()
+host_only = []
+for _ in range(20):
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    fused()
+    host_only.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+print(f'fused step: enqueue of one step on an idle GPU: median {sorted(host_only)[10] * 1e3:.3f} ms, min {min(host_only) * 1e3:.3f} ms')
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(200):
+    fused()
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats('tottime').print_stats(14)
