@@ -172,6 +172,7 @@ int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, const float* c
  *   {weight_ih, weight_hh, bias_ih, bias_hh, ig.weight, ig.bias}.
  * h0 [N, nc] (nc must be 32), edgefeats [E, fnet_widths[0]]; out [N, nc*(nrepeats+1)] (cat_all) or [N, nc].
  * ---------------------------------------------------------------------------------------------- */
+#define SPG_MAX_PARTS 64
 typedef struct spg_eccrnn_cfg {
   int nc, nrepeats, matrix, layernorm, ingate, cat_all;
   int n_fnet;                           /* number of Linear layers of the filter network */
@@ -180,6 +181,14 @@ typedef struct spg_eccrnn_cfg {
   float bn_eps, bn_momentum;
   int cell;                             /* 0: GRUCellEx (gru_*), 1: LSTMCellEx (lstm_*; weights [128,32], cx starts at 0,
                                            learning/modules.py:168-169) */
+  /* Per-batch hint (0 = unknown): the batched graph's nodes [part_ptr[k], part_ptr[k+1]) , k < n_parts, are closed under
+   * edges -- the scenes of a batch (learning/spg.py:178-193 concatenates them with node offsets).  With it the
+   * dataflow-synchronised GRU recurrence (all iterations in ONE launch) also serves batches of more than 2048 nodes: whole
+   * scenes are packed into rounds of <= 2048 nodes.  Without it (or when a scene alone exceeds a round) larger graphs take
+   * one launch per iteration.  Results are identical either way.  Must be the same in the workspace-size queries, the
+   * forward and the backward of a batch. */
+  int n_parts;
+  int part_ptr[SPG_MAX_PARTS + 1];
 } spg_eccrnn_cfg;
 
 size_t spg_eccrnn_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, int E, int training);

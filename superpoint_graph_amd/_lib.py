@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libspg_hip.so')
 
 SPG_MAX_LAYERS = 8
+SPG_MAX_PARTS = 64
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 
 
@@ -32,7 +33,8 @@ class EccRnnCfg(ctypes.Structure):
     _fields_ = [('nc', ctypes.c_int), ('nrepeats', ctypes.c_int), ('matrix', ctypes.c_int), ('layernorm', ctypes.c_int),
                 ('ingate', ctypes.c_int), ('cat_all', ctypes.c_int), ('n_fnet', ctypes.c_int),
                 ('fnet_widths', ctypes.c_int * (SPG_MAX_LAYERS + 1)), ('bnidx', ctypes.c_int), ('llbias', ctypes.c_int),
-                ('bn_eps', ctypes.c_float), ('bn_momentum', ctypes.c_float), ('cell', ctypes.c_int)]
+                ('bn_eps', ctypes.c_float), ('bn_momentum', ctypes.c_float), ('cell', ctypes.c_int),
+                ('n_parts', ctypes.c_int), ('part_ptr', ctypes.c_int * (SPG_MAX_PARTS + 1))]
 
 
 _i, _l, _p, _sz = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_size_t

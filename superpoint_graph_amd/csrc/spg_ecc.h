@@ -137,7 +137,16 @@ int spg_launch_ecc_edge_wgrad(const SpgGraph& g, int matrix, const float* states
 int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, hipStream_t stream);
 
 // ---- persistent (one launch for all iterations) forms of the GRU recurrence, spg_ecc.hip ----
-#define SPG_PX_MAX_NODES 1024      // nodes per persistent launch (one wavefront each, all co-resident)
+#define SPG_PX_WG_NODES 1024       // nodes per round with ONE 4-wave workgroup per CU (one wavefront per node, all co-resident)
+#define SPG_PX_MAX_NODES 2048      // nodes per round with two workgroups per CU (fewer register-resident filters, gate rows from LDS)
+#define SPG_PX_MAX_GROUPS 8        // rounds per launch: groups of whole connected components (scenes) of <= SPG_PX_MAX_NODES nodes
+struct SpgPxGroups {               // node ranges [ptr[g], ptr[g+1]) of the rounds; n = 1: the whole graph in one round
+  int n;
+  int ptr[SPG_PX_MAX_GROUPS + 1];
+};
+// rounds for a batch whose connected components are unions of the node ranges part_ptr[0..n_parts] (scenes of a batch; n_parts
+// = 0: unknown -- one round if the whole graph fits); false when a part exceeds a round or too many rounds would be needed
+bool spg_px_plan_groups(int N, int n_parts, const int* part_ptr, SpgPxGroups* out);
 #define SPG_PX_SAVE_F 12           // floats per lane and (node, iteration) of forward internals kept for the backward (3 quads)
 struct SpgEccPersistFwd {
   SpgGraph g;
@@ -149,8 +158,9 @@ struct SpgEccPersistFwd {
   float* out; long ldo;     // cat_all: [N][(R+1)*32], else [N][32] = h^R
   int cat_all;
   SpgGruParams gru;
-  unsigned long long* gran; // [SPG_PX_MAX_ITERS][SPG_PX_MAX_NODES][32] granules
+  unsigned long long* gran; // [SPG_PX_MAX_GROUPS][SPG_PX_MAX_ITERS][SPG_PX_MAX_NODES][32] granules
   unsigned* ctl;            // {epoch base, workgroups done, error count, -}
+  SpgPxGroups groups;
   float* fsave;             // [N][R][3 quads][64 lanes][4] forward internals kept for the backward (training), or null
   unsigned* fsave_tag;      // set to a magic word by the persistent forward when fsave was written
 };
@@ -169,6 +179,7 @@ struct SpgEccPersistBwd {
   SpgGruParams gru;
   unsigned long long* gran;
   unsigned* ctl;
+  SpgPxGroups groups;
   const float* fsave;       // forward internals (see SpgEccPersistFwd) -- used when *fsave_tag carries the magic word
   const unsigned* fsave_tag;
 };

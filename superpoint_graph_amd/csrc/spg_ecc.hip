@@ -937,7 +937,9 @@ int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long row
 // wave that waits longer than SPG_PX_SPIN_LIMIT sweeps raises the error word of the control block (spg_ecc_persistent_errors)
 // and carries on, so a logic error can never hang the GPU.
 #define SPG_PX_MAX_ITERS 16
-#define SPG_PX_KMAX 12         // edges per node whose filters stay in registers (16 VGPRs each in matrix mode)
+#define SPG_PX_KMAX1 12        // edges per node whose filters stay in registers (16 VGPRs each in matrix mode), one workgroup per CU
+#define SPG_PX_KMAX2 6         // ... with two workgroups per CU (256 VGPRs per wave), forward
+#define SPG_PX_KMAX2B 2        // ... backward
 #define SPG_PX_CH 32           // edges gathered per pass (wave-private LDS staging)
 #define SPG_PX_SPIN_LIMIT 400000
 
@@ -1023,33 +1025,61 @@ __device__ __forceinline__ void spg_px_finish(unsigned* ctl, unsigned base, unsi
   }
 }
 
-template <bool MATRIX>
-__global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEccPersistFwd p) {
+__device__ __forceinline__ int spg_opaque_lane_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+// the cell's gate rows of a lane: a register copy (one workgroup per CU) or the LDS row pointers themselves
+template <bool REG> struct SpgPxRows { typedef GruRowsReg type; };
+template <> struct SpgPxRows<false> { typedef GruRowsLds type; };
+__device__ __forceinline__ void spg_px_rows_init(GruRowsReg& w, const GruRowsLds& l) { w.load(l); }
+__device__ __forceinline__ void spg_px_rows_init(GruRowsLds& w, const GruRowsLds& l) { w = l; }
+
+// KMAX: in-edges per node whose filters stay in registers; WPC: workgroups per CU (1: 512 VGPRs per wave -- 12 filters and the
+// cell's gate rows in registers; 2: 256 VGPRs -- 6 filters, gate rows read from the workgroup's LDS copy: twice the nodes per
+// round).  Rounds (p.groups): wave slot s = 4 * blockIdx.x + wave owns node ptr[g] + s of group g for the whole recurrence, then
+// of group g + 1, ...; a group is a union of whole connected components, so everything a node waits for belongs to its own
+// group, whose waves are all resident and at this group or beyond -- no deadlock.  Every group has its own granule region.
+template <bool MATRIX, int KMAX, int WPC, bool GROUPS>
+__global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const SpgEccPersistFwd p) {
   __shared__ float sw[(2 * 96 + 32) * SPG_WLD];
   __shared__ __attribute__((aligned(16))) float lds[4][3][32];
   __shared__ __attribute__((aligned(16))) float hsb[4][SPG_PX_CH * 32];
   __shared__ int idb[4][SPG_PX_CH];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + wave;
-  const bool active = i < p.g.N;
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = blockIdx.x * 4 + wave;
   spg_stage_cell_weights<96>(p.gru, sw);
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   GruRowsLds wr;
-  spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane, wr);
+  spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane0, wr);
   float* sa = lds[wave][0];
   float* sh = lds[wave][1];
   float* sx = lds[wave][2];
   float* hs = hsb[wave];
   int* ids = idb[wave];
-  int e0 = 0, deg = 0;
-  float invdeg = 0.f;
-  if (active) { e0 = p.g.rowptr[i]; deg = p.g.rowptr[i + 1] - e0; invdeg = p.g.invdeg[i]; }
-  // resident for all iterations: the filters of the first SPG_PX_KMAX in-edges
-  f32x4 wc[MATRIX ? SPG_PX_KMAX : 1][4];
-  float wv[SPG_PX_KMAX];
+  __syncthreads();            // the cell weights are in LDS; from here on the waves run on their own
+  if (p.fsave_tag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *p.fsave_tag = SPG_PX_SAVE_MAGIC;
+  using Rows = typename SpgPxRows<WPC == 1>::type;
+  Rows wq;                    // this lane's gate rows: in registers for all iterations (WPC == 1) or read from LDS
+  spg_px_rows_init(wq, wr);
+  // (GROUPS = false: one round -- the loop and everything it costs in registers is compiled away)
+  const int ngroups = GROUPS ? p.groups.n : 1;
+#pragma nounroll
+  for (int grp = 0; grp < ngroups; ++grp) {
+  // (an opaque zero: the per-lane address arithmetic of a group's body must not be hoisted out of the group loop -- it would
+  //  stay live across the whole body, in registers the resident filters need)
+  const int lane = lane0 + spg_opaque_lane_zero();
+  const int gbase = p.groups.ptr[grp];
+  const int i = gbase + slot;
+  if (i >= p.groups.ptr[grp + 1]) continue;
+  // this group's granule region, addressed with GLOBAL node ids
+  unsigned long long* gran = p.gran + ((long)grp * SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES - gbase) * 32;
+  spg_node_sync<true>();      // (the wave's LDS regions were last read by the previous group's final iteration)
+  const int e0 = p.g.rowptr[i], deg = p.g.rowptr[i + 1] - e0;
+  const float invdeg = p.g.invdeg[i];
+  // resident for all iterations: the filters of the first KMAX in-edges
+  f32x4 wc[MATRIX ? KMAX : 1][4];
+  float wv[KMAX];
   const int kb = lane >> 3;
 #pragma unroll
-  for (int u = 0; u < SPG_PX_KMAX; ++u) {
+  for (int u = 0; u < KMAX; ++u) {
     wv[u] = 0.f;
     if (u < deg) {
       if constexpr (MATRIX) {
@@ -1063,16 +1093,11 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEc
   }
   if (deg <= SPG_PX_CH && lane < deg) ids[lane] = p.g.src[e0 + lane];
   float hcur = 0.f;
-  if (active && lane < 32) {
+  if (lane < 32) {
     hcur = p.h0[(long)i * 32 + lane];
     p.states[(long)i * p.ldS + lane] = hcur;
     if (p.cat_all) p.out[(long)i * p.ldo + lane] = hcur;
   }
-  __syncthreads();            // the cell weights are in LDS; from here on the waves run on their own
-  if (p.fsave_tag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *p.fsave_tag = SPG_PX_SAVE_MAGIC;
-  if (!active) return;
-  GruRowsReg wq;              // this lane's gate rows, in registers for all iterations
-  wq.load(wr);
   for (int r = 0; r < p.R; ++r) {
     // ---- what depends on the node's own state only (input gate, W_hh h, its normalisation): BEFORE waiting for the neighbours ----
     if (lane < 32) sh[lane] = hcur;
@@ -1089,12 +1114,12 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEc
       }
       spg_node_sync<true>();
       if (r == 0) spg_px_gather_plain(p.h0, 32, ids, n, lane, hs);
-      else spg_px_gather_granules(p.gran + (long)r * SPG_PX_MAX_NODES * 32, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl);
+      else spg_px_gather_granules(gran + (long)r * SPG_PX_MAX_NODES * 32, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl);
       spg_node_sync<true>();
       if constexpr (MATRIX) {
         if (c0 == 0) {
 #pragma unroll
-          for (int u = 0; u < SPG_PX_KMAX; ++u) {
+          for (int u = 0; u < KMAX; ++u) {
             if (u < n) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
@@ -1105,7 +1130,7 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEc
             }
           }
         }
-        for (int u = (c0 == 0 ? SPG_PX_KMAX : 0); u < n; ++u) {      // beyond the register-resident filters: through L2
+        for (int u = (c0 == 0 ? KMAX : 0); u < n; ++u) {      // beyond the register-resident filters: through L2
           const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)(e0 + c0 + u) * 1024);
           f32x4 w[4];
 #pragma unroll
@@ -1120,10 +1145,10 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEc
       } else if (lane < 32) {
         if (c0 == 0) {
 #pragma unroll
-          for (int u = 0; u < SPG_PX_KMAX; ++u)
+          for (int u = 0; u < KMAX; ++u)
             if (u < n) a4[0] = fmaf(hs[u * 32 + lane], wv[u], a4[0]);
         }
-        for (int u = (c0 == 0 ? SPG_PX_KMAX : 0); u < n; ++u)
+        for (int u = (c0 == 0 ? KMAX : 0); u < n; ++u)
           a4[0] = fmaf(hs[u * 32 + lane], p.W[(long)(e0 + c0 + u) * 32 + lane], a4[0]);
       }
     }
@@ -1142,11 +1167,11 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEc
     }
     spg_node_sync<true>();
     // ---- the input half of the GRU ----
-    spg_gru_input_part<GruRowsReg, true>(p.gru, wq, sa, sx, lane, st);
+    spg_gru_input_part<Rows, true>(p.gru, wq, sa, sx, lane, st);
     if (lane < 32) {
       hcur = st.n + st.z * (hcur - st.n);      // hy = newgate + inputgate * (hidden - newgate), learning/modules.py:250
       // publish FIRST: the neighbours wait for this; everything the later kernels need follows behind it in the memory pipeline
-      if (r + 1 < p.R) spg_px_store_granule(p.gran + ((long)(r + 1) * SPG_PX_MAX_NODES + i) * 32 + lane, base + (unsigned)r + 2u, hcur);
+      if (r + 1 < p.R) spg_px_store_granule(gran + ((long)(r + 1) * SPG_PX_MAX_NODES + i) * 32 + lane, base + (unsigned)r + 2u, hcur);
       p.states[(long)i * p.ldS + (long)(r + 1) * 32 + lane] = hcur;
       if (p.cat_all) p.out[(long)i * p.ldo + (long)(r + 1) * 32 + lane] = hcur;
       else if (r + 1 == p.R) p.out[(long)i * p.ldo + lane] = hcur;
@@ -1155,20 +1180,20 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_fwd_kernel(const SpgEc
     if (p.fsave != nullptr) spg_px_save_state(reinterpret_cast<f32x4*>(p.fsave) + ((long)i * p.R + r) * (SPG_PX_SAVE_F / 4) * 64 + lane, st);
     spg_node_sync<true>();      // sa / sh / sx are rewritten by the next iteration
   }
+  }      // groups
   spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
 }
 
-template <bool MATRIX>
-__global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEccPersistBwd p) {
+template <bool MATRIX, int KMAX, int WPC, bool GROUPS>
+__global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const SpgEccPersistBwd p) {
   constexpr int GW = 96;
   __shared__ float sw[(2 * GW + 32) * SPG_WLD];
   __shared__ __attribute__((aligned(16))) float lds[4][4][GW];
   __shared__ __attribute__((aligned(16))) float hsb[4][SPG_PX_CH * 32];
   __shared__ int idb[4][SPG_PX_CH];
   __shared__ int eib[4][SPG_PX_CH];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = blockIdx.x * 4 + wave;
-  const bool active = j < p.g.N;
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = blockIdx.x * 4 + wave;
   spg_stage_cell_weights<GW>(p.gru, sw);
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float* sa = lds[wave][0];        // [32] aggregate   | later dgi [96]
@@ -1178,19 +1203,29 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
   float* hs = hsb[wave];
   int* ids = idb[wave];
   int* eis = eib[wave];
-  int b0 = 0, odeg = 0;
-  float invdeg = 0.f;
-  if (active) { b0 = p.g.rev_rowptr[j]; odeg = p.g.rev_rowptr[j + 1] - b0; invdeg = p.g.invdeg[j]; }
-  // out-edge list (edge id, destination) and the filters of the first SPG_PX_KMAX out-edges: resident for all iterations
+  __syncthreads();            // cell weights staged; the waves run on their own from here
+  // (GROUPS = false: one round -- the loop and everything it costs in registers is compiled away)
+  const int ngroups = GROUPS ? p.groups.n : 1;
+#pragma nounroll
+  for (int grp = 0; grp < ngroups; ++grp) {
+  const int lane = lane0 + spg_opaque_lane_zero();      // (see the forward kernel)
+  const int gbase = p.groups.ptr[grp];
+  const int j = gbase + slot;
+  if (j >= p.groups.ptr[grp + 1]) continue;
+  unsigned long long* gran = p.gran + ((long)grp * SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES - gbase) * 32;
+  spg_node_sync<true>();
+  const int b0 = p.g.rev_rowptr[j], odeg = p.g.rev_rowptr[j + 1] - b0;
+  const float invdeg = p.g.invdeg[j];
+  // out-edge list (edge id, destination) and the filters of the first KMAX out-edges: resident for all iterations
   if (odeg <= SPG_PX_CH && lane < odeg) {
     const int e = p.g.rev_eid[b0 + lane];
     eis[lane] = e; ids[lane] = p.g.dst[e];
   }
   spg_node_sync<true>();
-  f32x4 wc[MATRIX ? SPG_PX_KMAX : 1][4];
-  float wv[SPG_PX_KMAX];
+  f32x4 wc[MATRIX ? KMAX : 1][4];
+  float wv[KMAX];
 #pragma unroll
-  for (int u = 0; u < SPG_PX_KMAX; ++u) {
+  for (int u = 0; u < KMAX; ++u) {
     wv[u] = 0.f;
     if (u < odeg) {
       const int e = odeg <= SPG_PX_CH ? eis[u] : p.g.rev_eid[b0 + u];
@@ -1203,8 +1238,6 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
       }
     }
   }
-  __syncthreads();            // cell weights staged; the waves run on their own from here
-  if (!active) return;
   // slot R of the per-iteration gradient matrices has no producer, but the deferred weight-gradient GEMMs and column sums run
   // over all N * (R + 1) rows: zero it here (the per-iteration path clears the whole 20 MB region with a memset instead)
   {
@@ -1241,12 +1274,12 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
           if (lane < n) { const int e = p.g.rev_eid[b0 + c0 + lane]; eis[lane] = e; ids[lane] = p.g.dst[e]; }
         }
         spg_node_sync<true>();
-        spg_px_gather_granules(p.gran + (long)(r + 1) * SPG_PX_MAX_NODES * 32, base + (unsigned)(r + 1) + 1u, ids, n, lane, hs, p.ctl);
+        spg_px_gather_granules(gran + (long)(r + 1) * SPG_PX_MAX_NODES * 32, base + (unsigned)(r + 1) + 1u, ids, n, lane, hs, p.ctl);
         spg_node_sync<true>();
         if constexpr (MATRIX) {
           if (c0 == 0) {
 #pragma unroll
-            for (int u = 0; u < SPG_PX_KMAX; ++u) {
+            for (int u = 0; u < KMAX; ++u) {
               if (u < n) {
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(hs + u * 32 + 4 * (lane & 7));
 #pragma unroll
@@ -1255,7 +1288,7 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
               }
             }
           }
-          for (int u = (c0 == 0 ? SPG_PX_KMAX : 0); u < n; ++u) {
+          for (int u = (c0 == 0 ? KMAX : 0); u < n; ++u) {
             const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)eis[u] * 1024);
             f32x4 w[4];
 #pragma unroll
@@ -1267,10 +1300,10 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
         } else if (lane < 32) {
           if (c0 == 0) {
 #pragma unroll
-            for (int u = 0; u < SPG_PX_KMAX; ++u)
+            for (int u = 0; u < KMAX; ++u)
               if (u < n) acc = fmaf(wv[u], hs[u * 32 + lane], acc);
           }
-          for (int u = (c0 == 0 ? SPG_PX_KMAX : 0); u < n; ++u) acc = fmaf(p.W[(long)eis[u] * 32 + lane], hs[u * 32 + lane], acc);
+          for (int u = (c0 == 0 ? KMAX : 0); u < n; ++u) acc = fmaf(p.W[(long)eis[u] * 32 + lane], hs[u * 32 + lane], acc);
         }
       }
       if constexpr (MATRIX) {
@@ -1309,10 +1342,11 @@ __global__ __launch_bounds__(256, 1) void spg_ecc_persist_bwd_kernel(const SpgEc
     if (lane < 32) {
       dhdir = dh_acc;
       const float gc = da * invdeg;
-      spg_px_store_granule(p.gran + ((long)r * SPG_PX_MAX_NODES + j) * 32 + lane, base + (unsigned)r + 1u, gc);
+      spg_px_store_granule(gran + ((long)r * SPG_PX_MAX_NODES + j) * 32 + lane, base + (unsigned)r + 1u, gc);
       p.G[(long)j * p.ldS + (long)r * 32 + lane] = gc;
     }
   }
+  }      // groups
   spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
 }
 
@@ -1322,15 +1356,49 @@ static hipStream_t g_px_stream[SPG_MAX_DEVICES] = {nullptr};
 static bool g_px_stream_set[SPG_MAX_DEVICES] = {false};
 static std::mutex g_px_mutex;
 #define SPG_PX_CTL_BYTES 256
-static size_t px_bytes() { return SPG_PX_CTL_BYTES + (size_t)SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES * 32 * sizeof(unsigned long long); }
+static size_t px_bytes() {
+  return SPG_PX_CTL_BYTES + (size_t)SPG_PX_MAX_GROUPS * SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES * 32 * sizeof(unsigned long long);
+}
+
+// Rounds of a launch: consecutive parts (connected components / scenes) are packed greedily into groups of at most `cap` nodes
+bool spg_px_plan_groups(int N, int n_parts, const int* part_ptr, SpgPxGroups* out) {
+  const int cap = SPG_PX_MAX_NODES;
+  out->n = 0;
+  if (N <= 0) return false;
+  if (N <= cap) { out->n = 1; out->ptr[0] = 0; out->ptr[1] = N; return true; }      // one round, whatever the components
+  if (n_parts <= 0 || part_ptr == nullptr || part_ptr[0] != 0 || part_ptr[n_parts] != N) return false;      // components unknown
+  int start = 0;
+  out->ptr[0] = 0;
+  for (int k = 0; k < n_parts; ++k) {
+    const int a = part_ptr[k], b = part_ptr[k + 1];
+    if (b < a || b - a > cap) return false;
+    if (b - start > cap) {                // part k opens a new group
+      if (out->n + 1 >= SPG_PX_MAX_GROUPS) return false;
+      out->ptr[++out->n] = a;
+      start = a;
+    }
+  }
+  out->ptr[++out->n] = N;
+  return true;
+}
+
+// largest round of a plan -> workgroups per CU the launch needs (1: <= SPG_PX_WG_NODES nodes per round)
+static int px_max_group(const SpgPxGroups& g) {
+  int m = 0;
+  for (int k = 0; k < g.n; ++k) m = g.ptr[k + 1] - g.ptr[k] > m ? g.ptr[k + 1] - g.ptr[k] : m;
+  return m;
+}
 
 // returns the exchange buffer of the current device, or null when the persistent form must not be used for this launch
-static char* px_acquire(int N, int R, hipStream_t stream) {
-  if (spg_tune_get(SPG_TUNE_NO_PERSIST_ECC) || N > SPG_PX_MAX_NODES || R + 1 > SPG_PX_MAX_ITERS || R < 1) return nullptr;
+static char* px_acquire(const SpgPxGroups& groups, int R, hipStream_t stream) {
+  if (spg_tune_get(SPG_TUNE_NO_PERSIST_ECC) || groups.n < 1 || R + 1 > SPG_PX_MAX_ITERS || R < 1) return nullptr;
+  const int mg = px_max_group(groups);
+  if (mg > SPG_PX_MAX_NODES) return nullptr;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) return nullptr;
-  // every workgroup must be resident at once (the kernels run one 4-wave workgroup per CU): a few CUs of margin
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || spg_cdiv(N, 4) > cus - 4) return nullptr;
+  // every workgroup must be resident at once (one or two 4-wave workgroups per CU): a few CUs of margin
+  const int wpc = mg > SPG_PX_WG_NODES ? 2 : 1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || spg_cdiv(mg, 4) > wpc * (cus - 4)) return nullptr;
   std::lock_guard<std::mutex> lock(g_px_mutex);
   if (g_px_buf[dev] == nullptr) {
     void* b = nullptr;
@@ -1368,15 +1436,29 @@ extern "C" int spg_ecc_persistent_errors_clear(void) {
   return (int)ctl[2];
 }
 
+// KMAX of the variants: forward 12 / 6 register-resident filters (1 / 2 workgroups per CU); the backward's own working set is
+// larger (gate gradients, the kept forward internals): 12 / SPG_PX_KMAX2B
+template <bool MATRIX, bool GROUPS>
+static void px_launch_fwd(const SpgEccPersistFwd& p, int wpc, dim3 grid, hipStream_t stream) {
+  if (wpc == 1) hipLaunchKernelGGL((spg_ecc_persist_fwd_kernel<MATRIX, SPG_PX_KMAX1, 1, GROUPS>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((spg_ecc_persist_fwd_kernel<MATRIX, SPG_PX_KMAX2, 2, GROUPS>), grid, dim3(256), 0, stream, p);
+}
+template <bool MATRIX, bool GROUPS>
+static void px_launch_bwd(const SpgEccPersistBwd& p, int wpc, dim3 grid, hipStream_t stream) {
+  if (wpc == 1) hipLaunchKernelGGL((spg_ecc_persist_bwd_kernel<MATRIX, SPG_PX_KMAX1, 1, GROUPS>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((spg_ecc_persist_bwd_kernel<MATRIX, SPG_PX_KMAX2B, 2, GROUPS>), grid, dim3(256), 0, stream, p);
+}
+
 bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err) {
   *err = 0;
-  char* buf = px_acquire(p.g.N, p.R, stream);
+  char* buf = px_acquire(p.groups, p.R, stream);
   if (buf == nullptr) return false;
   p.ctl = (unsigned*)buf;
   p.gran = (unsigned long long*)(buf + SPG_PX_CTL_BYTES);
-  const dim3 grid(spg_cdiv(p.g.N, 4));
-  if (p.matrix) hipLaunchKernelGGL(spg_ecc_persist_fwd_kernel<true>, grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(spg_ecc_persist_fwd_kernel<false>, grid, dim3(256), 0, stream, p);
+  const int mg = px_max_group(p.groups), wpc = mg <= SPG_PX_WG_NODES ? 1 : 2;
+  const dim3 grid(spg_cdiv(mg, 4));
+  if (p.groups.n == 1) { if (p.matrix) px_launch_fwd<true, false>(p, wpc, grid, stream); else px_launch_fwd<false, false>(p, wpc, grid, stream); }
+  else { if (p.matrix) px_launch_fwd<true, true>(p, wpc, grid, stream); else px_launch_fwd<false, true>(p, wpc, grid, stream); }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { spg_set_error("persistent ECC forward launch failed: %s", hipGetErrorString(e)); *err = (int)e; }
   return true;
@@ -1384,13 +1466,14 @@ bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err
 
 bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err) {
   *err = 0;
-  char* buf = px_acquire(p.g.N, p.R, stream);
+  char* buf = px_acquire(p.groups, p.R, stream);
   if (buf == nullptr) return false;
   p.ctl = (unsigned*)buf;
   p.gran = (unsigned long long*)(buf + SPG_PX_CTL_BYTES);
-  const dim3 grid(spg_cdiv(p.g.N, 4));
-  if (p.matrix) hipLaunchKernelGGL(spg_ecc_persist_bwd_kernel<true>, grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(spg_ecc_persist_bwd_kernel<false>, grid, dim3(256), 0, stream, p);
+  const int mg = px_max_group(p.groups), wpc = mg <= SPG_PX_WG_NODES ? 1 : 2;
+  const dim3 grid(spg_cdiv(mg, 4));
+  if (p.groups.n == 1) { if (p.matrix) px_launch_bwd<true, false>(p, wpc, grid, stream); else px_launch_bwd<false, false>(p, wpc, grid, stream); }
+  else { if (p.matrix) px_launch_bwd<true, true>(p, wpc, grid, stream); else px_launch_bwd<false, true>(p, wpc, grid, stream); }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { spg_set_error("persistent ECC backward launch failed: %s", hipGetErrorString(e)); *err = (int)e; }
   return true;

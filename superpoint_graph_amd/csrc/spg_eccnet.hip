@@ -47,6 +47,8 @@ struct Plan {
   bool training = false;
   std::vector<FLayer> F;
   bool fold = false;            // train mode: the BatchNorm statistics travel as fixed-point slots from producer to consumer GEMM
+  bool px = false;              // the persistent (one launch for all iterations) GRU recurrence is applicable: rounds in `groups`
+  SpgPxGroups groups;
   SpgGruParams gru;
   float *states = nullptr, *agg = nullptr, *stat = nullptr, *stat_cnt = nullptr;
   float* cells = nullptr;       // LSTM cell states c^r, laid out like `states`
@@ -110,7 +112,8 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
   // persistent GRU recurrence in training: the forward keeps the cell's internals of every (node, iteration) for the backward
   // (12 x 64 floats each: 31 MB per 1000 nodes x 10 iterations) instead of the backward recomputing them on its critical path
   pl.fsave = nullptr; pl.fsave_tag = nullptr;
-  if (!pl.lstm && pl.training && N <= SPG_PX_MAX_NODES) {
+  pl.px = !pl.lstm && c.n_parts >= 0 && c.n_parts <= SPG_MAX_PARTS && spg_px_plan_groups(N, c.n_parts, c.part_ptr, &pl.groups);
+  if (pl.px && pl.training) {
     pl.fsave_tag = cv.take<unsigned>(64);
     pl.fsave = cv.take<float>((size_t)N * pl.R * SPG_PX_SAVE_F * 64);
   }
@@ -256,8 +259,9 @@ static void fnet_forward_stages(const Plan& pl0, const float* edgefeats, int bn_
 static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float* h0, float* out, hipStream_t st) {
   const int N = pl.N, E = pl.E;
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
-  if (!pl.lstm) {      // GRU, <= 1024 nodes: all iterations in one dataflow-synchronised launch (spg_ecc.hip)
+  if (pl.px) {      // GRU: all iterations in one dataflow-synchronised launch, whole scenes in rounds of <= 2048 nodes (spg_ecc.hip)
     SpgEccPersistFwd q; memset(&q, 0, sizeof(q));
+    q.groups = pl.groups;
     q.g = gr; q.W = pl.F.back().y; q.matrix = pl.cfg.matrix; q.R = pl.R; q.h0 = h0;
     q.states = pl.states; q.ldS = pl.ldS; q.agg = pl.training ? pl.agg : nullptr;
     q.out = out; q.cat_all = pl.cfg.cat_all; q.ldo = pl.cfg.cat_all ? pl.ldS : 32; q.gru = pl.gru;
@@ -482,8 +486,9 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
   const long ldS = pl.ldS, ld96 = (long)(R + 1) * GW;
   // ---- back-propagation through the R iterations ----
   bool persistent = false;
-  if (!pl.lstm) {      // GRU, <= 1024 nodes: one dataflow-synchronised launch for all iterations (spg_ecc.hip)
+  if (pl.px) {      // GRU: one dataflow-synchronised launch for all iterations (spg_ecc.hip)
     SpgEccPersistBwd q; memset(&q, 0, sizeof(q));
+    q.groups = pl.groups;
     q.g = gr; q.W = pl.F.back().y; q.matrix = pl.cfg.matrix; q.R = R; q.cat_all = pl.cfg.cat_all;
     q.grad_out = grad_out; q.ldgo = pl.cfg.cat_all ? ldS : 32;
     q.states = pl.states; q.ldS = ldS; q.agg = pl.agg; q.G = s.G;

@@ -96,15 +96,15 @@ class FusedStep:
                           nout=int(ecc_cfg.nc * (ecc_cfg.nrepeats + 1) if ecc_cfg.cat_all else ecc_cfg.nc))
         return self._plan
 
-    def _buffers(self, plan, B, N, E, dev):
+    def _buffers(self, plan, B, N, E, dev, ecc_cfg):
         """Workspaces and activations of one step, re-used from step to step while the sizes stay the same (one stream: the
         next step overwrites them only after this one has consumed them)."""
-        key = (B, N, E, dev)
+        key = (B, N, E, dev, tuple(ecc_cfg.part_ptr[:ecc_cfg.n_parts + 1]) if ecc_cfg.n_parts > 0 else ())
         b = self._bufs.get(key)
         if b is not None:
             return b
         L = _lib.lib()
-        pc, ec = ctypes.byref(plan['ptn_cfg']), ctypes.byref(plan['ecc_cfg'])
+        pc, ec = ctypes.byref(plan['ptn_cfg']), ctypes.byref(ecc_cfg)
         nf, nout, C = plan['nf'], plan['nout'], self.fc.out_features
         u8 = lambda n: torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -151,7 +151,8 @@ class FusedStep:
         if plan['ecc_cfg'].bnidx >= 0 and E == 1:
             raise ValueError('Expected more than 1 value per channel when training (filter-network BatchNorm over one edge)')
         target = ops._req(target.contiguous(), torch.int64, 'target')
-        b = self._buffers(plan, B, N, E, dev)
+        ecc_cfg, _ = conv._cfg_for(gc_info, N)              # (+ the batch's scene boundaries for graphs above one round)
+        b = self._buffers(plan, B, N, E, dev, ecc_cfg)
         C = fc.out_features
         logits = torch.empty(N, C, dtype=torch.float32, device=dev)
         loss_buf = torch.empty(N + 2, dtype=torch.float32, device=dev)
@@ -170,7 +171,7 @@ class FusedStep:
         a.N, a.nf = N, plan['nf']
         a.slot_of_row, a.idx_valid = slot_of_row.data_ptr(), idx_valid.data_ptr()
         a.desc, a.grad_desc = b['desc'].data_ptr(), b['grad_desc'].data_ptr()
-        a.ecc_cfg, a.E, a.graph_ws = ctypes.pointer(plan['ecc_cfg']), E, graph.ws.data_ptr()
+        a.ecc_cfg, a.E, a.graph_ws = ctypes.pointer(ecc_cfg), E, graph.ws.data_ptr()
         a.edgefeats = edgefeats.data_ptr() if E else None
         a.ecc_params, a.ecc_grads = plan['ecc_params'], plan['ecc_grads']
         a.ecc_ws, a.ecc_bwd_ws = b['ecc_ws'].data_ptr(), b['ecc_bwd_ws'].data_ptr()

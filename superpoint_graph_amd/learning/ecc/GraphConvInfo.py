@@ -27,6 +27,7 @@ class GraphConvInfo(object):
         self._degrees_gpu = None
         self._edgefeats = None
         self._edge_indexes = None
+        self._parts = None          # node offsets of the batch's graphs (scenes), when the batch was built from graphs
         self._graph = None          # superpoint_graph_amd.ops.DeviceGraph after .cuda()
         if len(args) > 0 or len(kwargs) > 0:
             self.set_batch(*args, **kwargs)
@@ -35,6 +36,7 @@ class GraphConvInfo(object):
         """graphs: igraph-like objects (get_edgelist(), es[...], es.attributes(), indegree(), vcount())."""
         graphs = graphs if isinstance(graphs, (list, tuple)) else [graphs]
         p = 0
+        parts = [0]
         idxn, degrees, edge_indexes = [], [], []
         edgeattrs = defaultdict(list)
         for G in graphs:
@@ -47,6 +49,8 @@ class GraphConvInfo(object):
             degrees += G.indegree(G.vs, loops=True)
             edge_indexes.append(np.asarray(p + E[idx]))
             p += G.vcount()
+            parts.append(p)
+        self._parts = parts         # node offsets of the batch's graphs: [parts[k], parts[k+1]) is closed under edges
         self._edgefeats, self._idxe = edge_feat_func(edgeattrs)
         self._idxn = torch.LongTensor(np.concatenate(idxn))
         if self._idxe is not None:
@@ -66,6 +70,7 @@ class GraphConvInfo(object):
         graphs = graphs if isinstance(graphs, (list, tuple)) else [graphs]
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
         p, edges = 0, []
+        parts = [0]
         edgeattrs = defaultdict(list)
         for G in graphs:
             E = getattr(G, '_edges', None)
@@ -76,6 +81,8 @@ class GraphConvInfo(object):
                 # per-graph [E_g, width] arrays when the graph offers them (SuperpointGraph), else igraph's value lists
                 edgeattrs[a].append(fast(a) if fast is not None else np.asarray(G.es.get_attribute_values(a)))
             p += G.vcount()
+            parts.append(p)
+        self._parts = parts
         edgeattrs = {a: _concat_edge_attribute(v) for a, v in edgeattrs.items()}
         edges_h = np.concatenate(edges) if edges else np.zeros((0, 2), dtype=np.int64)
         if edges_h.size and (int(edges_h.min()) < 0 or int(edges_h.max()) >= p):
@@ -102,10 +109,12 @@ class GraphConvInfo(object):
         self._graph = ops.DeviceGraph(self._idxn, self._degrees_gpu)
 
     @classmethod
-    def from_buffers(cls, idxn, degs, edgefeats, idxe=None, edge_indexes=None):
-        """Build directly from already-batched buffers (synthetic scenes, tests)."""
+    def from_buffers(cls, idxn, degs, edgefeats, idxe=None, edge_indexes=None, parts=None):
+        """Build directly from already-batched buffers (synthetic scenes, tests).  parts: node offsets [0, n_0, n_0 + n_1, ...] of
+        the batch's graphs, if known (lets the one-launch GRU recurrence serve batches above 2048 nodes scene by scene)."""
         gi = cls()
         gi._idxn, gi._degrees, gi._edgefeats, gi._idxe, gi._edge_indexes = idxn, degs, edgefeats, idxe, edge_indexes
+        gi._parts = None if parts is None else [int(v) for v in parts]
         return gi
 
     def _validate(self):

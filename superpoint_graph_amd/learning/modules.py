@@ -174,7 +174,7 @@ def _fnet_groups(fnet):
 class _EccRnnFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, hx, edgefeats, graph, training, *flat_params):
-        cfg, groups = module._cfg_and_groups()
+        cfg, groups = module._cfg_for(module._gci, graph.N)
         out, state = ops.eccrnn_forward(cfg, graph, hx.contiguous(), edgefeats, groups, training, 1)
         ctx.module, ctx.state, ctx.groups, ctx.nflat = module, state, groups, len(flat_params)
         return out
@@ -236,6 +236,28 @@ class RNNGraphConvModule(nn.Module):
                            None if b is None else b.running_mean, None if b is None else b.running_var))
         groups.append(self._cell.param_tensors())
         return cfg, groups
+
+    def _cfg_for(self, gci, n_nodes):
+        """(cfg, groups) of this batch: the cached configuration, with the batch's scene boundaries attached when the graph is
+        too large for one round of the one-launch GRU recurrence (include/spg_hip.h: spg_eccrnn_cfg.n_parts) -- whole scenes are
+        then processed in rounds instead of one launch per iteration.  A copy per distinct partition: the configuration object of
+        a forward travels with its saved state to the backward."""
+        cfg, groups = self._cfg_and_groups()
+        parts = getattr(gci, '_parts', None)
+        if parts is None or n_nodes <= 2048 or len(parts) - 1 > ops._lib.SPG_MAX_PARTS or len(parts) < 3:
+            return cfg, groups
+        key = tuple(parts)
+        cache = self.__dict__.setdefault('_cfg_parts_cache', {})
+        c2 = cache.get(key)
+        if c2 is None:
+            c2 = type(cfg).from_buffer_copy(cfg)
+            c2.n_parts = len(parts) - 1
+            for i, v in enumerate(parts):
+                c2.part_ptr[i] = int(v)
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            cache[key] = c2
+        return c2, groups
 
     def _build_cfg_and_modules(self):
         fg, bnidx = _fnet_groups(self._fnet)

@@ -98,3 +98,58 @@ def test_persistent_recurrence_eval_mode_and_above_the_node_limit(hip):
                 hip.spg_tune(8, old)
         assert torch.equal(outs[0], outs[1])
     assert hip.spg_ecc_persistent_errors() == 0
+
+
+def _multi_scene(sizes, edges_per_node, seed):
+    """A batch of disjoint scenes (no edge crosses a scene boundary), edges sorted by target: (idxn, degs, parts)."""
+    rng = np.random.default_rng(seed)
+    src, tgt, off, parts = [], [], 0, [0]
+    for n in sizes:
+        e = int(n * edges_per_node)
+        t = rng.integers(0, n, size=e); s_ = rng.integers(0, n, size=e)
+        if n > 200:
+            t[:40] = 7                     # a hub above the register-resident filters and one gather pass
+        src.append(s_ + off); tgt.append(t + off)
+        off += n
+        parts.append(off)
+    src, tgt = np.concatenate(src), np.concatenate(tgt)
+    order = np.argsort(tgt, kind='stable')
+    return torch.from_numpy(src[order].astype(np.int64)), torch.from_numpy(np.bincount(tgt, minlength=off).astype(np.int64)), parts
+
+
+@pytest.mark.parametrize('config,sizes', [('gru_10_0,f_13', [1000, 1000]),                 # 2 scenes: one round, two workgroups per CU
+                                          ('gru_10_0,f_13', [1000] * 5),                   # 3 rounds of <= 2048 nodes
+                                          ('gru_4_1,f_8', [700, 900, 300, 1200, 50]),      # vector filters, ragged scenes
+                                          ('gru_3_0_1_1_0,f_5', [400, 300, 200, 100])])    # 1000 nodes in 4 scenes: still one round
+def test_persistent_recurrence_multi_scene_batches(hip, config, sizes):
+    """Batches of several scenes: up to 2048 nodes run as ONE round with two workgroups per CU, larger batches
+    in rounds of whole scenes (the scene boundaries travel in spg_eccrnn_cfg.n_parts) -- bit-identical to the per-iteration
+    launches, forward, input gradient and every parameter gradient; the time-out counter stays 0."""
+    from superpoint_graph_amd.learning import ecc, graphnet
+    idxn, degs, parts = _multi_scene(sizes, 5, seed=sum(sizes))
+    n, e = int(degs.numel()), int(idxn.numel())
+    edgefeats = torch.randn(e, 13, generator=torch.Generator().manual_seed(1))
+    x = torch.randn(n, 32, generator=torch.Generator().manual_seed(2)).to(DEV)
+    torch.manual_seed(7)
+    net = graphnet.GraphNetwork(config, 32, [13, 32, 128, 64], 1, 0, 2, 30000, use_pyg=0, cuda=1).to(DEV).train()
+    gi = ecc.GraphConvInfo.from_buffers(idxn.clone(), degs.clone(), edgefeats.clone(), None, None, parts=parts)
+    with torch.no_grad():
+        net.set_info([gi], 1)
+        width = net(x).shape[1]
+    go = torch.randn(n, width, generator=torch.Generator().manual_seed(3)).to(DEV)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    ref = _run(net, gi, x, go, legacy=True)
+    for rep in range(3):
+        net.load_state_dict(state0)
+        got = _run(net, gi, x, go, legacy=False)
+        assert torch.equal(got[0], ref[0]), f'forward differs (repetition {rep})'
+        assert torch.equal(got[1], ref[1]), f'input gradient differs (repetition {rep})'
+        for k in ref[2]:
+            assert torch.equal(got[2][k], ref[2][k]), f'{k} differs (repetition {rep})'
+    assert hip.spg_ecc_persistent_errors() == 0
+    # without the scene boundaries a graph above one round takes the per-iteration launches: same results
+    if n > 2048:
+        gi2 = ecc.GraphConvInfo.from_buffers(idxn.clone(), degs.clone(), edgefeats.clone(), None, None)
+        net.load_state_dict(state0)
+        got = _run(net, gi2, x, go, legacy=False)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
