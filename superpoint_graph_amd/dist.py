@@ -83,6 +83,25 @@ def shard_scenes(n_scenes: int, rank: int, world: int):
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
+def balanced_shards(costs, world: int):
+    """Scene positions of EVERY rank for one global batch whose scenes cost `costs` (superpoints per scene): the same scene
+    COUNTS as shard_scenes (ceil / floor of n / world -- memory and the per-rank BatchNorm batch stay comparable), but which
+    scene goes where is chosen greedily, largest first, to the least-loaded rank that still has a free slot (LPT).  A step takes
+    as long as its slowest rank (bench.py: max over ranks), real scenes differ several-fold in size, and contiguous blocks
+    leave that to chance.  Deterministic (ties by position), so every rank computes the same assignment without communication.
+    -> list of `world` lists of positions into `costs`."""
+    n = len(costs)
+    base, rem = divmod(n, world)
+    slots = [base + (1 if r < rem else 0) for r in range(world)]
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for pos in sorted(range(n), key=lambda i: (-float(costs[i]), i)):
+        r = min((r for r in range(world) if len(out[r]) < slots[r]), key=lambda r: (load[r], r))
+        out[r].append(pos)
+        load[r] += float(costs[pos])
+    return [sorted(o) for o in out]
+
+
 class GradBucket:
     """One flat fp32 buffer for all gradients (+1 slot for the loss weight), reused every step."""
 

@@ -225,8 +225,11 @@ class _ShardedBatches(torch.utils.data.Sampler):
     the same on every rank --, cut into global batches of `batch_size` scenes (incomplete last one dropped, as the
     reference's drop_last=True), and the rank keeps its contiguous shard of every batch (dist.shard_scenes)."""
 
-    def __init__(self, n, batch_size, rank, world, seed, shuffle):
+    def __init__(self, n, batch_size, rank, world, seed, shuffle, costs=None):
         self.n, self.bs, self.rank, self.world, self.seed, self.shuffle, self.epoch = n, batch_size, rank, world, seed, shuffle, 0
+        # superpoints per scene (if the dataset knows them): the scenes of a global batch are then dealt to the ranks by size
+        # (dist.balanced_shards) instead of in contiguous blocks -- a step lasts as long as its slowest rank
+        self.costs = None if costs is None or len(costs) != n else [float(c) for c in costs]
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -240,7 +243,11 @@ class _ShardedBatches(torch.utils.data.Sampler):
         full = self.n // self.bs if self.shuffle else (self.n + self.bs - 1) // self.bs
         for b in range(full):
             chunk = order[b * self.bs:(b + 1) * self.bs]
-            yield [chunk[i] for i in shard_scenes(len(chunk), self.rank, self.world)]
+            if self.costs is not None:
+                from ..dist import balanced_shards
+                yield [chunk[i] for i in balanced_shards([self.costs[j] for j in chunk], self.world)[self.rank]]
+            else:
+                yield [chunk[i] for i in shard_scenes(len(chunk), self.rank, self.world)]
 
     def __iter__(self):
         return self._batches()
@@ -339,7 +346,7 @@ class Session:
             return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=shard, num_workers=nw)
         if self.dp:
             if train:
-                sampler = _ShardedBatches(len(dataset), a.batch_size, self.rank, self.world, a.seed, True)
+                sampler = _ShardedBatches(len(dataset), a.batch_size, self.rank, self.world, a.seed, True, costs=self._scene_costs(dataset))
                 sampler.set_epoch(self._epoch)
                 return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=collate, num_workers=nw)
             own = list(range(self.rank, len(dataset), self.world))              # evaluation: scenes dealt round-robin
@@ -348,6 +355,16 @@ class Session:
             return torch.utils.data.DataLoader(dataset, batch_size=a.batch_size, collate_fn=collate, num_workers=nw,
                                                shuffle=True, drop_last=True)
         return torch.utils.data.DataLoader(dataset, batch_size=1, collate_fn=collate, num_workers=nw)
+
+    def _scene_costs(self, dataset):
+        """Superpoints per training scene as the loader will deliver it (the graphs are read up front, learning/spg.py:67-106;
+        `--spg_augm_hardcutoff` caps the sampled sub-graph), or None when the dataset's elements are not graphs."""
+        try:
+            cut = getattr(self.args, 'spg_augm_hardcutoff', 0)
+            sizes = [int(g.vcount()) for g in dataset.list]
+            return [min(v, cut) if cut and cut > 0 else v for v in sizes]
+        except Exception:
+            return None
 
     def _forward(self, targets, GIs, clouds_data):
         self.model.ecc.set_info(GIs, self.args.cuda)

@@ -152,3 +152,25 @@ def test_flat_parameters_keeps_state_dict():
         arena.flat.add_(1.0)                                 # the module parameters are views of the arena
     for k, v in model.state_dict().items():
         assert torch.allclose(v, sd0[k] + 1.0)
+
+
+def test_balanced_shards_deal_scenes_by_size():
+    """dist.balanced_shards: same scene counts per rank as the contiguous blocks, every scene exactly once,
+    identical on every rank (deterministic), and the slowest rank's load never above the contiguous assignment's on skewed
+    sizes; equal sizes reproduce a valid partition."""
+    import numpy as np
+    from superpoint_graph_amd.dist import balanced_shards, shard_scenes
+    rng = np.random.default_rng(0)
+    for n, world in ((8, 8), (16, 8), (10, 4), (7, 2), (3, 4)):
+        costs = np.clip(rng.lognormal(np.log(900.0), 0.8, n), 50, 6000)
+        shards = balanced_shards(list(costs), world)
+        assert shards == balanced_shards(list(costs), world)
+        assert sorted(i for s in shards for i in s) == list(range(n))
+        assert [len(s) for s in shards] == [len(shard_scenes(n, r, world)) for r in range(world)]
+        worst = max(sum(costs[i] for i in s) for s in shards)
+        contiguous = max(sum(costs[i] for i in shard_scenes(n, r, world)) for r in range(world))
+        assert worst <= contiguous + 1e-9
+    assert sorted(i for s in balanced_shards([5.0] * 6, 3) for i in s) == list(range(6))
+    # two scenes per rank, sizes 1..8: LPT pairs large with small
+    sh = balanced_shards([1, 2, 3, 4, 5, 6, 7, 8], 4)
+    assert max(sum([1, 2, 3, 4, 5, 6, 7, 8][i] for i in s) for s in sh) == 9

@@ -329,3 +329,40 @@ def test_batchnorm_option_checks(hip):
     net.__dict__.pop('_cfg_cache', None)
     with pytest.raises(ValueError, match='more than 1 value per channel'):
         net(x[:1], d[:1])
+
+
+def test_graph_conv_module_matrix_and_vector_filters(hip):
+    """ecc.GraphConvModule (reference learning/ecc/GraphConvModule.py:156-193: the non-recurrent ECC layer with its own
+    filter-generating network) through the generic HIP operator: out[i] = mean over the in-edges e = (j -> i) of x[j] @ W_e
+    (matrix filters) resp. x[j] * w_e (vector filters), forward and gradients wrt the input and the filter network, against
+    plain torch on the CPU."""
+    from superpoint_graph_amd.learning import ecc
+    rng = np.random.default_rng(4)
+    n, e = 40, 170
+    tgt = np.sort(rng.integers(0, n, e)); src = rng.integers(0, n, e)
+    idxn, degs = torch.from_numpy(src.astype(np.int64)), torch.from_numpy(np.bincount(tgt, minlength=n).astype(np.int64))
+    ef = torch.randn(e, 13, generator=torch.Generator().manual_seed(1))
+    x = torch.randn(n, 8, generator=torch.Generator().manual_seed(2))
+    go = torch.randn(n, 5, generator=torch.Generator().manual_seed(3))
+    for cin, cout, wout in ((8, 5, 40), (5, 5, 5)):
+        torch.manual_seed(9)
+        fnet = torch.nn.Linear(13, wout)
+        xi = x[:, :cin].clone()
+        # reference on the CPU
+        fr = torch.nn.Linear(13, wout); fr.load_state_dict(fnet.state_dict())
+        xr = xi.clone().requires_grad_(True)
+        w = fr(ef)
+        msg = torch.bmm(xr[idxn].unsqueeze(1), w.view(e, cin, cout)).squeeze(1) if wout == cin * cout else xr[idxn] * w
+        out_r = torch.zeros(n, cout).index_add(0, torch.from_numpy(tgt.astype(np.int64)), msg) / degs.clamp(min=1).unsqueeze(1).float()
+        out_r.backward(go[:, :cout])
+        # the module on the GPU
+        mod = ecc.GraphConvModule(cin, cout, fnet.to(DEV))
+        gi = ecc.GraphConvInfo.from_buffers(idxn.clone(), degs.clone(), ef.clone())
+        gi.cuda()
+        mod.set_info(gi)
+        xg = xi.to(DEV).requires_grad_(True)
+        out = mod(xg)
+        out.backward(go[:, :cout].to(DEV))
+        assert maxrel(out, out_r) < 1e-5
+        assert maxrel(xg.grad, xr.grad) < 1e-5
+        assert maxrel(fnet.weight.grad, fr.weight.grad) < 1e-5 and maxrel(fnet.bias.grad, fr.bias.grad) < 1e-5
