@@ -5,7 +5,7 @@
 # over the steady-state window (tools/prof_summary.py), (3)+(4) --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes
 # (never with other trace domains), each followed by the known-byte-count calibration of tools/pmc_calib.py.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -13,34 +13,45 @@ cd /tmp && export TMPDIR=/tmp
 STEPS="--no-cpu-baseline --no-forward-only --no-trainer-window --no-roofline --no-extras"
 db() { find $1 -name '*.db' | head -1; }
 
-timeout 600 python $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-tail -c 2000 $OUT/${TAG}_bench.json
+timeout 900 python $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+tail -c 1500 $OUT/${TAG}_bench.err
+python - <<EOF2
+import json
+d = json.load(open('$OUT/${TAG}_bench.json'))
+print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline frac', d['roofline']['frac'], 'hbm_frac', d['roofline'].get('hbm_frac'))
+EOF2
 
-# the opt-in precision modes: separate lines, same box, same session (they never replace the f32 headline)
-for P in bf16x3 bf16; do
-  timeout 300 python $ROOT/bench.py --precision $P --no-cpu-baseline --no-trainer-window --no-forward-only --no-live-pmc > $OUT/${TAG}_bench_$P.json 2>> $OUT/${TAG}_bench.err
-done
-timeout 300 python $ROOT/bench.py --precision bf16x3 --no-cpu-baseline --no-trainer-window --no-forward-only --no-live-pmc --n-sp 10000 --n-edges 50000 --n-feat 11 --model-config gru_10,f_8 > $OUT/${TAG}_bench_sema3d_bf16x3.json 2>> $OUT/${TAG}_bench.err
-timeout 300 python $ROOT/bench.py --precision f32 --no-cpu-baseline --no-trainer-window --no-forward-only --no-live-pmc --n-sp 10000 --n-edges 50000 --n-feat 11 --model-config gru_10,f_8 > $OUT/${TAG}_bench_sema3d_f32.json 2>> $OUT/${TAG}_bench.err
-timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_trace_x3 -- python $ROOT/bench.py --precision bf16x3 --steps 20 --warmup 5 $STEPS > /dev/null 2> $OUT/${TAG}_trace_x3.err
-python $ROOT/tools/prof_summary.py $(db /tmp/p_trace_x3) 70 > $OUT/${TAG}_kernel_stats_bf16x3.txt
+# the module-level path (no spg_train_step) and the ungrouped launches on the same box: what the round's changes are worth
+for V in "--fused-step 0 --tune 11:1" "--fused-step 0" "--fused-step 1"; do
+  timeout 300 python $ROOT/bench.py --steps 40 --warmup 10 $STEPS $V 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('[$V]', round(d['ms_per_step'],4), 'min', round(d['ms_per_step_min'],4), 'median', round(d['ms_per_step_median'],4))"
+done > $OUT/${TAG}_ab_step_paths.txt
+cat $OUT/${TAG}_ab_step_paths.txt
 
 timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_trace -- python $ROOT/bench.py --steps 20 --warmup 5 $STEPS > /dev/null 2> $OUT/${TAG}_trace.err
 python $ROOT/tools/prof_summary.py $(db /tmp/p_trace) 70 > $OUT/${TAG}_kernel_stats.txt
+python $ROOT/tools/prof_timeline.py $(db /tmp/p_trace) 25 > $OUT/${TAG}_timeline.txt
 head -5 $OUT/${TAG}_kernel_stats.txt
+for S in 2 8; do
+  timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_trace_s$S -- python $ROOT/bench.py --scenes $S --steps 10 --warmup 4 $STEPS > /dev/null 2>> $OUT/${TAG}_trace.err
+  python $ROOT/tools/prof_summary.py $(db /tmp/p_trace_s$S) 40 > $OUT/${TAG}_kernel_stats_scenes$S.txt
+done
+timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p_trace_x3 -- python $ROOT/bench.py --precision bf16x3 --n-sp 10000 --n-edges 50000 --n-feat 11 --model-config gru_10,f_8 --steps 8 --warmup 3 $STEPS > /dev/null 2>> $OUT/${TAG}_trace.err
+python $ROOT/tools/prof_summary.py $(db /tmp/p_trace_x3) 40 > $OUT/${TAG}_kernel_stats_sema3d_bf16x3.txt
 
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format rocpd -d /tmp/p_$C -- python $ROOT/bench.py --steps 4 --warmup 2 $STEPS > /dev/null 2> $OUT/${TAG}_pmc_$C.err
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format rocpd -d /tmp/c_$C -- python $ROOT/tools/pmc_calib.py 1024 > /dev/null 2>> $OUT/${TAG}_pmc_$C.err
-  python $ROOT/tools/pmc_summary.py $(db /tmp/p_$C) 20 > $OUT/${TAG}_pmc_$(echo $C | tr A-Z a-z).txt
+  python $ROOT/tools/pmc_summary.py $(db /tmp/p_$C) 24 > $OUT/${TAG}_pmc_$(echo $C | tr A-Z a-z).txt
   python $ROOT/tools/pmc_summary.py $(db /tmp/c_$C) 0 > $OUT/${TAG}_pmc_calib_$(echo $C | tr A-Z a-z).txt
 done
 python $ROOT/tools/pmc_traffic.py $(db /tmp/p_FETCH_SIZE) $(db /tmp/p_WRITE_SIZE) $(db /tmp/c_FETCH_SIZE) $(db /tmp/c_WRITE_SIZE) 1024 > $OUT/${TAG}_gemm_traffic.json
-head -c 1500 $OUT/${TAG}_gemm_traffic.json
+head -c 800 $OUT/${TAG}_gemm_traffic.json
 
-# MFMA utilisation evidence: SQ counters of the same command (own pass, no other trace domains), f32 and split-bf16
-for P in f32 bf16x3; do
-  timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
-    --output-format rocpd -d /tmp/p_sq_$P -- python $ROOT/bench.py --precision $P --steps 4 --warmup 2 $STEPS > /dev/null 2> $OUT/${TAG}_pmc_sq_$P.err
-  python $ROOT/tools/pmc_summary.py $(db /tmp/p_sq_$P) 20 > $OUT/${TAG}_pmc_sq_counters_$P.txt
-done
+# MFMA utilisation evidence: SQ counters of the same command (own pass, no other trace domains)
+timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+  --output-format rocpd -d /tmp/p_sq_f32 -- python $ROOT/bench.py --steps 4 --warmup 2 $STEPS > /dev/null 2> $OUT/${TAG}_pmc_sq_f32.err
+python $ROOT/tools/pmc_summary.py $(db /tmp/p_sq_f32) 24 > $OUT/${TAG}_pmc_sq_counters_f32.txt
+# host enqueue time of a step, module path and spg_train_step
+timeout 300 python $ROOT/tools/host_time.py 2>&1 | grep -v "^ \|^$\|function calls\|Ordered\|List reduced\|ncalls" > $OUT/${TAG}_host_enqueue.txt
+cat $OUT/${TAG}_host_enqueue.txt
