@@ -287,7 +287,8 @@ class Session:
             self.arena = FlatParameters(model, lazy_zero=True, host_counters=True)
             self.arena.attach_optimizer(optimizer)    # the Adam moments live in `optimizer.state` (checkpoint format kept)
         self.fused = None
-        if self.arena is not None and getattr(args, 'fused_step', 1) and args.cuda:
+        # (not with synchronised BatchNorm: its all-reduce callbacks sit between producer and consumer launches -- the module path)
+        if self.arena is not None and getattr(args, 'fused_step', 1) and args.cuda and not getattr(args, 'sync_bn', 0):
             from .. import fused
             if fused.supports(model):
                 self.fused = fused.FusedStep(model, self.arena, class_weights=dbinfo['class_weights'],

@@ -25,20 +25,30 @@ def main():
     clouds_d, diam_d, label = clouds.to(dev), diam.to(dev), targets[:, 0].to(dev)
     model.ecc.set_info(GIs, 1)
     emb_er = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
-    arena = FlatParameters(model)
+    fused = len(sys.argv) > 2 and sys.argv[2] == 'fused'       # the step as ONE library call (spg_train_step), as bench.py / the CLI run it
+    arena = FlatParameters(model, lazy_zero=fused, host_counters=fused)
+    fstep = None
+    if fused:
+        from superpoint_graph_amd.fused import FusedStep
+        fstep = FusedStep(model, arena)
+        print('step: spg_train_step')
     losses = []
     for it in range(301):
         arena.zero_grad()
-        out = model.ecc(emb_er.run(model, None, flag, clouds_d, diam_d))
-        loss = F.cross_entropy(out, label)
-        loss.backward()
-        emb_er.bw_hook()
+        if fused:
+            loss, out = fstep(flag, clouds_d, diam_d, GIs[0], label)
+        else:
+            out = model.ecc(emb_er.run(model, None, flag, clouds_d, diam_d))
+            loss = F.cross_entropy(out, label)
+            loss.backward()
+            emb_er.bw_hook()
         arena.adam_step(lr=1e-3, weight_decay=0.0, grad_clip=1.0)
         if it % 50 == 0:
             acc = float((out.argmax(1) == label)[label >= 0].float().mean())
             losses.append(float(loss))
             print(f'step {it:4d}  loss {float(loss):.4f}  train accuracy {acc:.3f}', flush=True)
     assert losses[-1] < 0.7 * losses[0], losses
+    assert _lib.lib().spg_ecc_persistent_errors() == 0
     print('ok: loss decreased')
 
 
