@@ -152,7 +152,8 @@ struct SpgEccPersistFwd {
   SpgGraph g;
   const float* W;
   int matrix, R;
-  const float* h0;          // [N, 32]
+  const float* h0;          // [N, 32]; with h0_rows: row i = h0[h0_rows[i]] (a zero row where < 0): the embedding scatter in place
+  const int64_t* h0_rows;   // [N] or null
   float* states; long ldS;  // [N][(R+1)*32]: h^0 .. h^R (kept for the backward)
   float* agg;               // [N][(R+1)*32] aggregates per iteration, or null (inference)
   float* out; long ldo;     // cat_all: [N][(R+1)*32], else [N][32] = h^R
@@ -175,7 +176,8 @@ struct SpgEccPersistBwd {
   float* G;                 // [N][(R+1)*32]: gradient wrt the aggregate of iteration r (already / deg), slot r
   float* dgi; float* dgh; float* dui; float* duh; long ld96;    // [N][(R+1)*96]
   float* dpre; float* xg; long ld32;                            // [N][(R+1)*32]
-  float* gx;                // [N, 32] gradient wrt h^0
+  float* gx;                // [N, 32] gradient wrt h^0; with gx_rows: node j writes row gx_rows[j] (none where < 0)
+  const int64_t* gx_rows;   // [N] or null
   SpgGruParams gru;
   unsigned long long* gran;
   unsigned* ctl;
@@ -188,3 +190,15 @@ struct SpgEccPersistBwd {
 // the exchange buffer): the caller then runs the per-iteration launches; *err != 0: the launch itself failed
 bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err);
 bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err);
+
+// spg_train_step: CloudEmbedder's scatter of the embeddings to all superpoints (learning/pointnet.py:177-179) and the gather of
+// their gradients, fused into the one-launch recurrence (it reads row slot_of_row[i] of `emb`, a zero row where < 0, and writes
+// the gradient of node j to row slot_of_row[j] of grad_emb); the per-iteration fallback materialises desc / gathers grad_desc
+struct SpgEccScatter {
+  const float* emb;               // [B, 32]
+  const int64_t* slot_of_row;     // [N]
+  const int64_t* idx_valid;       // [B]
+  float* desc;                    // [N, 32] (fallback only)
+  float* grad_emb;                // [B, 32]
+  int B;
+};

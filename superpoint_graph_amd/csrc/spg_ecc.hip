@@ -954,14 +954,19 @@ __device__ __forceinline__ void spg_px_store_granule(unsigned long long* g, unsi
 // One wave gathers the 32-float vectors of `n` (<= SPG_PX_CH) peers into hs[u][0..31]: lanes 0..31 take even, lanes 32..63 odd
 // list positions.  Plain form (rows of a finished matrix, leading dimension ld) or granule form (tags must equal `tag`;
 // swept until they do).  ids: wave-private LDS list of the peers' node indices.
-__device__ __forceinline__ void spg_px_gather_plain(const float* __restrict__ X, long ld, const int* ids, int n, int lane, float* hs) {
+// rowidx (optional): row i of X is X[rowidx[i]], a ZERO row where rowidx[i] < 0 -- the embedding scatter of CloudEmbedder
+// (learning/pointnet.py:177-179) read in place instead of through a materialised descriptor matrix
+__device__ __forceinline__ void spg_px_gather_plain(const float* __restrict__ X, long ld, const int* ids, int n, int lane, float* hs,
+                                                    const int64_t* __restrict__ rowidx = nullptr) {
   const int half = lane >> 5, c = lane & 31;
   for (int p = 0; p < n; p += 8) {
     float v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int u = p + 2 * k + half;
-      v[k] = X[(long)ids[u < n ? u : 0] * ld + c];
+      long row = ids[u < n ? u : 0];
+      if (rowidx != nullptr) row = rowidx[row];
+      v[k] = row >= 0 ? X[row * ld + c] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1094,7 +1099,8 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   if (deg <= SPG_PX_CH && lane < deg) ids[lane] = p.g.src[e0 + lane];
   float hcur = 0.f;
   if (lane < 32) {
-    hcur = p.h0[(long)i * 32 + lane];
+    const long hrow = p.h0_rows != nullptr ? p.h0_rows[i] : (long)i;
+    hcur = hrow >= 0 ? p.h0[hrow * 32 + lane] : 0.f;
     p.states[(long)i * p.ldS + lane] = hcur;
     if (p.cat_all) p.out[(long)i * p.ldo + lane] = hcur;
   }
@@ -1113,7 +1119,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
         if (lane < n) ids[lane] = p.g.src[e0 + c0 + lane];
       }
       spg_node_sync<true>();
-      if (r == 0) spg_px_gather_plain(p.h0, 32, ids, n, lane, hs);
+      if (r == 0) spg_px_gather_plain(p.h0, 32, ids, n, lane, hs, p.h0_rows);
       else spg_px_gather_granules(gran + (long)r * SPG_PX_MAX_NODES * 32, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl);
       spg_node_sync<true>();
       if constexpr (MATRIX) {
@@ -1324,7 +1330,10 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
       }
     }
     if (r < 0) {
-      if (lane < 32) p.gx[(long)j * 32 + lane] = dH;
+      if (lane < 32) {
+        const long grow = p.gx_rows != nullptr ? p.gx_rows[j] : (long)j;      // (< 0: a node without an embedding -- nobody reads its gradient)
+        if (grow >= 0) p.gx[grow * 32 + lane] = dH;
+      }
       break;
     }
     // ---- phase 2: GRU recompute + backward of iteration r ----

@@ -256,18 +256,25 @@ static void fnet_forward_stages(const Plan& pl0, const float* edgefeats, int bn_
   }
 }
 
-static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float* h0, float* out, hipStream_t st) {
+static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float* h0, float* out, hipStream_t st,
+                                    const SpgEccScatter* sc) {
   const int N = pl.N, E = pl.E;
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
+  const int64_t* h0_rows = nullptr;
+  if (sc != nullptr) { h0 = sc->emb; h0_rows = sc->slot_of_row; }      // the embedding scatter read in place (persistent launch)
   if (pl.px) {      // GRU: all iterations in one dataflow-synchronised launch, whole scenes in rounds of <= 2048 nodes (spg_ecc.hip)
     SpgEccPersistFwd q; memset(&q, 0, sizeof(q));
     q.groups = pl.groups;
-    q.g = gr; q.W = pl.F.back().y; q.matrix = pl.cfg.matrix; q.R = pl.R; q.h0 = h0;
+    q.g = gr; q.W = pl.F.back().y; q.matrix = pl.cfg.matrix; q.R = pl.R; q.h0 = h0; q.h0_rows = h0_rows;
     q.states = pl.states; q.ldS = pl.ldS; q.agg = pl.training ? pl.agg : nullptr;
     q.out = out; q.cat_all = pl.cfg.cat_all; q.ldo = pl.cfg.cat_all ? pl.ldS : 32; q.gru = pl.gru;
     q.fsave = pl.fsave; q.fsave_tag = pl.fsave_tag;
     int err = 0;
     if (spg_launch_ecc_persist_fwd(q, st, &err)) return err;
+  }
+  if (sc != nullptr) {      // per-iteration launches read a materialised descriptor matrix
+    SPG_TRY(spg_gather_rows(sc->emb, 32, sc->slot_of_row, N, 32, sc->desc, 32, (void*)st));
+    h0 = sc->desc;
   }
   if (pl.fsave_tag != nullptr) SPG_TRY(zero_async(pl.fsave_tag, sizeof(unsigned), st));      // per-iteration path: nothing was kept
   SPG_TRY(spg_launch_copy2d(h0, 32, pl.states, pl.ldS, N, 32, st));
@@ -289,8 +296,8 @@ static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float*
 // the caller's next grouped launches; phase 2: the recurrent part only (the caller has drained the riders)
 int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0, const float* edgefeats,
                              const void* const* params, float* out, void* workspace, int training, int bn_update_times, void* stream,
-                             int phase) {
-  SPG_CHECK_ARG(graph_ws && params && workspace && (phase == 1 || (h0 && out)), "null pointer");
+                             int phase, const SpgEccScatter* sc) {
+  SPG_CHECK_ARG(graph_ws && params && workspace && (phase == 1 || ((h0 || sc) && out)), "null pointer");
   SPG_CHECK_ARG(E == 0 || edgefeats != nullptr, "edgefeats");
   hipStream_t st = (hipStream_t)stream;
   Plan pl;
@@ -313,13 +320,13 @@ int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void
     }
   }
   if (phase == 1) return 0;
-  return eccrnn_recurrent_forward(pl, graph_ws, h0, out, st);
+  return eccrnn_recurrent_forward(pl, graph_ws, h0, out, st, sc);
 }
 
 extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0,
                                   const float* edgefeats, const void* const* params, float* out, void* workspace,
                                   int training, int bn_update_times, void* stream) {
-  return spg_eccrnn_forward_phase(cfg, N, E, graph_ws, h0, edgefeats, params, out, workspace, training, bn_update_times, stream, 0);
+  return spg_eccrnn_forward_phase(cfg, N, E, graph_ws, h0, edgefeats, params, out, workspace, training, bn_update_times, stream, 0, nullptr);
 }
 
 extern "C" long spg_eccrnn_debug_offset(const spg_eccrnn_cfg* cfg, int N, int E, int training, int layer, int what) {
@@ -355,10 +362,12 @@ struct BwdCtx {
 // the tail of the backward: {cell parameter gradients + per-edge filter gradient}, then one stage per filter-network layer
 // ({weight gradient, bias column sums, data gradient}: mutually independent), then the hand-over of the split partials
 void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage>& out) {
-  out.push_back([c](hipStream_t st) -> int {
+  // the recurrent cell's parameter gradients: three weight gradients + three bias column sums over all (node, iteration) rows.
+  // A LEAF -- nothing in the chain below depends on them -- so they do not sit in front of the filter network's chain: they
+  // leave with the stage of filter layer n-2 (their ~2000 small workgroups next to that layer's few)
+  auto cell_grads = [c](hipStream_t st) -> int {
     Plan& pl = c->pl; BwdScratch& s = c->s;
     const int R = pl.R, GW = pl.GW, rows = pl.N * (R + 1);
-    const long ldS = pl.ldS;
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = op_ident(s.dgi, GW); w.b = op_ident(s.xg, 32); w.M = rows; w.N = GW; w.K = 32;
     SPG_TRY(spg_queue_wgrad(c->rq2, w, pl.cell_grads[0], st));
@@ -375,6 +384,15 @@ void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage
       SPG_TRY(spg_queue_wgrad(c->rq2, w, pl.cell_grads[4], st));
       SPG_TRY(spg_queue_colsum(c->rq2, s.dpre, 32, rows, 32, pl.cell_grads[5], st));
     }
+    return 0;
+  };
+  const int nF = (int)c->pl.F.size();
+  const int leaf_with = c->pl.E > 0 && nF >= 2 ? nF - 2 : -1;      // the filter-layer stage the cell gradients travel with (-1: the first stage)
+  out.push_back([c, cell_grads, leaf_with](hipStream_t st) -> int {
+    Plan& pl = c->pl; BwdScratch& s = c->s;
+    const int R = pl.R;
+    const long ldS = pl.ldS;
+    if (leaf_with < 0) SPG_TRY(cell_grads(st));
     if (pl.E == 0) {   // no edges: the filter network received no gradient
       for (FLayer& l : pl.F) {
         SPG_TRY(spg_group_zero(l.dW, (size_t)l.cin * l.cout, st));
@@ -384,16 +402,17 @@ void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage
       }
       return 0;
     }
-    // per-edge filter gradients (sum over the iterations)
+    // per-edge filter gradients (sum over the iterations): the head of the filter network's chain
     SPG_TRY(spg_launch_ecc_edge_wgrad(c->gr, pl.cfg.matrix, pl.states, ldS, s.G, ldS, R, s.dWts, st));
     c->cur = op_ident(s.dWts, pl.nout);
     return 0;
   });
   for (int i = (int)c->pl.F.size() - 1; i >= 0 && c->pl.E > 0; --i) {
-    out.push_back([c, i](hipStream_t st) -> int {
+    out.push_back([c, i, cell_grads, leaf_with](hipStream_t st) -> int {
       Plan& pl = c->pl; BwdScratch& s = c->s;
       const int E = pl.E;
       FLayer& l = pl.F[i];
+      if (i == leaf_with) SPG_TRY(cell_grads(st));
       const SpgOperand cur = c->cur;
       const SpgBnFoldBwd fold_i = c->pending;
       memset(&c->pending, 0, sizeof(c->pending));
@@ -459,7 +478,7 @@ void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage
 // call spg_riders_drain + spg_flush_deferred_reduce before the gradients are consumed or the workspaces released
 int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
                               const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
-                              void* workspace, void* bwd_workspace, void* stream, int phase) {
+                              void* workspace, void* bwd_workspace, void* stream, int phase, const SpgEccScatter* sc) {
   SPG_CHECK_ARG(graph_ws && params && grad_out && grad_h0 && grads && workspace && bwd_workspace, "null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (phase == 0) spg_reduce_deferred_clear();      // (nothing may be left over from a call that failed half-way)
@@ -494,6 +513,7 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
     q.states = pl.states; q.ldS = ldS; q.agg = pl.agg; q.G = s.G;
     q.dgi = s.dgi; q.dgh = s.dgh; q.dui = s.dui; q.duh = s.duh; q.ld96 = ld96;
     q.dpre = s.dpre; q.xg = s.xg; q.ld32 = ldS; q.gx = grad_h0; q.gru = pl.gru;
+    if (sc != nullptr) { q.gx = sc->grad_emb; q.gx_rows = sc->slot_of_row; }      // the gradient gather written in place
     q.fsave = pl.fsave; q.fsave_tag = pl.fsave_tag;
     int err = 0;
     persistent = spg_launch_ecc_persist_bwd(q, st, &err);      // writes every row of [G .. xg] itself (slot R: zeros)
@@ -525,6 +545,8 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
     p.gru = pl.gru; p.cell = pl.cfg.cell;
     SPG_TRY(spg_launch_ecc_step_bwd(p, st));
   }
+  if (sc != nullptr && !persistent)       // per-iteration launches wrote grad_h0 [N, 32]: gather the embeddable rows
+    SPG_TRY(spg_gather_rows(grad_h0, 32, sc->idx_valid, sc->B, 32, sc->grad_emb, 32, stream));
   // ---- the tail: nothing below depends on it, it depends on nothing but the recurrence's outputs ----
   std::vector<SpgStage> stages;
   eccrnn_backward_tail_stages(c, stages);
@@ -543,5 +565,5 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
 extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
                                    const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
                                    void* workspace, void* bwd_workspace, void* stream) {
-  return spg_eccrnn_backward_phase(cfg, N, E, graph_ws, edgefeats, params, grad_out, grad_h0, grads, workspace, bwd_workspace, stream, 0);
+  return spg_eccrnn_backward_phase(cfg, N, E, graph_ws, edgefeats, params, grad_out, grad_h0, grads, workspace, bwd_workspace, stream, 0, nullptr);
 }

@@ -17,10 +17,10 @@
 
 int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0, const float* edgefeats,
                              const void* const* params, float* out, void* workspace, int training, int bn_update_times, void* stream,
-                             int phase);
+                             int phase, const SpgEccScatter* sc);
 int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
                               const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
-                              void* workspace, void* bwd_workspace, void* stream, int phase);
+                              void* workspace, void* bwd_workspace, void* stream, int phase, const SpgEccScatter* sc);
 int spg_linear_backward_deferred(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K, float* dX,
                                  long lddx, float* dW, float* dbias, float* work, hipStream_t st);
 
@@ -46,12 +46,14 @@ extern "C" int spg_train_step(const spg_step_args* a, void* stream) {
   spg_reduce_deferred_clear();
   // ---------------- forward ----------------
   // the filter network's layers travel with PointNet's few-row launches
-  SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, N, E, a->graph_ws, nullptr, a->edgefeats, a->ecc_params, nullptr, a->ecc_ws, 1, 1, stream, 1));
+  SpgEccScatter sc;
+  sc.emb = a->emb; sc.slot_of_row = a->slot_of_row; sc.idx_valid = a->idx_valid; sc.desc = a->desc; sc.grad_emb = a->grad_emb; sc.B = B;
+  SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, N, E, a->graph_ws, nullptr, a->edgefeats, a->ecc_params, nullptr, a->ecc_ws, 1, 1, stream, 1, nullptr));
   SPG_TRY(spg_pointnet_forward_ext(a->ptn_cfg, B, a->clouds, a->clouds_global, nullptr, a->ptn_params, a->emb, a->ptn_ws, 1,
                                    a->bn_update_times, stream));
   SPG_TRY(spg_riders_drain(st));
-  SPG_TRY(spg_gather_rows(a->emb, a->nf, a->slot_of_row, N, a->nf, a->desc, a->nf, stream));
-  SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, N, E, a->graph_ws, a->desc, a->edgefeats, a->ecc_params, a->ecc_out, a->ecc_ws, 1, 1, stream, 2));
+  // (the embedding scatter is read in place by the one-launch recurrence; its per-iteration fallback materialises a->desc)
+  SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, N, E, a->graph_ws, nullptr, a->edgefeats, a->ecc_params, a->ecc_out, a->ecc_ws, 1, 1, stream, 2, &sc));
   SPG_TRY(spg_linear_fwd(a->ecc_out, a->nout, N, a->nout, a->cls_W, a->cls_b, a->n_classes, nullptr, nullptr, 0, a->logits, a->n_classes, stream));
   SPG_TRY(spg_cross_entropy_fwd_bwd(a->logits, a->target, a->class_weight, N, a->n_classes, a->ignore_index, a->reduction_mean,
                                     a->loss_buf + N, a->loss_buf, a->loss_buf + N + 1, a->grad_logits, stream));
@@ -60,8 +62,7 @@ extern "C" int spg_train_step(const spg_step_args* a, void* stream) {
                                        a->grad_ecc_out, a->nout, a->cls_dW, a->cls_db, a->cls_work, st));
   // through the recurrence; its tail rides with PointNet's backward
   SPG_TRY(spg_eccrnn_backward_phase(a->ecc_cfg, N, E, a->graph_ws, a->edgefeats, a->ecc_params, a->grad_ecc_out, a->grad_desc, a->ecc_grads,
-                                    a->ecc_ws, a->ecc_bwd_ws, stream, 1));
-  SPG_TRY(spg_gather_rows(a->grad_desc, a->nf, a->idx_valid, B, a->nf, a->grad_emb, a->nf, stream));
+                                    a->ecc_ws, a->ecc_bwd_ws, stream, 1, &sc));
   SPG_TRY(spg_pointnet_backward_ext(a->ptn_cfg, B, a->clouds, a->clouds_global, nullptr, a->ptn_params, a->grad_emb, a->ptn_grads, nullptr,
                                     nullptr, a->ptn_ws, a->ptn_bwd_ws, stream));
   SPG_TRY(spg_riders_drain(st));

@@ -185,5 +185,12 @@ class FusedStep:
         a.ignore_index, a.reduction_mean, a.loss_buf = self.ignore_index, int(self.mean), loss_buf.data_ptr()
         _lib.check(_lib.lib().spg_train_step(ctypes.byref(a), ops._stream()), 'spg_train_step')
         self.normaliser = loss_buf[N + 1:N + 2]       # sum of the labelled rows' class weights (data-parallel loss weight w_r)
-        self.embeddings = b['desc']                   # [N, nf] descriptors of this step (overwritten by the next one)
+        self._emb, self._slot = b['emb'], slot_of_row   # (the descriptors are read in place by the recurrence: see `embeddings`)
         return loss_buf[N], logits
+
+    @property
+    def embeddings(self):
+        """[N, nf] superpoint descriptors of the last step (CloudEmbedder.run's return value: PointNet embeddings scattered to all
+        superpoints, zero rows for the too-small ones) -- built on request: the step itself never materialises them when the
+        one-launch recurrence reads the scatter in place."""
+        return ops.gather_rows(self._emb, self._slot)
