@@ -429,6 +429,8 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * per layer (the pre-round-3 path, still used with synchronised BatchNorm) instead of fixed-point slots finished by the
  * consuming GEMM.  key 11: 1 = no grouped launches (round 4: mutually independent few-row GEMMs / small reductions leave as
  * jobs of ONE kernel; the bodies are unchanged, results bit-identical -- A/B timing and the equality test).
+ * key 12: 1 = few-row GEMMs with a reduction of >= 128 run in the split-K form (a 32 x 32 tile per workgroup, the four waves
+ * split the reduction chunks; an experiment: measured no faster, off by default).
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* ------------------------------------------------------------------------------------------------

@@ -176,6 +176,10 @@ constexpr int spg_gemm_variant(bool wred, int amode, bool full) {
 // A group is launched with the light build unless one of its jobs is a heavy variant (register counts of the stand-alone
 // instantiations, -Rpass-analysis=kernel-resource-usage).
 constexpr bool spg_gemm_variant_light(int v) { return v != 8; }      // 8 = data gradient, BNBWD prologue, full tiles: 144 VGPRs
+// split-K few-row bodies spg_fewrow_sk_body<WRED, AMODE>: ids 10 .. 13
+constexpr int spg_gemm_sk_variant(bool wred, int amode) {
+  return amode == SPG_PRO_IDENT ? (wred ? 12 : 10) : ((!wred && amode == SPG_PRO_AFFINE) ? 11 : ((wred && amode == SPG_PRO_BNBWD) ? 13 : -1));
+}
 // weight-gradient bodies the group can run (the shapes the few-row layers of the S3DIS / Semantic3D configurations produce)
 //   X(id, IT, JT, WI, WJ, AMODE, BMODE, FULL, COLSUM, LIGHT)
 #define SPG_WGRAD_VARIANTS(X)                                                                                    \
@@ -1105,6 +1109,95 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// few-row GEMM with the REDUCTION split over the four waves (round 4)
+// ---------------------------------------------------------------------------------------------
+// The FC layers over superpoints / edges (M = 1000 ... 5000 rows) are dependent chains of launches whose length is the length
+// of ONE workgroup's reduction: with the 32 x 128 tile above every wave owns 32 output columns and walks ALL K / 32 chunks
+// (~0.75 us each: 16 MFMAs + LDS staging + a barrier) -- PointNet's 257 -> 256 layer 9 chunks, the classifier 11, the filter
+// network's last data gradient (K = 1024) 32: a 24 us launch for 0.6 GFLOP.  Here a workgroup owns a 32 x 32 output tile and its
+// four waves split the CHUNKS (wave w takes chunks w, w + 4, ...): the chain is 4x shorter and there are 4x as many workgroups
+// (N / 32 column tiles); no LDS staging and no barrier in the loop -- a lane loads its MFMA operands straight from global memory
+// (lane (r, h) owns row r / output column r and the 16 reduction indices 16h .. 16h + 15 of the chunk: four 16-byte loads per
+// operand) and applies the operand prologue in registers; the four partial accumulators are summed through LDS in wave order
+// (deterministic) and wave 0 runs the ordinary tile epilogue.  For K >= 128 (below that the waves would idle).
+// AN EXPERIMENT, off by default (spg_tune key 12 = 1 enables it): see launch_gemm_shape.
+template <bool WRED, int AMODE>
+__device__ __forceinline__ void spg_fewrow_sk_body(const SpgGemmParams& p, const int bx, const int by) {
+  extern __shared__ f32x4 smem[];
+  float* red = reinterpret_cast<float*>(smem);        // [3][16][64] partial accumulators of waves 1..3
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  if constexpr (!WRED) {
+    if (p.fold.slots != nullptr) spg_bn_fold_fwd(p.fold, bx == 0 && by == 0);
+  } else {
+    if (p.fold_bwd.slots != nullptr) spg_bn_fold_bwd(p.fold_bwd, false);
+  }
+  const long m0 = (long)bx * 32;
+  const int mvalid = (int)min(32L, (long)p.M - m0);
+  const int n0 = by * 32;
+  const bool rowok = r < mvalid;
+  const long row = m0 + (rowok ? r : 0);
+  const int col = n0 + r;
+  const bool colok = col < p.N;
+  const int colc = colok ? col : 0;
+  const int K = p.K, nchunk = (K + SPG_KC - 1) / SPG_KC;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  for (int c = wave; c < nchunk; c += 4) {
+    const int k0 = c * SPG_KC + 16 * h;
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + 4 * q;
+      const bool kin = k < K;                      // (a quad is addressable up to the next multiple of 4 of K: padded leading dimensions)
+      const int kc = kin ? k : 0;
+      const SpgQuad qc = spg_quad_consts<AMODE>(p.a, kc, K);
+      SpgRaw raw;
+      spg_load_raw1<AMODE>(p.a, row, kc, qc.nvalid, raw);
+      a[q] = spg_finish_raw<AMODE>(qc, raw, rowok && kin);
+      if constexpr (!WRED) {                       // weights [N, K]: this lane's output column, four consecutive reduction indices
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.W + (long)colc * p.ldw + kc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[q][e] = (kin && k + e < K) ? w[e] : 0.f;
+      } else {                                     // weights [K, N] untransposed: one element per reduction index
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = k + e < K;
+          const float w = p.W[(long)(ok ? k + e : 0) * p.ldw + colc];
+          b[q][e] = ok ? w : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b[q][e], acc, 0, 0, 0);
+  }
+  // ---- the four waves' partial sums, in wave order ----
+  if (wave != 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[((wave - 1) * 16 + q) * 64 + lane] = acc[q];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] += red[(w * 16 + q) * 64 + lane];
+  f32x16 accs[1][1];
+  accs[0][0] = acc;
+  spg_tile_epilogue<32, 32, 1, 1, WRED, false, false>(p, accs, red, bx, m0, mvalid, n0);
+}
+
+template <bool WRED, int AMODE>
+__global__ __launch_bounds__(SPG_THREADS) void spg_fewrow_sk_kernel(const SpgGemmParams p) {
+  spg_fewrow_sk_body<WRED, AMODE>(p, (int)blockIdx.x, (int)blockIdx.y);
+}
+#define SPG_SK_MIN_K 128
+#define SPG_SK_LDS (3 * 16 * 64 * sizeof(float))
+
 // ---- weights for the bf16 MFMA modes: split (hi = bf16(w), lo = bf16(w - hi)) and, for the data gradient, transposed ----
 __global__ __launch_bounds__(256) void spg_split_weights_kernel(const SpgSplitBatch b) {
   const SpgSplitJob j = b.jobs[blockIdx.y];
@@ -1257,8 +1350,35 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
   return 0;
 }
 
+// few rows, long reduction: the split-K form (spg_fewrow_sk_body) -- stand-alone or as a job of the open group
+template <bool WRED, int AMODE>
+static int launch_fewrow_sk(const SpgGemmParams& p, hipStream_t stream, int* stat_parts) {
+  const dim3 grid(spg_gemm_ntiles(p), spg_cdiv(p.N, 32));
+  if (stat_parts != nullptr) *stat_parts = (int)grid.x;
+  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  const bool grouped = spg_group_accepts(stream);
+  ProfScope prof(stream, flops, SPG_PROF_TAG(1, 32, 32, WRED ? 1 : 0, AMODE, 0), !grouped);
+  prof.r.M = p.M; prof.r.N = p.N; prof.r.K = p.K;
+  auto direct = [p, grid, stream]() -> int {
+    hipLaunchKernelGGL((spg_fewrow_sk_kernel<WRED, AMODE>), grid, dim3(SPG_THREADS), SPG_SK_LDS, stream, p);
+    SPG_LAUNCH_CHECK();
+    return 0;
+  };
+  if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_sk_variant(WRED, AMODE), &p, sizeof(p), grid, SPG_SK_LDS, flops, stream,
+                               2 + 2 * spg_cdiv(spg_cdiv(p.K, SPG_KC), 4), direct))
+    return 0;
+  return direct();
+}
+
 template <bool WRED, int AMODE>
 static int launch_gemm_shape(const SpgGemmParams& p, hipStream_t stream, int* sp) {
+  if constexpr (AMODE == SPG_PRO_IDENT || (!WRED && AMODE == SPG_PRO_AFFINE) || (WRED && AMODE == SPG_PRO_BNBWD)) {
+    // OPT-IN (spg_tune key 12): measured no faster than the 32 x 128 kernel on the step (1.404 vs 1.401 ms, same box,
+    // profiles/r04_splitk_experiment.txt) -- a link of an FC chain is dispatch + statistics fold + first loads + epilogue; the
+    // chunk loop this form shortens is the smaller part, and without operand prefetch its chunks pay the memory latency each
+    if (spg_tune_get(SPG_TUNE_SPLITK) && p.rows_per_tile == SPG_FC_ROWS && p.K >= SPG_SK_MIN_K && p.pool_out == nullptr)
+      return launch_fewrow_sk<WRED, AMODE>(p, stream, sp);
+  }
   if (p.rows_per_tile <= 32) return launch_gemm_t<32, 128, 1, 4, WRED, AMODE>(p, stream, sp);   // few rows (FC layers, filter net)
   if (p.N <= 32) return launch_gemm_t<128, 32, 4, 1, WRED, AMODE>(p, stream, sp);
   if (p.N <= 64) return launch_gemm_t<128, 64, 2, 2, WRED, AMODE>(p, stream, sp);
@@ -2482,6 +2602,10 @@ __device__ __forceinline__ void spg_multi_body() {
       case 7: spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_BNBWD, false>(SPG_P(SpgGemmParams), bx, by); break;
       case 8: if constexpr (HEAVY) spg_rowgemm_body<32, 128, 1, 4, true, SPG_PRO_BNBWD, true>(SPG_P(SpgGemmParams), bx, by); break;
       case 9: spg_rowgemm_body<32, 128, 1, 4, true, -1, false>(SPG_P(SpgGemmParams), bx, by); break;
+      case 10: spg_fewrow_sk_body<false, SPG_PRO_IDENT>(SPG_P(SpgGemmParams), bx, by); break;
+      case 11: spg_fewrow_sk_body<false, SPG_PRO_AFFINE>(SPG_P(SpgGemmParams), bx, by); break;
+      case 12: spg_fewrow_sk_body<true, SPG_PRO_IDENT>(SPG_P(SpgGemmParams), bx, by); break;
+      case 13: spg_fewrow_sk_body<true, SPG_PRO_BNBWD>(SPG_P(SpgGemmParams), bx, by); break;
       default: break;
     }
   } else if (h.kind == SPG_JOB_WGRAD) {
