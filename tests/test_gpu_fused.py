@@ -120,3 +120,34 @@ def test_fused_step_refuses_what_it_does_not_serve(hip):
     assert not supports(other)
     with pytest.raises(NotImplementedError):
         FusedStep(other, arena)
+
+
+def test_fused_step_edge_less_batch_and_refusals(hip):
+    """A training batch WITHOUT superedges (sub-sampled graphs may lose all edges, learning/spg.py:150-167): no filter network
+    launches, zero aggregates, the filter network's gradients are exact zeros -- bit-identical to the module path; a batch with
+    a single embeddable superpoint is refused like torch's BatchNorm refuses one row per channel."""
+    from oracle import spg_oracle as O
+    from superpoint_graph_amd import synth
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep
+    from superpoint_graph_amd.learning import ecc
+    spec = O.ModelSpec()
+    col = synth.collate_numpy([synth.scene(3, n_sp=40, n_edges=0)])
+    idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef).reshape(0, 13), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    assert batch['idxn'].numel() == 0
+    torch.manual_seed(1)
+    state0 = {k: v.clone() for k, v in build_model(spec).state_dict().items()}
+    _compare(spec, state0, batch, None, 'mean', nsteps=2)
+    model = build_model(spec, state0).to(DEV).train()
+    arena = FlatParameters(model, lazy_zero=True)
+    step = FusedStep(model, arena)
+    flag = batch['clouds_flag'].clone()
+    flag[1:] = -1                                    # one embeddable superpoint left
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+    arena.zero_grad()
+    with pytest.raises(ValueError, match='more than 1 value per channel'):
+        step(flag, batch['clouds'][:1], batch['clouds_global'][:1], gi, batch['label_mode'].to(DEV))
