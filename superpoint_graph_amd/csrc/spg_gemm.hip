@@ -1337,15 +1337,20 @@ static int launch_gemm_t(const SpgGemmParams& p, hipStream_t stream, int* stat_p
     }
   }
   prof.r.tag = SPG_PROF_TAG(1, IT, JT, WRED ? 1 : 0, AMODE, 0);
+  // The masked pipelines too (a reduction that is no multiple of 32 -- the first convolution's 14 / 11 input channels --, a ragged
+  // last row tile): forward tiles that ARE complete leave through the vector store (dwordx4 row segments staged through LDS)
+  // instead of 16 dword stores per accumulator block -- the epilogue decides per tile (spg_tile_epilogue)
+  SpgGemmParams pv = p;
+  pv.vec_store = !WRED && p.Y != nullptr && (p.ldy & 3) == 0 && (((uintptr_t)p.Y) & 15) == 0 && !spg_tune_get(SPG_TUNE_NO_VEC_GENERIC);
   if constexpr (IT == 32 && spg_gemm_variant(WRED, AMODE, false) >= 0) {
-    if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, false), &p, sizeof(p), grid, lds, flops, stream, 2 + 2 * spg_cdiv(p.K, SPG_KC),
-                                 [p, grid, lds, stream]() -> int {
-                                   hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
+    if (grouped && spg_group_add(SPG_JOB_GEMM, spg_gemm_variant(WRED, AMODE, false), &pv, sizeof(pv), grid, lds, flops, stream, 2 + 2 * spg_cdiv(p.K, SPG_KC),
+                                 [pv, grid, lds, stream]() -> int {
+                                   hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, pv);
                                    SPG_LAUNCH_CHECK();
                                    return 0;
                                  })) return 0;
   }
-  hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
+  hipLaunchKernelGGL((spg_rowgemm_kernel<IT, JT, WI, WJ, WRED, AMODE>), grid, dim3(SPG_THREADS), lds, stream, pv);
   SPG_LAUNCH_CHECK();
   return 0;
 }
