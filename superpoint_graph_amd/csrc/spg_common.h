@@ -21,7 +21,7 @@ extern "C" const char* spg_last_error(void);
 void spg_set_error(const char* fmt, ...);
 // tuning knobs (process-global; defaults are the production values): see spg_tune in include/spg_hip.h
 enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_FIN_SLICE_MIN = 4, SPG_TUNE_NO_STAT_ACCUM = 5, SPG_TUNE_PRECISION = 7,
-       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_SIDE_STREAM = 9, SPG_TUNE_NO_BN_FOLD = 10, SPG_TUNE_NO_GROUP = 11, SPG_TUNE_SPLITK = 12, SPG_TUNE_NO_VEC_GENERIC = 13, SPG_TUNE_COUNT = 16 };
+       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_SIDE_STREAM = 9, SPG_TUNE_NO_BN_FOLD = 10, SPG_TUNE_NO_GROUP = 11, SPG_TUNE_SPLITK = 12, SPG_TUNE_NO_VEC_GENERIC = 13, SPG_TUNE_NO_BWD_PAIR = 14, SPG_TUNE_COUNT = 16 };
 int spg_tune_get(int key);
 
 // Fork / join of a library-owned side stream (one per device, created on first use): a latency-bound chain of small-grid
@@ -475,6 +475,61 @@ __device__ __forceinline__ void spg_mfma_chunk_rr(const float* __restrict__ As, 
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// A = TRANSPOSE of an out-major tile (reduction over its ROWS, its channels become the rows of the product), B red-major:
+// the weight gradient computed from the very LDS copy of dz the data gradient reads as its out-major A operand
+// (spg_bwdpair_kernel).  As: floats of the whole out-major tile [channel quad][strideA4 slots][4]; row0: first row of the chunk.
+// Element (row, ch) sits at ((ch / 4) * strideA4 + row) * 4 + ch % 4: 32 consecutive channels = 32 different banks.
+template <int TI, int TJ, int TA>
+__device__ __forceinline__ void spg_mfma_chunk_tr(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                  int strideA4, int strideB, int row0, int colA, int colB, int h,
+                                                  f32x16 (&acc)[TA][TJ]) {      // the first TI rows of acc are used
+  static_assert(TI <= TA, "accumulator array too small");
+  int oa[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = colA + 32 * i;
+    oa[i] = ((co >> 2) * strideA4 + row0 + h) * 4 + (co & 3);
+  }
+  const float* __restrict__ Bh = Bs + h * strideB + colB;
+#pragma unroll
+  for (int kk = 0; kk < SPG_KC / 2; ++kk) {
+    float a[TI], b[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) a[i] = As[oa[i] + 8 * kk];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) b[j] = Bh[2 * kk * strideB + 32 * j];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// the same with the B operand finished on the fly: b = ReLU(raw * sc + sh), sc / sh of the lane's (fixed) channel
+template <int TI, int TA>
+__device__ __forceinline__ void spg_mfma_chunk_tr_aff(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                      int strideA4, int strideB, int row0, int colA, int colB, int h,
+                                                      float sc, float sh, f32x16 (&acc)[TA][1]) {
+  static_assert(TI <= TA, "accumulator array too small");
+  int oa[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = colA + 32 * i;
+    oa[i] = ((co >> 2) * strideA4 + row0 + h) * 4 + (co & 3);
+  }
+  const float* __restrict__ Bh = Bs + h * strideB + colB;
+#pragma unroll
+  for (int kk = 0; kk < SPG_KC / 2; ++kk) {
+    float a[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) a[i] = As[oa[i] + 8 * kk];
+    const float b = fmaxf(fmaf(Bh[2 * kk * strideB], sc, sh), 0.f);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b, acc[i][0], 0, 0, 0);
   }
 }
 

@@ -203,6 +203,11 @@ struct SpgReduceQueue {
 };
 // db (optional): also the column sums of the `a` operand (= bias gradient), from the same launch
 int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream, float* db = nullptr);
+// data gradient + weight gradient of a 64-input-channel convolution from ONE pass over dz (spg_gemm.hip: spg_bwdpair_kernel);
+// g as for spg_launch_gemm (the data-gradient problem, statistics into slots, fold_bwd = the layer's pending sums), b = the
+// layer's input operand, dW [g.K, 64] through the queue's batched reduction
+bool spg_bwdpair_supported(const SpgGemmParams& g, const SpgOperand& b);
+int spg_queue_bwdpair(SpgReduceQueue& q, SpgGemmParams g, const SpgOperand& b, float* dW, hipStream_t stream);
 int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, float* out, hipStream_t stream);
 int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream);
 // jobs whose partials are complete (in stream order) but whose summation may wait for the next batched reduction of this

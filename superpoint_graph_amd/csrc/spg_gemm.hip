@@ -1967,6 +1967,346 @@ int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t 
   return 0;
 }
 
+// spg_epilogue_bwd_vec with the producer's raw output read from LDS (the tile the loaders staged: [IT][ldl] floats, all JT
+// channels) instead of from global memory: no load latency inside the epilogue -- its four waves are the only ones that run it
+template <int IT, int JT, int WI, int WJ>
+__device__ __forceinline__ void spg_epilogue_bwd_vec_lds(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
+                                                         float* __restrict__ red, const float* __restrict__ ylds, int ldl, long m0,
+                                                         SpgStatAcc<JT / WJ / 32>& sacc) {
+  constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32, RW = IT / WI, CW = JT / WJ;
+  constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR, NIT = SPG_EPI_PIECE_ROWS / RPI;
+  const int tid = threadIdx.x + spg_opaque_zero(), lane = tid & 63, wave = (tid >> 6) & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int colw = wj * CW, roww = wi * RW;
+  float* st = red + wave * SPG_EPI_WAVE_FLOATS(RW, CW);
+  const int lr = lane / LPR, lc = 4 * (lane % LPR);
+  const int col = colw + lc;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.ms + col), sh = *reinterpret_cast<const f32x4*>(p.mt + col);
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(p.mmean + col), rstd = *reinterpret_cast<const f32x4*>(p.mrstd + col);
+  const float* yl = ylds + (roww + lr) * ldl + col;
+  float* yo = p.Y + (m0 + roww) * p.ldy + colw;
+  const unsigned oo0 = (unsigned)lr * (unsigned)p.ldy + (unsigned)lc;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int rb = 32 * i + 16 * half;       // first row of this piece inside the wave's sub-tile
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) st[((u & 3) + 8 * (u >> 2) + 4 * h) * LD + 32 * j + r] = acc[i][j][8 * half + u];
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * u) * LD + lc);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(yl + (rb + RPI * u) * ldl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = yv[e];
+          if (!(fmaf(y, sc[e], sh[e]) > 0.f)) v[e] = 0.f;
+          s1[e] += v[e];
+          s2[e] = fmaf(v[e], (y - mean[e]) * rstd[e], s2[e]);
+        }
+        *reinterpret_cast<f32x4*>(yo + oo0 + (unsigned)(rb + RPI * u) * (unsigned)p.ldy) = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  sacc.s1 += s1; sacc.s2 += s2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of a narrow convolution in ONE pass over dz (round 4)
+// ---------------------------------------------------------------------------------------------
+// The data gradient and the weight gradient of a layer both start from dz = BatchNorm-backward(g, y): as two launches each
+// reads g and y from HBM and re-runs the prologue.  For the 64-input-channel layers (64 -> 64, 64 -> 128) the matrix work is
+// a fraction of the memory time (conv2: 2 x 1 GFLOP = 13 us of MFMA against 131 MB = 26 us of HBM per launch PAIR), so one
+// workgroup of TWELVE waves with fixed roles does both from one LDS copy of each 64-row tile:
+//   waves 8-11 (loaders)  global -> registers -> LDS, two tiles ahead of the matrix waves: while tile t is multiplied they
+//                         finish tile t+1 into the OTHER LDS buffer (dz with the prologue applied, out-major; the producer's RAW
+//                         output y_prev, red-major) and then issue the loads of tile t+2 -- one barrier per tile
+//   waves 0-3             data gradient  g_prev[64, 64] = dz[64, CO] W[CO, 64]  (W red-major, resident in LDS for the whole
+//                         launch) and the ordinary backward epilogue: ReLU mask of the producer, vector store, the producer's
+//                         BatchNorm-backward sums (accumulated over the workgroup's tiles: ONE slot contribution)
+//   waves 4-7             weight gradient dW[CO, 64] += dz^T x: the SAME dz tile read transposed (spg_mfma_chunk_tr), accumulated
+//                         in registers over all tiles of the workgroup: one partial per workgroup for the batched reduction
+// One workgroup per CU (97 / 149 KB of LDS), tiles b, b + grid, ...; both matrix roles issue the same number of MFMAs per tile.
+// HBM per tile: g + y + y_prev (twice: staging and epilogue mask -- the second read hits L2) + g_prev, against twice g + y and
+// three times y_prev before.  Arithmetic per element is that of the separate kernels (same prologue expression, fp32 MFMA);
+// the summation ORDER of dW and of the statistics differs from theirs (spg_tune key 14 = 1 restores the separate launches).
+// The three roles run their own loops with the same number of workgroup barriers (s_barrier counts waves, not code addresses).
+struct SpgBwdPairParams {
+  SpgGemmParams g;      // the data-gradient problem: a = dz operand (BNBWD / POOLBWD), W [CO, 64], Y, Yp, ms / mt / mmean / mrstd,
+                        // stat_slots (producer), fold_bwd (this layer's sums -> constants, dgamma / dbeta), ntile = M / 64
+  SpgOperand b;         // the layer's input: AFFINE + ReLU over the producer's raw output (64 channels)
+  float* partial;       // [grid][CO][64]
+};
+#define SPG_PAIR_THREADS 768
+#define SPG_PAIR_ROWS 64
+template <int CO>
+constexpr size_t spg_bwdpair_lds_bytes() {
+  return 2 * ((size_t)(CO / 4) * (SPG_PAIR_ROWS + 1) * 16 + (size_t)SPG_PAIR_ROWS * 68 * 4) + (size_t)CO * 68 * 4 +
+         (size_t)4 * SPG_EPI_WAVE_FLOATS(32, 32) * 4 + (size_t)(CO + 32) * 16;
+}
+
+template <int CO, int AMODE>
+__global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const SpgBwdPairParams p) {
+  constexpr int IT = SPG_PAIR_ROWS, CI = 64, SA = IT + 1, SX = CI + 4;
+  constexpr int CQ = CO / 4, XQ = CI / 4;
+  constexpr int NDZ = IT * CQ / 256, NX = IT * XQ / 256;          // quads per loader thread
+  constexpr int RDZ = 256 / CQ, RX = 256 / XQ;                    // rows one pass of the 256 loader threads covers
+  constexpr int TIW = CO / 64;                                    // 32 x 32 blocks of dW per weight-gradient wave
+  constexpr int BUF4 = CQ * SA + IT * SX / 4;                     // float4 slots of one LDS tile buffer (dz, then x)
+  static_assert(CO == 64 || CO == 128, "64 or 128 output channels");
+  extern __shared__ f32x4 smem[];
+  float* wl = reinterpret_cast<float*>(smem + 2 * BUF4);          // [CO][CI + 4]: red-major W (whole launch)
+  float* red = wl + CO * SX;                                      // epilogue staging of the data-gradient waves
+  f32x4* kst = reinterpret_cast<f32x4*>(red + 4 * SPG_EPI_WAVE_FLOATS(32, 32));      // [4][CQ] dz constants, [2][XQ] x constants
+  const SpgGemmParams& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the role branches below are uniform
+  const int r = lane & 31, h = lane >> 5;
+  const int role = wave >> 2;                                     // 0 data gradient, 1 weight gradient, 2 loader
+  const int wi = (wave & 3) >> 1, wj = wave & 1;
+
+  // constants of the dz prologue: finished here from the layer's slots (ends with a barrier), or already there (finalize launch)
+  if (g.fold_bwd.slots != nullptr) spg_bn_fold_bwd(g.fold_bwd, blockIdx.x == 0);
+  // the per-channel constants wait in LDS (a loader thread needs the same 6 quads for every tile: 24 registers otherwise)
+  if (tid < CQ) {
+    kst[0 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c0 + 4 * tid); kst[1 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c1 + 4 * tid);
+    kst[2 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c2 + 4 * tid); kst[3 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c3 + 4 * tid);
+  }
+  if (tid < XQ) {
+    kst[4 * CQ + tid] = *reinterpret_cast<const f32x4*>(p.b.c0 + 4 * tid); kst[4 * CQ + XQ + tid] = *reinterpret_cast<const f32x4*>(p.b.c1 + 4 * tid);
+  }
+  for (int i = tid; i < CO * XQ; i += SPG_PAIR_THREADS) {
+    const int co = i / XQ, q = i % XQ;
+    *reinterpret_cast<f32x4*>(wl + co * SX + 4 * q) = *reinterpret_cast<const f32x4*>(g.W + (long)co * g.ldw + 4 * q);
+  }
+  const int ntile = g.ntile, stride = (int)gridDim.x;
+  int tile = (int)blockIdx.x;                     // < ntile (host)
+
+  if (role == 2) {
+    // ---------------- loaders ----------------
+    const int lt = tid - 512;
+    const int cq = lt % CQ, rdz = lt / CQ;        // this thread's channel quad of dz (fixed) and its first row
+    const int xq = lt % XQ, rx = lt / XQ;
+    // byte offsets of this thread's quads inside a tile (32-bit; the tile's base pointer is wave-uniform)
+    const unsigned odz = ((unsigned)rdz * (unsigned)g.a.ld + 4u * (unsigned)cq) * 4u, sdz = (unsigned)RDZ * (unsigned)g.a.ld * 4u;
+    const unsigned ox = ((unsigned)rx * (unsigned)p.b.ld + 4u * (unsigned)xq) * 4u, sx = (unsigned)RX * (unsigned)p.b.ld * 4u;
+    f32x4 pg[AMODE == SPG_PRO_POOLBWD ? 1 : NDZ], py[NDZ], px[NX];
+    int4 pai = {0, 0, 0, 0};
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+      const long m0 = (long)t * IT;
+      if constexpr (AMODE == SPG_PRO_POOLBWD) {   // a group (P = 128 rows) is two tiles: its pooled gradient / arg-max rows, this thread's quad
+        pg[0] = spg_ld16(g.a.X + (long)(t >> 1) * g.a.ldg, 16u * (unsigned)cq);
+        pai = spg_ld16i(g.a.aidx + (long)(t >> 1) * g.a.ldg, 16u * (unsigned)cq);
+      } else {
+        const float* gb = g.a.X + m0 * g.a.ld;
+#pragma unroll
+        for (int i = 0; i < NDZ; ++i) pg[i] = spg_ld16(gb, odz + sdz * i);
+      }
+      const float* yb = g.a.X2 + m0 * g.a.ld;
+#pragma unroll
+      for (int i = 0; i < NDZ; ++i) py[i] = spg_ld16(yb, odz + sdz * i);
+      const float* xb = p.b.X + m0 * p.b.ld;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) px[i] = spg_ld16(xb, ox + sx * i);
+    };
+    auto store_tile = [&](int t, int buf) __attribute__((always_inline)) {
+      f32x4* dz4 = smem + buf * BUF4;
+      float* xs = reinterpret_cast<float*>(dz4 + CQ * SA);
+      const f32x4 ka = kst[0 * CQ + cq], kb = kst[1 * CQ + cq], kc = kst[2 * CQ + cq], kd = kst[3 * CQ + cq];
+      const int prow = (t & 1) * IT;              // POOLBWD: first row of this tile inside its group
+#pragma unroll
+      for (int i = 0; i < NDZ; ++i) {
+        const int row = rdz + RDZ * i;
+        f32x4 gv;
+        if constexpr (AMODE == SPG_PRO_POOLBWD) {
+          gv[0] = pai.x == prow + row ? pg[0][0] : 0.f; gv[1] = pai.y == prow + row ? pg[0][1] : 0.f;
+          gv[2] = pai.z == prow + row ? pg[0][2] : 0.f; gv[3] = pai.w == prow + row ? pg[0][3] : 0.f;
+        } else {
+          gv = pg[i];
+        }
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = spg_bnbwd_value(ka[e], gv[e], kb[e], py[i][e], kc[e], kd[e]);
+        dz4[cq * SA + row] = v;
+      }
+      // the producer's RAW output: the weight-gradient waves apply scale / shift / ReLU when they read their operand, the
+      // data-gradient waves' epilogue needs the raw value (ReLU mask, xhat)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(xs + (rx + RX * i) * SX + 4 * xq) = px[i];
+    };
+    load_tile(tile);
+    __syncthreads();                              // the constants are in LDS
+    store_tile(tile, 0);
+    if (tile + stride < ntile) load_tile(tile + stride);
+    __syncthreads();
+    int buf = 0;
+    for (;;) {
+      const int nxt = tile + stride;
+      const bool has_next = nxt < ntile;          // uniform
+      if (has_next) {
+        store_tile(nxt, buf ^ 1);
+        if (nxt + stride < ntile) load_tile(nxt + stride);
+      }
+      __syncthreads();
+      if (!has_next) break;
+      tile = nxt; buf ^= 1;
+    }
+    __syncthreads();
+    return;
+  }
+
+  if (role == 0) {
+    // ---------------- data gradient ----------------
+    f32x16 acc[1][1];
+    SpgStatAcc<1> sacc;
+    sacc.n = 0.f; sacc.a[0] = 0.f; sacc.b[0] = 0.f;
+    sacc.s1 = f32x4{0.f, 0.f, 0.f, 0.f}; sacc.s2 = sacc.s1;
+    __syncthreads();
+    __syncthreads();
+    int buf = 0;
+    for (;;) {
+      const int nxt = tile + stride;
+      const bool has_next = nxt < ntile;
+      const f32x4* dz4 = smem + buf * BUF4;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[0][0][q] = 0.f;
+#pragma nounroll
+      for (int c = 0; c < CO / SPG_KC; ++c)
+        spg_mfma_chunk_or<1, 1>(dz4 + c * (SPG_KC / 4) * SA, wl + c * SPG_KC * SX, SA, SX, wi * 32 + r, wj * 32 + r, h, acc);
+      spg_epilogue_bwd_vec_lds<64, 64, 2, 2>(g, acc, red, reinterpret_cast<const float*>(dz4 + CQ * SA), SX, (long)tile * IT, sacc);
+      __syncthreads();
+      if (!has_next) break;
+      tile = nxt; buf ^= 1;
+    }
+    // the workgroup's ONE statistics contribution (as at the end of a persistent data-gradient stream)
+    constexpr int CW = 32, LPR = CW / 4, JT = 64;
+    float* xch = red;                             // [2][JT][2]
+    f32x4 s1 = sacc.s1, s2 = sacc.s2;
+    const int cl = wj * CW + 4 * (lane % LPR);
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+    }
+    if (wi != 0 && lane < LPR) {
+      *reinterpret_cast<f32x4*>(xch + (wi * JT + cl) * 2) = s1;
+      *reinterpret_cast<f32x4*>(xch + (wi * JT + cl) * 2 + 4) = s2;
+    }
+    __syncthreads();
+    if (wi == 0 && lane < LPR) {
+      s1 += *reinterpret_cast<const f32x4*>(xch + (1 * JT + cl) * 2);
+      s2 += *reinterpret_cast<const f32x4*>(xch + (1 * JT + cl) * 2 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) spg_slots_add(g.stat_slots, g.n_mask, cl + e, (double)s1[e], (double)s2[e]);
+    }
+    return;
+  }
+
+  // ---------------- weight gradient ----------------
+  f32x16 acc[TIW][1];
+#pragma unroll
+  for (int i = 0; i < TIW; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][0][q] = 0.f;
+  __syncthreads();
+  __syncthreads();
+  // this lane's input channel is fixed: BatchNorm scale / shift of the producer applied (+ ReLU) to every B operand it reads
+  const float xsc = reinterpret_cast<const float*>(kst + 4 * CQ)[wj * 32 + r], xsh = reinterpret_cast<const float*>(kst + 4 * CQ + XQ)[wj * 32 + r];
+  int buf = 0;
+  for (;;) {
+    const int nxt = tile + stride;
+    const bool has_next = nxt < ntile;
+    const float* dzf = reinterpret_cast<const float*>(smem + buf * BUF4);
+    const float* xs = dzf + CQ * SA * 4;
+#pragma nounroll
+    for (int c = 0; c < IT / SPG_KC; ++c)
+      spg_mfma_chunk_tr_aff<TIW>(dzf, xs + c * SPG_KC * SX, SA, SX, c * SPG_KC, wi * (32 * TIW) + r, wj * 32 + r, h, xsc, xsh, acc);
+    __syncthreads();
+    if (!has_next) break;
+    tile = nxt; buf ^= 1;
+  }
+  __syncthreads();
+  float* pb = p.partial + (long)blockIdx.x * CO * CI;
+  const int kl = wj * 32 + r;
+#pragma unroll
+  for (int i = 0; i < TIW; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int nl = wi * (32 * TIW) + 32 * i + spg_acc_row(q, h);
+      pb[nl * CI + kl] = acc[i][0][q];
+    }
+}
+
+bool spg_bwdpair_supported(const SpgGemmParams& g, const SpgOperand& b) {
+  if (g_tune[SPG_TUNE_NO_BWD_PAIR] || g_tune[SPG_TUNE_PRECISION] != 0) return false;
+  if (!(g.w_red && g.epi == SPG_EPI_BWD && g.N == 64 && (g.K == 64 || g.K == 128))) return false;
+  if (g.M < SPG_PAIR_ROWS || g.M % SPG_PAIR_ROWS != 0) return false;
+  const SpgOperand& a = g.a;
+  if (a.mode != SPG_PRO_BNBWD && a.mode != SPG_PRO_POOLBWD) return false;
+  if (!spg_operand_vec_ok(a) || a.ld < g.K) return false;
+  if (a.mode == SPG_PRO_POOLBWD && (a.P != 128 || a.ldg < g.K)) return false;
+  if (b.mode != SPG_PRO_AFFINE || !b.relu || b.c0 == nullptr || b.n_affine != 64 || !spg_operand_vec_ok(b) || b.ld < 64) return false;
+  if ((g.ldw & 3) != 0 || (((uintptr_t)g.W) & 15) != 0 || g.ldw < 64) return false;
+  if (g.Y == nullptr || g.Yp == nullptr || (g.ldy & 3) != 0 || (g.ldyp & 3) != 0 || ((((uintptr_t)g.Y) | ((uintptr_t)g.Yp)) & 15) != 0) return false;
+  if (g.stat_slots == nullptr || g.mmean == nullptr || g.mrstd == nullptr || g.ms == nullptr || g.mt == nullptr) return false;
+  if (!g.mask_relu || g.n_mask != 64) return false;
+  if ((((uintptr_t)g.ms) | ((uintptr_t)g.mt) | ((uintptr_t)g.mmean) | ((uintptr_t)g.mrstd)) & 15) return false;
+  const long ntile = g.M / SPG_PAIR_ROWS;
+  const long grid = ntile < spg_num_cus() ? ntile : spg_num_cus();
+  return (size_t)grid * g.K * 64 <= spg_wgrad_workspace_floats(g.M, g.K, 64);      // the layer's slice of the reduction arena
+}
+
+template <int CO, int AMODE>
+static int launch_bwdpair_t(const SpgBwdPairParams& p, int grid, hipStream_t stream) {
+  static bool attr_done = false;
+  const size_t lds = spg_bwdpair_lds_bytes<CO>();
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spg_bwdpair_kernel<CO, AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { spg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((spg_bwdpair_kernel<CO, AMODE>), dim3(grid), dim3(SPG_PAIR_THREADS), lds, stream, p);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+// g: the data-gradient problem as for spg_launch_gemm (w_red = 1, epi = BWD, stat_slots, fold_bwd = this layer's pending sums or none);
+// b: the layer's input operand; dW [g.K, 64].  The caller checks spg_bwdpair_supported first.
+int spg_queue_bwdpair(SpgReduceQueue& q, SpgGemmParams g, const SpgOperand& b, float* dW, hipStream_t stream) {
+  SPG_CHECK_ARG(spg_bwdpair_supported(g, b), "shape not supported by the fused backward");
+  const int ntile = g.M / SPG_PAIR_ROWS;
+  const int grid = ntile < spg_num_cus() ? ntile : spg_num_cus();
+  SpgBwdPairParams p;
+  memset(&p, 0, sizeof(p));
+  g.ntile = ntile; g.vec_store = 1; g.rows_per_tile = SPG_PAIR_ROWS;
+  p.g = g; p.b = b;
+  if (q.njobs + 1 > SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(q, stream));
+  float* part = dW;
+  if (grid > 1) SPG_TRY(queue_take(q, (size_t)grid * g.K * 64, &part, stream));
+  p.partial = part;
+  {
+    const double flops = 4.0 * (double)g.M * (double)g.K * 64.0;      // data gradient + weight gradient
+    ProfScope prof(stream, flops, SPG_PROF_TAG(4, SPG_PAIR_ROWS, 64, g.a.mode, SPG_PRO_AFFINE, 1));
+    prof.r.M = g.M; prof.r.N = 64; prof.r.K = g.K;
+    if (g.K == 64) {
+      if (g.a.mode == SPG_PRO_BNBWD) SPG_TRY((launch_bwdpair_t<64, SPG_PRO_BNBWD>(p, grid, stream)));
+      else SPG_TRY((launch_bwdpair_t<64, SPG_PRO_POOLBWD>(p, grid, stream)));
+    } else {
+      if (g.a.mode == SPG_PRO_BNBWD) SPG_TRY((launch_bwdpair_t<128, SPG_PRO_BNBWD>(p, grid, stream)));
+      else SPG_TRY((launch_bwdpair_t<128, SPG_PRO_POOLBWD>(p, grid, stream)));
+    }
+  }
+  if (grid > 1) {
+    SpgReduceJob& j = q.jobs[q.njobs++];
+    j.partial = part; j.out = dW; j.nsplit = grid; j.n = g.K * 64;
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm statistics
 // ---------------------------------------------------------------------------------------------

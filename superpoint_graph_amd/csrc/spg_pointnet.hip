@@ -452,6 +452,26 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
   flip = 0;
   for (int k = (int)sg.convs.size() - 1; k >= 0; --k) {
     Layer& l = pl.L[sg.convs[k]];
+    if (k > 0 && pl.fold) {      // (pending: this layer's sums, or none when a finalize launch already made the constants)
+      // 64-input-channel layers: data gradient + weight gradient from ONE pass over dz (spg_gemm.h: spg_queue_bwdpair)
+      Layer& prod = pl.L[sg.convs[k - 1]];
+      float* out = dz[flip];
+      SpgGemmParams g; memset(&g, 0, sizeof(g));
+      g.a = cur; g.W = l.W; g.ldw = l.cin; g.w_red = 1;
+      g.M = (int)pl.M; g.N = l.cin; g.K = l.cout; g.rows_per_tile = pl.P;
+      g.epi = SPG_EPI_BWD; g.Y = out; g.ldy = l.cin; g.Yp = prod.y; g.ldyp = prod.ldy;
+      g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
+      g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat_slots = prod.slots_bwd; g.fold_bwd = pending;
+      const SpgOperand xin = input_operand(pl, sg, false, k, clouds, stnT);
+      if (spg_bwdpair_supported(g, xin)) {
+        SPG_TRY(spg_queue_bwdpair(rq, g, xin, l.dW, st));
+        if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
+        flip ^= 1;
+        pending = fold_bwd_of(pl, prod, pl.M, s.consts);      // (the launch consumed this layer's; these are the producer's)
+        cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, prod.cout);
+        continue;
+      }
+    }
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, false, k, clouds, stnT); w.M = (int)pl.M; w.N = l.cout; w.K = l.cin;
     w.fold = pending; memset(&pending, 0, sizeof(pending));
