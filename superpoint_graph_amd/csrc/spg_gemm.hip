@@ -2016,156 +2016,181 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec_lds(const SpgGemmParams& p,
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward of a narrow convolution in ONE pass over dz (round 4)
+// backward of a convolution in ONE pass over dz (round 4)
 // ---------------------------------------------------------------------------------------------
 // The data gradient and the weight gradient of a layer both start from dz = BatchNorm-backward(g, y): as two launches each
-// reads g and y from HBM and re-runs the prologue.  For the 64-input-channel layers (64 -> 64, 64 -> 128) the matrix work is
-// a fraction of the memory time (conv2: 2 x 1 GFLOP = 13 us of MFMA against 131 MB = 26 us of HBM per launch PAIR), so one
-// workgroup of TWELVE waves with fixed roles does both from one LDS copy of each 64-row tile:
-//   waves 8-11 (loaders)  global -> registers -> LDS, two tiles ahead of the matrix waves: while tile t is multiplied they
+// reads g and y from HBM and re-runs the prologue.  For the layers whose whole weight matrix fits LDS next to two tile buffers
+// (64 -> 64, 64 -> 128, 128 -> 128) one workgroup of SIXTEEN waves with fixed roles does both from one LDS copy of each tile
+// of IT = 4096 / CI rows:
+//   waves 8-15 (loaders)  global -> registers -> LDS, three tiles ahead of the matrix waves: while tile t is multiplied they
 //                         finish tile t+1 into the OTHER LDS buffer (dz with the prologue applied, out-major; the producer's RAW
-//                         output y_prev, red-major) and then issue the loads of tile t+2 -- one barrier per tile
-//   waves 0-3             data gradient  g_prev[64, 64] = dz[64, CO] W[CO, 64]  (W red-major, resident in LDS for the whole
-//                         launch) and the ordinary backward epilogue: ReLU mask of the producer, vector store, the producer's
-//                         BatchNorm-backward sums (accumulated over the workgroup's tiles: ONE slot contribution)
-//   waves 4-7             weight gradient dW[CO, 64] += dz^T x: the SAME dz tile read transposed (spg_mfma_chunk_tr), accumulated
-//                         in registers over all tiles of the workgroup: one partial per workgroup for the batched reduction
-// One workgroup per CU (97 / 149 KB of LDS), tiles b, b + grid, ...; both matrix roles issue the same number of MFMAs per tile.
-// HBM per tile: g + y + y_prev (twice: staging and epilogue mask -- the second read hits L2) + g_prev, against twice g + y and
-// three times y_prev before.  Arithmetic per element is that of the separate kernels (same prologue expression, fp32 MFMA);
-// the summation ORDER of dW and of the statistics differs from theirs (spg_tune key 14 = 1 restores the separate launches).
+//                         output y_prev, red-major) and then issue the loads of tile t+3 (two tiles are always in flight) --
+//                         one workgroup barrier per tile
+//   waves 0-3             data gradient  g_prev[IT, CI] = dz[IT, CO] W[CO, CI]  (W red-major, resident in LDS for the whole
+//                         launch; one 32 x 32 block per wave) and the backward epilogue fed from LDS: ReLU mask of the producer,
+//                         vector store, the producer's BatchNorm-backward sums (accumulated over the workgroup's tiles: ONE
+//                         slot contribution per workgroup -- no finalize launch behind a 128-column data gradient any more)
+//   waves 4-7             weight gradient dW[CO, CI] += dz^T ReLU(s y_prev + t): the SAME dz tile read transposed
+//                         (spg_mfma_chunk_tr_aff; scale / shift / ReLU applied to the operand as it is read), accumulated in
+//                         registers over all tiles of the workgroup: one partial per workgroup for the batched reduction
+// One workgroup per CU (97 ... 149 KB of LDS), tiles b, b + grid, ...; both matrix roles issue CO / 2 MFMAs per wave and tile.
+// HBM per tile: g + y + y_prev + g_prev, each ONCE (before: g and y twice, y_prev three times).  Measured on the unit scene
+// (profiles/r04_bwdpair.txt): 64 -> 64  50.7 -> 35.5 us (131 MB: 3.7 TB/s including ~8 us of launch, prologue and tail),
+// 64 -> 128  75 -> 57.5 us.  Arithmetic per element is that of the separate kernels (same prologue expressions, fp32 MFMA); the
+// summation ORDER of dW and of the statistics differs from theirs (spg_tune key 14 = 1 restores the separate launches).
 // The three roles run their own loops with the same number of workgroup barriers (s_barrier counts waves, not code addresses).
 struct SpgBwdPairParams {
-  SpgGemmParams g;      // the data-gradient problem: a = dz operand (BNBWD / POOLBWD), W [CO, 64], Y, Yp, ms / mt / mmean / mrstd,
-                        // stat_slots (producer), fold_bwd (this layer's sums -> constants, dgamma / dbeta), ntile = M / 64
-  SpgOperand b;         // the layer's input: AFFINE + ReLU over the producer's raw output (64 channels)
-  float* partial;       // [grid][CO][64]
+  SpgGemmParams g;      // the data-gradient problem: a = dz operand (BNBWD / POOLBWD), W [CO, CI], Y, Yp, ms / mt / mmean / mrstd,
+                        // stat_slots (producer), fold_bwd (this layer's sums -> constants, dgamma / dbeta; or none), ntile = M / IT
+  SpgOperand b;         // the layer's input: AFFINE + ReLU over the producer's raw output (CI channels)
+  float* partial;       // [grid][CO][CI]
 };
-#define SPG_PAIR_THREADS 768
-#define SPG_PAIR_ROWS 64
-template <int CO>
+#define SPG_PAIR_THREADS 1024
+constexpr int spg_bwdpair_rows(int ci) { return 4096 / ci; }
+template <int CO, int CI>
 constexpr size_t spg_bwdpair_lds_bytes() {
-  return 2 * ((size_t)(CO / 4) * (SPG_PAIR_ROWS + 1) * 16 + (size_t)SPG_PAIR_ROWS * 68 * 4) + (size_t)CO * 68 * 4 +
-         (size_t)4 * SPG_EPI_WAVE_FLOATS(32, 32) * 4 + (size_t)(CO + 32) * 16;
+  return 2 * ((size_t)(CO / 4) * (spg_bwdpair_rows(CI) + 1) * 16 + (size_t)spg_bwdpair_rows(CI) * (CI + 4) * 4) + (size_t)CO * (CI + 4) * 4 +
+         (size_t)4 * SPG_EPI_WAVE_FLOATS(32, 32) * 4 + (size_t)(CO + CI / 2) * 16;
 }
 
-template <int CO, int AMODE>
+template <int CO, int CI, int AMODE>
 __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const SpgBwdPairParams p) {
-  constexpr int IT = SPG_PAIR_ROWS, CI = 64, SA = IT + 1, SX = CI + 4;
+  constexpr int IT = spg_bwdpair_rows(CI), SA = IT + 1, SX = CI + 4;
   constexpr int CQ = CO / 4, XQ = CI / 4;
-  constexpr int NDZ = IT * CQ / 256, NX = IT * XQ / 256;          // quads per loader thread
-  constexpr int RDZ = 256 / CQ, RX = 256 / XQ;                    // rows one pass of the 256 loader threads covers
-  constexpr int TIW = CO / 64;                                    // 32 x 32 blocks of dW per weight-gradient wave
-  constexpr int BUF4 = CQ * SA + IT * SX / 4;                     // float4 slots of one LDS tile buffer (dz, then x)
-  static_assert(CO == 64 || CO == 128, "64 or 128 output channels");
+  constexpr int NDZ = IT * CQ / 512, NX = IT * XQ / 512;          // quads per loader thread
+  constexpr int RDZ = 512 / CQ, RX = 512 / XQ;                    // rows one pass of the 512 loader threads covers
+  constexpr int WJ = CI / 32 > 4 ? 4 : CI / 32, WI = 4 / WJ;      // wave grid of both matrix roles (columns = input channels)
+  constexpr int TIW = CO / 32 / WI;                               // 32 x 32 blocks of dW per weight-gradient wave
+  constexpr int BUF4 = CQ * SA + IT * SX / 4;                     // float4 slots of one LDS tile buffer (dz, then y_prev)
+  constexpr int TPG = 128 / IT;                                   // POOLBWD: tiles per group (P = 128 rows)
+  static_assert((CO == 64 || CO == 128) && (CI == 64 || CI == 128) && IT * WJ * 32 == 4096 * (WJ * 32 / CI), "supported shapes");
+  static_assert(NDZ >= 1 && NX >= 1 && IT % RDZ == 0 && IT % RX == 0, "loader map");
   extern __shared__ f32x4 smem[];
   float* wl = reinterpret_cast<float*>(smem + 2 * BUF4);          // [CO][CI + 4]: red-major W (whole launch)
   float* red = wl + CO * SX;                                      // epilogue staging of the data-gradient waves
-  f32x4* kst = reinterpret_cast<f32x4*>(red + 4 * SPG_EPI_WAVE_FLOATS(32, 32));      // [4][CQ] dz constants, [2][XQ] x constants
+  f32x4* kst = reinterpret_cast<f32x4*>(red + 4 * SPG_EPI_WAVE_FLOATS(32, 32));      // [4][CQ] dz constants, [2][XQ] y_prev constants
   const SpgGemmParams& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the role branches below are uniform
   const int r = lane & 31, h = lane >> 5;
-  const int role = wave >> 2;                                     // 0 data gradient, 1 weight gradient, 2 loader
-  const int wi = (wave & 3) >> 1, wj = wave & 1;
-
-  // constants of the dz prologue: finished here from the layer's slots (ends with a barrier), or already there (finalize launch)
-  if (g.fold_bwd.slots != nullptr) spg_bn_fold_bwd(g.fold_bwd, blockIdx.x == 0);
-  // the per-channel constants wait in LDS (a loader thread needs the same 6 quads for every tile: 24 registers otherwise)
-  if (tid < CQ) {
-    kst[0 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c0 + 4 * tid); kst[1 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c1 + 4 * tid);
-    kst[2 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c2 + 4 * tid); kst[3 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c3 + 4 * tid);
-  }
-  if (tid < XQ) {
-    kst[4 * CQ + tid] = *reinterpret_cast<const f32x4*>(p.b.c0 + 4 * tid); kst[4 * CQ + XQ + tid] = *reinterpret_cast<const f32x4*>(p.b.c1 + 4 * tid);
-  }
-  for (int i = tid; i < CO * XQ; i += SPG_PAIR_THREADS) {
-    const int co = i / XQ, q = i % XQ;
-    *reinterpret_cast<f32x4*>(wl + co * SX + 4 * q) = *reinterpret_cast<const f32x4*>(g.W + (long)co * g.ldw + 4 * q);
-  }
+  const int role = wave >> 2;                                     // 0 data gradient, 1 weight gradient, 2 / 3 loaders
+  const int wi = (wave & 3) / WJ, wj = (wave & 3) % WJ;
   const int ntile = g.ntile, stride = (int)gridDim.x;
   int tile = (int)blockIdx.x;                     // < ntile (host)
 
-  if (role == 2) {
-    // ---------------- loaders ----------------
+  // what every role does before its loop: (loaders: the first two tiles' loads, below) -- the constants of the dz prologue,
+  // finished here from the layer's slots (ends with a barrier) or already there (finalize launch) -- constants and W into LDS
+  auto prologue = [&]() __attribute__((always_inline)) {
+    if (g.fold_bwd.slots != nullptr) spg_bn_fold_bwd(g.fold_bwd, blockIdx.x == 0);
+    if (tid < CQ) {
+      kst[0 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c0 + 4 * tid); kst[1 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c1 + 4 * tid);
+      kst[2 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c2 + 4 * tid); kst[3 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c3 + 4 * tid);
+    }
+    if (tid < XQ) {
+      kst[4 * CQ + tid] = *reinterpret_cast<const f32x4*>(p.b.c0 + 4 * tid); kst[4 * CQ + XQ + tid] = *reinterpret_cast<const f32x4*>(p.b.c1 + 4 * tid);
+    }
+    for (int i = tid; i < CO * XQ; i += SPG_PAIR_THREADS) {
+      const int co = i / XQ, q = i % XQ;
+      *reinterpret_cast<f32x4*>(wl + co * SX + 4 * q) = *reinterpret_cast<const f32x4*>(g.W + (long)co * g.ldw + 4 * q);
+    }
+    __syncthreads();                              // constants and W are in LDS
+  };
+
+  if (role >= 2) {
+    // ---------------- loaders (8 waves) ----------------
+    // TWO tiles in flight per workgroup (register sets R0 / R1, tiles k+2 and k+3 while tile k is multiplied)
     const int lt = tid - 512;
     const int cq = lt % CQ, rdz = lt / CQ;        // this thread's channel quad of dz (fixed) and its first row
     const int xq = lt % XQ, rx = lt / XQ;
     // byte offsets of this thread's quads inside a tile (32-bit; the tile's base pointer is wave-uniform)
     const unsigned odz = ((unsigned)rdz * (unsigned)g.a.ld + 4u * (unsigned)cq) * 4u, sdz = (unsigned)RDZ * (unsigned)g.a.ld * 4u;
     const unsigned ox = ((unsigned)rx * (unsigned)p.b.ld + 4u * (unsigned)xq) * 4u, sx = (unsigned)RX * (unsigned)p.b.ld * 4u;
-    f32x4 pg[AMODE == SPG_PRO_POOLBWD ? 1 : NDZ], py[NDZ], px[NX];
-    int4 pai = {0, 0, 0, 0};
-    auto load_tile = [&](int t) __attribute__((always_inline)) {
+    struct Regs {
+      f32x4 pg[AMODE == SPG_PRO_POOLBWD ? 1 : NDZ], py[NDZ], px[NX];
+      int4 pai;
+    };
+    Regs R0, R1;
+    auto load_tile = [&](Regs& R, int t) __attribute__((always_inline)) {
       const long m0 = (long)t * IT;
-      if constexpr (AMODE == SPG_PRO_POOLBWD) {   // a group (P = 128 rows) is two tiles: its pooled gradient / arg-max rows, this thread's quad
-        pg[0] = spg_ld16(g.a.X + (long)(t >> 1) * g.a.ldg, 16u * (unsigned)cq);
-        pai = spg_ld16i(g.a.aidx + (long)(t >> 1) * g.a.ldg, 16u * (unsigned)cq);
+      if constexpr (AMODE == SPG_PRO_POOLBWD) {   // a group (P = 128 rows) is TPG tiles: its pooled gradient / arg-max rows, this thread's quad
+        R.pg[0] = spg_ld16(g.a.X + (long)(t / TPG) * g.a.ldg, 16u * (unsigned)cq);
+        R.pai = spg_ld16i(g.a.aidx + (long)(t / TPG) * g.a.ldg, 16u * (unsigned)cq);
       } else {
         const float* gb = g.a.X + m0 * g.a.ld;
 #pragma unroll
-        for (int i = 0; i < NDZ; ++i) pg[i] = spg_ld16(gb, odz + sdz * i);
+        for (int i = 0; i < NDZ; ++i) R.pg[i] = spg_ld16(gb, odz + sdz * i);
       }
       const float* yb = g.a.X2 + m0 * g.a.ld;
 #pragma unroll
-      for (int i = 0; i < NDZ; ++i) py[i] = spg_ld16(yb, odz + sdz * i);
+      for (int i = 0; i < NDZ; ++i) R.py[i] = spg_ld16(yb, odz + sdz * i);
       const float* xb = p.b.X + m0 * p.b.ld;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) px[i] = spg_ld16(xb, ox + sx * i);
+      for (int i = 0; i < NX; ++i) R.px[i] = spg_ld16(xb, ox + sx * i);
     };
-    auto store_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    auto store_tile = [&](const Regs& R, int t, int buf) __attribute__((always_inline)) {
       f32x4* dz4 = smem + buf * BUF4;
       float* xs = reinterpret_cast<float*>(dz4 + CQ * SA);
       const f32x4 ka = kst[0 * CQ + cq], kb = kst[1 * CQ + cq], kc = kst[2 * CQ + cq], kd = kst[3 * CQ + cq];
-      const int prow = (t & 1) * IT;              // POOLBWD: first row of this tile inside its group
+      const int prow = (t % TPG) * IT;            // POOLBWD: first row of this tile inside its group
 #pragma unroll
       for (int i = 0; i < NDZ; ++i) {
         const int row = rdz + RDZ * i;
         f32x4 gv;
         if constexpr (AMODE == SPG_PRO_POOLBWD) {
-          gv[0] = pai.x == prow + row ? pg[0][0] : 0.f; gv[1] = pai.y == prow + row ? pg[0][1] : 0.f;
-          gv[2] = pai.z == prow + row ? pg[0][2] : 0.f; gv[3] = pai.w == prow + row ? pg[0][3] : 0.f;
+          gv[0] = R.pai.x == prow + row ? R.pg[0][0] : 0.f; gv[1] = R.pai.y == prow + row ? R.pg[0][1] : 0.f;
+          gv[2] = R.pai.z == prow + row ? R.pg[0][2] : 0.f; gv[3] = R.pai.w == prow + row ? R.pg[0][3] : 0.f;
         } else {
-          gv = pg[i];
+          gv = R.pg[i];
         }
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = spg_bnbwd_value(ka[e], gv[e], kb[e], py[i][e], kc[e], kd[e]);
+        for (int e = 0; e < 4; ++e) v[e] = spg_bnbwd_value(ka[e], gv[e], kb[e], R.py[i][e], kc[e], kd[e]);
         dz4[cq * SA + row] = v;
       }
       // the producer's RAW output: the weight-gradient waves apply scale / shift / ReLU when they read their operand, the
       // data-gradient waves' epilogue needs the raw value (ReLU mask, xhat)
 #pragma unroll
-      for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(xs + (rx + RX * i) * SX + 4 * xq) = px[i];
+      for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(xs + (rx + RX * i) * SX + 4 * xq) = R.px[i];
     };
-    load_tile(tile);
-    __syncthreads();                              // the constants are in LDS
-    store_tile(tile, 0);
-    if (tile + stride < ntile) load_tile(tile + stride);
+    load_tile(R0, tile);                          // (no constant needed yet: in flight under the prologue)
+    if (tile + stride < ntile) load_tile(R1, tile + stride);
+    prologue();
+    store_tile(R0, tile, 0);
+    if (tile + 2 * stride < ntile) load_tile(R0, tile + 2 * stride);
     __syncthreads();
-    int buf = 0;
     for (;;) {
-      const int nxt = tile + stride;
-      const bool has_next = nxt < ntile;          // uniform
+      // tile k is being multiplied from buffer 0: tile k+1 (R1) -> buffer 1, then the loads of tile k+3 into R1
+      int nxt = tile + stride;
+      bool has_next = nxt < ntile;                // uniform
       if (has_next) {
-        store_tile(nxt, buf ^ 1);
-        if (nxt + stride < ntile) load_tile(nxt + stride);
+        store_tile(R1, nxt, 1);
+        if (nxt + 2 * stride < ntile) load_tile(R1, nxt + 2 * stride);
       }
       __syncthreads();
       if (!has_next) break;
-      tile = nxt; buf ^= 1;
+      tile = nxt;
+      // tile k+1 from buffer 1: tile k+2 (R0) -> buffer 0, then the loads of tile k+4 into R0
+      nxt = tile + stride;
+      has_next = nxt < ntile;
+      if (has_next) {
+        store_tile(R0, nxt, 0);
+        if (nxt + 2 * stride < ntile) load_tile(R0, nxt + 2 * stride);
+      }
+      __syncthreads();
+      if (!has_next) break;
+      tile = nxt;
     }
     __syncthreads();
     return;
   }
 
+  prologue();
   if (role == 0) {
     // ---------------- data gradient ----------------
     f32x16 acc[1][1];
     SpgStatAcc<1> sacc;
     sacc.n = 0.f; sacc.a[0] = 0.f; sacc.b[0] = 0.f;
     sacc.s1 = f32x4{0.f, 0.f, 0.f, 0.f}; sacc.s2 = sacc.s1;
-    __syncthreads();
     __syncthreads();
     int buf = 0;
     for (;;) {
@@ -2177,14 +2202,14 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
 #pragma nounroll
       for (int c = 0; c < CO / SPG_KC; ++c)
         spg_mfma_chunk_or<1, 1>(dz4 + c * (SPG_KC / 4) * SA, wl + c * SPG_KC * SX, SA, SX, wi * 32 + r, wj * 32 + r, h, acc);
-      spg_epilogue_bwd_vec_lds<64, 64, 2, 2>(g, acc, red, reinterpret_cast<const float*>(dz4 + CQ * SA), SX, (long)tile * IT, sacc);
+      spg_epilogue_bwd_vec_lds<IT, CI, WI, WJ>(g, acc, red, reinterpret_cast<const float*>(dz4 + CQ * SA), SX, (long)tile * IT, sacc);
       __syncthreads();
       if (!has_next) break;
       tile = nxt; buf ^= 1;
     }
     // the workgroup's ONE statistics contribution (as at the end of a persistent data-gradient stream)
-    constexpr int CW = 32, LPR = CW / 4, JT = 64;
-    float* xch = red;                             // [2][JT][2]
+    constexpr int CW = 32, LPR = CW / 4;
+    float* xch = red;                             // [2][CI][2]
     f32x4 s1 = sacc.s1, s2 = sacc.s2;
     const int cl = wj * CW + 4 * (lane % LPR);
 #pragma unroll
@@ -2192,14 +2217,16 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
     }
-    if (wi != 0 && lane < LPR) {
-      *reinterpret_cast<f32x4*>(xch + (wi * JT + cl) * 2) = s1;
-      *reinterpret_cast<f32x4*>(xch + (wi * JT + cl) * 2 + 4) = s2;
+    if (WI > 1 && wi != 0 && lane < LPR) {
+      *reinterpret_cast<f32x4*>(xch + (wi * CI + cl) * 2) = s1;
+      *reinterpret_cast<f32x4*>(xch + (wi * CI + cl) * 2 + 4) = s2;
     }
     __syncthreads();
     if (wi == 0 && lane < LPR) {
-      s1 += *reinterpret_cast<const f32x4*>(xch + (1 * JT + cl) * 2);
-      s2 += *reinterpret_cast<const f32x4*>(xch + (1 * JT + cl) * 2 + 4);
+      if (WI > 1) {
+        s1 += *reinterpret_cast<const f32x4*>(xch + (1 * CI + cl) * 2);
+        s2 += *reinterpret_cast<const f32x4*>(xch + (1 * CI + cl) * 2 + 4);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) spg_slots_add(g.stat_slots, g.n_mask, cl + e, (double)s1[e], (double)s2[e]);
     }
@@ -2212,10 +2239,9 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
   for (int i = 0; i < TIW; ++i)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[i][0][q] = 0.f;
-  __syncthreads();
-  __syncthreads();
   // this lane's input channel is fixed: BatchNorm scale / shift of the producer applied (+ ReLU) to every B operand it reads
   const float xsc = reinterpret_cast<const float*>(kst + 4 * CQ)[wj * 32 + r], xsh = reinterpret_cast<const float*>(kst + 4 * CQ + XQ)[wj * 32 + r];
+  __syncthreads();
   int buf = 0;
   for (;;) {
     const int nxt = tile + stride;
@@ -2243,66 +2269,72 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
 
 bool spg_bwdpair_supported(const SpgGemmParams& g, const SpgOperand& b) {
   if (g_tune[SPG_TUNE_NO_BWD_PAIR] || g_tune[SPG_TUNE_PRECISION] != 0) return false;
-  if (!(g.w_red && g.epi == SPG_EPI_BWD && g.N == 64 && (g.K == 64 || g.K == 128))) return false;
-  if (g.M < SPG_PAIR_ROWS || g.M % SPG_PAIR_ROWS != 0) return false;
+  const int CI = g.N, CO = g.K;
+  if (!(g.w_red && g.epi == SPG_EPI_BWD && ((CI == 64 && (CO == 64 || CO == 128)) || (CI == 128 && CO == 128)))) return false;
+  const int IT = spg_bwdpair_rows(CI);
+  if (g.M < IT || g.M % IT != 0) return false;
   const SpgOperand& a = g.a;
   if (a.mode != SPG_PRO_BNBWD && a.mode != SPG_PRO_POOLBWD) return false;
-  if (!spg_operand_vec_ok(a) || a.ld < g.K) return false;
-  if (a.mode == SPG_PRO_POOLBWD && (a.P != 128 || a.ldg < g.K)) return false;
-  if (b.mode != SPG_PRO_AFFINE || !b.relu || b.c0 == nullptr || b.n_affine != 64 || !spg_operand_vec_ok(b) || b.ld < 64) return false;
-  if ((g.ldw & 3) != 0 || (((uintptr_t)g.W) & 15) != 0 || g.ldw < 64) return false;
+  if (!spg_operand_vec_ok(a) || a.ld < CO) return false;
+  if (a.mode == SPG_PRO_POOLBWD && (a.P != 128 || a.ldg < CO)) return false;
+  if (b.mode != SPG_PRO_AFFINE || !b.relu || b.c0 == nullptr || b.n_affine != CI || !spg_operand_vec_ok(b) || b.ld < CI) return false;
+  if ((g.ldw & 3) != 0 || (((uintptr_t)g.W) & 15) != 0 || g.ldw < CI) return false;
   if (g.Y == nullptr || g.Yp == nullptr || (g.ldy & 3) != 0 || (g.ldyp & 3) != 0 || ((((uintptr_t)g.Y) | ((uintptr_t)g.Yp)) & 15) != 0) return false;
+  if (g.Yp != b.X || g.ldyp != b.ld) return false;      // the epilogue's producer output IS the layer's input (read once, from LDS)
   if (g.stat_slots == nullptr || g.mmean == nullptr || g.mrstd == nullptr || g.ms == nullptr || g.mt == nullptr) return false;
-  if (!g.mask_relu || g.n_mask != 64) return false;
+  if (g.ms != b.c0 || g.mt != b.c1) return false;
+  if (!g.mask_relu || g.n_mask != CI) return false;
   if ((((uintptr_t)g.ms) | ((uintptr_t)g.mt) | ((uintptr_t)g.mmean) | ((uintptr_t)g.mrstd)) & 15) return false;
-  const long ntile = g.M / SPG_PAIR_ROWS;
+  const long ntile = g.M / IT;
   const long grid = ntile < spg_num_cus() ? ntile : spg_num_cus();
-  return (size_t)grid * g.K * 64 <= spg_wgrad_workspace_floats(g.M, g.K, 64);      // the layer's slice of the reduction arena
+  return (size_t)grid * CO * CI <= spg_wgrad_workspace_floats(g.M, CO, CI);      // the layer's slice of the reduction arena
 }
 
-template <int CO, int AMODE>
+template <int CO, int CI, int AMODE>
 static int launch_bwdpair_t(const SpgBwdPairParams& p, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  const size_t lds = spg_bwdpair_lds_bytes<CO>();
+  const size_t lds = spg_bwdpair_lds_bytes<CO, CI>();
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spg_bwdpair_kernel<CO, AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spg_bwdpair_kernel<CO, CI, AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { spg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((spg_bwdpair_kernel<CO, AMODE>), dim3(grid), dim3(SPG_PAIR_THREADS), lds, stream, p);
+  hipLaunchKernelGGL((spg_bwdpair_kernel<CO, CI, AMODE>), dim3(grid), dim3(SPG_PAIR_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
 }
+template <int AMODE>
+static int launch_bwdpair_shape(const SpgBwdPairParams& p, int grid, hipStream_t stream) {
+  if (p.g.N == 64 && p.g.K == 64) return launch_bwdpair_t<64, 64, AMODE>(p, grid, stream);
+  if (p.g.N == 64) return launch_bwdpair_t<128, 64, AMODE>(p, grid, stream);
+  return launch_bwdpair_t<128, 128, AMODE>(p, grid, stream);
+}
 
 // g: the data-gradient problem as for spg_launch_gemm (w_red = 1, epi = BWD, stat_slots, fold_bwd = this layer's pending sums or none);
-// b: the layer's input operand; dW [g.K, 64].  The caller checks spg_bwdpair_supported first.
+// b: the layer's input operand; dW [g.K, g.N].  The caller checks spg_bwdpair_supported first.
 int spg_queue_bwdpair(SpgReduceQueue& q, SpgGemmParams g, const SpgOperand& b, float* dW, hipStream_t stream) {
   SPG_CHECK_ARG(spg_bwdpair_supported(g, b), "shape not supported by the fused backward");
-  const int ntile = g.M / SPG_PAIR_ROWS;
+  const int IT = spg_bwdpair_rows(g.N);
+  const int ntile = g.M / IT;
   const int grid = ntile < spg_num_cus() ? ntile : spg_num_cus();
   SpgBwdPairParams p;
   memset(&p, 0, sizeof(p));
-  g.ntile = ntile; g.vec_store = 1; g.rows_per_tile = SPG_PAIR_ROWS;
+  g.ntile = ntile; g.vec_store = 1; g.rows_per_tile = IT;
   p.g = g; p.b = b;
   if (q.njobs + 1 > SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(q, stream));
   float* part = dW;
-  if (grid > 1) SPG_TRY(queue_take(q, (size_t)grid * g.K * 64, &part, stream));
+  if (grid > 1) SPG_TRY(queue_take(q, (size_t)grid * g.K * g.N, &part, stream));
   p.partial = part;
   {
-    const double flops = 4.0 * (double)g.M * (double)g.K * 64.0;      // data gradient + weight gradient
-    ProfScope prof(stream, flops, SPG_PROF_TAG(4, SPG_PAIR_ROWS, 64, g.a.mode, SPG_PRO_AFFINE, 1));
-    prof.r.M = g.M; prof.r.N = 64; prof.r.K = g.K;
-    if (g.K == 64) {
-      if (g.a.mode == SPG_PRO_BNBWD) SPG_TRY((launch_bwdpair_t<64, SPG_PRO_BNBWD>(p, grid, stream)));
-      else SPG_TRY((launch_bwdpair_t<64, SPG_PRO_POOLBWD>(p, grid, stream)));
-    } else {
-      if (g.a.mode == SPG_PRO_BNBWD) SPG_TRY((launch_bwdpair_t<128, SPG_PRO_BNBWD>(p, grid, stream)));
-      else SPG_TRY((launch_bwdpair_t<128, SPG_PRO_POOLBWD>(p, grid, stream)));
-    }
+    const double flops = 4.0 * (double)g.M * (double)g.K * (double)g.N;      // data gradient + weight gradient
+    ProfScope prof(stream, flops, SPG_PROF_TAG(4, 64, 64, g.a.mode, SPG_PRO_AFFINE, 1));
+    prof.r.M = g.M; prof.r.N = g.N; prof.r.K = g.K;
+    if (g.a.mode == SPG_PRO_BNBWD) SPG_TRY(launch_bwdpair_shape<SPG_PRO_BNBWD>(p, grid, stream));
+    else SPG_TRY(launch_bwdpair_shape<SPG_PRO_POOLBWD>(p, grid, stream));
   }
   if (grid > 1) {
     SpgReduceJob& j = q.jobs[q.njobs++];
-    j.partial = part; j.out = dW; j.nsplit = grid; j.n = g.K * 64;
+    j.partial = part; j.out = dW; j.nsplit = grid; j.n = g.K * g.N;
   }
   return 0;
 }

@@ -1,4 +1,4 @@
-"""Fused backward of the 64-input-channel convolutions (round 4; superpoint_graph_amd/csrc/spg_gemm.hip: spg_bwdpair_kernel):
+"""Fused backward of the convolutions with 64 / 128 input channels (round 4; superpoint_graph_amd/csrc/spg_gemm.hip: spg_bwdpair_kernel):
 the data gradient and the weight gradient of a layer come from ONE pass over dz instead of two launches that each re-read
 g and y.  Per element the arithmetic is that of the separate kernels, the summation order of dW and of the BatchNorm-backward
 sums differs -- so a whole training step is compared with the separate launches (spg_tune key 14 = 1) at fp32 round-off, not
@@ -65,7 +65,7 @@ def test_fused_narrow_backward_matches_separate_launches(hip, tag):
     sep, n_sep = _run(hip, spec, batch, state0, cw, True)
     fus, n_fus = _run(hip, spec, batch, state0, cw, False)
     assert n_sep == 0
-    assert n_fus == (4 if tag == 's3dis_gru10_matrix' else 2), 'conv2 / conv3 of the main network (and of the STN where it has 64-channel layers)'
+    assert n_fus == (5 if tag == 's3dis_gru10_matrix' else 2), 'conv2 / conv3 / conv4 of the main network, conv2 / conv3 of the STN (where they have 64 / 128 input channels)'
     worst = _compare(sep, fus, 2e-5)
     print(f'{tag}: {n_fus} fused launches, worst gradient difference {worst[1]:.2e} ({worst[0]})')
     again, _ = _run(hip, spec, batch, state0, cw, False)
@@ -91,6 +91,6 @@ def test_fused_narrow_backward_on_scenes(hip, n_sp, n_edges):
     state0 = {k: v.clone() for k, v in ref.state_dict().items()}
     sep, n_sep = _run(hip, spec, batch, state0, None, True)
     fus, n_fus = _run(hip, spec, batch, state0, None, False)
-    assert n_sep == 0 and n_fus == 4      # conv2 / conv3 of the STN, conv2 / conv3 of the main network
+    assert n_sep == 0 and n_fus == 5      # conv2 / conv3 of the STN, conv2 / conv3 / conv4 of the main network
     worst = _compare(sep, fus, 2e-5)
     print(f'{n_sp} superpoints: worst gradient difference {worst[1]:.2e} ({worst[0]})')
