@@ -39,7 +39,10 @@ def main():
         F.cross_entropy(out, label).backward()
         emb_er.bw_hook()
         return out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    # (local BatchNorm with the separate backward launches the synchronised mode uses: spg_tune key 14, tests/test_gpu_bwdpair.py)
+    old = L.spg_tune(14, 1)
     out0, g0 = run()
+    L.spg_tune(14, old)
     st = spd.enable_sync_bn(dev)
     assert st.get('native') is True
     try:
