@@ -486,6 +486,10 @@ typedef struct spg_step_args {
   int64_t ignore_index;
   int reduction_mean;                     /* 1: mean over the labelled rows (single process); 0: sum (data parallel) */
   float* loss_buf;                        /* out [N + 2]: log-sum-exp per row | loss | sum of the labelled rows' class weights */
+  /* in: 1 = the BatchNorm statistics slots inside ptn_ws are zero -- true when the previous call that used this ptn_ws was a
+   * spg_train_step that returned 0 (every step leaves them zero: the clearing rides with its last launch) and nothing else has
+   * written ptn_ws since; 0 (always safe): the step clears them itself first (one more launch) */
+  int ptn_slots_clean;
 } spg_step_args;
 int spg_train_step(const spg_step_args* args, void* stream);
 /* loss, log-sum-exp, normaliser AND the gradient wrt the logits (for d loss = 1) in one single-workgroup launch */

@@ -61,7 +61,7 @@ class StepArgs(ctypes.Structure):
                 ('cls_dW', ctypes.c_void_p), ('cls_db', ctypes.c_void_p), ('cls_work', ctypes.c_void_p), ('logits', ctypes.c_void_p),
                 ('grad_logits', ctypes.c_void_p),
                 ('target', ctypes.c_void_p), ('class_weight', ctypes.c_void_p), ('ignore_index', ctypes.c_int64),
-                ('reduction_mean', ctypes.c_int), ('loss_buf', ctypes.c_void_p)]
+                ('reduction_mean', ctypes.c_int), ('loss_buf', ctypes.c_void_p), ('ptn_slots_clean', ctypes.c_int)]
 
 
 class EdgeFeatureSpecs(ctypes.Structure):

@@ -16,6 +16,7 @@
 #include "../../include/spg_hip.h"
 #include "spg_ecc.h"
 #include "spg_gemm.h"
+#include <limits.h>
 #include <vector>
 
 namespace {
@@ -532,6 +533,13 @@ extern "C" int spg_pointnet_forward(const spg_pointnet_cfg* cfg, int B, const fl
   return spg_pointnet_forward_ext(cfg, B, clouds, clouds_global, nullptr, params, emb, workspace, training, bn_update_times, stream);
 }
 
+// spg_train_step (spg_step.hip), per thread: `clean` -- a train-mode forward does NOT clear the statistics slots (the caller
+// vouches that the previous step on the same workspace left them zero); `clear_at_end` -- the backward clears them as a job of
+// its final batched reduction (a reduction over ZERO partials writes zeros): the last launch of the step, behind every producer
+// and consumer of the slots
+static thread_local bool g_slots_clean = false, g_slots_clear_at_end = false;
+void spg_pointnet_set_step_flags(bool clean, bool clear_at_end) { g_slots_clean = clean; g_slots_clear_at_end = clear_at_end; }
+
 extern "C" int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, const float* clouds, const float* clouds_global,
                                         const float* ext_transform, const void* const* params, float* emb, void* workspace,
                                         int training, int bn_update_times, void* stream) {
@@ -564,7 +572,7 @@ extern "C" int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, cons
   // finalize launches; not with synchronised BatchNorm (the ranks' all-reduce sits between producer and consumer)
   // (every tile contributes at most 4 wave partials per channel: far below the slots' capacity up to ~500 k superpoints)
   pl.fold = pl.training && !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && 4L * B <= SPG_FOLD_MAX_CONTRIBUTIONS;
-  if (pl.training) {      // always in train mode: the backward decides about its own slots independently (they are cleared here too)
+  if (pl.training && !g_slots_clean) {      // always in train mode: the backward decides about its own slots independently (they are cleared here too)
     hipError_t me = hipMemsetAsync(pl.slots_all, 0, pl.slots_words * sizeof(unsigned long long), st);
     if (me != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(me)); return (int)me; }
   }
@@ -643,6 +651,13 @@ extern "C" int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, con
   if (pl.has_stn) {
     SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, s.dT, st));
     SPG_TRY(backward_segment(pl, pl.stn, s, rq, op_ident(s.dT, 4), clouds, nullptr, false, st, true));
+  }
+  if (g_slots_clear_at_end && pl.slots_all != nullptr && pl.slots_words > 0) {
+    SPG_CHECK_ARG(2 * pl.slots_words < (size_t)INT_MAX, "statistics slots too large for one reduction job");
+    SpgReduceJob j;
+    j.partial = reinterpret_cast<const float*>(pl.slots_all); j.out = reinterpret_cast<float*>(pl.slots_all);
+    j.nsplit = 0; j.n = (int)(2 * pl.slots_words);
+    spg_reduce_defer(j);
   }
   return spg_flush_reduce(rq, st);      // ONE launch sums the split partials of all weight / bias gradients
 }

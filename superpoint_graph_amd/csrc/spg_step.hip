@@ -24,10 +24,12 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
 int spg_linear_backward_deferred(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K, float* dX,
                                  long lddx, float* dW, float* dbias, float* work, hipStream_t st);
 
+void spg_pointnet_set_step_flags(bool clean, bool clear_at_end);
+
 namespace {
 // whatever happens inside the step, no rider / deferred reduction survives the call (their buffers belong to the caller)
 struct StepGuard {
-  ~StepGuard() { spg_riders_clear(); spg_reduce_deferred_clear(); }
+  ~StepGuard() { spg_riders_clear(); spg_reduce_deferred_clear(); spg_pointnet_set_step_flags(false, false); }
 };
 }  // namespace
 
@@ -49,8 +51,12 @@ extern "C" int spg_train_step(const spg_step_args* a, void* stream) {
   SpgEccScatter sc;
   sc.emb = a->emb; sc.slot_of_row = a->slot_of_row; sc.idx_valid = a->idx_valid; sc.desc = a->desc; sc.grad_emb = a->grad_emb; sc.B = B;
   SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, N, E, a->graph_ws, nullptr, a->edgefeats, a->ecc_params, nullptr, a->ecc_ws, 1, 1, stream, 1, nullptr));
+  // BatchNorm statistics slots inside ptn_ws: every step leaves them ZERO (the clearing rides with the final reduction below), so
+  // a caller that runs step after step on the same workspace saves the memset launch in front of every forward
+  spg_pointnet_set_step_flags(a->ptn_slots_clean != 0, false);
   SPG_TRY(spg_pointnet_forward_ext(a->ptn_cfg, B, a->clouds, a->clouds_global, nullptr, a->ptn_params, a->emb, a->ptn_ws, 1,
                                    a->bn_update_times, stream));
+  spg_pointnet_set_step_flags(false, false);
   SPG_TRY(spg_riders_drain(st));
   // (the embedding scatter is read in place by the one-launch recurrence; its per-iteration fallback materialises a->desc)
   SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, N, E, a->graph_ws, nullptr, a->edgefeats, a->ecc_params, a->ecc_out, a->ecc_ws, 1, 1, stream, 2, &sc));
@@ -63,8 +69,10 @@ extern "C" int spg_train_step(const spg_step_args* a, void* stream) {
   // through the recurrence; its tail rides with PointNet's backward
   SPG_TRY(spg_eccrnn_backward_phase(a->ecc_cfg, N, E, a->graph_ws, a->edgefeats, a->ecc_params, a->grad_ecc_out, a->grad_desc, a->ecc_grads,
                                     a->ecc_ws, a->ecc_bwd_ws, stream, 1, &sc));
+  spg_pointnet_set_step_flags(false, true);
   SPG_TRY(spg_pointnet_backward_ext(a->ptn_cfg, B, a->clouds, a->clouds_global, nullptr, a->ptn_params, a->grad_emb, a->ptn_grads, nullptr,
                                     nullptr, a->ptn_ws, a->ptn_bwd_ws, stream));
+  spg_pointnet_set_step_flags(false, false);
   SPG_TRY(spg_riders_drain(st));
   return spg_flush_deferred_reduce(st);
 }

@@ -183,7 +183,11 @@ class FusedStep:
         a.target = target.data_ptr()
         a.class_weight = None if self.class_weights is None else self.class_weights.data_ptr()
         a.ignore_index, a.reduction_mean, a.loss_buf = self.ignore_index, int(self.mean), loss_buf.data_ptr()
+        # the statistics slots inside ptn_ws are zero after every successful step on these buffers (include/spg_hip.h)
+        a.ptn_slots_clean = 1 if b.get('slots_clean') else 0
+        b['slots_clean'] = False
         _lib.check(_lib.lib().spg_train_step(ctypes.byref(a), ops._stream()), 'spg_train_step')
+        b['slots_clean'] = True
         self.normaliser = loss_buf[N + 1:N + 2]       # sum of the labelled rows' class weights (data-parallel loss weight w_r)
         self._emb, self._slot = b['emb'], slot_of_row   # (the descriptors are read in place by the recurrence: see `embeddings`)
         return loss_buf[N], logits
