@@ -431,6 +431,14 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * jobs of ONE kernel; the bodies are unchanged, results bit-identical -- A/B timing and the equality test).
  * key 12: 1 = few-row GEMMs with a reduction of >= 128 run in the split-K form (a 32 x 32 tile per workgroup, the four waves
  * split the reduction chunks; an experiment: measured no faster, off by default).
+ * key 13: 1 = the masked (incomplete-tile) forward pipelines store scalars instead of vectors.  key 14: 1 = the backward of the
+ * 64- / 128-input-channel convolutions runs as separate data-gradient and weight-gradient launches instead of the fused
+ * one-pass kernel (same arithmetic per element, different summation order of dW and of the BatchNorm-backward sums).
+ * key 15: 1 = spg_train_step runs the classifier and the cross entropy as separate launches instead of inside the one-launch
+ * RNN-ECC recurrence (per element the same expressions; the dot products over the 32 state channels / the classes are
+ * sequential fma chains instead of MFMA chunks: differences at fp32 round-off).  key 6: 1 = with the classifier inside the
+ * recurrence, its weight / bias gradient leaves as a job of a grouped launch (+10 us) instead of being formed by service
+ * workgroups of the persistent backward launch on the CUs the recurrence leaves idle.
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* ------------------------------------------------------------------------------------------------

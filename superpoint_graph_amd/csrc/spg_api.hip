@@ -540,6 +540,22 @@ extern "C" int spg_linear_backward(const float* dY, long lddy, const float* X, l
   return linear_backward_impl(dY, lddy, X, ldx, W, M, N, K, dX, lddx, dW, dbias, work, (hipStream_t)stream, false);
 }
 
+// inside spg_train_step, as part of a rider stage: weight + bias gradient only, as jobs of the group that is open on this
+// thread (no scope of its own), the split partials left to the step's final batched reduction
+int spg_linear_wgrad_bias_queue_deferred(const float* dY, long lddy, const float* X, long ldx, int M, int N, int K, float* dW,
+                                         float* dbias, float* work, hipStream_t st) {
+  SPG_CHECK_ARG(dY && X && dW && work, "null pointer");
+  SpgReduceQueue rq;
+  rq.arena = work; rq.arena_floats = spg_linear_wgrad_bias_work_floats(M, N, K);
+  SpgWgradParams w; memset(&w, 0, sizeof(w));
+  w.a = affine_operand(dY, lddy, N, nullptr, nullptr, 0);
+  w.b = affine_operand(X, ldx, K, nullptr, nullptr, 0);
+  w.M = M; w.N = N; w.K = K;
+  SPG_TRY(spg_queue_wgrad(rq, w, dW, st, dbias));
+  for (int j = 0; j < rq.njobs; ++j) spg_reduce_defer(rq.jobs[j]);
+  return 0;
+}
+
 // inside spg_train_step: the reduction of the partials waits for the step's final batched reduction
 int spg_linear_backward_deferred(const float* dY, long lddy, const float* X, long ldx, const float* W, int M, int N, int K, float* dX,
                                  long lddx, float* dW, float* dbias, float* work, hipStream_t st) {

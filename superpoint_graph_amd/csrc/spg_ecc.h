@@ -148,6 +148,33 @@ struct SpgPxGroups {               // node ranges [ptr[g], ptr[g+1]) of the roun
 // = 0: unknown -- one round if the whole graph fits); false when a part exceeds a round or too many rounds would be needed
 bool spg_px_plan_groups(int N, int n_parts, const int* part_ptr, SpgPxGroups* out);
 #define SPG_PX_SAVE_F 12           // floats per lane and (node, iteration) of forward internals kept for the backward (3 quads)
+// What follows the recurrence in the standard model -- the classifier Linear(nin -> C) on the module's output (h^R, or all of
+// h^0 .. h^R with cat_all: nin = 32 or 32 (R + 1); learning/graphnet.py:47-49,81) and the weighted cross entropy of the trainer
+// (learning/main.py:205) -- computed by the wavefront that owns the node: the logits grow by W[:, 32r : 32r + 32] h^r while the
+// wave has h^r in LDS anyway (before it waits for its neighbours), log-sum-exp, the gradient wrt the logits and wrt the module's
+// output follow its last iteration; the loss is summed by workgroup 0 of the NEXT launch (the persistent backward, at its end)
+// with the summation order of ce_fwd_kernel (spg_loss.hip).  Replaces three latency-bound launches (classifier forward, cross entropy, classifier
+// data gradient) between the two recurrences.  W == nullptr: no head.  The classifier's rows live in LDS (dynamic, C rows of
+// nin + 4 floats): at most SPG_PX_HEAD_LDS bytes, so that two workgroups per CU stay resident.
+#define SPG_PX_HEAD_MAXC 32
+#define SPG_PX_HEAD_LDS 24576
+struct SpgEccHead {
+  const float* W;              // [C, nin]
+  const float* b;              // [C] or null
+  const int64_t* target;       // [N] class index or ignore_index
+  const float* class_weight;   // [C] or null
+  int64_t ignore_index;
+  int C, reduction_mean, N, nin;
+  float* logits;               // out [N, C]
+  float* grad_logits;          // out [N, C]  d loss / d logits (for d loss = 1)
+  float* grad_out;             // out [N, nin] d loss / d (module output)
+  float* lse;                  // out [N] log-sum-exp per row
+  float* loss;                 // out [1]
+  float* wsum;                 // out [1] sum of the labelled rows' class weights
+  float* dW;                   // out [C, nin] / [C] (or null): the classifier's parameter gradients, formed by SERVICE workgroups
+  float* db;                   //   of the persistent backward launch when CUs are left for them (see node_wgs below)
+};
+inline size_t spg_px_head_lds_bytes(const SpgEccHead& h) { return h.W == nullptr ? 0 : (size_t)h.C * (size_t)(h.nin + 4) * sizeof(float); }
 struct SpgEccPersistFwd {
   SpgGraph g;
   const float* W;
@@ -164,6 +191,8 @@ struct SpgEccPersistFwd {
   SpgPxGroups groups;
   float* fsave;             // [N][R][3 quads][64 lanes][4] forward internals kept for the backward (training), or null
   unsigned* fsave_tag;      // set to a magic word by the persistent forward when fsave was written
+  SpgEccHead head;          // classifier + cross entropy behind the last iteration (head.W == nullptr: none)
+  int node_wgs;             // = gridDim.x (set by the launcher)
 };
 
 struct SpgEccPersistBwd {
@@ -184,12 +213,19 @@ struct SpgEccPersistBwd {
   SpgPxGroups groups;
   const float* fsave;       // forward internals (see SpgEccPersistFwd) -- used when *fsave_tag carries the magic word
   const unsigned* fsave_tag;
+  SpgEccHead head;          // the head the forward launch ran (W == nullptr: none)
+  // workgroups [0, node_wgs) own nodes; workgroups beyond are SERVICE workgroups on CUs the recurrence leaves idle (set by the
+  // launcher, within the residency bound; nobody waits for them): node_wgs sums the head's loss (without one, workgroup 0 does
+  // at its end) and then, with all n_wgrad service workgroups, forms the classifier's weight / bias gradient: every wave takes
+  // blocks of 64 columns (n_wgrad = 0: the caller queues them as a job of a grouped launch instead)
+  int node_wgs, n_wgrad;
 };
 
 // return false when the persistent form is not applicable (too many nodes / iterations, switched off, another stream owns
 // the exchange buffer): the caller then runs the per-iteration launches; *err != 0: the launch itself failed
 bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err);
-bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err);
+// *head_wgrad_done (optional): the launch formed head.dW / head.db itself
+bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err, bool* head_wgrad_done = nullptr);
 
 // spg_train_step: CloudEmbedder's scatter of the embeddings to all superpoints (learning/pointnet.py:177-179) and the gather of
 // their gradients, fused into the one-launch recurrence (it reads row slot_of_row[i] of `emb`, a zero row where < 0, and writes

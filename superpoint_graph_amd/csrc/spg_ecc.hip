@@ -1037,6 +1037,197 @@ template <> struct SpgPxRows<false> { typedef GruRowsLds type; };
 __device__ __forceinline__ void spg_px_rows_init(GruRowsReg& w, const GruRowsLds& l) { w.load(l); }
 __device__ __forceinline__ void spg_px_rows_init(GruRowsLds& w, const GruRowsLds& l) { w = l; }
 
+// ---- the head behind the recurrence (SpgEccHead, spg_ecc.h): classifier + weighted cross entropy per node, in the owning wave ----
+// Sum over ALL rows of the labelled rows' class weights -- the normaliser of the mean reduction -- by the 256 threads of a
+// workgroup, with the summation order of ce_fwd_kernel (spg_loss.hip): 1024 virtual threads striding the rows, a 64-lane butterfly
+// per virtual wave, the 16 wave sums added in order.  Thread p plays the virtual threads p, p + 256, p + 512, p + 768 (virtual
+// wave (p >> 6) + 4q = its own wave's butterfly).  part: [16] doubles in LDS; every caller adds them up itself after the next
+// workgroup barrier (spg_px_head_wsum_finish) -- the same value in every workgroup and every launch.
+__device__ __forceinline__ void spg_px_head_wsum_partials(const SpgEccHead& hd, double* part) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    for (int i = (int)threadIdx.x + 256 * q; i < hd.N; i += 1024) {
+      const int64_t t = hd.target[i];
+      if (t != hd.ignore_index && t >= 0 && t < hd.C) acc[q] += (double)(hd.class_weight ? hd.class_weight[t] : 1.f);
+    }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    for (int off = 32; off >= 1; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
+    if ((threadIdx.x & 63) == 0) part[(threadIdx.x >> 6) + 4 * q] = acc[q];
+  }
+}
+__device__ __forceinline__ float spg_px_head_wsum_finish(const double* part) {
+  double b = 0.0;
+  for (int k = 0; k < 16; ++k) b += part[k];
+  return (float)b;
+}
+
+// logits of this node += W[:, col0 : col0 + 32] h, h = sh[0..31] (the wave's LDS copy of a state); lane c < C owns class c
+__device__ __forceinline__ void spg_px_head_accum(const float* wc, int ldw, int col0, const float* sh, int lane, int C, float& hlog) {
+  if (lane < C) {
+    const f32x4* wr = reinterpret_cast<const f32x4*>(wc + lane * ldw + col0);
+    const f32x4* hv = reinterpret_cast<const f32x4*>(sh);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 w = wr[q], h = hv[q];
+      hlog = fmaf(h[0], w[0], hlog); hlog = fmaf(h[1], w[1], hlog); hlog = fmaf(h[2], w[2], hlog); hlog = fmaf(h[3], w[3], hlog);
+    }
+  }
+}
+
+// One node behind its last iteration: hlog = the finished logit of class `lane` (lanes < C).  Per element the expressions of
+// spg_loss.hip (ce_fwd_bwd_kernel); every lane reads the node's C logits back from LDS and forms the max and the sum of the
+// exponentials itself, in class order -- ce_fwd_kernel's own loops (no cross-lane reduction on the tail of the launch).
+// d loss / d (module output) = W^T g: column lane + 64 j of the output per lane and j (all states at once: consecutive lanes,
+// consecutive LDS words, the j-th read 256 bytes further), the classes in order.
+// t: the node's class index, -1 when it carries no loss (ignore_index / out of range); w: its class weight; sq: >= 2 * 32 floats
+__device__ __forceinline__ void spg_px_head_node(const SpgEccHead& hd, const float* wc, int ldw, float wsum, int i, int lane,
+                                                 float hlog, float* sq, long t, float w) {
+  const int C = hd.C;
+  constexpr int MQ = SPG_PX_HEAD_MAXC / 4;
+  if (lane < C) hd.logits[(long)i * C + lane] = hlog;
+  if (lane < SPG_PX_HEAD_MAXC) sq[lane] = lane < C ? hlog : -FLT_MAX;
+  spg_node_sync<true>();
+  float m = -FLT_MAX;
+#pragma unroll
+  for (int q = 0; q < MQ; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sq + 4 * q);
+    m = fmaxf(fmaxf(fmaxf(fmaxf(m, v[0]), v[1]), v[2]), v[3]);
+  }
+  const float ex = lane < C ? expf(hlog - m) : 0.f;
+  if (lane < SPG_PX_HEAD_MAXC) sq[SPG_PX_HEAD_MAXC + lane] = ex;
+  spg_node_sync<true>();
+  float ssum = 0.f;
+#pragma unroll
+  for (int q = 0; q < MQ; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sq + SPG_PX_HEAD_MAXC + 4 * q);
+    ssum += v[0]; ssum += v[1]; ssum += v[2]; ssum += v[3];      // (zeros beyond C)
+  }
+  const float l = m + logf(ssum);
+  float g = 0.f;
+  if (t >= 0 && lane < C) {
+    const float scale = 1.f * w / (hd.reduction_mean ? wsum : 1.f);
+    g = scale * (expf(hlog - l) - (lane == (int)t ? 1.f : 0.f));
+  }
+  if (lane < C) hd.grad_logits[(long)i * C + lane] = g;
+  if (lane == 0) hd.lse[i] = l;
+  spg_node_sync<true>();
+  if (lane < SPG_PX_HEAD_MAXC) sq[lane] = g;
+  spg_node_sync<true>();
+  constexpr int NJ = SPG_PX_MAX_ITERS * 32 / 64;      // nin <= 32 (R + 1) <= 512 columns: 8 per lane
+  float d[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) d[j] = 0.f;
+  const float* wl = wc + lane;
+  for (int c = 0; c < C; ++c) {
+    const float gc = sq[c];
+    const float* wr = wl + c * ldw;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (64 * j < hd.nin) d[j] = fmaf(gc, lane + 64 * j < hd.nin ? wr[64 * j] : 0.f, d[j]);      // (outer test: uniform)
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (lane + 64 * j < hd.nin) hd.grad_out[(long)i * hd.nin + lane + 64 * j] = d[j];
+  spg_node_sync<true>();
+}
+
+// The loss: sum over the rows of w_t (lse - x_t) with ce_fwd_kernel's summation order (see spg_px_head_wsum_partials), by ONE
+// workgroup of the launch BEHIND the one that ran the head -- workgroup 0 of the persistent backward, once its own nodes are
+// through (a launch boundary orders the head's stores in front of these loads; inside the forward launch the same sum would
+// need agent-scope release fences in every wave: an L2 write-back each -- measured +38 us on a 54 us kernel).
+__device__ __forceinline__ void spg_px_head_loss(const SpgEccHead& hd, double* part_l, double* part_w, int* flag) {
+  if (threadIdx.x == 0) flag[0] = 0;
+  __syncthreads();
+  double accl[4] = {0.0, 0.0, 0.0, 0.0}, accw[4] = {0.0, 0.0, 0.0, 0.0};
+  const int C = hd.C;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    for (int i = (int)threadIdx.x + 256 * q; i < hd.N; i += 1024) {
+      const int64_t t = hd.target[i];
+      if (t != hd.ignore_index && t >= 0 && t < C) {
+        const float w = hd.class_weight ? hd.class_weight[t] : 1.f;
+        accl[q] += (double)(w * (hd.lse[i] - hd.logits[(long)i * C + t]));
+        accw[q] += (double)w;
+      } else if (t != hd.ignore_index) {
+        flag[0] = 1;      // a class index outside [0, C) that is not ignore_index: the loss becomes NaN (spg_loss.hip)
+      }
+    }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    for (int off = 32; off >= 1; off >>= 1) { accl[q] += __shfl_xor(accl[q], off, 64); accw[q] += __shfl_xor(accw[q], off, 64); }
+    if ((threadIdx.x & 63) == 0) { part_l[(threadIdx.x >> 6) + 4 * q] = accl[q]; part_w[(threadIdx.x >> 6) + 4 * q] = accw[q]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < 16; ++k) { a += part_l[k]; b += part_w[k]; }
+    *hd.wsum = (float)b;
+    *hd.loss = flag[0] ? __builtin_nanf("") : (float)(hd.reduction_mean ? a / b : a);
+  }
+}
+
+// The classifier's weight and bias gradient by the service workgroups of the persistent backward (CUs the recurrence leaves
+// idle; measured as a job of a grouped launch: +10 us wherever it rides): dW[c][k] = sum_i g[i][c] X[i][k], db[c] = sum_i g[i][c].
+// Work items of ONE wave each: a block of 64 columns over all rows -- no LDS, no synchronisation.
+// dW^T block = G^T X as v_mfma_f32_16x16x4_f32 (C <= 16 classes x 16 columns x 4 rows per instruction; four column blocks share
+// the G operand and one 16-byte load of X): 4 MFMAs + 2 loads per 4 rows, 2 U = 32 row groups of loads in flight (the loop is
+// bound by load latency, ~1.1 us per dependent batch); rows in order (deterministic).  X = the
+// module's output = the recurrence's states.  ~13 us per item at 1000 rows next to a >= 75 us recurrence (a plain fma loop with
+// one column per lane took ~90 us: 16 fmas + 16 broadcasts per row on one wave).  sw = this wave's index among nsw waves.
+__device__ __forceinline__ void spg_px_head_wgrad(const SpgEccHead& hd, const float* __restrict__ X, long ldx, int sw, int nsw) {
+  constexpr int U = 16;
+  const int C = hd.C, N = hd.N, lane = threadIdx.x & 63;
+  const int nb = (hd.nin + 63) / 64;
+  const float* __restrict__ G = hd.grad_logits;
+  const int lr = lane >> 4, lc = lane & 15;      // operand layout: row (K index) lr of the group, class / column index lc
+  for (int item = sw; item < nb; item += nsw) {
+    const bool with_db = item == 0 && hd.db != nullptr;      // the bias gradient = G^T 1: a fifth MFMA of the first item
+    // this lane's quad of columns: element j of it is column index lc of MFMA j, i.e. D_j[c][lc] = dW[c][col0 + 4 lc + j]
+    const int kq = 64 * item + 4 * lc;
+    const bool xon = kq < hd.nin, gon = lc < C;      // (nin is a multiple of 32: whole quads)
+    const float* xp = X + (xon ? kq : 0);
+    const float* gp = G + (gon ? lc : 0);
+    f32x4 acc[4], accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ga[U], gb[U];
+    f32x4 xa[U], xb[U];
+    auto load = [&](float (&g)[U], f32x4 (&x)[U], int i0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long row = min(i0 + 4 * u + lr, N - 1);
+        g[u] = gp[row * C];
+        x[u] = *reinterpret_cast<const f32x4*>(xp + row * ldx);
+      }
+    };
+    auto compute = [&](const float (&g)[U], const f32x4 (&x)[U], int i0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float gv = (gon && i0 + 4 * u + lr < N) ? g[u] : 0.f;      // (rows beyond N, classes beyond C: zero products)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv, xon ? x[u][j] : 0.f, acc[j], 0, 0, 0);
+        if (with_db) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(gv, 1.f, accb, 0, 0, 0);
+      }
+    };
+    load(ga, xa, 0);
+    for (int i0 = 0; i0 < N; i0 += 8 * U) {
+      load(gb, xb, i0 + 4 * U);
+      compute(ga, xa, i0);
+      load(ga, xa, i0 + 8 * U);
+      compute(gb, xb, i0 + 4 * U);
+    }
+    // D_j[c = 4 lr + v][lc] in acc[j][v]
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int c = 4 * lr + v;
+      if (c < C && xon) *reinterpret_cast<f32x4*>(hd.dW + (long)c * hd.nin + kq) = f32x4{acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
+      if (with_db && c < C && lc == 0) hd.db[c] = accb[v];
+    }
+  }
+}
+
 // KMAX: in-edges per node whose filters stay in registers; WPC: workgroups per CU (1: 512 VGPRs per wave -- 12 filters and the
 // cell's gate rows in registers; 2: 256 VGPRs -- 6 filters, gate rows read from the workgroup's LDS copy: twice the nodes per
 // round).  Rounds (p.groups): wave slot s = 4 * blockIdx.x + wave owns node ptr[g] + s of group g for the whole recurrence, then
@@ -1048,9 +1239,21 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   __shared__ __attribute__((aligned(16))) float lds[4][3][32];
   __shared__ __attribute__((aligned(16))) float hsb[4][SPG_PX_CH * 32];
   __shared__ int idb[4][SPG_PX_CH];
+  extern __shared__ __attribute__((aligned(16))) float swc[];      // the head's classifier rows [C][nin + 4] (SpgEccHead)
+  __shared__ double hd_part[16];
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = blockIdx.x * 4 + wave;
+  const bool with_head = p.head.W != nullptr;      // (uniform)
   spg_stage_cell_weights<96>(p.gru, sw);
+  const int hd_ldw = p.head.nin + 4;
+  if (with_head) {
+    const int nq = p.head.nin >> 2;      // (nin = 32 or 32 (R + 1): whole quads; W is 16-byte aligned -- checked by the launcher)
+    for (int e = threadIdx.x; e < p.head.C * nq; e += 256) {
+      const int c = e / nq, q = e - c * nq;
+      *reinterpret_cast<f32x4*>(swc + c * hd_ldw + 4 * q) = *reinterpret_cast<const f32x4*>(p.head.W + (long)c * p.head.nin + 4 * q);
+    }
+    if (p.head.reduction_mean) spg_px_head_wsum_partials(p.head, hd_part);
+  }
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   GruRowsLds wr;
   spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane0, wr);
@@ -1097,6 +1300,17 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     }
   }
   if (deg <= SPG_PX_CH && lane < deg) ids[lane] = p.g.src[e0 + lane];
+  float hlog = with_head && lane < p.head.C && p.head.b != nullptr ? p.head.b[lane] : 0.f;      // the head: logit of class `lane`
+  // the node's label and its class weight: wave-uniform, fetched now (two dependent loads that would sit on the tail otherwise)
+  long hd_t = -1;
+  float hd_w = 0.f;
+  if (with_head) {
+    const int iu = __builtin_amdgcn_readfirstlane(i);
+    hd_t = p.head.target[iu];
+    const bool ok = hd_t != p.head.ignore_index && hd_t >= 0 && hd_t < p.head.C;
+    hd_w = ok ? (p.head.class_weight != nullptr ? p.head.class_weight[hd_t] : 1.f) : 0.f;
+    if (!ok) hd_t = -1;
+  }
   float hcur = 0.f;
   if (lane < 32) {
     const long hrow = p.h0_rows != nullptr ? p.h0_rows[i] : (long)i;
@@ -1110,6 +1324,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     spg_node_sync<true>();
     GruFwdState st;
     spg_gru_hidden_part(p.gru, wq, sh, lane, st);
+    if (with_head && p.cat_all) spg_px_head_accum(swc, hd_ldw, 32 * r, sh, lane, p.head.C, hlog);      // the classifier's share of h^r
     // ---- aggregate over the in-edges: mean of h_src (.) W_e ----
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < deg; c0 += SPG_PX_CH) {
@@ -1186,6 +1401,14 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     if (p.fsave != nullptr) spg_px_save_state(reinterpret_cast<f32x4*>(p.fsave) + ((long)i * p.R + r) * (SPG_PX_SAVE_F / 4) * 64 + lane, st);
     spg_node_sync<true>();      // sa / sh / sx are rewritten by the next iteration
   }
+  // ---- the head: classifier + cross entropy of this node, and the gradient the backward recurrence starts from ----
+  if (with_head) {
+    if (lane < 32) sh[lane] = hcur;
+    spg_node_sync<true>();
+    spg_px_head_accum(swc, hd_ldw, p.cat_all ? 32 * p.R : 0, sh, lane, p.head.C, hlog);
+    const float wsum = p.head.reduction_mean ? spg_px_head_wsum_finish(hd_part) : 1.f;
+    spg_px_head_node(p.head, swc, hd_ldw, wsum, i, lane, hlog, hs, hd_t, hd_w);
+  }
   }      // groups
   spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
 }
@@ -1198,8 +1421,21 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
   __shared__ __attribute__((aligned(16))) float hsb[4][SPG_PX_CH * 32];
   __shared__ int idb[4][SPG_PX_CH];
   __shared__ int eib[4][SPG_PX_CH];
+  __shared__ double hd_part[2][16];
+  __shared__ int hd_flag[1];
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = blockIdx.x * 4 + wave;
+  if ((int)blockIdx.x >= p.node_wgs) {
+    // ---- service workgroups (CUs the recurrence leaves idle): the head's loss; the classifier's parameter gradients ----
+    const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int sv = (int)blockIdx.x - p.node_wgs;
+    if (p.head.W != nullptr) {
+      if (sv == 0) spg_px_head_loss(p.head, hd_part[0], hd_part[1], hd_flag);
+      if (p.n_wgrad > 0) spg_px_head_wgrad(p.head, p.cat_all ? p.states : p.states + (long)p.R * 32, p.ldS, sv * 4 + wave, 4 * p.n_wgrad);
+    }
+    spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
+    return;
+  }
   spg_stage_cell_weights<GW>(p.gru, sw);
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float* sa = lds[wave][0];        // [32] aggregate   | later dgi [96]
@@ -1356,6 +1592,8 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
     }
   }
   }      // groups
+  // the loss of the head the forward launch ran (SpgEccHead): nobody on the device waits for it
+  if (p.head.W != nullptr && blockIdx.x == 0 && (int)gridDim.x == p.node_wgs) spg_px_head_loss(p.head, hd_part[0], hd_part[1], hd_flag);
   spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
 }
 
@@ -1424,6 +1662,14 @@ static char* px_acquire(const SpgPxGroups& groups, int R, hipStream_t stream) {
   return (char*)g_px_buf[dev];
 }
 
+// workgroups the launch may add beyond its node workgroups without leaving the residency bound px_acquire checked
+static int px_spare_wgs(int node_wgs, int wpc) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  const int spare = wpc * (cus - 4) - node_wgs;
+  return spare > 0 ? spare : 0;
+}
+
 extern "C" int spg_ecc_persistent_errors(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES || g_px_buf[dev] == nullptr) return 0;
@@ -1449,8 +1695,9 @@ extern "C" int spg_ecc_persistent_errors_clear(void) {
 // larger (gate gradients, the kept forward internals): 12 / SPG_PX_KMAX2B
 template <bool MATRIX, bool GROUPS>
 static void px_launch_fwd(const SpgEccPersistFwd& p, int wpc, dim3 grid, hipStream_t stream) {
-  if (wpc == 1) hipLaunchKernelGGL((spg_ecc_persist_fwd_kernel<MATRIX, SPG_PX_KMAX1, 1, GROUPS>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((spg_ecc_persist_fwd_kernel<MATRIX, SPG_PX_KMAX2, 2, GROUPS>), grid, dim3(256), 0, stream, p);
+  const size_t dyn = spg_px_head_lds_bytes(p.head);      // <= SPG_PX_HEAD_LDS: two workgroups per CU stay resident
+  if (wpc == 1) hipLaunchKernelGGL((spg_ecc_persist_fwd_kernel<MATRIX, SPG_PX_KMAX1, 1, GROUPS>), grid, dim3(256), dyn, stream, p);
+  else hipLaunchKernelGGL((spg_ecc_persist_fwd_kernel<MATRIX, SPG_PX_KMAX2, 2, GROUPS>), grid, dim3(256), dyn, stream, p);
 }
 template <bool MATRIX, bool GROUPS>
 static void px_launch_bwd(const SpgEccPersistBwd& p, int wpc, dim3 grid, hipStream_t stream) {
@@ -1460,12 +1707,22 @@ static void px_launch_bwd(const SpgEccPersistBwd& p, int wpc, dim3 grid, hipStre
 
 bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err) {
   *err = 0;
+  if (p.head.W != nullptr && (p.head.nin != (p.cat_all ? 32 * (p.R + 1) : 32) || p.head.C < 1 || p.head.C > SPG_PX_HEAD_MAXC ||
+                              spg_px_head_lds_bytes(p.head) > SPG_PX_HEAD_LDS || p.head.N != p.g.N || !p.head.target || !p.head.logits ||
+                              !p.head.grad_logits || !p.head.grad_out || !p.head.lse || !p.head.loss || !p.head.wsum ||
+                              (((uintptr_t)p.head.W) & 15) != 0)) {
+    spg_set_error("persistent ECC forward: the head needs nin = the module's output width, <= %d classes, <= %d bytes of rows and all of its buffers",
+                  SPG_PX_HEAD_MAXC, SPG_PX_HEAD_LDS);
+    *err = -1;
+    return true;
+  }
   char* buf = px_acquire(p.groups, p.R, stream);
   if (buf == nullptr) return false;
   p.ctl = (unsigned*)buf;
   p.gran = (unsigned long long*)(buf + SPG_PX_CTL_BYTES);
   const int mg = px_max_group(p.groups), wpc = mg <= SPG_PX_WG_NODES ? 1 : 2;
-  const dim3 grid(spg_cdiv(mg, 4));
+  p.node_wgs = spg_cdiv(mg, 4);
+  const dim3 grid(p.node_wgs);
   if (p.groups.n == 1) { if (p.matrix) px_launch_fwd<true, false>(p, wpc, grid, stream); else px_launch_fwd<false, false>(p, wpc, grid, stream); }
   else { if (p.matrix) px_launch_fwd<true, true>(p, wpc, grid, stream); else px_launch_fwd<false, true>(p, wpc, grid, stream); }
   hipError_t e = hipGetLastError();
@@ -1473,14 +1730,31 @@ bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err
   return true;
 }
 
-bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err) {
+bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err, bool* head_wgrad_done) {
   *err = 0;
+  if (head_wgrad_done != nullptr) *head_wgrad_done = false;
   char* buf = px_acquire(p.groups, p.R, stream);
   if (buf == nullptr) return false;
   p.ctl = (unsigned*)buf;
   p.gran = (unsigned long long*)(buf + SPG_PX_CTL_BYTES);
   const int mg = px_max_group(p.groups), wpc = mg <= SPG_PX_WG_NODES ? 1 : 2;
-  const dim3 grid(spg_cdiv(mg, 4));
+  p.node_wgs = spg_cdiv(mg, 4);
+  p.n_wgrad = 0;
+  int service = 0;
+  if (p.head.W != nullptr) {
+    const int spare = px_spare_wgs(p.node_wgs, wpc);
+    if (spare >= 1) service = 1;                                     // the loss
+    if (spare >= 1 && p.head.dW != nullptr && head_wgrad_done != nullptr && p.head.C <= 16 && !spg_tune_get(SPG_TUNE_NO_HEAD_SERVICE) &&
+        (((uintptr_t)p.states | (uintptr_t)p.head.dW) & 15) == 0 && (p.ldS & 3) == 0) {
+      // the classifier's parameter gradients: every wave of up to three service workgroups takes 64-column blocks
+      const int nb = (p.head.nin + 63) / 64;
+      service = spare < 3 ? spare : 3;
+      while (service > 1 && 4 * (service - 1) >= nb) --service;
+      p.n_wgrad = service;
+      *head_wgrad_done = true;
+    }
+  }
+  const dim3 grid(p.node_wgs + service);
   if (p.groups.n == 1) { if (p.matrix) px_launch_bwd<true, false>(p, wpc, grid, stream); else px_launch_bwd<false, false>(p, wpc, grid, stream); }
   else { if (p.matrix) px_launch_bwd<true, true>(p, wpc, grid, stream); else px_launch_bwd<false, true>(p, wpc, grid, stream); }
   hipError_t e = hipGetLastError();

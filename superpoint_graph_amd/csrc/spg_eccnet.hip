@@ -256,8 +256,11 @@ static void fnet_forward_stages(const Plan& pl0, const float* edgefeats, int bn_
   }
 }
 
+// head (optional, spg_train_step): classifier + cross entropy behind the last iteration, inside the persistent launch
+// (SpgEccHead, spg_ecc.h); *head_done says whether that launch took it -- the caller runs the separate launches otherwise
 static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float* h0, float* out, hipStream_t st,
-                                    const SpgEccScatter* sc) {
+                                    const SpgEccScatter* sc, const SpgEccHead* head = nullptr, bool* head_done = nullptr) {
+  if (head_done != nullptr) *head_done = false;
   const int N = pl.N, E = pl.E;
   SpgGraph gr = spg_graph_view(graph_ws, N, E);
   const int64_t* h0_rows = nullptr;
@@ -269,8 +272,14 @@ static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float*
     q.states = pl.states; q.ldS = pl.ldS; q.agg = pl.training ? pl.agg : nullptr;
     q.out = out; q.cat_all = pl.cfg.cat_all; q.ldo = pl.cfg.cat_all ? pl.ldS : 32; q.gru = pl.gru;
     q.fsave = pl.fsave; q.fsave_tag = pl.fsave_tag;
+    const bool with_head = head != nullptr && head_done != nullptr && head->nin == (pl.cfg.cat_all ? 32 * (pl.R + 1) : 32) &&
+                           head->C <= SPG_PX_HEAD_MAXC && spg_px_head_lds_bytes(*head) <= SPG_PX_HEAD_LDS;
+    if (with_head) q.head = *head;
     int err = 0;
-    if (spg_launch_ecc_persist_fwd(q, st, &err)) return err;
+    if (spg_launch_ecc_persist_fwd(q, st, &err)) {
+      if (with_head && err == 0) *head_done = true;
+      return err;
+    }
   }
   if (sc != nullptr) {      // per-iteration launches read a materialised descriptor matrix
     SPG_TRY(spg_gather_rows(sc->emb, 32, sc->slot_of_row, N, 32, sc->desc, 32, (void*)st));
@@ -296,7 +305,7 @@ static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float*
 // the caller's next grouped launches; phase 2: the recurrent part only (the caller has drained the riders)
 int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0, const float* edgefeats,
                              const void* const* params, float* out, void* workspace, int training, int bn_update_times, void* stream,
-                             int phase, const SpgEccScatter* sc) {
+                             int phase, const SpgEccScatter* sc, const SpgEccHead* head, bool* head_done) {
   SPG_CHECK_ARG(graph_ws && params && workspace && (phase == 1 || ((h0 || sc) && out)), "null pointer");
   SPG_CHECK_ARG(E == 0 || edgefeats != nullptr, "edgefeats");
   hipStream_t st = (hipStream_t)stream;
@@ -320,13 +329,13 @@ int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void
     }
   }
   if (phase == 1) return 0;
-  return eccrnn_recurrent_forward(pl, graph_ws, h0, out, st, sc);
+  return eccrnn_recurrent_forward(pl, graph_ws, h0, out, st, sc, head, head_done);
 }
 
 extern "C" int spg_eccrnn_forward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* h0,
                                   const float* edgefeats, const void* const* params, float* out, void* workspace,
                                   int training, int bn_update_times, void* stream) {
-  return spg_eccrnn_forward_phase(cfg, N, E, graph_ws, h0, edgefeats, params, out, workspace, training, bn_update_times, stream, 0, nullptr);
+  return spg_eccrnn_forward_phase(cfg, N, E, graph_ws, h0, edgefeats, params, out, workspace, training, bn_update_times, stream, 0, nullptr, nullptr, nullptr);
 }
 
 extern "C" long spg_eccrnn_debug_offset(const spg_eccrnn_cfg* cfg, int N, int E, int training, int layer, int what) {
@@ -361,7 +370,7 @@ struct BwdCtx {
 
 // the tail of the backward: {cell parameter gradients + per-edge filter gradient}, then one stage per filter-network layer
 // ({weight gradient, bias column sums, data gradient}: mutually independent), then the hand-over of the split partials
-void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage>& out) {
+void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage>& out, SpgStage extra_leaf) {
   // the recurrent cell's parameter gradients: three weight gradients + three bias column sums over all (node, iteration) rows.
   // A LEAF -- nothing in the chain below depends on them -- so they do not sit in front of the filter network's chain: they
   // leave with the stage of filter layer n-2 (their ~2000 small workgroups next to that layer's few)
@@ -388,10 +397,15 @@ void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage
   };
   const int nF = (int)c->pl.F.size();
   const int leaf_with = c->pl.E > 0 && nF >= 2 ? nF - 2 : -1;      // the filter-layer stage the cell gradients travel with (-1: the first stage)
-  out.push_back([c, cell_grads, leaf_with](hipStream_t st) -> int {
+  // the caller's own leaf (spg_train_step: the classifier's parameter gradients -- a body of the 2-per-CU build of the grouped
+  // kernel): with the LAST filter layer's stage, which needs that build anyway (in the first stage it pushed the per-edge filter
+  // gradient's 1300 small workgroups off the 4-per-CU build: 14.5 -> 24.6 us; measured: +10 us whichever stage carries it)
+  const int extra_with = c->pl.E > 0 && nF >= 1 ? nF - 1 : -1;
+  out.push_back([c, cell_grads, leaf_with, extra_leaf, extra_with](hipStream_t st) -> int {
     Plan& pl = c->pl; BwdScratch& s = c->s;
     const int R = pl.R;
     const long ldS = pl.ldS;
+    if (extra_leaf && extra_with < 0) SPG_TRY(extra_leaf(st));
     if (leaf_with < 0) SPG_TRY(cell_grads(st));
     if (pl.E == 0) {   // no edges: the filter network received no gradient
       for (FLayer& l : pl.F) {
@@ -408,11 +422,12 @@ void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage
     return 0;
   });
   for (int i = (int)c->pl.F.size() - 1; i >= 0 && c->pl.E > 0; --i) {
-    out.push_back([c, i, cell_grads, leaf_with](hipStream_t st) -> int {
+    out.push_back([c, i, cell_grads, leaf_with, extra_leaf, extra_with](hipStream_t st) -> int {
       Plan& pl = c->pl; BwdScratch& s = c->s;
       const int E = pl.E;
       FLayer& l = pl.F[i];
       if (i == leaf_with) SPG_TRY(cell_grads(st));
+      if (extra_leaf && i == extra_with) SPG_TRY(extra_leaf(st));
       const SpgOperand cur = c->cur;
       const SpgBnFoldBwd fold_i = c->pending;
       memset(&c->pending, 0, sizeof(c->pending));
@@ -478,7 +493,8 @@ void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage
 // call spg_riders_drain + spg_flush_deferred_reduce before the gradients are consumed or the workspaces released
 int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
                               const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
-                              void* workspace, void* bwd_workspace, void* stream, int phase, const SpgEccScatter* sc) {
+                              void* workspace, void* bwd_workspace, void* stream, int phase, const SpgEccScatter* sc,
+                              SpgStage extra_leaf, const SpgEccHead* head) {
   SPG_CHECK_ARG(graph_ws && params && grad_out && grad_h0 && grads && workspace && bwd_workspace, "null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (phase == 0) spg_reduce_deferred_clear();      // (nothing may be left over from a call that failed half-way)
@@ -515,10 +531,16 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
     q.dpre = s.dpre; q.xg = s.xg; q.ld32 = ldS; q.gx = grad_h0; q.gru = pl.gru;
     if (sc != nullptr) { q.gx = sc->grad_emb; q.gx_rows = sc->slot_of_row; }      // the gradient gather written in place
     q.fsave = pl.fsave; q.fsave_tag = pl.fsave_tag;
+    if (head != nullptr) q.head = *head;      // the head the forward launch ran: this launch sums its loss
     int err = 0;
-    persistent = spg_launch_ecc_persist_bwd(q, st, &err);      // writes every row of [G .. xg] itself (slot R: zeros)
+    bool wgrad_done = false;
+    persistent = spg_launch_ecc_persist_bwd(q, st, &err, head != nullptr ? &wgrad_done : nullptr);      // writes every row of [G .. xg] itself (slot R: zeros)
     if (err != 0) return err;
+    if (wgrad_done) extra_leaf = SpgStage();      // the launch formed the classifier's parameter gradients on idle CUs
   }
+  if (head != nullptr && !persistent)      // (the per-iteration fallback: the loss from the head's logits, as its own launch)
+    SPG_TRY(spg_cross_entropy_fwd(head->logits, head->target, head->class_weight, N, head->C, head->ignore_index, head->reduction_mean,
+                                  head->loss, head->lse, head->wsum, stream));
   if (!persistent) SPG_TRY(zero_async(bwd_workspace, s.zero_bytes, st));
   for (int r = R - 1; r >= 0 && !persistent; --r) {
     SpgEccStepBwd p; memset(&p, 0, sizeof(p));
@@ -549,7 +571,7 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
     SPG_TRY(spg_gather_rows(grad_h0, 32, sc->idx_valid, sc->B, 32, sc->grad_emb, 32, stream));
   // ---- the tail: nothing below depends on it, it depends on nothing but the recurrence's outputs ----
   std::vector<SpgStage> stages;
-  eccrnn_backward_tail_stages(c, stages);
+  eccrnn_backward_tail_stages(c, stages, std::move(extra_leaf));
   if (phase == 1) {
     for (SpgStage& sg : stages) spg_riders_push(std::move(sg));
     return 0;
@@ -565,5 +587,5 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
 extern "C" int spg_eccrnn_backward(const spg_eccrnn_cfg* cfg, int N, int E, const void* graph_ws, const float* edgefeats,
                                    const void* const* params, const float* grad_out, float* grad_h0, void* const* grads,
                                    void* workspace, void* bwd_workspace, void* stream) {
-  return spg_eccrnn_backward_phase(cfg, N, E, graph_ws, edgefeats, params, grad_out, grad_h0, grads, workspace, bwd_workspace, stream, 0, nullptr);
+  return spg_eccrnn_backward_phase(cfg, N, E, graph_ws, edgefeats, params, grad_out, grad_h0, grads, workspace, bwd_workspace, stream, 0, nullptr, SpgStage(), nullptr);
 }
