@@ -21,8 +21,9 @@ d = json.load(open('$OUT/${TAG}_bench.json'))
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline frac', d['roofline']['frac'], 'hbm_frac', d['roofline'].get('hbm_frac'))
 EOF2
 
-# the module-level path (no spg_train_step) and the ungrouped launches on the same box: what the round's changes are worth
-for V in "--fused-step 0 --tune 11:1" "--fused-step 0" "--fused-step 1"; do
+# the round's launch structures on the same box: module path ungrouped / grouped (both with separate backward launches), one-call
+# step, + fused convolution backward (key 14 off), + classifier / cross entropy inside the recurrence (key 15 off) = the default
+for V in "--fused-step 0 --tune 11:1,14:1" "--fused-step 0 --tune 14:1" "--fused-step 1 --tune 14:1,15:1" "--fused-step 1 --tune 15:1" "--fused-step 1"; do
   timeout 300 python $ROOT/bench.py --steps 40 --warmup 10 $STEPS $V 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('[$V]', round(d['ms_per_step'],4), 'min', round(d['ms_per_step_min'],4), 'median', round(d['ms_per_step_median'],4))"
 done > $OUT/${TAG}_ab_step_paths.txt
