@@ -445,9 +445,12 @@ int spg_tune(int key, int value);
  * One training step's forward AND backward in ONE call (round 4): CloudEmbedder.run -> model.ecc (RNN-ECC module +
  * classifier) -> weighted cross entropy -> backward -> bw_hook, i.e. learning/main.py:199-208 for the standard model
  * (`gru_R.../lstm_R...` followed by `f_K`), with every gradient written to the caller's buffers (the flat gradient arena).
- * Same kernels, same arithmetic and the same results as the module-level calls it replaces (spg_pointnet_forward_ext,
- * spg_gather_rows, spg_eccrnn_forward, spg_linear_fwd, spg_cross_entropy_*, spg_linear_backward, spg_eccrnn_backward,
- * spg_pointnet_backward_ext) -- what it adds is the ORDER of launches: inside one call the library knows the whole step, so
+ * Same expressions as the module-level calls it replaces (spg_pointnet_forward_ext, spg_gather_rows, spg_eccrnn_forward,
+ * spg_linear_fwd, spg_cross_entropy_*, spg_linear_backward, spg_eccrnn_backward, spg_pointnet_backward_ext); with spg_tune key
+ * 15 = 1 the same kernels and bit-identical results.  By default the classifier and the cross entropy are computed inside the
+ * one-launch GRU recurrence, per node by the wavefront that owns it (the classifier's weight gradient by service workgroups of
+ * the backward recurrence's launch): no launches of their own, results equal at fp32 round-off (other summation order of the
+ * 32-channel dot products; tests/test_gpu_fused.py).  Otherwise what the call adds is the ORDER of launches: inside one call the library knows the whole step, so
  * the filter network's forward (needs only the superedge features) leaves next to PointNet's few-row launches and the tail of
  * the RNN-ECC backward (cell and filter-network parameter gradients, needed by nobody before the optimiser) next to
  * PointNet's backward, as jobs of the same grouped launches instead of ~12 latency-bound launches of their own; and the host
