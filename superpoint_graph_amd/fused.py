@@ -7,8 +7,10 @@ costs ~15 autograd nodes / ctypes calls and, on the device, orders the filter ne
 and the tail of the RNN-ECC backward in front of PointNet's backward although neither depends on PointNet.  For the standard
 model -- `gru_R...` / `lstm_R...` followed by `f_K` (every documented configuration) -- with its parameters in a
 FlatParameters arena this object issues the same kernels through one C call that knows the whole step (the two chains travel
-next to PointNet's launches, superpoint_graph_amd/csrc/spg_step.hip).  Results are those of the module-level path:
-tests/test_gpu_fused.py compares loss, logits, every gradient and the BatchNorm statistics bit for bit.
+next to PointNet's launches, superpoint_graph_amd/csrc/spg_step.hip).  For GRU models the classifier and the cross entropy
+run inside the one-launch recurrence (per node, in the wavefront that owns it).  Results are those of the
+module-level path: tests/test_gpu_fused.py compares loss, logits, every gradient and the BatchNorm statistics bit for bit with
+the classifier / loss as separate launches (spg_tune key 15 = 1) and at fp32 round-off in the default form.
 
 What it keeps of the module API's observable behaviour: BatchNorm batch counters advance (twice for PointNet with
 `ptn_mem_monger`, like the reference's forward + re-forward), too-small superpoints get exact-zero descriptors, the gradients
