@@ -265,22 +265,28 @@ def forward_only(dev, flag, clouds_d, diam_d, GIs, n_feat, iters=40):
     model = build_model('gru_1_0,f_13', dev, n_feat)
     model.ecc.set_info(GIs, 1)
     embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
-    out = {'workload': 'same scene, PointNet + gru_1_0,f_13 (one ECC iteration), forward only, no_grad'}
-    for mode in ('eval', 'train'):
-        model.train(mode == 'train')
+    out = {'workload': 'same scene, PointNet + gru_1_0,f_13 (one ECC iteration), forward only, no_grad; eval_bn: the evaluation '
+                       'forward as ONE library call (spg_infer_step; eval_bn_modules: the same through the Python modules -- host-bound), '
+                       'train_bn: batch statistics, through the modules'}
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep
+    step = FusedStep(model, FlatParameters(model, lazy_zero=True))
 
-        def fwd():
-            with torch.no_grad():
-                return model.ecc(embedder.run(model, None, flag, clouds_d, diam_d))
+    def modules():
+        with torch.no_grad():
+            return model.ecc(embedder.run(model, None, flag, clouds_d, diam_d))
+    for name, train, fwd, n in (('eval_bn', False, lambda: step.infer(flag, clouds_d, diam_d, GIs[0]), 5 * iters),
+                                ('eval_bn_modules', False, modules, iters), ('train_bn', True, modules, iters)):
+        model.train(train)
         for _ in range(5):
             fwd()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(iters):
+        for _ in range(n):
             fwd()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / iters
-        out[mode + '_bn'] = {'ms': dt * 1e3, 'superpoints_per_s': int(flag.numel()) / dt}
+        dt = (time.perf_counter() - t0) / n
+        out[name] = {'ms': dt * 1e3, 'superpoints_per_s': int(flag.numel()) / dt}
     return out
 
 

@@ -503,6 +503,12 @@ typedef struct spg_step_args {
   int ptn_slots_clean;
 } spg_step_args;
 int spg_train_step(const spg_step_args* args, void* stream);
+/* The forward of the same model in INFERENCE mode (BatchNorm running statistics) as one call: the evaluation loop's body
+ * (learning/main.py:256-262: ptnCloudEmbedder.run + model.ecc under model.eval()).  Same kernels and results as the module-level
+ * calls.  Reads of spg_step_args: the forward inputs, parameters, ptn_ws / ecc_ws (sizes from the *_workspace_bytes queries with
+ * training = 0, or larger), emb, the scatter tables (desc: written only by the per-iteration RNN-ECC fallback), ecc_out, the
+ * classifier and logits; the gradient / loss fields are ignored. */
+int spg_infer_step(const spg_step_args* args, void* stream);
 /* loss, log-sum-exp, normaliser AND the gradient wrt the logits (for d loss = 1) in one single-workgroup launch */
 int spg_cross_entropy_fwd_bwd(const float* logits, const int64_t* target, const float* weight, int N, int C, int64_t ignore_index,
                               int reduction_mean, float* loss, float* lse, float* wsum, float* grad_logits, void* stream);

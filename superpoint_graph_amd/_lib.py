@@ -133,6 +133,7 @@ SIGNATURES = {
     'spg_cross_entropy_bwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, ctypes.c_int64, _i, _p, _p]),
     'spg_cross_entropy_fwd_bwd': (_i, [_p, _p, _p, _i, _i, ctypes.c_int64, _i, _p, _p, _p, _p, _p]),
     'spg_train_step': (_i, [ctypes.POINTER(StepArgs), _p]),
+    'spg_infer_step': (_i, [ctypes.POINTER(StepArgs), _p]),
     'spg_eval_accumulate': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
     'spg_set_bn_allreduce': (_i, [_p, _p, _p, _l]),
     'spg_rccl_unique_id': (_i, [_p]),

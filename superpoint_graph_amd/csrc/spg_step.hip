@@ -102,3 +102,24 @@ extern "C" int spg_train_step(const spg_step_args* a, void* stream) {
   SPG_TRY(spg_riders_drain(st));
   return spg_flush_deferred_reduce(st);
 }
+
+// The forward of the same model in INFERENCE mode (BatchNorm running statistics, no gradients kept) as one call:
+// CloudEmbedder.run -> model.ecc under model.eval() / torch.no_grad() (learning/main.py:256-262, the evaluation loop's body).
+// Same kernels and results as the module-level calls; the host enqueues it once instead of walking ~10 modules.  Uses of
+// spg_step_args: the forward inputs / parameters / workspaces (ptn_ws, ecc_ws sized for training = 0 or larger), emb, the
+// scatter tables, ecc_out, the classifier and logits; everything about gradients and the loss is ignored.
+extern "C" int spg_infer_step(const spg_step_args* a, void* stream) {
+  SPG_CHECK_ARG(a != nullptr, "null arguments");
+  SPG_CHECK_ARG(a->ptn_cfg && a->ecc_cfg && a->B > 0 && a->N > 0 && a->E >= 0, "cfg / sizes");
+  SPG_CHECK_ARG(a->clouds && a->ptn_params && a->ptn_ws && a->emb, "PointNet buffers");
+  SPG_CHECK_ARG(a->slot_of_row && a->idx_valid && a->desc && a->nf == a->ecc_cfg->nc, "scatter buffers / embedding width");
+  SPG_CHECK_ARG(a->graph_ws && a->ecc_params && a->ecc_ws && a->ecc_out, "RNN-ECC buffers");
+  SPG_CHECK_ARG(a->cls_W && a->logits && a->nout > 0 && (a->nout & 3) == 0 && a->n_classes > 0, "classifier buffers");
+  SPG_CHECK_ARG(spg_riders_pending() == 0, "a rider chain is already registered on this thread");
+  SpgEccScatter sc;
+  sc.emb = a->emb; sc.slot_of_row = a->slot_of_row; sc.idx_valid = a->idx_valid; sc.desc = a->desc; sc.grad_emb = nullptr; sc.B = a->B;
+  SPG_TRY(spg_pointnet_forward_ext(a->ptn_cfg, a->B, a->clouds, a->clouds_global, nullptr, a->ptn_params, a->emb, a->ptn_ws, 0, 1, stream));
+  SPG_TRY(spg_eccrnn_forward_phase(a->ecc_cfg, a->N, a->E, a->graph_ws, nullptr, a->edgefeats, a->ecc_params, a->ecc_out, a->ecc_ws, 0, 1, stream, 0, &sc,
+                                   nullptr, nullptr));
+  return spg_linear_fwd(a->ecc_out, a->nout, a->N, a->nout, a->cls_W, a->cls_b, a->n_classes, nullptr, nullptr, 0, a->logits, a->n_classes, stream);
+}

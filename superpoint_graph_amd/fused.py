@@ -194,6 +194,65 @@ class FusedStep:
         self._emb, self._slot = b['emb'], slot_of_row   # (the descriptors are read in place by the recurrence: see `embeddings`)
         return loss_buf[N], logits
 
+    def infer(self, clouds_flag, clouds, clouds_global, gc_info):
+        """-> logits [N, n_classes] of the model in EVALUATION mode (model.eval(): BatchNorm running statistics), the body of
+        the evaluation loop (learning/main.py:256-262) as ONE library call (spg_infer_step); same kernels and results as
+        `model.ecc(CloudEmbedder.run(...))` under torch.no_grad()."""
+        from .learning.pointnet import stage_flags
+        ptn, conv, fc = self.ptn, self.conv, self.fc
+        if ptn.training or conv.training:
+            raise RuntimeError('FusedStep.infer is the EVALUATION forward (model.eval()); train with __call__')
+        dev = torch.device('cuda', torch.cuda.current_device())
+        idx_valid, slot_of_row = stage_flags(clouds_flag)
+        clouds = ops.upload(clouds, dev) if not clouds.is_cuda else clouds
+        clouds_global = ops.upload(clouds_global, dev) if not clouds_global.is_cuda else clouds_global
+        clouds = ops._req(clouds.contiguous(), torch.float32, 'clouds')
+        B, N = int(clouds.shape[0]), int(clouds_flag.shape[0])
+        if B < 1:
+            raise ValueError('no embeddable superpoint in the batch')
+        plan = self._tables(int(clouds.shape[2]))
+        if clouds.shape[1] != plan['ptn_cfg'].nfeat:
+            raise ValueError('clouds: wrong number of point features')
+        clouds_global = ops._req(clouds_global.reshape(B, -1).contiguous(), torch.float32, 'clouds_global')
+        idxn, idxe, degs, degs_gpu, edgefeats = gc_info.get_buffers()
+        if idxe is not None:
+            raise NotImplementedError('filter sharing (idxe) is not supported by the fused RNN-ECC path')
+        graph = gc_info.device_graph()
+        E = int(graph.E)
+        if graph.N != N:
+            raise ValueError(f'the batched graph has {graph.N} nodes, clouds_flag has {N} rows')
+        edgefeats = ops._req(edgefeats.contiguous().float(), torch.float32, 'edgefeats')
+        ecc_cfg, _ = conv._cfg_for(gc_info, N)
+        key = ('infer', B, N, E, dev)
+        b = self._bufs.get(key)
+        if b is None:
+            L = _lib.lib()
+            pc, ec = ctypes.byref(plan['ptn_cfg']), ctypes.byref(ecc_cfg)
+            sizes = (L.spg_pointnet_workspace_bytes(pc, B, 0), L.spg_eccrnn_workspace_bytes(ec, N, E, 0))
+            if min(sizes) == 0:
+                raise RuntimeError('workspace query failed: ' + L.spg_last_error().decode())
+            u8 = lambda n: torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
+            f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+            b = dict(ptn_ws=u8(sizes[0]), ecc_ws=u8(sizes[1]), emb=f32(B, plan['nf']), desc=f32(N, plan['nf']), ecc_out=f32(N, plan['nout']))
+            if len(self._bufs) >= 4:
+                self._bufs.pop(next(iter(self._bufs)))
+            self._bufs[key] = b
+        C = fc.out_features
+        logits = torch.empty(N, C, dtype=torch.float32, device=dev)
+        a = _lib.StepArgs()
+        a.ptn_cfg, a.B, a.bn_update_times = ctypes.pointer(plan['ptn_cfg']), B, 1
+        a.clouds, a.clouds_global = clouds.data_ptr(), clouds_global.data_ptr()
+        a.ptn_params, a.ptn_ws, a.emb = plan['ptn_params'], b['ptn_ws'].data_ptr(), b['emb'].data_ptr()
+        a.N, a.nf = N, plan['nf']
+        a.slot_of_row, a.idx_valid, a.desc = slot_of_row.data_ptr(), idx_valid.data_ptr(), b['desc'].data_ptr()
+        a.ecc_cfg, a.E, a.graph_ws = ctypes.pointer(ecc_cfg), E, graph.ws.data_ptr()
+        a.edgefeats = edgefeats.data_ptr() if E else None
+        a.ecc_params, a.ecc_ws, a.ecc_out = plan['ecc_params'], b['ecc_ws'].data_ptr(), b['ecc_out'].data_ptr()
+        a.nout, a.n_classes = plan['nout'], C
+        a.cls_W, a.cls_b, a.logits = fc.weight.data_ptr(), None if fc.bias is None else fc.bias.data_ptr(), logits.data_ptr()
+        _lib.check(_lib.lib().spg_infer_step(ctypes.byref(a), ops._stream()), 'spg_infer_step')
+        return logits
+
     @property
     def embeddings(self):
         """[N, nf] superpoint descriptors of the last step (CloudEmbedder.run's return value: PointNet embeddings scattered to all

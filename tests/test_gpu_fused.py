@@ -203,6 +203,46 @@ def test_head_inside_the_recurrence_on_multi_scene_batches(hip, model_config, n_
     print(f'{model_config} x {n_scenes} scenes: loss {float(head[0]):.6f} (separate launches {float(sep[0]):.6f})')
 
 
+@pytest.mark.parametrize('tag', ['s3dis_gru10_matrix', 'vector_gru4_small', 'lstm3_matrix_small', 'scene600'])
+def test_infer_step_bit_identical_to_modules(hip, tag):
+    """spg_infer_step (FusedStep.infer): the evaluation forward (model.eval(), running statistics) as one call -- logits
+    bit-identical to model.ecc(CloudEmbedder.run(...)) under no_grad, on the goldens and on a scene with too-small superpoints
+    (zero descriptors); after a training step (so that the running statistics are not the initial ones); refused in train mode."""
+    from oracle import spg_oracle as O
+    from superpoint_graph_amd import synth
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep
+    from superpoint_graph_amd.learning import ecc, pointnet
+    if tag == 'scene600':
+        spec = O.ModelSpec()
+        col = synth.collate_numpy([synth.scene(5, n_sp=600, n_edges=2900, small_frac=0.1)])
+        idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+        batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                     clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                     edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+        torch.manual_seed(2)
+        state0 = {k: v.clone() for k, v in build_model(spec).state_dict().items()}
+    else:
+        spec, batch, state0, g = load_golden(tag)
+    model = build_model(spec, state0).to(DEV).train()
+    arena = FlatParameters(model, lazy_zero=True, host_counters=True)
+    step = FusedStep(model, arena)
+    _fused(model, arena, step, batch)                      # one training step: the running statistics move
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    with pytest.raises(RuntimeError, match='EVALUATION'):
+        step.infer(batch['clouds_flag'], batch['clouds'], batch['clouds_global'], gi)
+    model.eval()
+    model.ecc.set_info([gi], 1)
+    embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=0))
+    with torch.no_grad():
+        ref = model.ecc(embedder.run(model, None, batch['clouds_flag'], batch['clouds'], batch['clouds_global'])).clone()
+    out = step.infer(batch['clouds_flag'], batch['clouds'], batch['clouds_global'], gi)
+    out2 = step.infer(batch['clouds_flag'], batch['clouds'], batch['clouds_global'], gi)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    assert torch.equal(out, ref) and torch.equal(out, out2)
+
+
 def test_fused_step_refuses_what_it_does_not_serve(hip):
     from superpoint_graph_amd.flat import FlatParameters
     from superpoint_graph_amd.fused import FusedStep, supports
