@@ -1134,9 +1134,10 @@ __device__ __forceinline__ void spg_px_head_node(const SpgEccHead& hd, const flo
 }
 
 // The loss: sum over the rows of w_t (lse - x_t) with ce_fwd_kernel's summation order (see spg_px_head_wsum_partials), by ONE
-// workgroup of the launch BEHIND the one that ran the head -- workgroup 0 of the persistent backward, once its own nodes are
-// through (a launch boundary orders the head's stores in front of these loads; inside the forward launch the same sum would
-// need agent-scope release fences in every wave: an L2 write-back each -- measured +38 us on a 54 us kernel).
+// workgroup of the launch BEHIND the one that ran the head -- a service workgroup of the persistent backward (without a spare
+// CU: its workgroup 0, once its own nodes are through).  A launch boundary orders the head's stores in front of these loads;
+// inside the forward launch the same sum would need agent-scope release fences in every wave: an L2 write-back each -- measured
+// +38 us on a 54 us kernel.
 __device__ __forceinline__ void spg_px_head_loss(const SpgEccHead& hd, double* part_l, double* part_w, int* flag) {
   if (threadIdx.x == 0) flag[0] = 0;
   __syncthreads();
@@ -1173,9 +1174,9 @@ __device__ __forceinline__ void spg_px_head_loss(const SpgEccHead& hd, double* p
 // Work items of ONE wave each: a block of 64 columns over all rows -- no LDS, no synchronisation.
 // dW^T block = G^T X as v_mfma_f32_16x16x4_f32 (C <= 16 classes x 16 columns x 4 rows per instruction; four column blocks share
 // the G operand and one 16-byte load of X): 4 MFMAs + 2 loads per 4 rows, 2 U = 32 row groups of loads in flight (the loop is
-// bound by load latency, ~1.1 us per dependent batch); rows in order (deterministic).  X = the
-// module's output = the recurrence's states.  ~13 us per item at 1000 rows next to a >= 75 us recurrence (a plain fma loop with
-// one column per lane took ~90 us: 16 fmas + 16 broadcasts per row on one wave).  sw = this wave's index among nsw waves.
+// bound by load latency, ~2.5 us per dependent batch of 64 rows); rows in order (deterministic).  X = the module's output = the
+// recurrence's states.  ~40 us per item at 1000 rows, six items on eight waves, next to a >= 75 us recurrence (a plain fma loop
+// with one column per lane took ~90 us: 16 fmas + 16 broadcasts per row on one wave).  sw = this wave's index among nsw waves.
 __device__ __forceinline__ void spg_px_head_wgrad(const SpgEccHead& hd, const float* __restrict__ X, long ldx, int sw, int nsw) {
   constexpr int U = 16;
   const int C = hd.C, N = hd.N, lane = threadIdx.x & 63;
