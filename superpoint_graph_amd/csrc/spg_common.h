@@ -439,22 +439,33 @@ template <int TI, int TJ>
 __device__ __forceinline__ void spg_mfma_chunk_or(const f32x4* __restrict__ As, const float* __restrict__ Bs,
                                                   int strideA, int strideB, int rowA, int colB, int h,
                                                   f32x16 (&acc)[TI][TJ]) {
+  // register double-buffering of the LDS fragments, as in spg_mfma_chunk: the reads of group g+1 are issued before the MFMAs of
+  // group g (left to the compiler the first MFMA of every group waits for the reads issued right in front of it: one LDS
+  // round trip per 8 MFMAs of a wave with a single accumulator chain -- the data-gradient waves of spg_bwdpair_kernel)
+  f32x4 a[2][TI];
+  float b[2][4][TJ];
+  auto fetch = [&](int buf, int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) a[buf][i] = As[(2 * g + h) * strideA + rowA + 32 * i];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b[buf][s][j] = Bs[(8 * g + 4 * h + s) * strideB + colB + 32 * j];
+  };
+  fetch(0, 0);
 #pragma unroll
   for (int g = 0; g < SPG_KC / 8; ++g) {
-    f32x4 a[TI];
+    const int cur = g & 1;
+    if (g + 1 < SPG_KC / 8) fetch(cur ^ 1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);      // (the next group's reads stay in front of this group's MFMAs ...)
 #pragma unroll
-    for (int i = 0; i < TI; ++i) a[i] = As[(2 * g + h) * strideA + rowA + 32 * i];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float b[TJ];
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) b[j] = Bs[(8 * g + 4 * h + s) * strideB + colB + 32 * j];
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][s], b[cur][s][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);      // (... and this group's MFMAs in front of the reads after next)
   }
 }
 
