@@ -7,9 +7,10 @@ weighted cross entropy -> backward -> bw_hook (PointNet backward) -> [N>1: ONE f
 -> element-wise gradient clamp -> Adam step      (the reference's trainer window, learning/main.py:199-213).
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches it with torch.distributed.run (one rank per GPU, RANK/LOCAL_RANK/WORLD_SIZE in
-the environment); every rank holds its own scene(s) (weak scaling), no data-path collective besides the
-gradient all-reduce.  Rank 0 prints ONE JSON line."""
+For N > 1 one rank per GPU: either the caller launches it with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the
+environment) or -- a plain `python bench.py --gpus N` without WORLD_SIZE -- the script re-launches ITSELF under
+torch.distributed.run with N ranks on 127.0.0.1 (it refuses when the node has fewer than N GPUs).  Every rank holds its
+own scene(s) (weak scaling), no data-path collective besides the gradient all-reduce.  Rank 0 prints ONE JSON line."""
 import argparse
 import json
 import os
@@ -290,6 +291,28 @@ def forward_only(dev, flag, clouds_d, diam_d, GIs, n_feat, iters=40):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: run N ranks of this very command line under
+    torch.distributed.run on this node and hand their exit code back.  The reference has no counterpart (single process,
+    learning/main.py:180); this is the launcher the multi-GPU rows of BASELINE.json need."""
+    import socket
+    import subprocess
+    if args.device_index < 0:           # one rank per GPU: every rank needs its own device (RCCL refuses two ranks on one)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but this node has {have} GPU(s) visible; refusing to report fewer ranks '
+                             f'than asked for (use --device-index D --backend gloo to put all ranks on one device for a control-flow test)')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), SPG_BENCH_SELF_LAUNCHED='1')
+    print(f'[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks under torch.distributed.run (port {port})', file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -318,6 +341,8 @@ def main():
     ap.add_argument('--fused-step', type=int, default=1, help='1 (default): forward + backward as ONE library call (superpoint_graph_amd/fused.py: spg_train_step; same kernels and results as the module path, tests/test_gpu_fused.py); 0: CloudEmbedder.run -> model.ecc -> cross_entropy -> backward -> bw_hook through the modules')
     ap.add_argument('--no-extras', action='store_true', help='skip the short runs of the other BASELINE.json configurations (2 / 8 scenes per step, Semantic3D scale in f32 and split-bf16) and the sustained repeat')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import faulthandler
     faulthandler.enable()
@@ -335,7 +360,7 @@ def main():
     rank, local, world = spd.init_from_env(args.backend)
     if args.device_index >= 0:
         local = args.device_index
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
     torch.cuda.set_device(local)
@@ -381,7 +406,7 @@ def main():
     def fwd_bwd():
         arena.zero_grad()
         if fstep is not None:      # the same step as ONE call into the library (include/spg_hip.h: spg_train_step)
-            fstep(flag, clouds_d, diam_d, GIs[0], label_mode)
+            exchange['loss'], _ = fstep(flag, clouds_d, diam_d, GIs[0], label_mode)
             exchange['w'] = fstep.normaliser
             return
         emb = embedder.run(model, None, flag, clouds_d, diam_d)
@@ -392,6 +417,7 @@ def main():
             loss, exchange['w'] = ops.cross_entropy(out, label_mode, reduction='sum', return_normaliser=True)
         else:
             loss = ops.cross_entropy(out, label_mode)    # learning/main.py:205, one launch each way
+        exchange['loss'] = loss.detach()
         loss.backward(arena.one)                         # (a cached 1: autograd's implicit ones_like(loss) is a fill launch)
         embedder.bw_hook()
 
@@ -459,16 +485,62 @@ def main():
     value = n_sp_step * world * args.steps / dt
     log(f'timed region done: {ms_per_step:.3f} ms/step')
 
+    # who took part: every rank contributes 1 (all-reduce on the bench's process group) -- the line says how many ranks the
+    # collectives actually saw, not what --gpus asked for
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_seen = int(t.item())
+    # the gradient exchange alone, event-bracketed on the compute stream in a short pass OUTSIDE the timed region
+    ar_us = None
+    if dp:
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        for i in range(8):
+            fwd_bwd()
+            e0[i].record()
+            arena.allreduce_sums(exchange['w'])
+            e1[i].record()
+            update()
+        barrier()
+        ar = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
+        ar_us = ar[len(ar) // 2] * 1e3
+        if world > 1:
+            t = torch.tensor([ar_us], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ar_us = float(t.item())
+
+    # the run checks itself: the loss of the last step is finite and no dataflow-synchronised RNN-ECC launch timed out (a spin
+    # time-out carries on with stale states -- the number would still print; learning/main.py of this package checks the same)
+    def self_check(where):
+        torch.cuda.synchronize()
+        nerr = int(_lib.lib().spg_ecc_persistent_errors())
+        loss_v = float(exchange['loss'].item())
+        if dp:                                   # SUM-reduced loss of this rank / its own normaliser = its mean loss
+            w = float(exchange['w'].item())
+            loss_v = loss_v / w if w > 0 else float('nan')
+        gfin = bool(torch.isfinite(arena.flat.grad).all().item())
+        if nerr != 0 or not gfin or not np.isfinite(loss_v):
+            raise SystemExit(f'bench.py self-check FAILED after the {where}: persistent RNN-ECC time-outs {nerr}, loss {loss_v}, gradients finite {gfin}')
+        return {'loss': loss_v, 'persistent_errors': nerr, 'grads_finite': gfin, 'checked_after': where}
+    check = self_check('timed region')
+
+    wl = f'{args.model_config} fwd+bwd+Adam; {args.scenes} scene/GPU x {args.n_sp} sp x 128 pts x {args.n_feat} f, {args.n_edges} edges x 13 f'
     result = {
         'metric': 'superpoints/sec (embed+ECC fwd+bwd), S3DIS-shaped SPG', 'value': value, 'unit': 'superpoints/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'ms_per_step_min': step_ms[0], 'ms_per_step_median': step_ms[len(step_ms) // 2], 'ms_per_step_max': step_ms[-1],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'f32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 MFMA operands of the wide row-GEMMs, f32 accumulate and f32 everywhere else; NOT the headline arithmetic)', 'bf16': 'bf16 (MFMA operands of the wide row-GEMMs, f32 accumulate and f32 everywhere else; NOT the headline arithmetic)'}[args.precision], 'data': 'synthetic',
-        'config': {'workload': f'synthetic SPG: {args.scenes} scene(s)/GPU/step x {args.n_sp} superpoints x 128 pts x {args.n_feat} feats, '
-                               f'{args.n_edges} superedges x 13 feats; PointNet + {args.model_config}' + (' (S3DIS production model, matrix filters, 10 GRU iterations)' if args.model_config == 'gru_10_0,f_13' else '') + ', train step fwd+bwd+Adam',
+        'config': {'workload': wl,
+                   'workload_detail': f'synthetic S3DIS-shaped SPG (SURVEY.md 8d scene(seed)): PointNet + {args.model_config}' + (' = S3DIS production model, matrix filters, 10 GRU iterations' if args.model_config == 'gru_10_0,f_13' else '') + '; one step = zero_grad, forward, weighted CE, backward, bw_hook, clamp + Adam on resident inputs',
                    'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'step_call': 'spg_train_step (one library call: forward + backward)' if fstep is not None else 'module API (CloudEmbedder.run, model.ecc, cross_entropy, backward, bw_hook)', 'parallelism': (f'dp{world} (one scene shard per GPU, one flat-bucket RCCL all-reduce, ' + ('issued by libspg_hip' if native else 'torch.distributed') + ')') if world > 1 else 'single GPU',
                    'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics', 'precision': args.precision},
+        'ranks_seen': ranks_seen, 'allreduce_us_per_step': ar_us, 'batchnorm': 'sync' if args.sync_bn else 'per-rank',
+        'self_check': check,
     }
+    if ranks_seen != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the collectives saw {ranks_seen} rank(s)')
 
     if not args.no_roofline:
         # dominant kernels = the MFMA row-GEMMs (PointNet convs/FCs + filter net, fwd/dgrad/wgrad): each launch bracketed by
@@ -572,6 +644,7 @@ def main():
         sus = (time.perf_counter() - t0) / n_sus
         result['sustained'] = {'seconds': time.perf_counter() - t0, 'steps': n_sus, 'ms_per_step': sus * 1e3, 'superpoints_per_s': n_sp_step / sus}
         log(f'sustained: {n_sus} steps, {sus * 1e3:.3f} ms/step')
+        result['self_check'] = self_check('timed region and the sustained repeat')
         if 'roofline' in result:
             result['roofline']['sustained_ms_per_step'] = sus * 1e3
             result['roofline']['sustained_superpoints_per_s'] = n_sp_step / sus

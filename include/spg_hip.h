@@ -439,6 +439,9 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * sequential fma chains instead of MFMA chunks: differences at fp32 round-off).  key 6: 1 = with the classifier inside the
  * recurrence, its weight / bias gradient leaves as a job of a grouped launch (+10 us) instead of being formed by service
  * workgroups of the persistent backward launch on the CUs the recurrence leaves idle.
+ * key 16: 1 = spg_pointnet_backward issues the weight gradients of the pooled and of the first convolution where they stand
+ * instead of as LEAVES (round 5: slices of those launches travel next to the STN head's latency-bound grouped launches;
+ * every split of the weight gradient is computed by the same body with the same split plan -- results bit-identical).
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* ------------------------------------------------------------------------------------------------

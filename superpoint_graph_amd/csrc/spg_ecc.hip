@@ -930,7 +930,7 @@ int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long row
 // its edge list, the cell's weights in LDS, its own state.  The plain outputs the later kernels need (states, aggregates,
 // gate gradients) are written with ordinary stores; only the exchanged vectors travel as granules.
 //
-// The exchange buffer is the second piece of device memory the library owns (per device, 4 MiB + a control block): epochs are
+// The exchange buffer is the second piece of device memory the library owns (per device, SPG_PX_MAX_GROUPS x SPG_PX_MAX_ITERS x SPG_PX_MAX_NODES x 256 B = 64 MiB + a control block; allocated on first use): epochs are
 // drawn from a device-side counter that the last workgroup of a launch advances, so a tag is never reused -- neither across
 // launches nor under hipGraph replay -- and the buffer needs no clearing.  One persistent launch is in flight per device at a
 // time (launches of one stream serialise; a second stream falls back to the per-iteration kernels).  Spins are bounded: a

@@ -221,7 +221,10 @@ static void fnet_forward_stages(const Plan& pl0, const float* edgefeats, int bn_
       if (i == 0 && pl.fold)                 // the statistics slots of both directions: cleared launches before their first use
         for (const FLayer& f : pl.F)
           if (f.bn) {
-            SPG_TRY(spg_group_zero(reinterpret_cast<float*>(f.slots), 2 * spg_fold_slot_words(f.cout), st));
+            // BatchNorm behind the FIRST layer (--fnet_bnidx 0 is legal, learning/graphnet.py:17-37): this very stage's GEMM is the
+            // slots' first producer, so a zero job in the same group would race with it -- clear them in stream order instead
+            if (&f == &pl.F[0]) SPG_TRY(zero_async(f.slots, sizeof(float) * 2 * spg_fold_slot_words(f.cout), st));
+            else SPG_TRY(spg_group_zero(reinterpret_cast<float*>(f.slots), 2 * spg_fold_slot_words(f.cout), st));
             SPG_TRY(spg_group_zero(reinterpret_cast<float*>(f.slots_bwd), 2 * spg_fold_slot_words(f.cout), st));
           }
       SpgGemmParams g; memset(&g, 0, sizeof(g));

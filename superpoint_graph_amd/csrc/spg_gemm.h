@@ -171,6 +171,19 @@ int spg_riders_pending();
 int spg_riders_drain(hipStream_t stream);
 void spg_riders_clear();
 
+// ---- leaves (round 5): work nobody waits for before the optimiser step, issued in SLICES next to later latency-bound launches ----
+// A rider chain (above) keeps an order; a leaf does not: it is a closure that issues independent jobs into the group that is open
+// when it runs.  PointNet's backward pushes the weight gradient of the pooled convolution (128 -> 256: 8.4 GFLOP, 88 us as a
+// launch of its own in front of the data gradient everything else waits for) and of the first convolution as leaves -- split by
+// row ranges of their split plan -- and the STN head's three grouped launches (~55 us of dependent few-row links on 32
+// workgroups) each take a share: spg_leaf_ride(stream, launches_left) issues ~1 / launches_left of the pending cost.  The owner
+// drains what is left before anything consumes the results.  Leaves never outlive the C call that pushed them.
+void spg_leaf_push(SpgStage issue, double cost);
+int spg_leaf_pending();
+int spg_leaf_ride(hipStream_t stream, int launches_left);
+int spg_leaf_drain(hipStream_t stream);
+void spg_leaf_clear();
+
 int spg_gemm_ntiles(const SpgGemmParams& p);
 // Data-gradient launches with 128-column tiles keep one workgroup per tile (no persistent stream: registers), i.e. one
 // statistics contribution per tile and row-wave -- 2000 per channel on the unit scene.  That many atomics cost more on the
@@ -203,6 +216,9 @@ struct SpgReduceQueue {
 };
 // db (optional): also the column sums of the `a` operand (= bias gradient), from the same launch
 int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t stream, float* db = nullptr);
+// the same weight gradient as `nslice` LEAVES (above): nothing is launched now; false = not possible for this launch (no grouped
+// body for its shape, a precision mode, grouping switched off): the caller then uses spg_queue_wgrad.  `q` must outlive the leaves.
+bool spg_queue_wgrad_leaf(SpgReduceQueue& q, SpgWgradParams p, float* dW, int nslice, hipStream_t stream);
 // data gradient + weight gradient of a 64-input-channel convolution from ONE pass over dz (spg_gemm.hip: spg_bwdpair_kernel);
 // g as for spg_launch_gemm (the data-gradient problem, statistics into slots, fold_bwd = the layer's pending sums), b = the
 // layer's input operand, dW [g.K, 64] through the queue's batched reduction

@@ -152,7 +152,7 @@ struct SpgSmallJob {            // column sums: src [M, ld] -> dst [slices][N] (
 };
 // Kernel arguments of a grouped launch (<= 4 KiB): a table of job headers in launch order + the jobs' parameter structs packed
 // back to back (16-byte aligned) in one byte arena -- 12 small jobs or e.g. 2 row-GEMMs + 4 weight gradients + 4 small ones.
-struct SpgJobHdr { int kind, variant, gx, gy, gz, offset, weight, pad; };
+struct SpgJobHdr { int kind, variant, gx, gy, gz, offset, weight, bx0; };      // bx0: first x index of the job's grid (a SLICE of a larger launch)
 #define SPG_GROUP_MAX_JOBS 16
 #define SPG_GROUP_ARENA_BYTES 3440
 #define SPG_GROUP_MAX_WGRAD_ROWS 65536      // weight gradients over more rows than this are never grouped
@@ -193,7 +193,10 @@ constexpr int spg_gemm_sk_variant(bool wred, int amode) {
   X(12, 128, 32, 4, 1, 0, 1, false, true, false)    X(13, 128, 32, 4, 1, 0, 1, true, true, false)                \
   X(14, 64, 64, 2, 2, 0, 1, false, false, true)     X(15, 64, 64, 2, 2, 0, 1, true, false, true)                 \
   X(16, 128, 128, 2, 2, 0, 1, false, true, false)   X(17, 128, 128, 2, 2, 0, 1, true, true, false)               \
-  X(18, 128, 64, 2, 2, 3, 1, false, false, false)   X(19, 128, 64, 2, 2, 3, 1, true, false, false)
+  X(18, 128, 64, 2, 2, 3, 1, false, false, false)   X(19, 128, 64, 2, 2, 3, 1, true, false, false)               \
+  /* leaves of PointNet's backward that travel in slices next to the STN head's launches (spg_gemm.h: spg_leaf_*): the      \
+     pooled convolution's weight gradient (max-pool scatter x affine) and the first convolution's (BatchNorm-backward x cloud) */ \
+  X(20, 128, 128, 2, 2, 4, 1, true, false, false)   X(21, 128, 32, 4, 1, 3, 2, false, false, false)
 constexpr int spg_wgrad_variant(int it, int jt, int amode, int bmode, bool full, bool colsum) {
 #define SPG_X(id, IT_, JT_, WI_, WJ_, AM_, BM_, FU_, CS_, LI_) \
   if (it == IT_ && jt == JT_ && amode == AM_ && bmode == BM_ && full == FU_ && colsum == CS_) return id;
@@ -210,7 +213,7 @@ constexpr bool spg_wgrad_variant_light(int v) {
 // host side (end of this file): true = the job was taken by the group that is open on this thread
 static bool spg_group_accepts(hipStream_t stream);
 static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight,
-                          std::function<int()> direct = nullptr);
+                          std::function<int()> direct = nullptr, int bx0 = 0);
 
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
@@ -1708,16 +1711,31 @@ size_t spg_wgrad_workspace_floats(long M, int N, int K) {
   return w > c ? w : c;
 }
 
+// Slices and probes (spg_gemm.h: spg_queue_wgrad_leaf): while g_wgrad_slice_n > 0 the launch functions below issue ONLY the
+// splits [g_wgrad_slice0, g_wgrad_slice0 + g_wgrad_slice_n) of the weight gradient, as a job of the open group (never as a
+// kernel of its own: the stand-alone kernels have no split offset); while g_wgrad_probe is set nothing is launched and the id
+// of the grouped body the launch WOULD use is left in g_wgrad_probe_variant (-1: none -- the launch cannot be sliced).
+namespace { thread_local int g_wgrad_slice0 = 0, g_wgrad_slice_n = 0, g_wgrad_probe_variant = -1; thread_local bool g_wgrad_probe = false; }
+
 template <int IT, int JT, int WI, int WJ, int AMODE, int BMODE>
 static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t stream) {
   const size_t lds = (size_t)((AMODE >= 0 && BMODE >= 0) ? 2 : 1) * SPG_KC * (IT + 4 + JT + 4) * sizeof(float);
-  dim3 grid(nsplit, spg_cdiv(p.N, IT), spg_cdiv(p.K, JT));
-  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  const bool sliced = g_wgrad_slice_n > 0;
+  dim3 grid(sliced ? g_wgrad_slice_n : nsplit, spg_cdiv(p.N, IT), spg_cdiv(p.K, JT));
+  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K * (sliced ? (double)g_wgrad_slice_n / nsplit : 1.0);
   // reductions over few rows (FC layers, filter net, recurrent cell) inside an open group become jobs of its one launch; the
-  // wide convolutions' weight gradients (performance-critical, own occupancy bounds) never do
-  const bool grouped = p.M <= SPG_GROUP_MAX_WGRAD_ROWS && spg_group_accepts(stream);
-  ProfScope prof(stream, flops, 0, !grouped);
-  auto try_group = [&](int variant) { return grouped && variant >= 0 && spg_group_add(SPG_JOB_WGRAD, variant, &p, sizeof(p), grid, lds, flops, stream, 2 + 2 * (p.rows_per_split / SPG_KC)); };
+  // wide convolutions' weight gradients (performance-critical, own occupancy bounds) never do -- except as slices (above)
+  const bool grouped = (sliced || p.M <= SPG_GROUP_MAX_WGRAD_ROWS) && spg_group_accepts(stream);
+  ProfScope prof(stream, flops, 0, !grouped && !g_wgrad_probe);
+  // -> 1: taken (by the group, or recorded by a probe), 0: launch it directly, < 0: error
+  auto try_group = [&](int variant) -> int {
+    if (g_wgrad_probe) { g_wgrad_probe_variant = variant; return 1; }
+    if (grouped && variant >= 0 && spg_group_add(SPG_JOB_WGRAD, variant, &p, sizeof(p), grid, lds, flops, stream, 2 + 2 * (p.rows_per_split / SPG_KC),
+                                                 nullptr, sliced ? g_wgrad_slice0 : 0)) return 1;
+    if (sliced) { spg_set_error("a weight-gradient slice needs an open group and a grouped body (variant %d)", variant); return -1; }
+    return 0;
+  };
+#define SPG_TRY_GROUP(v) { const int tg_ = try_group(v); if (tg_ != 0) return tg_ < 0 ? 1 : 0; }
   if constexpr (AMODE >= 0 && BMODE >= 0 && AMODE != SPG_PRO_CLOUD && BMODE != SPG_PRO_CLOUD) {
     auto mode_ok = [](int mode, const SpgOperand& d, int nch) {
       if (mode == SPG_PRO_AFFINE) return d.c0 != nullptr && d.n_affine >= nch;
@@ -1734,13 +1752,15 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
       const int prec = ((IT == 128 || JT >= 64) && p.colsum == nullptr && p.allow_lowp) ? g_tune[SPG_TUNE_PRECISION] : 0;
       if constexpr (AMODE == SPG_PRO_IDENT) {
         if (p.colsum != nullptr) {
-          if (try_group(spg_wgrad_variant(IT, JT, AMODE, BMODE, true, true))) return 0;
+          SPG_TRY_GROUP(spg_wgrad_variant(IT, JT, AMODE, BMODE, true, true));
           hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 0, true>), grid, dim3(SPG_THREADS), lds, stream, p);
           SPG_LAUNCH_CHECK();
           return 0;
         }
       }
-      if (prec == 0 && try_group(spg_wgrad_variant(IT, JT, AMODE, BMODE, true, false))) return 0;
+      if (prec == 0) SPG_TRY_GROUP(spg_wgrad_variant(IT, JT, AMODE, BMODE, true, false))
+      else if (g_wgrad_probe) { g_wgrad_probe_variant = -1; return 0; }
+      else if (sliced) { spg_set_error("weight-gradient slices are fp32-MFMA launches"); return 1; }
       if (prec == 3) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 3>), grid, dim3(SPG_THREADS), lds, stream, p);
       else if (prec == 1) hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, true, 1>), grid, dim3(SPG_THREADS), lds, stream, p);
       else
@@ -1752,14 +1772,15 @@ static int launch_wgrad_t(const SpgWgradParams& p, int nsplit, hipStream_t strea
   prof.r.tag = SPG_PROF_TAG(2, IT, JT, AMODE, BMODE, 0);
   if constexpr (AMODE == SPG_PRO_IDENT || AMODE < 0) {
     if (p.colsum != nullptr) {
-      if (try_group(spg_wgrad_variant(IT, JT, AMODE, BMODE, false, true))) return 0;
+      SPG_TRY_GROUP(spg_wgrad_variant(IT, JT, AMODE, BMODE, false, true));
       hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE, false, 0, true>), grid, dim3(SPG_THREADS), lds, stream, p);
       SPG_LAUNCH_CHECK();
       return 0;
     }
   }
   SPG_CHECK_ARG(p.colsum == nullptr, "column sums ride along only with an identity `a` operand");
-  if (try_group(spg_wgrad_variant(IT, JT, AMODE, BMODE, false, false))) return 0;
+  SPG_TRY_GROUP(spg_wgrad_variant(IT, JT, AMODE, BMODE, false, false));
+#undef SPG_TRY_GROUP
   hipLaunchKernelGGL((spg_wgrad_kernel<IT, JT, WI, WJ, AMODE, BMODE>), grid, dim3(SPG_THREADS), lds, stream, p);
   SPG_LAUNCH_CHECK();
   return 0;
@@ -2964,7 +2985,7 @@ __device__ __forceinline__ void spg_multi_body() {
   j = __builtin_amdgcn_readfirstlane(j);
   const SpgJobHdr h = a.hdr[j];
   const int b = (int)blockIdx.x - a.first_block[j];
-  const int bx = b % h.gx, by = (b / h.gx) % h.gy, bz = b / (h.gx * h.gy);
+  const int bx = b % h.gx + h.bx0, by = (b / h.gx) % h.gy, bz = b / (h.gx * h.gy);
   const unsigned char* P = a.arena + h.offset;
 #define SPG_P(T) (*reinterpret_cast<const T*>(P))
   if (h.kind == SPG_JOB_GEMM) {
@@ -3068,7 +3089,7 @@ static bool spg_group_accepts(hipStream_t stream) { return g_grp.open && g_grp.s
 
 // weight: relative duration of ONE workgroup of the job (sequential reduction chunks); decides the launch order
 static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight,
-                          std::function<int()> direct) {
+                          std::function<int()> direct, int bx0) {
   SpgGroupState& g = g_grp;
   const size_t need = (bytes + 15) & ~(size_t)15;
   if (!spg_group_accepts(stream) || variant < 0 || need > SPG_GROUP_ARENA_BYTES) return false;
@@ -3080,7 +3101,7 @@ static bool spg_group_add(int kind, int variant, const void* params, size_t byte
   }
   SpgJobHdr& h = g.a.hdr[g.a.njobs];
   h.kind = kind; h.variant = variant; h.gx = (int)grid.x; h.gy = (int)grid.y; h.gz = (int)grid.z;
-  h.offset = (int)g.used; h.weight = weight; h.pad = 0;
+  h.offset = (int)g.used; h.weight = weight; h.bx0 = bx0;
   g.direct = g.a.njobs == 0 ? std::move(direct) : nullptr;
   memcpy(g.a.arena + g.used, params, bytes);
   g.used += need;
@@ -3142,6 +3163,84 @@ int spg_riders_drain(hipStream_t stream) {
     SPG_TRY(grp.flush());               // flush() pulls exactly one stage
   }
   return 0;
+}
+
+// ---- leaves (spg_gemm.h) ----
+namespace {
+struct SpgLeaf { SpgStage issue; double cost; };
+thread_local std::vector<SpgLeaf> g_leaves;
+thread_local size_t g_leaf_next = 0;
+}  // namespace
+void spg_leaf_push(SpgStage issue, double cost) { g_leaves.push_back(SpgLeaf{std::move(issue), cost}); }
+int spg_leaf_pending() { return (int)(g_leaves.size() - g_leaf_next); }
+void spg_leaf_clear() { g_leaves.clear(); g_leaf_next = 0; }
+int spg_leaf_ride(hipStream_t stream, int launches_left) {
+  if (spg_leaf_pending() == 0 || !spg_group_accepts(stream)) return 0;
+  double total = 0.0;
+  for (size_t i = g_leaf_next; i < g_leaves.size(); ++i) total += g_leaves[i].cost;
+  const double share = total / (launches_left > 1 ? launches_left : 1);
+  double taken = 0.0;
+  while (g_leaf_next < g_leaves.size() && (taken == 0.0 || taken + 0.5 * g_leaves[g_leaf_next].cost <= share)) {
+    SpgLeaf leaf = std::move(g_leaves[g_leaf_next++]);
+    taken += leaf.cost;
+    SPG_TRY(leaf.issue(stream));
+  }
+  if (g_leaf_next >= g_leaves.size()) spg_leaf_clear();
+  return 0;
+}
+int spg_leaf_drain(hipStream_t stream) {
+  while (spg_leaf_pending() > 0) {
+    SpgGroupScope grp(stream);      // (a scope of its own when none is open; inside an open one the leaves join it)
+    while (spg_leaf_pending() > 0) {
+      SpgLeaf leaf = std::move(g_leaves[g_leaf_next++]);
+      SPG_TRY(leaf.issue(stream));
+    }
+    if (grp.active()) SPG_TRY(grp.flush());
+  }
+  spg_leaf_clear();
+  return 0;
+}
+
+// the weight gradient `p` -> dW as `nslice` leaves (splits of its plan in contiguous ranges); the LAST leaf queues the summation
+// of the partials in `q`, which must therefore outlive the leaves (spg_leaf_drain before its flush).  false: this launch has no
+// grouped body / a single split / no room -- the caller issues it the ordinary way.
+bool spg_queue_wgrad_leaf(SpgReduceQueue& q, SpgWgradParams p, float* dW, int nslice, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || nslice < 1 || g_tune[SPG_TUNE_NO_GROUP] || g_tune[SPG_TUNE_NO_LEAVES]) return false;
+  int it, jt, ns, rps;
+  wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
+  if (ns < 2) return false;
+  p.colsum = nullptr;
+  g_wgrad_probe = true; g_wgrad_probe_variant = -1;
+  const int prc = spg_launch_wgrad_partials(p, dW, stream);
+  g_wgrad_probe = false;
+  if (prc != 0 || g_wgrad_probe_variant < 0) return false;
+  if (q.njobs + 1 > SPG_MAX_REDUCE_JOBS || q.arena == nullptr || q.used + (size_t)ns * p.N * p.K > q.arena_floats) return false;
+  float* part = nullptr;
+  if (queue_take(q, (size_t)ns * p.N * p.K, &part, stream) != 0) return false;
+  if (nslice > ns) nslice = ns;
+  SpgReduceQueue* qp = &q;
+  const double cost = 2.0 * (double)p.M * p.N * p.K / nslice;
+  for (int sidx = 0; sidx < nslice; ++sidx) {
+    const int s0 = (int)((long)ns * sidx / nslice), s1 = (int)((long)ns * (sidx + 1) / nslice);
+    const bool last = sidx + 1 == nslice;
+    spg_leaf_push([p, part, dW, s0, s1, ns, last, qp](hipStream_t st) -> int {
+      int rc = 0;
+      {
+        SpgGroupScope own(st);      // no-op inside the caller's open scope; a launch of its own otherwise (drain without a scope)
+        g_wgrad_slice0 = s0; g_wgrad_slice_n = s1 - s0;
+        rc = spg_launch_wgrad_partials(p, part, st);
+        g_wgrad_slice0 = 0; g_wgrad_slice_n = 0;
+        if (rc == 0 && own.active()) rc = own.flush();
+      }
+      if (rc == 0 && last) {
+        if (qp->njobs == SPG_MAX_REDUCE_JOBS) { spg_set_error("reduction queue full behind a weight-gradient leaf"); return 1; }
+        SpgReduceJob& j = qp->jobs[qp->njobs++];
+        j.partial = part; j.out = dW; j.nsplit = ns; j.n = p.N * p.K;
+      }
+      return rc;
+    }, cost);
+  }
+  return true;
 }
 
 int SpgGroupScope::flush() {

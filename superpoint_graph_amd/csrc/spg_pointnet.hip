@@ -325,6 +325,10 @@ struct BwdScratch {
   float *dzA = nullptr, *dzB = nullptr;     // [M, cmax_conv] ping-pong for the dense conv gradients
   float *fzA = nullptr, *fzB = nullptr;     // [B, cmax_fc]
   float* consts = nullptr;                  // [4][cmax]
+  float* consts_leaf[2] = {nullptr, nullptr};   // the BatchNorm-backward constants of the layers whose weight gradient leaves later as
+                                            // leaves (spg_gemm.h): `consts` is rewritten by every layer in between
+  float *fzC = nullptr, *fzD = nullptr;     // the STN head's own ping-pong: the main segment's pooled gradient (fzA / fzB) is still
+                                            // read by the pooled convolution's weight-gradient leaves while the STN head runs
   double* fin = nullptr;                    // scratch of the sliced finalize
   float* work = nullptr;                    // reduction arena: split partials of all weight / bias gradients
   size_t work_floats = 0;
@@ -351,6 +355,8 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
   s.dzA = cv.take<float>((size_t)pl.M * cconv); s.dzB = cv.take<float>((size_t)pl.M * cconv);
   s.fzA = cv.take<float>((size_t)pl.B * cfc); s.fzB = cv.take<float>((size_t)pl.B * cfc);
   s.consts = cv.take<float>((size_t)4 * cmax);
+  s.consts_leaf[0] = cv.take<float>((size_t)4 * cmax); s.consts_leaf[1] = cv.take<float>((size_t)4 * cmax);
+  s.fzC = cv.take<float>((size_t)pl.B * cfc); s.fzD = cv.take<float>((size_t)pl.B * cfc);
   s.fin = cv.take<double>(spg_bn_finalize_scratch_doubles(cmax));
   s.work = cv.take<float>(workmax); s.work_floats = workmax;
   s.stat = cv.take<float>((size_t)pl.B * 4 * 2 * cmax);
@@ -383,15 +389,18 @@ SpgBnFoldBwd fold_bwd_of(const Plan& pl, const Layer& prod, long count, float* c
   return f;
 }
 
+// leaves: 1 = this segment's convolutions hand the weight gradients that are not fused with their data gradient (the pooled
+// layer's, the first layer's) to spg_queue_wgrad_leaf (a later segment's head takes them along); 2 = this segment's head takes
+// pending leaves along (and uses the second pair of head buffers)
 int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, SpgOperand cur, const float* clouds,
-                     const float* stnT, bool want_dxy, hipStream_t st, bool ride_reduce = false) {
+                     const float* stnT, bool want_dxy, hipStream_t st, bool ride_reduce = false, int leaves = 0) {
   const int B = pl.B;
   SpgBnFoldBwd pending; memset(&pending, 0, sizeof(pending));     // set by a data-gradient launch, consumed by the next weight gradient
   // ---- fc head ----
   // A layer's weight gradient and its data gradient depend on the same inputs and not on each other: both few-row launches
   // leave as ONE grouped launch (spg_gemm.h) -- three launches per head instead of six.  The data gradient then finishes the
   // BatchNorm-backward constants of its operand itself (fold_bwd), since the weight gradient is no longer ordered before it.
-  float* fz[2] = {s.fzA, s.fzB};
+  float* fz[2] = {leaves == 2 ? s.fzC : s.fzA, leaves == 2 ? s.fzD : s.fzB};
   int flip = 0;
   {
   SpgGroupScope grp(st);
@@ -429,6 +438,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     if (grp.active()) g.fold_bwd = fold_k;
     int nparts = 0;
     SPG_TRY(spg_launch_gemm(g, st, &nparts));
+    if (leaves == 2) SPG_TRY(spg_leaf_ride(st, k + 1));      // a share of the pending leaves (this head has k + 1 launches left)
     SPG_TRY(grp.flush());      // {weight gradient, bias column sums, data gradient} of this layer
     // the statistics cover the producer's channels only (N = l.cin may be larger by nextra for the pooled input)
     const int C = prod.cout;
@@ -477,7 +487,23 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     w.a = cur; w.b = input_operand(pl, sg, false, k, clouds, stnT); w.M = (int)pl.M; w.N = l.cout; w.K = l.cin;
     w.fold = pending; memset(&pending, 0, sizeof(pending));
     w.allow_lowp = 1;      // the opt-in precision modes act on the PointNet convolutions only
-    SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
+    // This weight gradient is a LEAF (nobody reads dW before the optimiser) that used to stand in front of the data gradient the
+    // rest of the backward waits for.  As leaves (spg_gemm.h) slices of it leave later, next to the STN head's few-row launches.
+    // It then applies its layer's BatchNorm-backward constants from a PRIVATE copy (finished in its own prologue from the same
+    // fixed-point sums: same bits), because `consts` is rewritten by the layers in between; the data gradient below finishes the
+    // shared copy itself, as it does inside a grouped launch.
+    bool leaf = false;
+    if (leaves == 1 && pl.fold && w.fold.slots != nullptr && (k == 0 || k + 1 == (int)sg.convs.size())) {
+      float* cl = s.consts_leaf[k == 0 ? 0 : 1];
+      SpgWgradParams wl = w;
+      const int C = w.fold.C;
+      wl.fold.consts = cl;
+      wl.a.c0 = cl; wl.a.c1 = cl + C; wl.a.c2 = cl + 2 * C; wl.a.c3 = cl + 3 * C;
+      // pooled layer: 8.4 GFLOP -> 6 slices of ~15 us; first layer (K = 14: bandwidth, ~25 us) -> 2
+      leaf = cur.c0 == s.consts && spg_queue_wgrad_leaf(rq, wl, l.dW, k == 0 ? 2 : 6, st);
+    }
+    const SpgBnFoldBwd fold_for_dgrad = leaf ? w.fold : SpgBnFoldBwd{};
+    if (!leaf) SPG_TRY(spg_queue_wgrad(rq, w, l.dW, st));
     if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
     if (k > 0) {
       Layer& prod = pl.L[sg.convs[k - 1]];
@@ -491,6 +517,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
       const bool foldk = pl.fold && !spg_gemm_bwd_stats_want_partials(g);
       if (foldk) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; }
+      g.fold_bwd = fold_for_dgrad;      // (the layer's weight gradient, which otherwise finishes the constants first, leaves later)
       int nparts = 0;
       SPG_TRY(spg_launch_gemm(g, st, &nparts));
       if (foldk) pending = fold_bwd_of(pl, prod, pl.M, s.consts);
@@ -504,6 +531,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       g.a = cur; g.W = l.Wpad ? l.Wpad : l.W; g.ldw = l.Wpad ? l.ldw : l.cin; g.w_red = 1;
       g.M = (int)pl.M; g.N = 2; g.K = l.cout; g.rows_per_tile = pl.P;
       g.epi = SPG_EPI_BWD; g.Y = s.dxy; g.ldy = 2;
+      g.fold_bwd = fold_for_dgrad;
       SPG_TRY(spg_launch_gemm(g, st));
     }
   }
@@ -645,13 +673,17 @@ extern "C" int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, con
   SpgReduceQueue rq;
   rq.arena = s.work; rq.arena_floats = s.work_floats;
   s.grad_global = grad_global;
-  SPG_TRY(backward_segment(pl, pl.main, s, rq, op_ident(grad_emb, cout), clouds, stnT, pl.has_stn || grad_transform != nullptr, st));
+  struct LeafGuard { ~LeafGuard() { spg_leaf_clear(); } } leaf_guard;      // no leaf survives this call (its buffers are the caller's)
+  SPG_CHECK_ARG(spg_leaf_pending() == 0, "leaves of another call are pending on this thread");
+  SPG_TRY(backward_segment(pl, pl.main, s, rq, op_ident(grad_emb, cout), clouds, stnT, pl.has_stn || grad_transform != nullptr, st, false,
+                           pl.has_stn ? 1 : 0));
   if (grad_transform != nullptr)      // gradient wrt the external 2x2 transforms (learning/pointnet.py:196-198)
     SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, grad_transform, st));
   if (pl.has_stn) {
     SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, s.dT, st));
-    SPG_TRY(backward_segment(pl, pl.stn, s, rq, op_ident(s.dT, 4), clouds, nullptr, false, st, true));
+    SPG_TRY(backward_segment(pl, pl.stn, s, rq, op_ident(s.dT, 4), clouds, nullptr, false, st, true, 2));
   }
+  SPG_TRY(spg_leaf_drain(st));      // (leaves no head took along: a launch of their own)
   if (g_slots_clear_at_end && pl.slots_all != nullptr && pl.slots_words > 0) {
     SPG_CHECK_ARG(2 * pl.slots_words < (size_t)INT_MAX, "statistics slots too large for one reduction job");
     SpgReduceJob j;

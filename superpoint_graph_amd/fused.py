@@ -55,7 +55,10 @@ class FusedStep:
         self.model, self.arena = model, arena
         self.ptn = model.ptn
         self.conv, self.fc = list(model.ecc.children())
-        self.class_weights = None if class_weights is None else class_weights.detach().float().contiguous()
+        # (validated like every other device operand: a CPU / other-GPU tensor here would reach the kernels as a wild pointer)
+        self.class_weights = None if class_weights is None else ops._req(class_weights.detach().float().contiguous(), torch.float32, 'class_weights')
+        if self.class_weights is not None and self.class_weights.numel() != list(model.ecc.children())[1].out_features:
+            raise ValueError('class_weights: one weight per class expected')
         self.mean = reduction == 'mean'
         self.ignore_index = int(ignore_index)
         self.bn_times = 2 if ptn_mem_monger else 1
@@ -101,7 +104,8 @@ class FusedStep:
     def _buffers(self, plan, B, N, E, dev, ecc_cfg):
         """Workspaces and activations of one step, re-used from step to step while the sizes stay the same (one stream: the
         next step overwrites them only after this one has consumed them)."""
-        key = (B, N, E, dev, tuple(ecc_cfg.part_ptr[:ecc_cfg.n_parts + 1]) if ecc_cfg.n_parts > 0 else ())
+        # (npts: the PointNet plan -- hence the workspace layout and the statistics slots -- depends on the points per cloud)
+        key = (B, N, E, dev, plan['npts'], tuple(ecc_cfg.part_ptr[:ecc_cfg.n_parts + 1]) if ecc_cfg.n_parts > 0 else ())
         b = self._bufs.get(key)
         if b is not None:
             return b
@@ -158,13 +162,6 @@ class FusedStep:
         C = fc.out_features
         logits = torch.empty(N, C, dtype=torch.float32, device=dev)
         loss_buf = torch.empty(N + 2, dtype=torch.float32, device=dev)
-        # module-level bookkeeping the C call does not do
-        ptn._bump_batches_tracked(self.bn_times)
-        for m in conv._fnet:
-            if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None:
-                m.num_batches_tracked += 1
-        for m in (ptn, conv, fc):
-            mark_direct_write(m)
         a = _lib.StepArgs()
         a.ptn_cfg, a.B, a.bn_update_times = ctypes.pointer(plan['ptn_cfg']), B, self.bn_times
         a.clouds, a.clouds_global = clouds.data_ptr(), clouds_global.data_ptr()
@@ -180,6 +177,8 @@ class FusedStep:
         a.ecc_out, a.grad_ecc_out = b['ecc_out'].data_ptr(), b['grad_ecc_out'].data_ptr()
         a.nout, a.n_classes = plan['nout'], C
         a.cls_W, a.cls_b = fc.weight.data_ptr(), None if fc.bias is None else fc.bias.data_ptr()
+        if fc.weight.grad is None or not fc.weight.grad.is_contiguous() or (fc.bias is not None and fc.bias.grad is None):
+            raise RuntimeError('FusedStep: the classifier has no contiguous .grad view into the gradient arena')
         a.cls_dW, a.cls_db = fc.weight.grad.data_ptr(), None if fc.bias is None else fc.bias.grad.data_ptr()
         a.cls_work, a.logits, a.grad_logits = b['cls_work'].data_ptr(), logits.data_ptr(), b['grad_logits'].data_ptr()
         a.target = target.data_ptr()
@@ -190,6 +189,15 @@ class FusedStep:
         b['slots_clean'] = False
         _lib.check(_lib.lib().spg_train_step(ctypes.byref(a), ops._stream()), 'spg_train_step')
         b['slots_clean'] = True
+        # module-level bookkeeping the C call does not do -- only once the call has succeeded (a refused step must not advance
+        # the BatchNorm batch counters or mark gradients as written)
+        ptn._bump_batches_tracked(self.bn_times)
+        for m in conv._fnet:
+            if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+        for m in (ptn, conv, fc):
+            mark_direct_write(m)
+        self._last = (plan['ptn_cfg'], B, b['ptn_ws'], ecc_cfg, graph, b['ecc_ws'], edgefeats)
         self.normaliser = loss_buf[N + 1:N + 2]       # sum of the labelled rows' class weights (data-parallel loss weight w_r)
         self._emb, self._slot = b['emb'], slot_of_row   # (the descriptors are read in place by the recurrence: see `embeddings`)
         return loss_buf[N], logits
@@ -252,6 +260,13 @@ class FusedStep:
         a.cls_W, a.cls_b, a.logits = fc.weight.data_ptr(), None if fc.bias is None else fc.bias.data_ptr(), logits.data_ptr()
         _lib.check(_lib.lib().spg_infer_step(ctypes.byref(a), ops._stream()), 'spg_infer_step')
         return logits
+
+    def debug_states(self):
+        """(PointNetState, EccRnnState) views of the LAST training step's forward workspaces -- what ops.pointnet_forward /
+        ops.eccrnn_forward return on the module path; the parity tests read the kernels' ReLU / max-pool decisions out of them
+        (spg_pointnet_debug_offset / spg_eccrnn_debug_offset).  Valid until the next step on the same buffers."""
+        ptn_cfg, B, ptn_ws, ecc_cfg, graph, ecc_ws, edgefeats = self._last
+        return (ops.PointNetState(ptn_cfg, B, None, None, ptn_ws, True), ops.EccRnnState(ecc_cfg, graph, edgefeats, ecc_ws, True))
 
     @property
     def embeddings(self):

@@ -130,6 +130,17 @@ class GraphConvInfo(object):
             raise IndexError(f'GraphConvInfo: idxn entries must be in [0, {N}), got [{int(idxn.min())}, {int(idxn.max())}]')
         if self._edgefeats is not None and self._idxe is None and self._edgefeats.shape[0] != E:
             raise ValueError(f'GraphConvInfo: {self._edgefeats.shape[0]} edge-feature rows for {E} edges')
+        if self._parts is not None:
+            # the scene boundaries are a promise to the one-launch recurrence ("every part is closed under edges": a wave only ever
+            # waits for nodes of its own round) -- a wrong hint would show up as spin time-outs / wrong outputs much later
+            parts = torch.as_tensor(self._parts, dtype=torch.int64)
+            if parts.numel() < 2 or int(parts[0]) != 0 or int(parts[-1]) != N or bool((parts[1:] < parts[:-1]).any()):
+                raise ValueError(f'GraphConvInfo: parts must be non-decreasing node offsets from 0 to {N}, got {self._parts}')
+            if E:
+                tgt = torch.repeat_interleave(torch.arange(N, dtype=torch.int64), degs.to(torch.int64))
+                inner = parts[1:-1].contiguous()
+                if bool((torch.bucketize(idxn.to(torch.int64), inner, right=True) != torch.bucketize(tgt, inner, right=True)).any()):
+                    raise ValueError('GraphConvInfo: an edge crosses a part boundary (parts must be unions of connected components)')
 
     def cuda(self):
         from ... import ops

@@ -363,9 +363,12 @@ class Session:
         try:
             cut = getattr(self.args, 'spg_augm_hardcutoff', 0)
             sizes = [int(g.vcount()) for g in dataset.list]
-            return [min(v, cut) if cut and cut > 0 else v for v in sizes]
-        except Exception:
+        except (AttributeError, TypeError):      # a dataset whose elements are not graphs (or that keeps no list): contiguous shards
+            self.log('data parallel: the training set exposes no per-scene sizes -- contiguous scene shards (no balancing by size)')
             return None
+        self.log(f'data parallel: scenes of a global batch are dealt to the ranks by size ({len(sizes)} training scenes, '
+                 f'{min(sizes)}-{max(sizes)} superpoints each); --dp_replicate_loader 1 keeps the single-process order instead')
+        return [min(v, cut) if cut and cut > 0 else v for v in sizes]
 
     def _forward(self, targets, GIs, clouds_data):
         self.model.ecc.set_info(GIs, self.args.cuda)

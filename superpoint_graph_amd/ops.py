@@ -432,19 +432,32 @@ def eccrnn_backward(state: EccRnnState, groups, grad_out, out_grads=None):
 # --------------------------------------------------------------------------------------------------
 # batch construction on the device
 # --------------------------------------------------------------------------------------------------
-def check_persistent_ecc(what='training'):
+def check_persistent_ecc(what='training', group=None):
     """Health check of the dataflow-synchronised RNN-ECC launches (include/spg_hip.h: spg_ecc_persistent_errors_clear): a
     wave whose bounded spin ran out (a peer workgroup was not resident in time: shared GPU, profiler, another stream holding
     CUs) carried on with stale neighbour states.  Synchronises the device; call it where the host synchronises anyway (epoch
     end, before a checkpoint).  Raises after clearing the counter and switching this process to the per-iteration kernels
-    (spg_tune key 8), so a caller that catches the error can repeat the affected work safely."""
+    (spg_tune key 8), so a caller that catches the error can repeat the affected work safely.  With an initialised process group
+    the count is summed over the ranks of `group` first (a collective: every rank must call it; group=False keeps it local)."""
     n = lib().spg_ecc_persistent_errors_clear()
-    if n == 0:
+    if n < 0:      # the counter could not be read (hipMemcpy failed): a different failure, not "-1 time-outs"
+        raise RuntimeError(f'spg_ecc_persistent_errors_clear failed during {what}: ' + lib().spg_last_error().decode())
+    total = n
+    if group is not False:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # data parallel: every rank must take the same decision (one rank raising alone leaves the others in the next
+            # collective until the RCCL time-out, and the ranks would run different kernels afterwards)
+            on_gpu = dist.get_backend(group) == 'nccl'
+            t = torch.tensor([float(n)], dtype=torch.float64, device=torch.device('cuda', torch.cuda.current_device()) if on_gpu else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            total = int(t.item())
+    if total == 0:
         return
     lib().spg_tune(8, 1)
-    raise RuntimeError(f'{n} persistent RNN-ECC spin time-out(s) during {what}: the ECC outputs / gradients of the affected steps '
-                       'are wrong (a workgroup of the dataflow-synchronised launch was not resident in time).  The process now '
-                       'uses the per-iteration kernels (spg_tune key 8); repeat the work since the last check')
+    raise RuntimeError(f'{total} persistent RNN-ECC spin time-out(s) ({n} on this rank) during {what}: the ECC outputs / gradients of the '
+                       'affected steps are wrong (a workgroup of the dataflow-synchronised launch was not resident in time).  The process '
+                       '(every rank of the job) now uses the per-iteration kernels (spg_tune key 8); repeat the work since the last check')
 
 
 def set_batch(edges, n_nodes: int):

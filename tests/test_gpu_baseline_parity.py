@@ -142,32 +142,54 @@ def test_decision_conditioned_gradients_at_baseline_size(hip, setup, monkeypatch
     _decision_conditioned(spec, batch, state0, torch.from_numpy(g['class_weights']), monkeypatch, free_run=True)
 
 
-def _decision_conditioned(spec, batch, state0, cw, monkeypatch, free_run):
+def _fused_train_step(spec, batch, state0, cw):
+    """One training step through superpoint_graph_amd.fused.FusedStep with its DEFAULTS -- what bench.py times and what the CLI
+    runs with --fused_step 1: spg_train_step, classifier + cross entropy inside the one-launch recurrence, fused convolution
+    backward, grouped launches.  -> (model, step, loss, logits, embeddings [N, nf])"""
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep
+    from superpoint_graph_amd.learning import ecc
+    model = build_model(spec, state0).to(DEV).train()
+    arena = FlatParameters(model, lazy_zero=True, host_counters=True)
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+    step = FusedStep(model, arena, class_weights=None if cw is None else cw.to(DEV))
+    arena.zero_grad()
+    loss, logits = step(batch['clouds_flag'], batch['clouds'], batch['clouds_global'], gi, batch['label_mode'].to(DEV))
+    torch.cuda.synchronize()
+    return model, step, loss, logits, step.embeddings
+
+
+def _decision_conditioned(spec, batch, state0, cw, monkeypatch, free_run, fused=False):
     """free_run: also run the fp64 oracle with its OWN decisions (near-tie statistics against the unconditioned values, the
     unconditioned gradient error for the log) -- one more fp64 pass; the large configurations check the near-ties on the
-    values of the conditioned pass instead."""
+    values of the conditioned pass instead.  fused: the step under test is FusedStep (spg_train_step) instead of the modules."""
     from superpoint_graph_amd import ops
-    model = build_model(spec, state0).to(DEV).train()
     captured = {}
-    real_forward = ops.pointnet_forward
+    if fused:
+        model, step, loss, logits, _ = _fused_train_step(spec, batch, state0, cw)
+        captured['state'], captured['ecc'] = step.debug_states()
+    else:
+        model = build_model(spec, state0).to(DEV).train()
+        real_forward = ops.pointnet_forward
 
-    def spy(*a, **kw):
-        out = real_forward(*a, **kw)
-        captured['state'] = out[1]
-        return out
-    monkeypatch.setattr(ops, 'pointnet_forward', spy)
-    real_ecc = ops.eccrnn_forward
+        def spy(*a, **kw):
+            out = real_forward(*a, **kw)
+            captured['state'] = out[1]
+            return out
+        monkeypatch.setattr(ops, 'pointnet_forward', spy)
+        real_ecc = ops.eccrnn_forward
 
-    def spy_ecc(*a, **kw):
-        out = real_ecc(*a, **kw)
-        captured['ecc'] = out[1]
-        return out
-    monkeypatch.setattr(ops, 'eccrnn_forward', spy_ecc)
-    emb, logits, embedder = _run(model, batch)
-    loss = F.cross_entropy(logits, batch['label_mode'].to(DEV), weight=None if cw is None else cw.to(DEV))
-    model.zero_grad()
-    loss.backward()
-    embedder.bw_hook()
+        def spy_ecc(*a, **kw):
+            out = real_ecc(*a, **kw)
+            captured['ecc'] = out[1]
+            return out
+        monkeypatch.setattr(ops, 'eccrnn_forward', spy_ecc)
+        emb, logits, embedder = _run(model, batch)
+        loss = F.cross_entropy(logits, batch['label_mode'].to(DEV), weight=None if cw is None else cw.to(DEV))
+        model.zero_grad()
+        loss.backward()
+        embedder.bw_hook()
     torch.cuda.synchronize()
     grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
     dec = _hip_decisions(model.ptn, captured['state'])
@@ -260,6 +282,52 @@ def test_two_scene_batch_vs_reference_golden(hip, setup):
     for k in g.files:
         if k.startswith('state1/'):
             assert maxrel(sd[k[7:]].double(), torch.from_numpy(g[k]).double()) < 1e-5, k
+
+
+_SMOOTH_1 = ('ecc.0._cell', 'ecc.1', 'ptn.fcs.', 'ecc.0._fnet.4', 'ecc.0._fnet.5', 'ecc.0._fnet.7')
+_SMOOTH_2 = ('ecc.0._cell', 'ecc.1', 'ecc.0._fnet.4', 'ecc.0._fnet.5', 'ecc.0._fnet.7')
+
+
+@pytest.mark.parametrize('which', ['baseline_size', 'two_scenes'])
+def test_fused_step_vs_reference_golden(hip, setup, which):
+    """the path bench.py TIMES -- FusedStep with its defaults (spg_train_step: classifier + cross entropy inside
+    the recurrence, fused convolution backward, grouped launches, riders) -- against the IMPORTED REFERENCE's outputs directly, at
+    BASELINE size (baseline_size.npz) and on the reference's default 2-scene batch (two_scenes.npz; 2000 nodes = one round of the
+    two-workgroups-per-CU recurrence): embeddings / logits element-wise 1e-4, loss 1e-5, decision-free gradients 1e-4, running
+    statistics 1e-5.  Until now this path was tied to the reference only through HIP-vs-HIP comparisons with the module path."""
+    g0, spec, batch, state0 = setup
+    g, smooth_pfx, loose = g0, _SMOOTH_1, 1e-2
+    if which == 'two_scenes':
+        g = np.load(os.path.join(GOLDEN, 'two_scenes.npz'))
+        assert str(g['state0_sha256']) == str(g0['state0_sha256'])
+        batch, smooth_pfx, loose = V.two_scene_batch(), _SMOOTH_2, 1e-1
+    cw = torch.from_numpy(g['class_weights'])
+    model, step, loss, logits, emb = _fused_train_step(spec, batch, state0, cw)
+    assert_elementwise(emb, g['train/emb'], what=f'{which}: FusedStep embeddings vs reference')
+    assert_elementwise(logits, g['train/logits'], what=f'{which}: FusedStep logits vs reference')
+    assert abs(float(loss) - float(g['train/loss'])) <= 1e-5 * abs(float(g['train/loss']))
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    gref = {k: torch.from_numpy(g['grad/' + k]) for k in grads}
+    err = {k: maxrel(grads[k], gref[k]) for k in grads if not noise_grad(k, gref)}
+    smooth = {k: e for k, e in err.items() if k.startswith(smooth_pfx)}
+    rest = {k: e for k, e in err.items() if k not in smooth}
+    print('%s, FusedStep gradients vs the reference: decision-free tensors worst %.2e; decision-dependent ones worst %.2e'
+          % (which, max(smooth.values()), max(rest.values())))
+    assert max(smooth.values()) < 1e-4, {k: e for k, e in smooth.items() if e >= 1e-4}
+    assert max(rest.values()) < loose, {k: e for k, e in rest.items() if e >= loose}
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith('state1/'):
+            assert maxrel(sd[k[7:]].double(), torch.from_numpy(g[k]).double()) < 1e-5, k
+    from superpoint_graph_amd import _lib
+    assert _lib.lib().spg_ecc_persistent_errors() == 0
+
+
+def test_fused_step_decision_conditioned_gradients_at_baseline_size(hip, setup, monkeypatch):
+    """... and the sharp check on the same path: the decisions FusedStep's kernels took (read from ITS workspaces), the fp64 oracle
+    backward with those decisions, every one of the 69 gradient tensors within 1e-4."""
+    g, spec, batch, state0 = setup
+    _decision_conditioned(spec, batch, state0, torch.from_numpy(g['class_weights']), monkeypatch, free_run=False, fused=True)
 
 
 _LARGE = {

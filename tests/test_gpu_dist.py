@@ -147,23 +147,44 @@ def test_bench_two_ranks_with_roofline_pass(hip):
     assert 'roofline' in d and 'cpu_baseline' not in d
 
 
+@pytest.mark.parametrize('launcher', ['torchrun', 'self'])
 @pytest.mark.parametrize('sync_bn', [0, 1])
-def test_bench_two_ranks_control_flow(hip, sync_bn):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one GPU of the
-    test box with the gloo backend: the data-parallel control flow (scene sharding, barrier + max-over-ranks timing,
-    weighted gradient all-reduce, rank 0 prints ONE JSON line with the whole-job value) without needing two devices."""
+def test_bench_two_ranks_control_flow(hip, sync_bn, launcher):
+    """bench.py for N > 1 on the one GPU of the test box with the gloo backend: the data-parallel control flow (scene sharding,
+    barrier + max-over-ranks timing, weighted gradient all-reduce, rank 0 prints ONE JSON line with the whole-job value)
+    without needing two devices.  launcher = torchrun: as torch.distributed.run starts it (one process per rank);
+    launcher = self: the PLAIN command `python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment -- the script has
+    to start its own ranks (that command used to print an N = 1 line)."""
     import json
     root = os.path.dirname(HERE)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
-           '--backend', 'gloo', '--device-index', '0', '--sync-bn', str(sync_bn), '--no-cpu-baseline', '--no-forward-only', '--no-roofline']
-    out = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    tail = [os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+            '--backend', 'gloo', '--device-index', '0', '--sync-bn', str(sync_bn), '--no-cpu-baseline', '--no-forward-only', '--no-roofline']
+    if launcher == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run(cmd, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY='0'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak' and d['unit'] == 'superpoints/s'
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak' and d['unit'] == 'superpoints/s'
     assert d['config']['superpoints_per_step'] == 2000 and d['value'] > 0
     assert abs(d['value'] - 2000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
-    assert ('synchronised' in d['config']['batchnorm']) == bool(sync_bn)
+    assert ('synchronised' in d['config']['batchnorm']) == bool(sync_bn) and d['batchnorm'] == ('sync' if sync_bn else 'per-rank')
+    assert d['allreduce_us_per_step'] > 0
+    assert d['self_check']['persistent_errors'] == 0 and d['self_check']['grads_finite']
+    assert len(d['config']['workload']) < 120 and d['config']['workload'].startswith('gru_10_0,f_13')
+
+
+def test_bench_refuses_more_ranks_than_gpus(hip):
+    """`python bench.py --gpus N` on a node with fewer than N GPUs must fail loudly instead of printing a smaller job's line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode != 0 and 'refusing' in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]

@@ -93,3 +93,131 @@ def test_baseline_scene_bit_identical_with_and_without_grouping(hip, n_sp, n_edg
     for k in a[4]:
         assert torch.equal(a[4][k], b[4][k]), k
     assert int(np.isfinite(a[1].cpu().numpy()).all())
+
+
+@pytest.mark.parametrize('bnidx', [0, 1])
+def test_filter_network_batchnorm_behind_an_early_layer(hip, bnidx):
+    """--fnet_bnidx 0 / 1 are legal in the reference (learning/graphnet.py:17-37; only BatchNorm behind the LAST
+    filter layer is rejected).  With BatchNorm behind layer 0 the layer's own GEMM is the first producer of its fixed-point
+    statistics slots, and the slot clearing used to travel as a job of the SAME grouped launch -- statistics partly wiped,
+    non-deterministically.  Checked here: grouped == ungrouped bit for bit (spg_tune key 11), the one-call step (where the filter
+    network's layers ride with PointNet's launches) agrees with both, repeated runs are bit-stable, and all of it matches the CPU
+    oracle."""
+    from conftest import maxrel, noise_grad
+    from oracle import spg_oracle as O
+    from superpoint_graph_amd import synth
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep
+    from superpoint_graph_amd.learning import ecc
+    spec = O.ModelSpec(fnet_bnidx=bnidx)
+    col = synth.collate_numpy([synth.scene(5, n_sp=300, n_edges=1500)])
+    idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    torch.manual_seed(1)
+    ref = build_model(spec)
+    with torch.no_grad():
+        ref.ptn.stn.proj.weight.normal_(0, 0.02)
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    res = []
+    for off in (1, 0, 0):
+        old = hip.spg_tune(11, off)
+        try:
+            model = build_model(spec, state0).to(DEV).train()
+            res.append(_step(model, batch, None, FlatParameters(model, lazy_zero=True)))
+        finally:
+            hip.spg_tune(11, old)
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+        for k in res[0][3]:
+            assert torch.equal(res[0][3][k], other[3][k]), k
+        for k in res[0][4]:
+            assert torch.equal(res[0][4][k], other[4][k]), k
+    # the one-call step: the filter network's stages are riders of PointNet's grouped launches
+    runs = []
+    for _ in range(2):
+        model = build_model(spec, state0).to(DEV).train()
+        arena = FlatParameters(model, lazy_zero=True, host_counters=True)
+        gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+        model.ecc.set_info([gi], 1)
+        arena.zero_grad()
+        loss, logits = FusedStep(model, arena)(batch['clouds_flag'], batch['clouds'], batch['clouds_global'], gi, batch['label_mode'].to(DEV))
+        torch.cuda.synchronize()
+        runs.append((loss.clone(), logits.clone(), {k: p.grad.clone() for k, p in model.named_parameters()},
+                     {k: v.clone() for k, v in model.state_dict().items() if 'running' in k}))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+    st = {k: v.clone() for k, v in state0.items()}
+    lo, logits_o, _, grads_o = O.train_step(batch, spec, st, None)
+    for name, (loss, logits, grads, running) in (('modules', (res[0][0], res[0][1], res[0][3], res[0][4])), ('one call', runs[0])):
+        assert maxrel(logits, logits_o) < 1e-4 and maxrel(loss, lo) < 1e-5, name
+        # the filter network and everything behind it sharply; PointNet's convolutions sit in front of ReLU / max-pool decisions
+        # (near-ties flip between two correct fp32 implementations: tests/test_gpu_baseline_parity.py has the conditioned check)
+        worst = max((maxrel(grads[k], grads_o[k]), k) for k in grads if not noise_grad(k, grads_o) and k.startswith('ecc.'))
+        assert worst[0] < 2e-3, (name, worst)
+        worst = max((maxrel(grads[k], grads_o[k]), k) for k in grads if not noise_grad(k, grads_o))
+        assert worst[0] < 2e-2, (name, worst)
+        for k, v in running.items():
+            assert maxrel(v.double().cpu(), st[k].double()) < 1e-5, (name, k)
+
+
+@pytest.mark.parametrize('n_sp,n_edges', [(1000, 5000), (300, 1500)])
+def test_weight_gradient_leaves_bit_identical(hip, n_sp, n_edges):
+    """Round 5 (spg_gemm.h: spg_leaf_*): the weight gradients of PointNet's pooled convolution and of its first convolution are
+    LEAVES -- nobody reads them before the optimiser -- that used to stand in front of the data gradients the rest of the backward
+    waits for; they now leave in slices (row ranges of their split plan) next to the STN head's latency-bound launches.  Every
+    split is computed by the same body with the same plan and summed by the same batched reduction, the BatchNorm-backward
+    constants come from the same exact fixed-point sums: a training step must be BIT-IDENTICAL with leaves on and off (spg_tune
+    key 16), on the module path and as one call."""
+    from oracle import spg_oracle as O
+    from superpoint_graph_amd import synth
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep
+    from superpoint_graph_amd.learning import ecc
+    spec = O.ModelSpec()
+    col = synth.collate_numpy([synth.scene(7, n_sp=n_sp, n_edges=n_edges)])
+    idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    torch.manual_seed(1)
+    ref = build_model(spec)
+    with torch.no_grad():
+        ref.ptn.stn.proj.weight.normal_(0, 0.02)
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+
+    def one_call():
+        model = build_model(spec, state0).to(DEV).train()
+        arena = FlatParameters(model, lazy_zero=True, host_counters=True)
+        gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+        model.ecc.set_info([gi], 1)
+        out = []
+        step = FusedStep(model, arena)
+        for _ in range(2):          # two steps: the second one runs on workspaces the first one left behind
+            arena.zero_grad()
+            loss, logits = step(batch['clouds_flag'], batch['clouds'], batch['clouds_global'], gi, batch['label_mode'].to(DEV))
+            torch.cuda.synchronize()
+            out.append((loss.clone(), logits.clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+            arena.adam_step(lr=1e-3, grad_clip=1.0)
+        return out
+
+    res, fused = [], []
+    for off in (1, 0):
+        old = hip.spg_tune(16, off)
+        try:
+            model = build_model(spec, state0).to(DEV).train()
+            res.append(_step(model, batch, None, FlatParameters(model, lazy_zero=True)))
+            fused.append(one_call())
+        finally:
+            hip.spg_tune(16, old)
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    for sa, sb in zip(*fused):
+        assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1], sb[1])
+        for k in sa[2]:
+            assert torch.equal(sa[2][k], sb[2][k]), k
+    assert float(a[3]['ptn.convs.12.weight'].abs().max()) > 0 and float(a[3]['ptn.convs.0.weight'].abs().max()) > 0

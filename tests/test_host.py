@@ -169,3 +169,31 @@ def test_concat_edge_attribute_skips_edgeless_graphs():
     assert out.shape == (5, 3) and np.array_equal(out[:2], a) and np.array_equal(out[2:], b)
     assert _concat_edge_attribute([np.zeros((0, 0)), a]) is a
     assert _concat_edge_attribute([np.asarray([]), np.zeros((0, 0))]).shape == (0, 0)
+
+
+def test_bench_refuses_to_report_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus N` with no torchrun environment starts its own ranks -- and on a node with fewer
+    than N GPUs (here: none) it must fail loudly instead of printing the line of a smaller job."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and 'refusing' in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_graphconvinfo_rejects_a_part_hint_that_is_not_closed_under_edges():
+    """GraphConvInfo.from_buffers(parts=...) is a promise to the one-launch recurrence (rounds of whole scenes); a hint
+    with an edge across a boundary is rejected on the host before the device graph is built."""
+    import torch
+    from superpoint_graph_amd.learning import ecc
+    # 4 nodes, edges (src -> tgt) sorted by target: 1->0, 0->1, 3->2, 2->3: two components {0,1}, {2,3}
+    idxn, degs = torch.tensor([1, 0, 3, 2]), torch.tensor([1, 1, 1, 1])
+    ef = torch.zeros(4, 13)
+    ecc.GraphConvInfo.from_buffers(idxn, degs, ef, parts=[0, 2, 4])._validate()
+    with pytest.raises(ValueError, match='crosses a part boundary'):
+        ecc.GraphConvInfo.from_buffers(idxn, degs, ef, parts=[0, 1, 4])._validate()
+    with pytest.raises(ValueError, match='non-decreasing node offsets'):
+        ecc.GraphConvInfo.from_buffers(idxn, degs, ef, parts=[0, 2, 3])._validate()
