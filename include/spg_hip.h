@@ -439,9 +439,15 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * sequential fma chains instead of MFMA chunks: differences at fp32 round-off).  key 6: 1 = with the classifier inside the
  * recurrence, its weight / bias gradient leaves as a job of a grouped launch (+10 us) instead of being formed by service
  * workgroups of the persistent backward launch on the CUs the recurrence leaves idle.
- * key 16: 1 = spg_pointnet_backward issues the weight gradients of the pooled and of the first convolution where they stand
- * instead of as LEAVES (round 5: slices of those launches travel next to the STN head's latency-bound grouped launches;
- * every split of the weight gradient is computed by the same body with the same split plan -- results bit-identical).
+ * key 16: 1 = spg_pointnet_backward hands the weight gradients of the pooled and of the first convolution to later launches as
+ * LEAVES (round 5 experiment, OFF by default: slices of those launches -- row ranges of their split plan, same body, same plan:
+ * results bit-identical -- travel next to the STN head's grouped launches instead of standing in front of the data gradients;
+ * measured +29 us per step: a workgroup of the pooled layer's weight gradient runs ~60-90 us whatever the slice, the head's
+ * launches are ~20 us each and already filled by the riding reductions -- DESIGN 4.16).
+ * key 17: 1 = spg_pointnet_forward runs the first two convolutions of a segment (cloud -> 64 -> 64) as two row-GEMM launches
+ * instead of the one-pass kernel of round 5 (spg_narrow.hip: first-layer statistics from the Gram matrix of the input, one
+ * wavefront per block of 32 points through both layers; same MFMA order per element, the first layer's statistics exact instead
+ * of accumulated from rounded outputs -- results agree at ~1e-6, tests/test_gpu_narrow.py).
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* ------------------------------------------------------------------------------------------------

@@ -14,7 +14,8 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libspg_hip.so')
+# SPG_HIP_LIB: another build of the same library (tools/ab_builds.sh: A/B timing of two builds on ONE box); never set in production
+LIB_PATH = os.environ.get('SPG_HIP_LIB') or os.path.join(CSRC, 'libspg_hip.so')
 
 SPG_MAX_LAYERS = 8
 SPG_MAX_PARTS = 64

@@ -228,6 +228,7 @@ static bool spg_group_add(int kind, int variant, const void* params, size_t byte
 // a zero the optimiser cannot see through: added to the thread index inside the epilogues so that their (many) per-lane
 // address computations are NOT hoisted out of the persistent tile loop (they would stay live across the main loop)
 __device__ __forceinline__ int spg_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+template <typename T> using spg_kernarg_ptr = __attribute__((address_space(4))) const T*;
 #define SPG_EPI_PIECE_ROWS 16
 #define SPG_EPI_WAVE_FLOATS(RW, CW) (SPG_EPI_PIECE_ROWS * ((CW) + 8))
 
@@ -263,65 +264,7 @@ __device__ __forceinline__ void spg_store_tile_vec(const f32x16 (&acc)[TI][TJ], 
   spg_store_tile_vec_impl<RW, CW, TI, TJ>(acc, st, ybase, ldy, lane);
 }
 
-// ---- fixed-point statistics slots (SpgBnFold, spg_gemm.h) ----
-// A double v is split as v * 2^SH = hi + lo * 2^-44 (hi = floor, lo in [0, 2^44)); each limb is an exact int64 sum, 2^19
-// contributions per slot without overflow, |hi| <= 2^44 per contribution.  Two scalings:
-//   forward sums (sum x, sum x^2), SH = -8: |v| <= 2^52 per contribution, quantum 2^-36 -- a persistent workgroup's partial
-//     over 512 rows stays in range up to a pre-BatchNorm rms of ~3e6 (un-normalised metre coordinates with pc_xyznormalize 0;
-//     the 2^36 range of round 3 turned rms > 1e4 into NaN statistics where the reference's fp32 stays finite);
-//     a quantum of 1.5e-11 per contribution is invisible next to eps = 1e-5 in var + eps and to fp32 in the mean;
-//   backward sums (sum dz, sum dz * xhat), SH = +8: gradients are SMALL numbers -- quantum 2^-52, |v| <= 2^36.
-template <int SH>
-__device__ __forceinline__ void spg_fx_split(double v, long long& hi, long long& lo) {
-  constexpr double LIM = SH < 0 ? 0x1p52 : 0x1p36, SC = SH < 0 ? 0x1p-8 : 0x1p8;
-  v = fmin(fmax(v, -LIM), LIM);
-  const double t = v * SC, f = floor(t);
-  hi = (long long)f;                        // |hi| <= 2^44
-  lo = (long long)((t - f) * 0x1p44);       // [0, 2^44): 2^19 contributions fit one int64 slot
-}
-// The consumer's side: the SPG_FOLD_SLOTS slots of one sum are added EXACTLY (128-bit integers: 8 x 2^63 * 2^44 fits) and
-// converted once -- the result does not depend on which workgroup used which slot, i.e. not on the launch geometry (a
-// grouped launch numbers its workgroups differently from the stand-alone launch of the same job; both give the same bits).
-// slots: first limb of slot 0 (hi); lo limb at +C; next slot at +stride
-template <int SH>
-__device__ __forceinline__ double spg_fx_sum(const unsigned long long* __restrict__ s, size_t C, size_t stride) {
-  __int128 t = 0;
-#pragma unroll
-  for (int k = 0; k < SPG_FOLD_SLOTS; ++k) {
-    const long long hi = (long long)s[k * stride], lo = (long long)s[k * stride + C];
-    t += ((__int128)hi << 44) + (__int128)lo;
-  }
-  // sign and magnitude: both halves of |t| are non-negative, so the two conversions cannot cancel (two's-complement halves of a
-  // small negative total would: -2^64 + (2^64 - x rounded to 53 bits))
-  const bool neg = t < 0;
-  const unsigned __int128 u = neg ? (unsigned __int128)(-t) : (unsigned __int128)t;
-  const double mag = (double)(unsigned long long)(u >> 64) * 0x1p64 + (double)(unsigned long long)u;
-  constexpr double ISC = SH < 0 ? 0x1p8 : 0x1p-8;
-  return (neg ? -mag : mag) * (0x1p-44 * ISC);
-}
-
-// one contribution (two sums) of column `col` into the layer's slots
-template <int SH>
-__device__ __forceinline__ void spg_slots_add_t(unsigned long long* slots, int C, int col, double sx, double sxx) {
-  constexpr double LIM = SH < 0 ? 0x1p52 : 0x1p36;
-  unsigned long long* s = slots + (size_t)(blockIdx.x & (SPG_FOLD_SLOTS - 1)) * 4 * C + col;
-  if (!(fabs(sx) <= LIM && fabs(sxx) <= LIM)) atomicOr(slots + (size_t)SPG_FOLD_SLOTS * 4 * C, 1ull);      // NaN / inf / out of range
-  long long hi, lo;
-  spg_fx_split<SH>(sx, hi, lo);
-  __hip_atomic_fetch_add(s, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(s + C, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  spg_fx_split<SH>(sxx, hi, lo);
-  __hip_atomic_fetch_add(s + 2 * (size_t)C, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(s + 3 * (size_t)C, (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// backward: (sum dz, sum dz * xhat)
-__device__ __forceinline__ void spg_slots_add(unsigned long long* slots, int C, int col, double sx, double sxx) {
-  spg_slots_add_t<8>(slots, C, col, sx, sxx);
-}
-// forward: (rows n, mean, M2 of those rows) -> (sum x, sum x^2)
-__device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int C, int col, float n, float mean, float m2) {
-  spg_slots_add_t<-8>(slots, C, col, (double)n * (double)mean, (double)m2 + (double)n * (double)mean * (double)mean);
-}
+#include "spg_fold.h"
 
 // backward consumer prologue (weight-gradient kernels): sums (sum dz, sum dz * xhat) of the layer whose BatchNorm-backward
 // formula this launch's `a` operand applies -> consts [4][C] = {s, c1, mean, s * c2 * rstd}; workgroup 0 also writes the
@@ -1107,7 +1050,12 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
 }
 
 template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false, bool STREAM = false, int PREC = 0>
-__global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGemmParams p) {
+__global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGemmParams p_by_value) {
+  // The parameters are read where they lie -- in the kernel-argument segment (constant address space: scalar loads at the point
+  // of use) -- instead of through the by-value struct, which the compiler preloads into SGPRs and then keeps alive across the
+  // whole tile loop: the persistent instantiations spilled 74-123 SGPRs to VGPR lanes / scratch that way;
+  // with the reference 10-46 (profiles/r05_kernel_resources.txt)
+  const SpgGemmParams& p = *(const SpgGemmParams*)(spg_kernarg_ptr<SpgGemmParams>)__builtin_amdgcn_kernarg_segment_ptr();
   spg_rowgemm_body<IT, JT, WI, WJ, WRED, AMODE, FULL, STREAM, PREC>(p, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -2056,7 +2004,7 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec_lds(const SpgGemmParams& p,
 //                         registers over all tiles of the workgroup: one partial per workgroup for the batched reduction
 // One workgroup per CU (97 ... 149 KB of LDS), tiles b, b + grid, ...; both matrix roles issue CO / 2 MFMAs per wave and tile.
 // HBM per tile: g + y + y_prev + g_prev, each ONCE (before: g and y twice, y_prev three times).  Measured on the unit scene
-// (profiles/r04_bwdpair.txt): 64 -> 64  50.7 -> 35.5 us (131 MB: 3.7 TB/s including ~8 us of launch, prologue and tail),
+// (profiles/r04_kernel_stats.txt, profiles/r04_ab_bwdpair_step.txt): 64 -> 64  50.7 -> 35.5 us (131 MB: 3.7 TB/s including ~8 us of launch, prologue and tail),
 // 64 -> 128  75 -> 57.5 us.  Arithmetic per element is that of the separate kernels (same prologue expressions, fp32 MFMA); the
 // summation ORDER of dW and of the statistics differs from theirs (spg_tune key 14 = 1 restores the separate launches).
 // The three roles run their own loops with the same number of workgroup barriers (s_barrier counts waves, not code addresses).
@@ -3205,7 +3153,7 @@ int spg_leaf_drain(hipStream_t stream) {
 // of the partials in `q`, which must therefore outlive the leaves (spg_leaf_drain before its flush).  false: this launch has no
 // grouped body / a single split / no room -- the caller issues it the ordinary way.
 bool spg_queue_wgrad_leaf(SpgReduceQueue& q, SpgWgradParams p, float* dW, int nslice, hipStream_t stream) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || nslice < 1 || g_tune[SPG_TUNE_NO_GROUP] || g_tune[SPG_TUNE_NO_LEAVES]) return false;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || nslice < 1 || g_tune[SPG_TUNE_NO_GROUP] || !g_tune[SPG_TUNE_LEAVES]) return false;
   int it, jt, ns, rps;
   wgrad_plan(p.M, p.N, p.K, &it, &jt, &ns, &rps);
   if (ns < 2) return false;

@@ -16,6 +16,7 @@
 #include "../../include/spg_hip.h"
 #include "spg_ecc.h"
 #include "spg_gemm.h"
+#include "spg_narrow.h"
 #include <limits.h>
 #include <vector>
 
@@ -47,6 +48,7 @@ struct Segment {           // convs (BN+ReLU each) -> max-pool (+concat) -> fcs 
   int* aidx = nullptr;      // [B, C_lastconv]
   int nextra = 0;
   const float* extra = nullptr;
+  unsigned long long* gram = nullptr;   // train mode: fixed-point slots of the Gram matrix of the segment's input (spg_narrow.h)
 };
 
 struct Plan {
@@ -152,6 +154,10 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
   if (pl.training) {
     size_t words = 0;
     for (const Layer& l : pl.L) if (l.bn) words += 2 * spg_fold_slot_words(l.cout);
+    // + per segment the slots of the input's Gram matrix (the first two convolutions as one pass, spg_narrow.hip): inside the
+    // same region, so they are cleared with the layers' slots
+    const size_t gw_stn = pl.has_stn ? spg_gram_slot_words(c.nfeat_stn) : 0, gw_main = spg_gram_slot_words(c.nfeat);
+    words += gw_stn + gw_main;
     pl.slots_all = cv.take<unsigned long long>(words); pl.slots_words = words;
     size_t off = 0;
     for (Layer& l : pl.L)
@@ -159,6 +165,8 @@ int make_plan(const spg_pointnet_cfg* cfg, int B, int training, void* ws, const 
         l.slots = pl.slots_all ? pl.slots_all + off : nullptr; off += spg_fold_slot_words(l.cout);
         l.slots_bwd = pl.slots_all ? pl.slots_all + off : nullptr; off += spg_fold_slot_words(l.cout);
       }
+    if (pl.has_stn) { pl.stn.gram = pl.slots_all ? pl.slots_all + off : nullptr; off += gw_stn; }
+    pl.main.gram = pl.slots_all ? pl.slots_all + off : nullptr; off += gw_main;
   }
   auto carve_segment = [&](Segment& sg, float* final_out) {
     for (size_t k = 0; k < sg.convs.size(); ++k) {
@@ -263,7 +271,28 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
     SPG_TRY(spg_launch_pool_select_parts(pl.pmax, pl.pmin, nullptr, nullptr, ll.s, pl.B, ll.cout, 4, sg.extra, sg.nextra,
                                          sg.pooled, sg.ldpool, nullptr, st));
   }
-  for (size_t k = 0; !fused && k < sg.convs.size(); ++k) {
+  size_t kfirst = 0;
+  // train mode: the first two convolutions (cloud -> 64 -> 64) as ONE pass over the points -- the first layer's batch statistics
+  // from the Gram matrix of the input, its raw output written once and never read back (spg_narrow.hip)
+  if (!fused && pl.training && pl.fold && sg.gram != nullptr && sg.convs.size() > 2) {
+    Layer& l0 = pl.L[sg.convs[0]];
+    Layer& l1 = pl.L[sg.convs[1]];
+    if (l0.bn && l1.bn && spg_narrow_pair_supported(l0.cin, l0.cout, l1.cout, pl.P, pl.M)) {
+      SpgGramParams gp; memset(&gp, 0, sizeof(gp));
+      gp.clouds = clouds; gp.stnT = stnT; gp.B = pl.B; gp.P = pl.P; gp.Ctot = pl.cfg.nfeat; gp.nfeat = l0.cin; gp.gram = sg.gram;
+      SPG_TRY(spg_launch_cloud_gram(gp, st));
+      SpgNarrowPairParams np; memset(&np, 0, sizeof(np));
+      np.clouds = clouds; np.stnT = stnT; np.P = pl.P; np.Ctot = pl.cfg.nfeat; np.nfeat = l0.cin; np.nblk = (int)(pl.M / 32);
+      np.count = (double)pl.M;
+      np.W1 = l0.W; np.b1 = l0.b; np.y1 = l0.y; np.gram = sg.gram; np.gamma1 = l0.gamma; np.beta1 = l0.beta; np.rm1 = l0.rm; np.rv1 = l0.rv;
+      np.mean1 = l0.mean; np.rstd1 = l0.rstd; np.s1 = l0.s; np.t1 = l0.t;
+      np.update_times = update_times; np.momentum = pl.cfg.bn_momentum; np.eps = pl.cfg.bn_eps;
+      np.W2 = l1.W; np.b2 = l1.b; np.y2 = l1.y; np.slots2 = l1.slots;
+      SPG_TRY(spg_launch_narrow_pair_fwd(np, st));
+      kfirst = 2;
+    }
+  }
+  for (size_t k = kfirst; !fused && k < sg.convs.size(); ++k) {
     Layer& l = pl.L[sg.convs[k]];
     const bool last = k + 1 == sg.convs.size();
     SpgGemmParams g; memset(&g, 0, sizeof(g));

