@@ -448,6 +448,10 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * instead of the one-pass kernel of round 5 (spg_narrow.hip: first-layer statistics from the Gram matrix of the input, one
  * wavefront per block of 32 points through both layers; same MFMA order per element, the first layer's statistics exact instead
  * of accumulated from rounded outputs -- results agree at ~1e-6, tests/test_gpu_narrow.py).
+ * key 18: 1 = spg_pointnet_backward runs the backward of a segment's first convolution as weight-gradient launch + xy data
+ * gradient + spg_stn_dT instead of the one-pass kernel of round 5 (spg_narrow.hip: the layer's raw output is linear in the cloud,
+ * so its part of the BatchNorm-backward formula collapses onto the Gram matrix -- one pass over the incoming gradient and the
+ * cloud; results agree at fp32 round-off, tests/test_gpu_narrow.py).
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* ------------------------------------------------------------------------------------------------

@@ -224,6 +224,7 @@ bool spg_queue_wgrad_leaf(SpgReduceQueue& q, SpgWgradParams p, float* dW, int ns
 // layer's input operand, dW [g.K, 64] through the queue's batched reduction
 bool spg_bwdpair_supported(const SpgGemmParams& g, const SpgOperand& b);
 int spg_queue_bwdpair(SpgReduceQueue& q, SpgGemmParams g, const SpgOperand& b, float* dW, hipStream_t stream);
+int spg_queue_partials(SpgReduceQueue& q, int nsplit, int n, float* out, float** partial, hipStream_t stream);
 int spg_queue_colsum(SpgReduceQueue& q, const float* X, long ld, long M, int N, float* out, hipStream_t stream);
 int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream);
 // jobs whose partials are complete (in stream order) but whose summation may wait for the next batched reduction of this

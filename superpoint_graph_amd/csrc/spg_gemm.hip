@@ -266,68 +266,6 @@ __device__ __forceinline__ void spg_store_tile_vec(const f32x16 (&acc)[TI][TJ], 
 
 #include "spg_fold.h"
 
-// backward consumer prologue (weight-gradient kernels): sums (sum dz, sum dz * xhat) of the layer whose BatchNorm-backward
-// formula this launch's `a` operand applies -> consts [4][C] = {s, c1, mean, s * c2 * rstd}; workgroup 0 also writes the
-// BatchNorm parameter gradients.  All threads of the workgroup; ends with a workgroup barrier.
-// `first`: exactly one workgroup of the step passes true (it writes dgamma / dbeta)
-__device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f, const bool first) {
-  const int C = f.C;
-  const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double a = spg_fx_sum<8>(f.slots + c, (size_t)C, (size_t)4 * C);
-    const double b = spg_fx_sum<8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
-    if (bad) a = __builtin_nan("");
-    const float ps = f.s[c], pmean = f.mean[c], prstd = f.rstd[c];
-    const double c1 = a / f.count, c2 = b / f.count;
-    f.consts[0 * C + c] = ps;
-    f.consts[1 * C + c] = (float)c1;
-    f.consts[2 * C + c] = pmean;
-    f.consts[3 * C + c] = (float)((double)ps * c2 * (double)prstd);
-    if (first) {
-      if (f.dbeta) f.dbeta[c] = (float)a;
-      if (f.dgamma) f.dgamma[c] = (float)b;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-
-// consumer prologue: all threads of the workgroup; ends with a workgroup barrier behind which s / t / mean / rstd are readable
-// `first`: exactly one workgroup of the launch passes true (it advances the running statistics)
-__device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f, const bool first) {
-  const int C = f.C;
-  const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    // every slot is an exact integer sum; the 8 slots are added exactly too (spg_fx_sum)
-    double sx = spg_fx_sum<-8>(f.slots + c, (size_t)C, (size_t)4 * C);
-    const double sxx = spg_fx_sum<-8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
-    const double M = f.count;
-    if (bad) sx = __builtin_nan("");
-    const double mean = sx / M;
-    double m2 = sxx - M * mean * mean;
-    if (m2 < 0.0) m2 = 0.0;
-    const double var = m2 / M;
-    const double rstd = 1.0 / sqrt(var + (double)f.eps);
-    const double g = f.gamma ? (double)f.gamma[c] : 1.0, be = f.beta ? (double)f.beta[c] : 0.0;
-    f.mean[c] = (float)mean;
-    f.rstd[c] = (float)rstd;
-    f.s[c] = (float)(g * rstd);
-    f.t[c] = (float)(be - mean * g * rstd);
-    if (first && f.rm != nullptr && f.update_times > 0) {
-      const double uvar = M > 1.0 ? m2 / (M - 1.0) : var;
-      float rm = f.rm[c], rv = f.rv[c];
-      for (int u = 0; u < f.update_times; ++u) {
-        rm = (1.f - f.momentum) * rm + f.momentum * (float)mean;
-        rv = (1.f - f.momentum) * rv + f.momentum * (float)uvar;
-      }
-      f.rm[c] = rm;
-      f.rv[c] = rv;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's copies of s / t have left for L2 ...
-  __syncthreads();                                         // ... before any of its waves loads them
-}
-
 // Statistics of a persistent workgroup: every wave keeps (rows, mean, M2) of ITS columns over the tiles it has seen
 // (merged tile by tile with Chan's formula) and writes ONE partial when the stream ends -- 4x fewer partials for the
 // finalize kernel, which then needs no slicing / last-arrival ticket.  Backward: plain running sums.
@@ -1909,6 +1847,17 @@ static int queue_take(SpgReduceQueue& q, size_t floats, float** out, hipStream_t
   SPG_CHECK_ARG(q.arena != nullptr && q.used + floats <= q.arena_floats, "reduction arena too small");
   *out = q.arena + q.used;
   q.used += (floats + 63) & ~(size_t)63;
+  return 0;
+}
+
+// room for `nsplit` partials of `n` floats each in the queue's arena + the job that sums them into `out` (the caller's kernel writes
+// the partials: in stream order before the queue is flushed)
+int spg_queue_partials(SpgReduceQueue& q, int nsplit, int n, float* out, float** partial, hipStream_t stream) {
+  SPG_CHECK_ARG(nsplit >= 1 && n >= 1 && out != nullptr && partial != nullptr, "partials");
+  if (q.njobs + 1 > SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(q, stream));
+  SPG_TRY(queue_take(q, (size_t)nsplit * n, partial, stream));
+  SpgReduceJob& j = q.jobs[q.njobs++];
+  j.partial = *partial; j.out = out; j.nsplit = nsplit; j.n = n;
   return 0;
 }
 

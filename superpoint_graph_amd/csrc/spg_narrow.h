@@ -35,3 +35,28 @@ struct SpgNarrowPairParams {
 };
 bool spg_narrow_pair_supported(int nfeat, int c1, int c2, int P, long M);
 int spg_launch_narrow_pair_fwd(const SpgNarrowPairParams& p, hipStream_t stream);
+
+// ---- backward of a segment's FIRST convolution without a pass over its raw output (round 5) ----------------------------------
+// dW1 = sum_rows dz1^T x and (main segment behind an STN) dT = sum_points x_raw (dz1 W1[:, 0:2]) used to be two row-GEMM launches
+// over (g, y1) -- 66 MB each -- plus spg_stn_dT.  With dz1 = s (g - c1) - d (y1 - mu) (BatchNorm backward; g = the masked data
+// gradient the 64 -> 64 layer's fused backward wrote, s / mu the forward constants, c1 = mean g, d = s c2 rstd) and y1 = W1 x + b1
+// LINEAR in the cloud, everything that involves y1 collapses onto the Gram matrix G of the input (spg_cloud_gram*, already in the
+// statistics slots).  With the input centred, x'' = x - mean x (so that sum x'' = 0: no large cancelling terms):
+//   dW1[c, k]  = s_c sum_rows g[row, c] x''[row, k]  -  d_c sum_j W1[c, j] Gc[j, k]             (Gc = G - M xbar xbar^T)
+//   dxy[row, n] = sum_c s_c W1[c, n] g[row, c]  -  sum_c s_c c1_c W1[c, n]  -  x''[row] . v_n,   v_n[k] = sum_c W1[c, k] d_c W1[c, n]
+// ONE pass over g (33 MB) and the cloud (7 MB): every wavefront takes the blocks of 32 points of a superpoint, accumulates
+// x''^T g on the matrix pipe over all its blocks, forms dxy per point with a transposing butterfly and the 2 x 2 gradient dT of
+// its superpoint in registers.  y1 is not read; spg_stn_dT and the dxy buffer are gone.
+struct SpgFirstConvBwdParams {
+  const float* clouds; const float* stnT;   // the segment's input (as the forward read it)
+  int B, P, Ctot, nfeat;
+  const float* g;                            // [B * P, 64]: masked gradient wrt the first layer's BatchNorm output (ld 64)
+  const float* W1;                           // [64, nfeat]
+  const unsigned long long* gram;            // the forward's Gram slots of this segment (still intact)
+  SpgBnFoldBwd fold;                         // the first layer's BatchNorm-backward sums -> constants, dgamma / dbeta
+  float* partial;                            // out [grid][64 * nfeat]: per-workgroup partials of dW1 for the batched reduction
+  float* dT;                                 // out [B, 4] or null
+};
+bool spg_first_conv_bwd_supported(int nfeat, int c1, int P, long M);
+int spg_first_conv_bwd_grid(int B);
+int spg_launch_first_conv_bwd(const SpgFirstConvBwdParams& p, hipStream_t stream);

@@ -421,8 +421,11 @@ SpgBnFoldBwd fold_bwd_of(const Plan& pl, const Layer& prod, long count, float* c
 // leaves: 1 = this segment's convolutions hand the weight gradients that are not fused with their data gradient (the pooled
 // layer's, the first layer's) to spg_queue_wgrad_leaf (a later segment's head takes them along); 2 = this segment's head takes
 // pending leaves along (and uses the second pair of head buffers)
+// dT_out / dT_done: with want_dxy, the one-pass backward of the first convolution (spg_narrow.h) writes the gradient of the 2 x 2
+// transforms [B, 4] itself and sets *dT_done; otherwise s.dxy holds the gradient wrt the transformed xy for spg_launch_stn_dT
 int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, SpgOperand cur, const float* clouds,
-                     const float* stnT, bool want_dxy, hipStream_t st, bool ride_reduce = false, int leaves = 0) {
+                     const float* stnT, bool want_dxy, hipStream_t st, bool ride_reduce = false, int leaves = 0,
+                     float* dT_out = nullptr, bool* dT_done = nullptr) {
   const int B = pl.B;
   SpgBnFoldBwd pending; memset(&pending, 0, sizeof(pending));     // set by a data-gradient launch, consumed by the next weight gradient
   // ---- fc head ----
@@ -511,6 +514,22 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
         cur = op_bnbwd(out, prod.y, prod.ldy, s.consts, prod.cout);
         continue;
       }
+    }
+    // The FIRST convolution behind a forward that left the Gram matrix of the input in the slots (spg_narrow.hip): weight gradient
+    // and -- main segment behind an STN -- the gradient of the 2 x 2 transforms from ONE pass over the incoming gradient and the
+    // cloud; the layer's raw output is not read (it is linear in the cloud: its part collapses onto the Gram matrix)
+    if (k == 0 && pl.fold && sg.gram != nullptr && sg.convs.size() > 2 && pending.slots != nullptr && cur.mode == SPG_PRO_BNBWD &&
+        cur.ld == l.cout && cur.c0 == s.consts && (!want_dxy || dT_out != nullptr) &&
+        spg_narrow_pair_supported(l.cin, l.cout, pl.L[sg.convs[1]].cout, pl.P, pl.M) && spg_first_conv_bwd_supported(l.cin, l.cout, pl.P, pl.M)) {
+      SpgFirstConvBwdParams fp; memset(&fp, 0, sizeof(fp));
+      fp.clouds = clouds; fp.stnT = stnT; fp.B = pl.B; fp.P = pl.P; fp.Ctot = pl.cfg.nfeat; fp.nfeat = l.cin;
+      fp.g = cur.X; fp.W1 = l.W; fp.gram = sg.gram; fp.fold = pending; memset(&pending, 0, sizeof(pending));
+      fp.dT = want_dxy ? dT_out : nullptr;
+      SPG_TRY(spg_queue_partials(rq, spg_first_conv_bwd_grid(pl.B), l.cout * l.cin, l.dW, &fp.partial, st));
+      SPG_TRY(spg_launch_first_conv_bwd(fp, st));
+      if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
+      if (want_dxy && dT_done != nullptr) *dT_done = true;
+      continue;
     }
     SpgWgradParams w; memset(&w, 0, sizeof(w));
     w.a = cur; w.b = input_operand(pl, sg, false, k, clouds, stnT); w.M = (int)pl.M; w.N = l.cout; w.K = l.cin;
@@ -704,12 +723,14 @@ extern "C" int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, con
   s.grad_global = grad_global;
   struct LeafGuard { ~LeafGuard() { spg_leaf_clear(); } } leaf_guard;      // no leaf survives this call (its buffers are the caller's)
   SPG_CHECK_ARG(spg_leaf_pending() == 0, "leaves of another call are pending on this thread");
+  bool dT_done = false;
+  float* dT_target = grad_transform != nullptr ? grad_transform : (pl.has_stn ? s.dT : nullptr);
   SPG_TRY(backward_segment(pl, pl.main, s, rq, op_ident(grad_emb, cout), clouds, stnT, pl.has_stn || grad_transform != nullptr, st, false,
-                           pl.has_stn ? 1 : 0));
-  if (grad_transform != nullptr)      // gradient wrt the external 2x2 transforms (learning/pointnet.py:196-198)
+                           pl.has_stn ? 1 : 0, dT_target, &dT_done));
+  if (grad_transform != nullptr && !dT_done)      // gradient wrt the external 2x2 transforms (learning/pointnet.py:196-198)
     SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, grad_transform, st));
   if (pl.has_stn) {
-    SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, s.dT, st));
+    if (!dT_done) SPG_TRY(spg_launch_stn_dT(clouds, pl.cfg.nfeat, pl.P, B, s.dxy, 2, s.dT, st));
     SPG_TRY(backward_segment(pl, pl.stn, s, rq, op_ident(s.dT, 4), clouds, nullptr, false, st, true, 2));
   }
   SPG_TRY(spg_leaf_drain(st));      // (leaves no head took along: a launch of their own)

@@ -43,7 +43,7 @@ def _state(spec):
     return {k: v.clone() for k, v in ref.state_dict().items()}
 
 
-def _step(hip, spec, state0, batch, two_launches):
+def _step(hip, spec, state0, batch, two_launches, key18=0):
     """one training step through the modules; -> results + the first two layers' raw outputs / constants of both segments.
     two_launches: spg_tune key 17 (0 = one pass, 1 = the two row-GEMM launches, 2 = one pass with the general Gram kernel)"""
     from superpoint_graph_amd import ops
@@ -56,6 +56,7 @@ def _step(hip, spec, state0, batch, two_launches):
         captured['st'] = out[1]
         return out
     old = hip.spg_tune(17, int(two_launches))
+    old18 = hip.spg_tune(18, int(key18))
     ops.pointnet_forward = spy
     try:
         model = build_model(spec, state0).to(DEV).train()
@@ -72,6 +73,7 @@ def _step(hip, spec, state0, batch, two_launches):
     finally:
         ops.pointnet_forward = real
         hip.spg_tune(17, old)
+        hip.spg_tune(18, old18)
     st = captured['st']
     B, Pn = st.B, st.cfg.npts
 
@@ -166,3 +168,31 @@ def test_one_pass_step_against_the_oracle(hip):
         assert maxrel(v.double().cpu(), st[k].double()) < 1e-5, k
     worst = max((maxrel(b['grads'][k], grads_o[k]), k) for k in grads_o if not noise_grad(k, grads_o))
     assert worst[0] < 2e-2, worst          # unconditioned (near-tie decisions); the conditioned tests of test_gpu_baseline_parity.py are the sharp ones
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_first_convolution_backward_in_one_pass(hip, case):
+    """Round 5 (spg_narrow.h: spg_first_conv_bwd_kernel; learning/pointnet.py:84-96 / :123 backward): the weight gradient of a
+    segment's first convolution and, for the main segment, the gradient of the STN's 2 x 2 transforms from ONE pass over the
+    incoming gradient and the cloud -- the layer's raw output is linear in the cloud, its part of the BatchNorm-backward formula
+    collapses onto the (centred) Gram matrix.  Against the weight-gradient launch + xy data gradient + spg_stn_dT it replaces
+    (spg_tune key 18 = 1): forward identical, the two first-layer weight gradients and everything upstream of the transforms (the
+    whole STN) at fp32 round-off, BatchNorm parameter gradients of the first layers, determinism."""
+    cfg = CASES[case]
+    spec = O.ModelSpec(**cfg['spec'])
+    batch = _batch(spec, cfg['n_sp'], cfg['n_edges'], cfg['n_pts'], seed=5)
+    state0 = _state(spec)
+    a = _step(hip, spec, state0, batch, two_launches=False, key18=1)
+    b = _step(hip, spec, state0, batch, two_launches=False, key18=0)
+    c = _step(hip, spec, state0, batch, two_launches=False, key18=0)
+    assert torch.equal(a['loss'], b['loss']) and torch.equal(a['logits'], b['logits']) and torch.equal(a['emb'], b['emb'])
+    err = {k: maxrel(b['grads'][k], a['grads'][k]) for k in a['grads'] if not noise_grad(k, a['grads'])}
+    for k, e in err.items():
+        if not k.startswith('ptn.stn.') and k != 'ptn.convs.0.weight':
+            assert torch.equal(a['grads'][k], b['grads'][k]), k          # nothing else is touched
+    print({k: f'{e:.1e}' for k, e in err.items() if k.startswith('ptn.stn.') or k.startswith('ptn.convs.0') or k.startswith('ptn.convs.1.')})
+    assert err['ptn.convs.0.weight'] < 2e-5 and err['ptn.stn.convs.0.weight'] < 2e-5, (err['ptn.convs.0.weight'], err['ptn.stn.convs.0.weight'])
+    worst = max((e, k) for k, e in err.items())
+    assert worst[0] < 1e-4, worst
+    for k in b['grads']:
+        assert torch.equal(b['grads'][k], c['grads'][k]), k
