@@ -382,6 +382,12 @@ def main():
     arena = FlatParameters(model, lazy_zero=True, host_counters=True)
     if _lib.lib().spg_tune(7, PREC) < 0:             # precision mode of the wide row-GEMMs (0 = fp32 MFMA)
         raise RuntimeError('libspg_hip.so has no precision switch (spg_tune key 7)')
+    shared_gpu = world > 1 and args.device_index >= 0
+    if shared_gpu:
+        # several ranks on ONE device (the control-flow test of a 1-GPU box): the one-launch RNN-ECC recurrence needs all of ITS
+        # workgroups resident at once, which two processes sharing the CUs cannot promise -- its bounded spins would time out (the
+        # self-check below catches exactly that).  The per-iteration kernels have no such assumption.
+        _lib.lib().spg_tune(8, 1)
     for kv in [t for t in args.tune.split(',') if t]:
         k, v = kv.split(':')
         if _lib.lib().spg_tune(int(k), int(v)) < 0:
@@ -537,6 +543,7 @@ def main():
                    'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'step_call': 'spg_train_step (one library call: forward + backward)' if fstep is not None else 'module API (CloudEmbedder.run, model.ecc, cross_entropy, backward, bw_hook)', 'parallelism': (f'dp{world} (one scene shard per GPU, one flat-bucket RCCL all-reduce, ' + ('issued by libspg_hip' if native else 'torch.distributed') + ')') if world > 1 else 'single GPU',
                    'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics', 'precision': args.precision},
         'ranks_seen': ranks_seen, 'allreduce_us_per_step': ar_us, 'batchnorm': 'sync' if args.sync_bn else 'per-rank',
+        'ranks_share_one_gpu': shared_gpu,
         'self_check': check,
     }
     if ranks_seen != args.gpus:

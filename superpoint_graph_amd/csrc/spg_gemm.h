@@ -184,6 +184,17 @@ int spg_leaf_ride(hipStream_t stream, int launches_left);
 int spg_leaf_drain(hipStream_t stream);
 void spg_leaf_clear();
 
+// hipEvent bracket of one MFMA launch for bench.py's instrumented pass (spg_prof_enable; nothing happens otherwise): the launch
+// counts with `flops` algorithmic FLOP under `tag` (spg_prof_tag); N, K label its row of the per-shape table
+struct SpgProfSpan {
+  SpgProfSpan(hipStream_t stream, double flops, int tag, int N, int K);
+  ~SpgProfSpan();
+  SpgProfSpan(const SpgProfSpan&) = delete;
+  SpgProfSpan& operator=(const SpgProfSpan&) = delete;
+ private:
+  void* impl_;
+};
+
 int spg_gemm_ntiles(const SpgGemmParams& p);
 // Data-gradient launches with 128-column tiles keep one workgroup per tile (no persistent stream: registers), i.e. one
 // statistics contribution per tile and row-wave -- 2000 per channel on the unit scene.  That many atomics cost more on the

@@ -54,6 +54,14 @@ struct ProfScope {
 };
 }  // namespace
 extern "C" void spg_prof_enable(int on) { g_prof_on = on != 0; }
+// the instrumentation for launchers outside this file (spg_gemm.h: SpgProfSpan)
+SpgProfSpan::SpgProfSpan(hipStream_t stream, double flops, int tag, int N, int K) : impl_(nullptr) {
+  if (!g_prof_on) return;
+  ProfScope* ps = new ProfScope(stream, flops, tag);
+  ps->r.N = N; ps->r.K = K;
+  impl_ = ps;
+}
+SpgProfSpan::~SpgProfSpan() { delete static_cast<ProfScope*>(impl_); }
 
 // tuning knobs (spg_tune): process-global, read by the launchers
 // Timing-attribution switches (spg_tune key 3: parts of the persistent forward kernel switched off, results WRONG) and the

@@ -54,9 +54,9 @@ struct SpgFirstConvBwdParams {
   const float* W1;                           // [64, nfeat]
   const unsigned long long* gram;            // the forward's Gram slots of this segment (still intact)
   SpgBnFoldBwd fold;                         // the first layer's BatchNorm-backward sums -> constants, dgamma / dbeta
-  float* partial;                            // out [grid][64 * nfeat]: per-workgroup partials of dW1 for the batched reduction
+  float* partial;                            // out [spg_first_conv_bwd_partials(B)][64 * nfeat]: partials of dW1 for the batched reduction
   float* dT;                                 // out [B, 4] or null
 };
 bool spg_first_conv_bwd_supported(int nfeat, int c1, int P, long M);
-int spg_first_conv_bwd_grid(int B);
+int spg_first_conv_bwd_partials(int B);
 int spg_launch_first_conv_bwd(const SpgFirstConvBwdParams& p, hipStream_t stream);

@@ -445,32 +445,44 @@ int launch_pair(const SpgNarrowPairParams& p, hipStream_t stream) {
 
 // ---- backward of the first convolution from ONE pass over the gradient and the cloud (spg_narrow.h) ----
 #define SPG_FCB_NW 4      // one wave per SIMD and workgroup (two workgroups fit a CU): a superpoint per wave at a time
+// Row <-> operand slot: MFMA (t) of a block takes rows rho(t, h) = 8 (t / 4) + 4 h + (t % 4) from lane half h -- ANY pairing of the
+// block's 32 rows with the 16 x 2 reduction slots gives the same sums, and this one lets lane (channel, h) fetch its 16 points as
+// four float4 (points 8 q + 4 h .. + 3): coalesced 32-byte runs per channel instead of 16 scattered words.
+__device__ __forceinline__ int spg_fcb_row(int t, int h) { return 8 * (t >> 2) + 4 * h + (t & 3); }
+
 // BPS: blocks of 32 points per superpoint (P / 32)
 template <bool WANT_DT, int BPS>
 __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(const SpgFirstConvBwdParams p) {
   constexpr int NW = SPG_FCB_NW, NT = 64 * NW;
-  __shared__ double Gs[(SPG_GRAM_MAXF + 1) * (SPG_GRAM_MAXF + 1)];      // Gram matrix of [x; 1]
-  __shared__ double Gc[SPG_GRAM_MAXF * SPG_GRAM_MAXF];                   // centred Gram matrix of x
-  __shared__ float W1s[SPG_NP_C * SPG_NP_W1LD];                           // [64][33]
+  __shared__ double Gs[(SPG_GRAM_MAXF + 1) * (SPG_GRAM_MAXF + 1)];      // workgroup 0 only: Gram matrix of [x; 1]
   __shared__ float cs[4 * SPG_NP_C];                                      // s, c1, mean, d of the 64 channels
   __shared__ float xbar[SPG_GRAM_MAXF + 1];
   __shared__ float vn[2][SPG_GRAM_MAXF + 1];
   __shared__ float k2[2];
-  __shared__ double Es[SPG_NP_C * SPG_GRAM_MAXF];                         // workgroup 0: the Gram term of dW1, -d_c sum_j W1[c][j] Gc[j][k]
-  extern __shared__ float red[];                                          // [(NW - 1) * 32][64]: the weight-gradient accumulators of waves 1 ..
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int nf = p.nfeat, Cg = nf + 1, npairs = Cg * (Cg + 1) / 2, P = p.P;
+  const double M = (double)p.B * (double)P;
 
-  // ---- prologue: BatchNorm-backward constants of the layer (every workgroup; workgroup 0 writes dgamma / dbeta), the centred
-  //      Gram matrix, the small vectors of the data gradient ----
+  // ---- prologue: the layer's BatchNorm-backward constants (every workgroup finishes them from the exact sums; workgroup 0 also
+  //      writes dgamma / dbeta), the mean of the input from the Gram slots, the small vectors of the data gradient ----
+  // (operands that do not depend on the constants are on their way first)
+  float w1n[2][2];      // W1[r + 32 j][n]
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) w1n[j][n] = p.W1[(long)(r + 32 * j) * nf + n];
+  if (tid < nf) {       // xbar_k = G[k][last] / M
+    const int i = tid, pr = i * Cg - i * (i - 1) / 2 + (nf - i);
+    xbar[tid] = (float)(spg_fx_sum<-8>(p.gram + pr, (size_t)npairs, (size_t)2 * npairs) / M);
+  }
   spg_bn_fold_bwd(p.fold, blockIdx.x == 0);      // -> p.fold.consts [4][64] in global memory (+ a workgroup barrier)
   for (int i = tid; i < 4 * SPG_NP_C; i += NT) cs[i] = p.fold.consts[i];
-  for (int i = tid; i < SPG_NP_C * SPG_NP_W1LD; i += NT) {
-    const int col = i / SPG_NP_W1LD, k = i - col * SPG_NP_W1LD;
-    W1s[i] = k < nf ? p.W1[(long)col * nf + k] : 0.f;
-  }
-  {
+  __syncthreads();
+  if (blockIdx.x + 1 == gridDim.x) {
+    // The LAST workgroup owns no superpoint: it forms the Gram term -d_c sum_j W1[c][j] Gc[j][k] of dW1 -- one more "partial" for the
+    // batched reduction -- from the full (centred) Gram matrix while the others are in their main loops (on a working workgroup
+    // these ~4 us of float64 were the launch's critical path)
     const bool bad = p.gram[(size_t)SPG_FOLD_SLOTS * 2 * npairs] != 0ull;
     for (int pr = tid; pr < npairs; pr += NT) {
       int i = 0, rem = pr;
@@ -481,28 +493,37 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
       Gs[i * Cg + j] = g;
       Gs[j * Cg + i] = g;
     }
-  }
-  __syncthreads();
-  const double M = (double)p.B * (double)P;
-  for (int e = tid; e < nf * nf; e += NT) {      // centred Gram: Gc[i][j] = G[i][j] - M xbar_i xbar_j
-    const int i = e / nf, j = e - i * nf;
-    const double xb_i = Gs[i * Cg + nf] / M, xb_j = Gs[j * Cg + nf] / M;
-    Gc[i * nf + j] = Gs[i * Cg + j] - M * xb_i * xb_j;
-  }
-  if (tid < nf) xbar[tid] = (float)(Gs[tid * Cg + nf] / M);
-  __syncthreads();
-  if (tid < 2 * nf) {      // v_n[k] = sum_c W1[c][k] d_c W1[c][n]
-    const int n = tid / nf, k = tid - n * nf;
-    double a = 0.0;
+    __syncthreads();
+    float* out = p.partial + (size_t)((int)gridDim.x - 1) * NW * (SPG_NP_C * nf);      // the extra partial
+    for (int e = tid; e < SPG_NP_C * nf; e += NT) {
+      const int c = e / nf, k = e - c * nf;
+      const double xk = Gs[k * Cg + nf] / M;
+      double a = 0.0;
 #pragma unroll 1
-    for (int c = 0; c < SPG_NP_C; ++c) a = fma((double)W1s[c * SPG_NP_W1LD + k] * (double)cs[3 * SPG_NP_C + c], (double)W1s[c * SPG_NP_W1LD + n], a);
-    vn[n][k] = (float)a;
-  } else if (tid >= 64 && tid < 66) {      // K2_n = sum_c s_c c1_c W1[c][n]
-    const int n = tid - 64;
-    double a = 0.0;
-#pragma unroll 1
-    for (int c = 0; c < SPG_NP_C; ++c) a = fma((double)cs[c] * (double)cs[SPG_NP_C + c], (double)W1s[c * SPG_NP_W1LD + n], a);
-    k2[n] = (float)a;
+      for (int jj = 0; jj < nf; ++jj) a = fma((double)p.W1[(long)c * nf + jj], Gs[jj * Cg + k] - Gs[jj * Cg + nf] * xk, a);      // Gc[jj][k]
+      out[e] = (float)(-(double)cs[3 * SPG_NP_C + c] * a);
+    }
+    return;
+  }
+  {
+    // v_n[k] = sum_c W1[c][k] d_c W1[c][n] (2 nf outputs) and K2_n = sum_c s_c c1_c W1[c][n] (2 outputs): 8 lanes per output
+    const int part = tid & 7, nout = 2 * nf + 2;
+    for (int o0 = 0; o0 < nout; o0 += NT / 8) {      // (uniform trip count: the exchanges below involve every lane)
+      const int o = o0 + (tid >> 3);
+      double a = 0.0;
+      if (o < nout) {
+        const bool isk2 = o >= 2 * nf;
+        const int n = isk2 ? o - 2 * nf : o / nf, k = isk2 ? 0 : o - n * nf;
+        for (int c = part; c < SPG_NP_C; c += 8) {
+          const double wn = (double)p.W1[(long)c * nf + n];
+          a = isk2 ? fma((double)cs[c] * (double)cs[SPG_NP_C + c], wn, a) : fma((double)p.W1[(long)c * nf + k] * (double)cs[3 * SPG_NP_C + c], wn, a);
+        }
+      }
+      a += spg_shfl_xor_d(a, 4); a += spg_shfl_xor_d(a, 2); a += spg_shfl_xor_d(a, 1);
+      if (o < nout && part == 0) {
+        if (o >= 2 * nf) k2[o - 2 * nf] = (float)a; else vn[o / nf][o - (o / nf) * nf] = (float)a;
+      }
+    }
   }
   __syncthreads();
 
@@ -510,55 +531,50 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
   float un[2][2], vl[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    un[n][0] = cs[r] * W1s[r * SPG_NP_W1LD + n];
-    un[n][1] = cs[r + 32] * W1s[(r + 32) * SPG_NP_W1LD + n];
+    un[n][0] = cs[r] * w1n[0][n];
+    un[n][1] = cs[r + 32] * w1n[1][n];
     vl[n] = r < nf ? vn[n][r] : 0.f;
   }
   const float xbl = r < nf ? xbar[r] : 0.f;
   const float k2l = k2[r >> 4];
-  const int total = (int)gridDim.x * NW;
+  const int total = ((int)gridDim.x - 1) * NW;      // (the last workgroup has left)
   f32x16 acc[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 
-  // loads of one block (32 points) of superpoint g: the gradient as B operand (rows 2t + h, channels r + 32 j), the cloud as A
-  // operand (input channel r, clamped; points 2t + h) and, for the transforms' gradient, the raw x / y of the point this lane holds
-  // after the butterfly (row 2 (r & 15) + h)
-  auto load_block = [&](int g, int b, float (&gv)[16][2], float (&xa)[16], float& xr0, float& xr1) __attribute__((always_inline)) {
-    const int p0 = 32 * b;
-    const float* gb = p.g + ((long)g * P + p0 + h) * SPG_NP_C + r;
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) gv[t][j] = gb[(2 * t) * SPG_NP_C + 32 * j];
-    const float* xb = p.clouds + ((long)g * p.Ctot + (r < nf ? r : 0)) * P + p0 + h;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) xa[t] = xb[2 * t];
-    if (WANT_DT) {
-      const float* rb = p.clouds + ((long)g * p.Ctot) * P + p0 + 2 * (r & 15) + h;
-      xr0 = rb[0]; xr1 = rb[P];
-    }
-  };
-  // One superpoint at a time per wave: the loads of ALL its blocks go out first (a wave alone on its SIMD owns 512 registers; a
-  // block's 50 loads cost ~2.5 us of latency, its arithmetic ~1 us -- block by block the latency is paid four times)
+  // One superpoint at a time per wave: the loads of ALL its blocks go out first (a wave alone on its SIMD owns 512 registers)
 #pragma unroll 1
   for (int g = (int)blockIdx.x * NW + wave; g < p.B; g += total) {
-    float gvS[BPS][16][2], xaS[BPS][16], xrS[BPS][2];
+    float gvS[BPS][16][2], xrS[BPS][2];
+    f32x4 x4S[BPS][4];
+    const float* xc = p.clouds + ((long)g * p.Ctot + (r < nf ? r : 0)) * P + 4 * h;
 #pragma unroll
-    for (int b = 0; b < BPS; ++b) { xrS[b][0] = 0.f; xrS[b][1] = 0.f; load_block(g, b, gvS[b], xaS[b], xrS[b][0], xrS[b][1]); }
+    for (int b = 0; b < BPS; ++b) {
+      const float* gb = p.g + ((long)g * P + 32 * b) * SPG_NP_C + r;
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) gvS[b][t][j] = gb[spg_fcb_row(t, h) * SPG_NP_C + 32 * j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x4S[b][q] = *reinterpret_cast<const f32x4*>(xc + 32 * b + 8 * q);
+      xrS[b][0] = 0.f; xrS[b][1] = 0.f;
+      if (WANT_DT) {      // raw x / y of the row this lane holds after the butterfly: entry t = r & 15
+        const float* rb = p.clouds + ((long)g * p.Ctot) * P + 32 * b + spg_fcb_row(r & 15, h);
+        xrS[b][0] = rb[0]; xrS[b][1] = rb[P];
+      }
+    }
     f32x4 T = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.stnT != nullptr) T = *reinterpret_cast<const f32x4*>(p.stnT + (long)g * 4);
     float dta0 = 0.f, dta1 = 0.f;
 #pragma unroll
     for (int b = 0; b < BPS; ++b) {
       float (&gv)[16][2] = gvS[b];
-      float (&xa)[16] = xaS[b];
-      const float xr0 = xrS[b][0], xr1 = xrS[b][1];
+      float xa[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        float v = xa[t];
+        float v = x4S[b][t >> 2][t & 3];
         if (p.stnT != nullptr) {      // channel 0 (x) and channel 1 (y) sit in neighbouring lanes: learning/pointnet.py:123, as spg_fetch
           const float other = __shfl_xor(v, 1, 64);
           const float tx = fmaf(v, T[0] + 1.f, other * T[2]), ty = fmaf(other, T[1], v * (T[3] + 1.f));      // (branch-free: selects)
@@ -571,9 +587,9 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t], gv[t][j], acc[j], 0, 0, 0);
       if (WANT_DT) {
-        // V[t]: this lane's share of dxy[row 2t + h][n].  A transposing butterfly over lane bits 0-3 leaves lane r with the sum over
-        // its 16-lane group of entry t = r & 15 (15 exchanges instead of 16 x 4), one more exchange completes the half-wave; lanes
-        // r < 16 keep n = 0, the others n = 1
+        // V[t]: this lane's share of dxy[row rho(t, h)][n].  A transposing butterfly over lane bits 0-3 leaves lane r with the sum
+        // over its 16-lane group of entry t = r & 15 (15 exchanges instead of 16 x 4), one more exchange completes the half-wave;
+        // lanes r < 16 keep n = 0, the others n = 1
         float dxy = 0.f;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -594,10 +610,10 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
             }
           }
           const float tot = V[0] + __shfl_xor(V[0], 16, 64);
-          if ((r >> 4) == n) dxy = tot - k2l;      // entry: n = r >> 4, row 2 (r & 15) + h
+          if ((r >> 4) == n) dxy = tot - k2l;      // entry: n = r >> 4, row rho(r & 15, h)
         }
-        dta0 = fmaf(xr0, dxy, dta0);
-        dta1 = fmaf(xr1, dxy, dta1);
+        dta0 = fmaf(xrS[b][0], dxy, dta0);
+        dta1 = fmaf(xrS[b][1], dxy, dta1);
       }
     }
     if (WANT_DT) {      // dT[g][2 a + n] = sum over the lanes that hold entry n
@@ -606,40 +622,16 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
       if (lane == 0) { float* o = p.dT + (long)g * 4; o[0] = a00; o[1] = a01; o[2] = a10; o[3] = a11; }
     }
   }
-  // ---- the workgroup's partial of dW1: waves 1 .. hand their accumulators (rows = input channels < 32, i.e. registers of rows
-  //      < nfeat) to wave 0, which adds them in wave order, scales by s_c and -- workgroup 0 -- adds the Gram term ----
-  __syncthreads();
-  if (wave > 0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) red[((wave - 1) * 32 + j * 16 + q) * 64 + lane] = acc[j][q];
-  }
-  if (blockIdx.x == 0) {
-    for (int e = tid; e < SPG_NP_C * nf; e += NT) {
-      const int c = e / nf, k = e - c * nf;
-      double a = 0.0;
-#pragma unroll 1
-      for (int jj = 0; jj < nf; ++jj) a = fma((double)W1s[c * SPG_NP_W1LD + jj], Gc[jj * nf + k], a);
-      Es[e] = -(double)cs[3 * SPG_NP_C + c] * a;
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* out = p.partial + (size_t)blockIdx.x * (SPG_NP_C * nf);
-    const bool first = blockIdx.x == 0;
+  // ---- every WAVE writes its own partial of dW1 (accumulator rows = input channels): s_c sum_rows g x''; no exchange, no barrier.
+  //      The Gram term -d_c sum_j W1[c][j] Gc[j][k] is one more "partial", formed by workgroup 0 from the full (centred) Gram matrix ----
+  {
+    float* out = p.partial + (size_t)((int)blockIdx.x * NW + wave) * (SPG_NP_C * nf);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        float a = acc[j][q];
-#pragma unroll
-        for (int w = 0; w < NW - 1; ++w) a += red[(w * 32 + j * 16 + q) * 64 + lane];
         const int k = spg_acc_row(q, h), c = r + 32 * j;
-        if (k < nf) {
-          const float o = cs[c] * a;
-          out[c * nf + k] = first ? (float)((double)o + Es[c * nf + k]) : o;
-        }
+        if (k < nf) out[c * nf + k] = cs[c] * acc[j][q];
       }
   }
 }
@@ -664,6 +656,8 @@ int spg_launch_cloud_gram(const SpgGramParams& p, hipStream_t stream) {
 int spg_launch_narrow_pair_fwd(const SpgNarrowPairParams& p, hipStream_t stream) {
   SPG_CHECK_ARG(p.clouds && p.W1 && p.W2 && p.y1 && p.y2 && p.gram && p.slots2 && p.mean1 && p.rstd1 && p.s1 && p.t1, "null pointer");
   SPG_CHECK_ARG(p.P % 32 == 0 && p.nblk > 0 && p.count > 0.0, "blocks of 32 points");
+  // (counted as what it replaces: the two forward GEMMs 2 M 64 nfeat + 2 M 64 64; tag kind 5 = one-pass narrow layers)
+  SpgProfSpan prof(stream, 2.0 * p.count * SPG_NP_C * (p.nfeat + SPG_NP_C), 5000000 + 1, SPG_NP_C, SPG_NP_C);
   return p.nfeat <= 16 ? launch_pair<2>(p, stream) : launch_pair<4>(p, stream);
 }
 
@@ -672,18 +666,22 @@ bool spg_first_conv_bwd_supported(int nfeat, int c1, int P, long M) {
          spg_tune_get(SPG_TUNE_NO_NARROW_PAIR) == 0 && !spg_tune_get(SPG_TUNE_NO_FIRST_CONV_BWD) && spg_gemm_precision() == 0;
 }
 
-int spg_first_conv_bwd_grid(int B) {
+static int fcb_grid(int B) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   const int need = spg_cdiv(B, SPG_FCB_NW);
-  return need < cus ? need : cus;
+  return need < 2 * cus ? need : 2 * cus;
 }
+// partials of dW1 the kernel writes: one per wave + the Gram term
+int spg_first_conv_bwd_partials(int B) { return fcb_grid(B) * SPG_FCB_NW + 1; }
 
 int spg_launch_first_conv_bwd(const SpgFirstConvBwdParams& p, hipStream_t stream) {
   SPG_CHECK_ARG(p.clouds && p.g && p.W1 && p.gram && p.partial && p.fold.slots && p.fold.consts && p.fold.C == SPG_NP_C, "first-convolution backward arguments");
-  const int grid = spg_first_conv_bwd_grid(p.B);
-  const size_t lds = (size_t)(SPG_FCB_NW - 1) * 32 * 64 * sizeof(float);
-  const dim3 gd(grid), bd(64 * SPG_FCB_NW);
+  const int grid = fcb_grid(p.B);
+  // (counted as what it replaces: the weight gradient 2 M 64 nfeat and, with dT, the two-column data gradient 2 M 2 64)
+  SpgProfSpan prof(stream, 2.0 * (double)p.B * p.P * SPG_NP_C * (p.nfeat + (p.dT != nullptr ? 2 : 0)), 5000000 + 2, SPG_NP_C, p.nfeat);
+  const size_t lds = 0;
+  const dim3 gd(grid + 1), bd(64 * SPG_FCB_NW);      // (+ the workgroup of the Gram term)
 #define SPG_FCB_LAUNCH(DT, BPS_) hipLaunchKernelGGL((spg_first_conv_bwd_kernel<DT, BPS_>), gd, bd, lds, stream, p)
   const int bps = p.P / 32;
   if (p.dT != nullptr) { if (bps == 1) SPG_FCB_LAUNCH(true, 1); else if (bps == 2) SPG_FCB_LAUNCH(true, 2); else if (bps == 3) SPG_FCB_LAUNCH(true, 3); else SPG_FCB_LAUNCH(true, 4); }

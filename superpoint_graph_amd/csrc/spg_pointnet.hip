@@ -380,6 +380,8 @@ void carve_bwd(const Plan& pl, void* ws, BwdScratch& s) {
     // every layer gets its own slice of the reduction arena (partials stay alive until the single batched reduce)
     workmax += ((spg_wgrad_workspace_floats(l.conv ? pl.M : pl.B, l.cout, l.cin) + 63) & ~(size_t)63) + 64 * (size_t)l.cout + 128 +
                ((spg_wgrad_colsum_floats(l.conv ? pl.M : pl.B, l.cout, l.cin) + 63) & ~(size_t)63);
+    // (the one-pass backward of a segment's first convolution writes one partial per wave, spg_narrow.h)
+    if (l.conv && l.cin <= SPG_GRAM_MAXF) workmax += ((size_t)spg_first_conv_bwd_partials(pl.B) * l.cout * l.cin + 63) & ~(size_t)63;
   }
   s.dzA = cv.take<float>((size_t)pl.M * cconv); s.dzB = cv.take<float>((size_t)pl.M * cconv);
   s.fzA = cv.take<float>((size_t)pl.B * cfc); s.fzB = cv.take<float>((size_t)pl.B * cfc);
@@ -525,7 +527,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
       fp.clouds = clouds; fp.stnT = stnT; fp.B = pl.B; fp.P = pl.P; fp.Ctot = pl.cfg.nfeat; fp.nfeat = l.cin;
       fp.g = cur.X; fp.W1 = l.W; fp.gram = sg.gram; fp.fold = pending; memset(&pending, 0, sizeof(pending));
       fp.dT = want_dxy ? dT_out : nullptr;
-      SPG_TRY(spg_queue_partials(rq, spg_first_conv_bwd_grid(pl.B), l.cout * l.cin, l.dW, &fp.partial, st));
+      SPG_TRY(spg_queue_partials(rq, spg_first_conv_bwd_partials(pl.B), l.cout * l.cin, l.dW, &fp.partial, st));
       SPG_TRY(spg_launch_first_conv_bwd(fp, st));
       if (l.db) SPG_TRY(zero_async(l.db, l.cout, st));
       if (want_dxy && dT_done != nullptr) *dT_done = true;

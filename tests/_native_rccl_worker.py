@@ -39,10 +39,12 @@ def main():
         F.cross_entropy(out, label).backward()
         emb_er.bw_hook()
         return out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
-    # (local BatchNorm with the separate backward launches the synchronised mode uses: spg_tune key 14, tests/test_gpu_bwdpair.py)
-    old = L.spg_tune(14, 1)
+    # (local BatchNorm with the separate launches the synchronised mode uses: spg_tune key 14, tests/test_gpu_bwdpair.py; keys 17 / 18,
+    #  tests/test_gpu_narrow.py)
+    old = [L.spg_tune(k, 1) for k in (14, 17, 18)]
     out0, g0 = run()
-    L.spg_tune(14, old)
+    for k, v in zip((14, 17, 18), old):
+        L.spg_tune(k, v)
     st = spd.enable_sync_bn(dev)
     assert st.get('native') is True
     try:
