@@ -83,6 +83,11 @@ __device__ __forceinline__ double spg_shfl_xor_d(double v, int m) {
 // instruction (u, e) takes element e.  The result D[i][j] (lane l, register v: i = l / 16 + 4 v, j = l % 16 -- pinned by
 // tools/probe/mfma_f64_probe.hip) goes to the
 // fixed-point slots for i <= j.  The 2 x 2 STN transform needs x and y of a point in one lane: neighbouring lanes exchange them.
+// the value of the neighbouring lane (lane ^ 1): a quad permutation on the vector ALU instead of a trip through the LDS crossbar
+__device__ __forceinline__ float spg_lane_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define SPG_GRAM16_SPW 2      // superpoints per wavefront (their points extend ONE reduction)
 __global__ __launch_bounds__(256) void spg_cloud_gram16_kernel(const SpgGramParams p) {
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void spg_cloud_gram16_kernel(const SpgGramPara
       for (int e = 0; e < 4; ++e) {
         float v = x[q][u][e];
         if (p.stnT != nullptr) {      // lanes i = 0 (x) and i = 1 (y) are neighbours: learning/pointnet.py:123, the expressions of spg_fetch
-          const float other = __shfl_xor(v, 1, 64);
+          const float other = spg_lane_xor1(v);
           if (i == 0) v = fmaf(v, T[q][0] + 1.f, other * T[q][2]);
           else if (i == 1) v = fmaf(other, T[q][1], v * (T[q][3] + 1.f));
         }
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
       Gs[j * Cg + i] = g;
     }
     __syncthreads();
-    float* out = p.partial + (size_t)((int)gridDim.x - 1) * NW * (SPG_NP_C * nf);      // the extra partial
+    float* out = p.partial + (size_t)((int)gridDim.x - 1) * (SPG_NP_C * nf);      // the extra partial
     for (int e = tid; e < SPG_NP_C * nf; e += NT) {
       const int c = e / nf, k = e - c * nf;
       const double xk = Gs[k * Cg + nf] / M;
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
       for (int t = 0; t < 16; ++t) {
         float v = x4S[b][t >> 2][t & 3];
         if (p.stnT != nullptr) {      // channel 0 (x) and channel 1 (y) sit in neighbouring lanes: learning/pointnet.py:123, as spg_fetch
-          const float other = __shfl_xor(v, 1, 64);
+          const float other = spg_lane_xor1(v);
           const float tx = fmaf(v, T[0] + 1.f, other * T[2]), ty = fmaf(other, T[1], v * (T[3] + 1.f));      // (branch-free: selects)
           v = r == 0 ? tx : (r == 1 ? ty : v);
         }
@@ -622,17 +627,27 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
       if (lane == 0) { float* o = p.dT + (long)g * 4; o[0] = a00; o[1] = a01; o[2] = a10; o[3] = a11; }
     }
   }
-  // ---- every WAVE writes its own partial of dW1 (accumulator rows = input channels): s_c sum_rows g x''; no exchange, no barrier.
-  //      The Gram term -d_c sum_j W1[c][j] Gc[j][k] is one more "partial", formed by workgroup 0 from the full (centred) Gram matrix ----
+  // ---- the workgroup's partial of dW1 (accumulator rows = input channels): the four waves' accumulators meet in LDS and are added in
+  //      wave order by all threads (one partial per WAVE made the step's batched reduction 4 us longer than this exchange costs);
+  //      s_c sum_rows g x'' ----
   {
-    float* out = p.partial + (size_t)((int)blockIdx.x * NW + wave) * (SPG_NP_C * nf);
+    extern __shared__ float red[];      // [NW][32][64]
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int k = spg_acc_row(q, h), c = r + 32 * j;
-        if (k < nf) out[c * nf + k] = cs[c] * acc[j][q];
+      for (int q = 0; q < 16; ++q) red[(wave * 32 + j * 16 + q) * 64 + lane] = acc[j][q];
+    __syncthreads();
+    float* out = p.partial + (size_t)blockIdx.x * (SPG_NP_C * nf);
+    for (int e = tid; e < 32 * 64; e += NT) {
+      const int jq = e >> 6, l = e & 63, j = jq >> 4, q = jq & 15;
+      const int k = spg_acc_row(q, l >> 5), c = (l & 31) + 32 * j;
+      if (k < nf) {
+        float a = red[e];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) a += red[w * 32 * 64 + e];
+        out[c * nf + k] = cs[c] * a;
       }
+    }
   }
 }
 
@@ -672,15 +687,15 @@ static int fcb_grid(int B) {
   const int need = spg_cdiv(B, SPG_FCB_NW);
   return need < 2 * cus ? need : 2 * cus;
 }
-// partials of dW1 the kernel writes: one per wave + the Gram term
-int spg_first_conv_bwd_partials(int B) { return fcb_grid(B) * SPG_FCB_NW + 1; }
+// partials of dW1 the kernel writes: one per workgroup + the Gram term
+int spg_first_conv_bwd_partials(int B) { return fcb_grid(B) + 1; }
 
 int spg_launch_first_conv_bwd(const SpgFirstConvBwdParams& p, hipStream_t stream) {
   SPG_CHECK_ARG(p.clouds && p.g && p.W1 && p.gram && p.partial && p.fold.slots && p.fold.consts && p.fold.C == SPG_NP_C, "first-convolution backward arguments");
   const int grid = fcb_grid(p.B);
   // (counted as what it replaces: the weight gradient 2 M 64 nfeat and, with dT, the two-column data gradient 2 M 2 64)
   SpgProfSpan prof(stream, 2.0 * (double)p.B * p.P * SPG_NP_C * (p.nfeat + (p.dT != nullptr ? 2 : 0)), 5000000 + 2, SPG_NP_C, p.nfeat);
-  const size_t lds = 0;
+  const size_t lds = (size_t)SPG_FCB_NW * 32 * 64 * sizeof(float);
   const dim3 gd(grid + 1), bd(64 * SPG_FCB_NW);      // (+ the workgroup of the Gram term)
 #define SPG_FCB_LAUNCH(DT, BPS_) hipLaunchKernelGGL((spg_first_conv_bwd_kernel<DT, BPS_>), gd, bd, lds, stream, p)
   const int bps = p.P / 32;
