@@ -631,14 +631,19 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
 
   // BatchNorm of the layer that produced operand `a`: its statistics arrive as fixed-point slots and are finished here (every
   // workgroup; spg_gemm.h) -- behind the barrier at its end the scale / shift arrays the staging pipes read exist
-  if constexpr (!WRED) {
-    if (p.fold.slots != nullptr) spg_bn_fold_fwd(p.fold, bx == 0 && by == 0);
-  } else {
-    // data gradient launched NEXT TO the layer's weight gradient (grouped launch): it finishes the BatchNorm-backward
-    // constants its own staging reads itself -- the weight gradient's workgroups (which write the same bits, and dgamma /
-    // dbeta) are not ordered before it any more
-    if (p.fold_bwd.slots != nullptr) spg_bn_fold_bwd(p.fold_bwd, false);
-  }
+  // (round 5: on the full-tile path the fold runs BEHIND the issue of the first chunk's raw global loads -- they do not depend on
+  //  the constants, only the staging arithmetic does -- so one global round trip of every folding launch hides behind the other)
+  auto fold_now = [&]() __attribute__((always_inline)) {
+    if constexpr (!WRED) {
+      if (p.fold.slots != nullptr) spg_bn_fold_fwd(p.fold, bx == 0 && by == 0);
+    } else {
+      // data gradient launched NEXT TO the layer's weight gradient (grouped launch): it finishes the BatchNorm-backward
+      // constants its own staging reads itself -- the weight gradient's workgroups (which write the same bits, and dgamma /
+      // dbeta) are not ordered before it any more
+      if (p.fold_bwd.slots != nullptr) spg_bn_fold_bwd(p.fold_bwd, false);
+    }
+  };
+  if constexpr (!(AMODE >= 0 && FULL)) fold_now();
 
   if constexpr (AMODE >= 0 && FULL) {
     static_assert(4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) + 2 * WI * JT <= 4 * (A_F4 + B_F4), "epilogue staging + pooling exchange must fit one LDS buffer");
@@ -686,11 +691,12 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
     else if (WRED) { pwr0.init(p.ldw, n0, p.N); pwr1.init(p.ldw, n0, p.N); } else { pw0.init(p.ldw, n0, p.N); pw1.init(p.ldw, n0, p.N); }
     // chunk 0 -> LDS buffer 0; chunk 1 in flight in set 1
     {
-      pa0.prepare(p.a, tile, 0);
 #pragma unroll
       for (int i = 0; i < NIA; ++i) pa0.load_part(p.a, m0, 0, i);
 #pragma unroll
       for (int i = 0; i < NIW; ++i) w_load(pw0, pwr0, pb0, 0, i);
+      fold_now();                      // (ends with a workgroup barrier: the constants `prepare` reads exist behind it)
+      pa0.prepare(p.a, tile, 0);
 #pragma unroll
       for (int i = 0; i < NIA; ++i) a_store(pa0, As, i);
 #pragma unroll
