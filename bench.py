@@ -406,7 +406,7 @@ def main():
     exchange = {}
     from superpoint_graph_amd import fused as spg_fused
     fstep = None
-    if args.fused_step and spg_fused.supports(model) and not args.sync_bn and not args.hipgraph:
+    if args.fused_step and spg_fused.supports(model) and (not args.sync_bn or spd.sync_bn_mode() == 'slots') and not args.hipgraph:
         fstep = spg_fused.FusedStep(model, arena, reduction='sum' if dp else 'mean', ptn_mem_monger=True)
 
     def fwd_bwd():
@@ -546,7 +546,7 @@ def main():
         'config': {'workload': wl,
                    'workload_detail': f'synthetic S3DIS-shaped SPG (SURVEY.md 8d scene(seed)): PointNet + {args.model_config}' + (' = S3DIS production model, matrix filters, 10 GRU iterations' if args.model_config == 'gru_10_0,f_13' else '') + '; one step = zero_grad, forward, weighted CE, backward, bw_hook, clamp + Adam on resident inputs',
                    'superpoints_per_step': n_sp_step * world, 'hipgraph': bool(args.hipgraph), 'step_call': 'spg_train_step (one library call: forward + backward)' if fstep is not None else 'module API (CloudEmbedder.run, model.ecc, cross_entropy, backward, bw_hook)', 'parallelism': (f'dp{world} (one scene shard per GPU, one flat-bucket RCCL all-reduce, ' + ('issued by libspg_hip' if native else 'torch.distributed') + ')') if world > 1 else 'single GPU',
-                   'batchnorm': 'synchronised over ranks' if args.sync_bn else 'per-rank statistics', 'precision': args.precision},
+                   'batchnorm': ('synchronised over ranks (' + str(spd.sync_bn_mode()) + ')') if args.sync_bn else 'per-rank statistics', 'precision': args.precision},
         'ranks_seen': ranks_seen, 'allreduce_us_per_step': ar_us, 'batchnorm': 'sync' if args.sync_bn else 'per-rank',
         'ranks_share_one_gpu': shared_gpu,
         'self_check': check,

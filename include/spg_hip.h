@@ -369,6 +369,19 @@ int spg_eval_accumulate(const float* logits, int n_samples, long sample_stride, 
  * ---------------------------------------------------------------------------------------------- */
 typedef int (*spg_allreduce_fn)(void* ctx, double* buf, long n, void* stream);
 int spg_set_bn_allreduce(spg_allreduce_fn fn, void* ctx, double* buf, long buf_doubles);
+/* Slot-synchronised BatchNorm (round 5; the same semantics -- statistics over the scenes of ALL ranks -- at the speed of the
+ * per-rank mode): train-mode BatchNorm statistics travel from producer to consumer launch as exact 64-bit fixed-point sums
+ * ("slots"); while a slot all-reduce is registered, the library calls
+ *   fn(ctx, words, nwords, stream)      -- element-wise SUM of `nwords` int64 words over the ranks, in place, in stream order
+ * behind every launch that produced such sums and before the launch that consumes them.  Integer sums are exact and
+ * order-independent: every rank holds bit-identical statistics, whatever the rank count.  Everything built on the slots keeps
+ * running (statistics folds, fused convolution backward, one-pass first layers, grouped launches, spg_train_step).
+ * counts: DEVICE pointer to two doubles the caller keeps up to date (all-reduced) before every step -- embeddable superpoints
+ * and superedges of all ranks; world: number of ranks (capacity check of the slots).  fn == NULL switches the mode off.
+ * All ranks must run the same launch sequence; a rank without edges cannot take part.  Mutually exclusive with
+ * spg_set_bn_allreduce. */
+typedef int (*spg_slot_allreduce_fn)(void* ctx, unsigned long long* words, long nwords, void* stream);
+int spg_set_slot_allreduce(spg_slot_allreduce_fn fn, void* ctx, const double* counts, int world);
 
 /* RCCL from inside the library: a communicator of the library's own, bootstrapped by the host --
  * rank 0 obtains 128 bytes with spg_rccl_unique_id and distributes them (any channel), every rank calls spg_rccl_init
@@ -381,6 +394,11 @@ int spg_rccl_init(const void* unique_id_128_bytes, int world_size, int rank);
 int spg_rccl_world_size(void);
 int spg_rccl_allreduce_sum_f32(float* buf, long n, void* stream);
 int spg_rccl_sync_bn(double* buf, long buf_doubles);
+/* slot-synchronised BatchNorm (spg_set_slot_allreduce) through the library's communicator: the slots are summed in place as
+ * 64-bit integers; counts = the caller's device buffer of two doubles (embeddable superpoints, superedges of ALL ranks), kept up
+ * to date before every step -- spg_rccl_allreduce_sum_f64 is there for that; NULL switches the mode off */
+int spg_rccl_sync_slots(const double* counts);
+int spg_rccl_allreduce_sum_f64(double* buf, long n, void* stream);
 int spg_rccl_destroy(void);
 
 /* ------------------------------------------------------------------------------------------------

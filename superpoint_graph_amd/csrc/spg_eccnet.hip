@@ -207,7 +207,7 @@ extern "C" size_t spg_eccrnn_workspace_bytes(const spg_eccrnn_cfg* cfg, int N, i
 // train-mode BatchNorm of the filter network without finalize launches, like PointNet's (spg_gemm.h: SpgBnFold): not with
 // synchronised BatchNorm (the ranks' all-reduce sits between producer and consumer), not beyond the slots' capacity
 static bool fnet_fold(const Plan& pl) {
-  return pl.training && !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && (long)spg_cdiv(pl.E > 0 ? pl.E : 1, SPG_FC_ROWS) <= SPG_FOLD_MAX_CONTRIBUTIONS;
+  return pl.training && !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && (long)spg_cdiv(pl.E > 0 ? pl.E : 1, SPG_FC_ROWS) * spg_slot_sync_world() <= SPG_FOLD_MAX_CONTRIBUTIONS;
 }
 
 // ---- filter-generating network (once per forward, shared by all iterations): one stage per layer; each stage issues its
@@ -238,6 +238,7 @@ static void fnet_forward_stages(const Plan& pl0, const float* edgefeats, int bn_
         SpgBnFold f; memset(&f, 0, sizeof(f));
         f.slots = p.slots; f.C = p.cout; f.update_times = bn_update_times; f.momentum = pl.cfg.bn_momentum; f.eps = pl.cfg.bn_eps;
         f.count = (double)pl.E; f.gamma = p.gamma; f.beta = p.beta; f.rm = p.rm; f.rv = p.rv;
+        if (spg_slot_sync_active()) { f.count_ptr = spg_slot_sync_counts() + 1; f.count_mul = 1.0; }      // superedges of ALL ranks
         f.mean = p.mean; f.rstd = p.rstd; f.s = p.s; f.t = p.t;
         g.fold = f;
       }
@@ -315,6 +316,8 @@ int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void
   Plan pl;
   SPG_TRY(make_plan(cfg, N, E, training, workspace, params, pl));
   pl.fold = fnet_fold(pl);
+  if (E == 0 && pl.training && spg_slot_sync_active())
+    for (const FLayer& l : pl.F) SPG_CHECK_ARG(!l.bn, "slot-synchronised BatchNorm: a rank with an edge-less batch cannot take part in the filter-network statistics");
   if (E == 0 && pl.training && spg_sync_bn_active())
     for (const FLayer& l : pl.F)      // the other ranks enter the layer's all-reduce: skipping it here would hang the job
       SPG_CHECK_ARG(!l.bn, "synchronised BatchNorm: a rank with an edge-less batch cannot take part in the filter-network statistics");
@@ -470,6 +473,7 @@ void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage
         } else {
           SpgBnFoldBwd f; memset(&f, 0, sizeof(f));
           f.slots = prod.slots_bwd; f.C = prod.cout; f.count = (double)E; f.s = prod.s; f.mean = prod.mean; f.rstd = prod.rstd;
+          if (spg_slot_sync_active()) { f.count_ptr = spg_slot_sync_counts() + 1; f.count_mul = 1.0; f.grad_div = (double)spg_slot_sync_world(); }
           f.consts = s.consts; f.dgamma = prod.dgamma; f.dbeta = prod.dbeta;
           c->pending = f;
         }

@@ -76,14 +76,16 @@ __device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f, const boo
     const double b = spg_fx_sum<8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
     if (bad) a = __builtin_nan("");
     const float ps = f.s[c], pmean = f.mean[c], prstd = f.rstd[c];
-    const double c1 = a / f.count, c2 = b / f.count;
+    const double cnt = f.count_ptr != nullptr ? *f.count_ptr * f.count_mul : f.count;
+    const double c1 = a / cnt, c2 = b / cnt;
     f.consts[0 * C + c] = ps;
     f.consts[1 * C + c] = (float)c1;
     f.consts[2 * C + c] = pmean;
     f.consts[3 * C + c] = (float)((double)ps * c2 * (double)prstd);
     if (first) {
-      if (f.dbeta) f.dbeta[c] = (float)a;
-      if (f.dgamma) f.dgamma[c] = (float)b;
+      const double gd = f.grad_div > 0.0 ? f.grad_div : 1.0;
+      if (f.dbeta) f.dbeta[c] = (float)(a / gd);
+      if (f.dgamma) f.dgamma[c] = (float)(b / gd);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -99,7 +101,7 @@ __device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f, const bool f
     // every slot is an exact integer sum; the 8 slots are added exactly too (spg_fx_sum)
     double sx = spg_fx_sum<-8>(f.slots + c, (size_t)C, (size_t)4 * C);
     const double sxx = spg_fx_sum<-8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
-    const double M = f.count;
+    const double M = f.count_ptr != nullptr ? *f.count_ptr * f.count_mul : f.count;
     if (bad) sx = __builtin_nan("");
     const double mean = sx / M;
     double m2 = sxx - M * mean * mean;

@@ -31,6 +31,8 @@ struct SpgBnFold {
   const float *gamma, *beta;
   float *rm, *rv;                    // running statistics (may be null)
   float *mean, *rstd, *s, *t;        // outputs [C]
+  const double* count_ptr;           // slot-synchronised BatchNorm: the rows of ALL ranks = *count_ptr * count_mul (else null: `count`)
+  double count_mul;
 };
 // backward: (sum dz, sum dz * xhat) of a layer -> the constants of the BatchNorm-backward prologue, finished by the first
 // launch that applies them (the layer's weight gradient); same slots layout
@@ -41,7 +43,22 @@ struct SpgBnFoldBwd {
   const float *s, *mean, *rstd;      // forward constants of the layer [C]
   float* consts;                     // out [4][C] = {s, c1, mean, s * c2 * rstd}
   float *dgamma, *dbeta;             // out [C] (may be null)
+  const double* count_ptr;           // slot-synchronised BatchNorm: see SpgBnFold
+  double count_mul;
+  double grad_div;                   // slot-synchronised BatchNorm: the sums are those of ALL ranks and every rank writes dgamma / dbeta,
+                                     // which the gradient all-reduce then adds up -- each writes sum / ranks (0 = 1: single rank)
 };
+// ---- slot-synchronised BatchNorm (round 5): data-parallel ranks normalise over the union of their batches by ALL-REDUCING THE
+// FIXED-POINT SLOTS THEMSELVES (int64 sums: exact and order-independent -- the synchronised statistics are bit-identical on every
+// rank and for every rank count) between the producer launch and the consumer launch.  Everything built on the slots keeps
+// working: the folds, the fused convolution backward, the one-pass first layers, grouped launches, riders, spg_train_step.  The
+// launch functions issue the collective themselves behind every launch that produced slots (behind the group's launch for a job
+// of a grouped launch); the row counts of the consumers come from a device buffer the host all-reduces once per step.
+bool spg_slot_sync_active();
+const double* spg_slot_sync_counts();      // device [2]: superpoints, edges of all ranks (valid while the mode is active)
+int spg_slot_sync_world();
+// to be called behind a launch that added to `slots` (words int64): immediately, or behind the open group's launch (deferred)
+int spg_slot_sync_after(unsigned long long* slots, size_t words, hipStream_t stream, bool deferred);
 #define SPG_FC_ROWS 32   // rows per workgroup for the few-row GEMMs (FC layers over superpoints, filter net over edges)
 
 // Y[M,N] = prologue(A)[M,K] @ W[N,K]^T (+ bias), with a fused epilogue.
@@ -199,7 +216,8 @@ int spg_gemm_ntiles(const SpgGemmParams& p);
 // Data-gradient launches with 128-column tiles keep one workgroup per tile (no persistent stream: registers), i.e. one
 // statistics contribution per tile and row-wave -- 2000 per channel on the unit scene.  That many atomics cost more on the
 // kernel's tail (+11 us measured) than the finalize launch they would save (6 us): such launches keep the partials path.
-inline bool spg_gemm_bwd_stats_want_partials(const SpgGemmParams& g) { return g.w_red && g.N > 64 && g.rows_per_tile > SPG_FC_ROWS; }
+// (not with slot-synchronised BatchNorm: partials + a finalize launch would normalise over this rank's rows only)
+inline bool spg_gemm_bwd_stats_want_partials(const SpgGemmParams& g) { return g.w_red && g.N > 64 && g.rows_per_tile > SPG_FC_ROWS && !spg_slot_sync_active(); }
 // number of statistics / pooling partials per row tile (= waves along the rows of the tile shape used for this problem)
 int spg_gemm_row_waves(int rows_per_tile, int N);
 int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts = nullptr);

@@ -1293,7 +1293,18 @@ static int launch_gemm_shape(const SpgGemmParams& p, hipStream_t stream, int* sp
   return launch_gemm_t<128, 128, 2, 2, WRED, AMODE>(p, stream, sp);                                // wider outputs: grid.y column tiles
 }
 
+static int spg_launch_gemm_impl(const SpgGemmParams& p, hipStream_t stream, int* stat_parts);
+static long group_njobs();
 int spg_launch_gemm(const SpgGemmParams& p, hipStream_t stream, int* stat_parts) {
+  if (p.stat_slots == nullptr || !spg_slot_sync_active()) return spg_launch_gemm_impl(p, stream, stat_parts);
+  // slot-synchronised BatchNorm: the slots this launch adds to are all-reduced behind it -- behind the group's launch when the
+  // launch became a job of the open group (the job table grew)
+  const long before = group_njobs();
+  SPG_TRY(spg_launch_gemm_impl(p, stream, stat_parts));
+  const int C = p.w_red ? p.n_mask : p.N;
+  return spg_slot_sync_after(p.stat_slots, spg_fold_slot_words(C), stream, group_njobs() > before);
+}
+static int spg_launch_gemm_impl(const SpgGemmParams& p, hipStream_t stream, int* stat_parts) {
   SPG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   SPG_CHECK_ARG(p.rows_per_tile >= 1 && p.rows_per_tile <= 128, "rows_per_tile must be in [1,128]");
   SPG_CHECK_ARG(p.epi == SPG_EPI_FWD || p.Y != nullptr, "backward epilogue needs an output");
@@ -2264,6 +2275,7 @@ int spg_queue_bwdpair(SpgReduceQueue& q, SpgGemmParams g, const SpgOperand& b, f
     if (g.a.mode == SPG_PRO_BNBWD) SPG_TRY(launch_bwdpair_shape<SPG_PRO_BNBWD>(p, grid, stream));
     else SPG_TRY(launch_bwdpair_shape<SPG_PRO_POOLBWD>(p, grid, stream));
   }
+  SPG_TRY(spg_slot_sync_after(g.stat_slots, spg_fold_slot_words(g.n_mask), stream, false));      // (slot-synchronised BatchNorm)
   if (grid > 1) {
     SpgReduceJob& j = q.jobs[q.njobs++];
     j.partial = part; j.out = dW; j.nsplit = grid; j.n = g.K * g.N;
@@ -2362,6 +2374,26 @@ bool spg_sync_bn_active() { return g_sync.fn != nullptr; }
 static int spg_sync_allreduce(long n, hipStream_t stream) {
   const int rc = g_sync.fn(g_sync.ctx, g_sync.buf, n, (void*)stream);
   if (rc != 0) { spg_set_error("the registered BatchNorm all-reduce failed (rc %d)", rc); return -1; }
+  return 0;
+}
+
+// ---- slot-synchronised BatchNorm (spg_gemm.h) ----
+struct SpgSlotSync { spg_slot_allreduce_fn fn = nullptr; void* ctx = nullptr; const double* counts = nullptr; int world = 1; };
+static SpgSlotSync g_slot_sync;
+extern "C" int spg_set_slot_allreduce(spg_slot_allreduce_fn fn, void* ctx, const double* counts, int world) {
+  if (fn != nullptr) {
+    SPG_CHECK_ARG(counts != nullptr && world >= 1, "slot-synchronised BatchNorm needs the device row counts and the world size");
+    SPG_CHECK_ARG(g_sync.fn == nullptr, "slot-synchronised BatchNorm and the finalize-based mode (spg_set_bn_allreduce) exclude each other");
+  }
+  g_slot_sync.fn = fn; g_slot_sync.ctx = ctx; g_slot_sync.counts = fn ? counts : nullptr; g_slot_sync.world = fn ? world : 1;
+  return 0;
+}
+bool spg_slot_sync_active() { return g_slot_sync.fn != nullptr; }
+const double* spg_slot_sync_counts() { return g_slot_sync.counts; }
+int spg_slot_sync_world() { return g_slot_sync.world; }
+static int slot_sync_now(unsigned long long* slots, size_t words, hipStream_t stream) {
+  const int rc = g_slot_sync.fn(g_slot_sync.ctx, slots, (long)words, (void*)stream);
+  if (rc != 0) { spg_set_error("the registered slot all-reduce failed (rc %d)", rc); return -1; }
   return 0;
 }
 
@@ -2957,6 +2989,8 @@ struct SpgGroupState {
   bool heavy = false;         // a job needs the 2-workgroups-per-CU build (spg_multi_kernel); else spg_multi_light_kernel
   int rc = 0;                 // first launch error since the scope was opened
   std::function<int()> direct;      // stand-alone launch of the group's FIRST job (a group of one leaves as the kernel it is)
+  std::vector<std::pair<unsigned long long*, size_t>> syncs;      // slot-synchronised BatchNorm: slots this group's jobs add to
+  long added = 0;             // jobs ever taken (monotonic: tells a launch function whether ITS launch became a job)
   SpgMultiArgs a;
 };
 thread_local SpgGroupState g_grp;
@@ -2987,13 +3021,23 @@ int group_flush() {
     else hipLaunchKernelGGL(spg_multi_light_kernel, dim3((unsigned)blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
   }
   g.a.njobs = 0; g.lds = 0; g.used = 0; g.flops = 0.0; g.heavy = false; g.direct = nullptr;
+  std::vector<std::pair<unsigned long long*, size_t>> syncs;
+  syncs.swap(g.syncs);
   if (rc != 0) return rc;
   SPG_LAUNCH_CHECK();
+  for (auto& sy : syncs) SPG_TRY(slot_sync_now(sy.first, sy.second, g.st));      // behind the launch that produced them
   return 0;
 }
 }  // namespace
 
+int spg_slot_sync_after(unsigned long long* slots, size_t words, hipStream_t stream, bool deferred) {
+  if (!spg_slot_sync_active() || slots == nullptr || words == 0) return 0;
+  if (deferred) { g_grp.syncs.emplace_back(slots, words); return 0; }
+  return slot_sync_now(slots, words, stream);
+}
+
 namespace { thread_local int g_bypass = 0; }
+static long group_njobs() { return g_grp.added; }
 SpgGroupBypass::SpgGroupBypass(bool on) : on_(on) { if (on_) ++g_bypass; }
 SpgGroupBypass::~SpgGroupBypass() { if (on_) --g_bypass; }
 static bool spg_group_accepts(hipStream_t stream) { return g_grp.open && g_grp.st == stream && g_grp.rc == 0 && g_bypass == 0; }
@@ -3017,6 +3061,7 @@ static bool spg_group_add(int kind, int variant, const void* params, size_t byte
   memcpy(g.a.arena + g.used, params, bytes);
   g.used += need;
   ++g.a.njobs;
+  ++g.added;
   if ((kind == SPG_JOB_GEMM && !spg_gemm_variant_light(variant)) || (kind == SPG_JOB_WGRAD && !spg_wgrad_variant_light(variant))) g.heavy = true;
   if (lds > g.lds) g.lds = lds;
   g.flops += flops;

@@ -19,6 +19,8 @@ struct SpgNarrowPairParams {
   const float* clouds; const float* stnT;
   int P, Ctot, nfeat, nblk;   // nblk = B * P / 32 blocks of 32 points
   double count;               // B * P: rows behind the first layer's statistics
+  const double* count_ptr;    // slot-synchronised BatchNorm: rows of ALL ranks = *count_ptr * count_mul (else null)
+  double count_mul;
   // first layer: y1 = W1 x + b1, train-mode BatchNorm from the Gram matrix
   const float *W1, *b1;       // [64, nfeat], [64] or null
   float* y1;                  // out [B * P, 64]

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NW) void spg_narrow_pair_fwd_kernel(const SpgN
 #pragma unroll
     for (int m = NW / 2; m >= 1; m >>= 1) { lin += spg_shfl_xor_d(lin, m); quad += spg_shfl_xor_d(quad, m); }
     // (the arithmetic of spg_bn_fold_fwd, spg_gemm.hip)
-    const double M = p.count;
+    const double M = p.count_ptr != nullptr ? *p.count_ptr * p.count_mul : p.count;
     mean = lin / M;
     m2 = quad - M * mean * mean;
     if (m2 < 0.0) m2 = 0.0;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int nf = p.nfeat, Cg = nf + 1, npairs = Cg * (Cg + 1) / 2, P = p.P;
-  const double M = (double)p.B * (double)P;
+  const double M = p.fold.count_ptr != nullptr ? *p.fold.count_ptr * p.fold.count_mul : (double)p.B * (double)P;      // rows behind the Gram matrix (all ranks)
 
   // ---- prologue: the layer's BatchNorm-backward constants (every workgroup finishes them from the exact sums; workgroup 0 also
   //      writes dgamma / dbeta), the mean of the input from the Gram slots, the small vectors of the data gradient ----
@@ -506,7 +506,8 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
       double a = 0.0;
 #pragma unroll 1
       for (int jj = 0; jj < nf; ++jj) a = fma((double)p.W1[(long)c * nf + jj], Gs[jj * Cg + k] - Gs[jj * Cg + nf] * xk, a);      // Gc[jj][k]
-      out[e] = (float)(-(double)cs[3 * SPG_NP_C + c] * a);
+      // (slot-synchronised BatchNorm: G is the Gram matrix of ALL ranks and every rank forms this term -- each contributes its share)
+      out[e] = (float)(-(double)cs[3 * SPG_NP_C + c] * a / (p.fold.grad_div > 0.0 ? p.fold.grad_div : 1.0));
     }
     return;
   }

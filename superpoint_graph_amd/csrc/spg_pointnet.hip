@@ -236,6 +236,9 @@ SpgBnFold fold_of(const Plan& pl, const Layer& prod, long count, int update_time
   f.slots = prod.slots; f.C = prod.cout; f.update_times = update_times; f.momentum = pl.cfg.bn_momentum; f.eps = pl.cfg.bn_eps;
   f.count = (double)count; f.gamma = prod.gamma; f.beta = prod.beta; f.rm = prod.rm; f.rv = prod.rv;
   f.mean = prod.mean; f.rstd = prod.rstd; f.s = prod.s; f.t = prod.t;
+  if (spg_slot_sync_active()) {      // rows of ALL ranks: superpoints (x points for the convolutions)
+    f.count_ptr = spg_slot_sync_counts(); f.count_mul = count == (long)pl.B ? 1.0 : (double)count / (double)pl.B;
+  }
   return f;
 }
 
@@ -281,14 +284,17 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
       SpgGramParams gp; memset(&gp, 0, sizeof(gp));
       gp.clouds = clouds; gp.stnT = stnT; gp.B = pl.B; gp.P = pl.P; gp.Ctot = pl.cfg.nfeat; gp.nfeat = l0.cin; gp.gram = sg.gram;
       SPG_TRY(spg_launch_cloud_gram(gp, st));
+      SPG_TRY(spg_slot_sync_after(sg.gram, spg_gram_slot_words(l0.cin), st, false));      // (slot-synchronised BatchNorm)
       SpgNarrowPairParams np; memset(&np, 0, sizeof(np));
       np.clouds = clouds; np.stnT = stnT; np.P = pl.P; np.Ctot = pl.cfg.nfeat; np.nfeat = l0.cin; np.nblk = (int)(pl.M / 32);
       np.count = (double)pl.M;
+      if (spg_slot_sync_active()) { np.count_ptr = spg_slot_sync_counts(); np.count_mul = (double)pl.P; }
       np.W1 = l0.W; np.b1 = l0.b; np.y1 = l0.y; np.gram = sg.gram; np.gamma1 = l0.gamma; np.beta1 = l0.beta; np.rm1 = l0.rm; np.rv1 = l0.rv;
       np.mean1 = l0.mean; np.rstd1 = l0.rstd; np.s1 = l0.s; np.t1 = l0.t;
       np.update_times = update_times; np.momentum = pl.cfg.bn_momentum; np.eps = pl.cfg.bn_eps;
       np.W2 = l1.W; np.b2 = l1.b; np.y2 = l1.y; np.slots2 = l1.slots;
       SPG_TRY(spg_launch_narrow_pair_fwd(np, st));
+      SPG_TRY(spg_slot_sync_after(l1.slots, spg_fold_slot_words(l1.cout), st, false));
       kfirst = 2;
     }
   }
@@ -417,6 +423,10 @@ SpgBnFoldBwd fold_bwd_of(const Plan& pl, const Layer& prod, long count, float* c
   SpgBnFoldBwd f; memset(&f, 0, sizeof(f));
   f.slots = prod.slots_bwd; f.C = prod.cout; f.count = (double)count; f.s = prod.s; f.mean = prod.mean; f.rstd = prod.rstd;
   f.consts = consts; f.dgamma = prod.dgamma; f.dbeta = prod.dbeta;
+  if (spg_slot_sync_active()) {
+    f.count_ptr = spg_slot_sync_counts(); f.count_mul = count == (long)pl.B ? 1.0 : (double)count / (double)pl.B;
+    f.grad_div = (double)spg_slot_sync_world();
+  }
   return f;
 }
 
@@ -649,7 +659,8 @@ extern "C" int spg_pointnet_forward_ext(const spg_pointnet_cfg* cfg, int B, cons
   // train mode: BatchNorm statistics travel as fixed-point slots from each producer GEMM to its consumer (spg_gemm.h) -- no
   // finalize launches; not with synchronised BatchNorm (the ranks' all-reduce sits between producer and consumer)
   // (every tile contributes at most 4 wave partials per channel: far below the slots' capacity up to ~500 k superpoints)
-  pl.fold = pl.training && !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && 4L * B <= SPG_FOLD_MAX_CONTRIBUTIONS;
+  pl.fold = pl.training && !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && 4L * B * spg_slot_sync_world() <= SPG_FOLD_MAX_CONTRIBUTIONS;
+  SPG_CHECK_ARG(!(pl.training && spg_slot_sync_active()) || pl.fold, "slot-synchronised BatchNorm needs the statistics slots (spg_tune key 10 off, batch within the slots' capacity)");
   if (pl.training && !g_slots_clean) {      // always in train mode: the backward decides about its own slots independently (they are cleared here too)
     hipError_t me = hipMemsetAsync(pl.slots_all, 0, pl.slots_words * sizeof(unsigned long long), st);
     if (me != hipSuccess) { spg_set_error("hipMemsetAsync: %s", hipGetErrorString(me)); return (int)me; }
@@ -714,7 +725,7 @@ extern "C" int spg_pointnet_backward_ext(const spg_pointnet_cfg* cfg, int B, con
   // the forward wrote the last fc output to `emb`; it is not needed by the backward, so pass a dummy
   SPG_TRY(make_plan(cfg, B, 1, workspace, params, (float*)grad_emb /*unused as y*/, pl));
   pl.main.extra = clouds_global;
-  pl.fold = !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && 4L * B <= SPG_FOLD_MAX_CONTRIBUTIONS;
+  pl.fold = !spg_sync_bn_active() && !spg_tune_get(SPG_TUNE_NO_BN_FOLD) && 4L * B * spg_slot_sync_world() <= SPG_FOLD_MAX_CONTRIBUTIONS;
   bind_grads(pl, grads);
   BwdScratch s;
   carve_bwd(pl, bwd_workspace, s);

@@ -15,7 +15,7 @@ namespace {
 
 typedef struct { char internal[128]; } UniqueId;       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
 typedef void* Comm;                                     // ncclComm_t
-enum { kFloat32 = 7, kFloat64 = 8, kSum = 0 };          // ncclFloat, ncclDouble, ncclSum (rccl.h)
+enum { kInt64 = 4, kFloat32 = 7, kFloat64 = 8, kSum = 0 };          // ncclInt64, ncclFloat, ncclDouble, ncclSum (rccl.h)
 
 struct Api {
   void* handle = nullptr;
@@ -61,6 +61,11 @@ int bn_allreduce(void* /*ctx*/, double* buf, long n, void* stream) {
   return nccl_check(g_api.AllReduce(buf, buf, (size_t)n, kFloat64, kSum, g_comm, (hipStream_t)stream), "ncclAllReduce (BatchNorm sums)");
 }
 
+// slot-synchronised BatchNorm: the fixed-point statistics slots themselves, summed as 64-bit integers in place (exact)
+int slot_allreduce(void* /*ctx*/, unsigned long long* words, long n, void* stream) {
+  return nccl_check(g_api.AllReduce(words, words, (size_t)n, kInt64, kSum, g_comm, (hipStream_t)stream), "ncclAllReduce (statistics slots)");
+}
+
 }  // namespace
 
 extern "C" int spg_rccl_unique_id(void* out_128_bytes) {
@@ -97,9 +102,22 @@ extern "C" int spg_rccl_sync_bn(double* buf, long buf_doubles) {
   return spg_set_bn_allreduce(&bn_allreduce, nullptr, buf, buf_doubles);
 }
 
+extern "C" int spg_rccl_sync_slots(const double* counts) {
+  if (counts == nullptr) return spg_set_slot_allreduce(nullptr, nullptr, nullptr, 1);
+  SPG_CHECK_ARG(g_comm != nullptr, "spg_rccl_init has not been called");
+  return spg_set_slot_allreduce(&slot_allreduce, nullptr, counts, g_world);
+}
+
+extern "C" int spg_rccl_allreduce_sum_f64(double* buf, long n, void* stream) {
+  SPG_CHECK_ARG(g_comm != nullptr, "spg_rccl_init has not been called");
+  SPG_CHECK_ARG(buf != nullptr && n > 0, "bad argument");
+  return nccl_check(g_api.AllReduce(buf, buf, (size_t)n, kFloat64, kSum, g_comm, (hipStream_t)stream), "ncclAllReduce");
+}
+
 extern "C" int spg_rccl_destroy(void) {
   if (g_comm != nullptr) {
     (void)spg_set_bn_allreduce(nullptr, nullptr, nullptr, 0);
+    (void)spg_set_slot_allreduce(nullptr, nullptr, nullptr, 1);
     const int rc = g_api.CommDestroy(g_comm);
     g_comm = nullptr; g_world = 0; g_rank = -1;
     return nccl_check(rc, "ncclCommDestroy");

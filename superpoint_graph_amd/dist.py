@@ -142,20 +142,103 @@ class GradBucket:
 _SYNC_BN = {}
 
 
-def enable_sync_bn(device, group=None, max_channels: int = 1024):
-    """Synchronise the BatchNorm statistics of the HIP path over `group` (all ranks must run the same layers).  With the
-    library's own communicator (`init_native_rccl`) the all-reduces are issued by the C library directly; otherwise
+class _DevicePtr:
+    """zero-copy torch view of `n` int64 words of device memory (the statistics slots inside a caller's workspace tensor)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<i8', 'data': (int(ptr), False), 'version': 3, 'strides': None}
+
+
+def sync_bn_mode():
+    """None (per-rank statistics), 'slots' or 'finalize'"""
+    return _SYNC_BN.get('mode')
+
+
+def _enable_slot_sync(device, group=None):
+    """Slot-synchronised BatchNorm (include/spg_hip.h: spg_set_slot_allreduce): the ranks all-reduce the exact fixed-point
+    statistics slots themselves (int64 sums) between producer and consumer launch -- synchronised statistics at the speed of the
+    per-rank mode (statistics folds, fused convolution backward, one-pass first layers, spg_train_step all keep running), and
+    bit-identical on every rank.  The consumers' row counts come from `counts` (device, [superpoints, superedges] of all ranks),
+    refreshed before every forward by slot_sync_count()."""
+    import ctypes
+    from ._lib import check, lib
+    counts = torch.zeros(2, dtype=torch.float64, device=device)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if lib().spg_rccl_world_size() > 0:
+        check(lib().spg_rccl_sync_slots(counts.data_ptr()), 'spg_rccl_sync_slots')
+        state = {'calls': None, 'error': None, 'native': True, 'mode': 'slots'}
+        _SYNC_BN.update(cb=None, counts=counts, state=state, mode='slots', group=group, staged=False, native=True, world=lib().spg_rccl_world_size())
+        return state
+    staged = dist.is_initialized() and dist.get_backend(group) == 'gloo'
+    state = {'calls': 0, 'error': None, 'mode': 'slots'}
+
+    def _allreduce(ctx, ptr, n, stream):
+        try:
+            state['calls'] += 1
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
+                view = torch.as_tensor(_DevicePtr(ptr, n), device=device)
+                if staged:                         # CPU-side test backend: through the host (synchronises)
+                    host = view.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                    view.copy_(host)
+                else:                              # RCCL: enqueued in stream order w.r.t. torch's current stream
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:                     # never let an exception cross the C boundary
+            state['error'] = e
+            return 1
+
+    cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p)(_allreduce)
+    check(lib().spg_set_slot_allreduce(ctypes.cast(cb, ctypes.c_void_p), None, counts.data_ptr(), world), 'spg_set_slot_allreduce')
+    _SYNC_BN.update(cb=cb, counts=counts, state=state, mode='slots', group=group, staged=staged, native=False, world=world)
+    return state
+
+
+def slot_sync_count(index: int, value: int):
+    """Slot-synchronised BatchNorm: this rank's row count of the coming forward (index 0: embeddable superpoints, 1: superedges) ->
+    the sum over the ranks in the device buffer the kernels read.  Asynchronous (stream order); a no-op in the other modes."""
+    if _SYNC_BN.get('mode') != 'slots':
+        return
+    from ._lib import check, lib
+    st = _SYNC_BN
+    c = st['counts'][index:index + 1]
+    c.fill_(float(value))
+    if st['native']:
+        if st['world'] > 1:
+            check(lib().spg_rccl_allreduce_sum_f64(c.data_ptr(), 1, torch.cuda.current_stream().cuda_stream), 'spg_rccl_allreduce_sum_f64')
+    elif dist.is_initialized() and dist.get_world_size(st['group']) > 1:
+        if st['staged']:
+            host = c.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=st['group'])
+            c.copy_(host)
+        else:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=st['group'])
+
+
+def enable_sync_bn(device, group=None, max_channels: int = 1024, mode=None):
+    """Synchronise the BatchNorm statistics of the HIP path over `group` (all ranks must run the same layers).
+    mode 'slots' (default, round 5): the ranks all-reduce the exact fixed-point statistics slots -- see _enable_slot_sync;
+    mode 'finalize' (rounds 1-4): every BatchNorm layer reduces into a finalize launch whose fp64 sums are all-reduced (no
+    statistics folds, no fused convolution backward, no spg_train_step).  SPG_SYNC_BN_MODE overrides the default.
+    With the library's own communicator (`init_native_rccl`) the all-reduces are issued by the C library directly; otherwise
     through a callback into torch.distributed (gloo staging for the CPU-side tests)."""
     import ctypes
     from ._lib import check, lib
+    mode = mode or os.environ.get('SPG_SYNC_BN_MODE', 'slots')
+    if mode not in ('slots', 'finalize'):
+        raise ValueError("sync-BN mode must be 'slots' or 'finalize'")
+    if _SYNC_BN:
+        disable_sync_bn()
+    if mode == 'slots':
+        return _enable_slot_sync(device, group)
     buf = torch.zeros(3 * max_channels + 16, dtype=torch.float64, device=device)
     if lib().spg_rccl_world_size() > 0:
         check(lib().spg_rccl_sync_bn(buf.data_ptr(), buf.numel()), 'spg_rccl_sync_bn')
-        state = {'calls': None, 'error': None, 'native': True}
-        _SYNC_BN.update(cb=None, buf=buf, state=state)
+        state = {'calls': None, 'error': None, 'native': True, 'mode': 'finalize'}
+        _SYNC_BN.update(cb=None, buf=buf, state=state, mode='finalize')
         return state
     staged = dist.is_initialized() and dist.get_backend(group) == 'gloo' and buf.is_cuda
-    state = {'calls': 0, 'error': None}
+    state = {'calls': 0, 'error': None, 'mode': 'finalize'}
 
     def _allreduce(ctx, ptr, n, stream):
         try:
@@ -176,13 +259,14 @@ def enable_sync_bn(device, group=None, max_channels: int = 1024):
     cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p)(_allreduce)
     check(lib().spg_set_bn_allreduce(ctypes.cast(cb, ctypes.c_void_p), None, buf.data_ptr(), buf.numel()),
           'spg_set_bn_allreduce')
-    _SYNC_BN.update(cb=cb, buf=buf, state=state)
+    _SYNC_BN.update(cb=cb, buf=buf, state=state, mode='finalize')
     return state
 
 
 def disable_sync_bn():
     from ._lib import check, lib
     check(lib().spg_set_bn_allreduce(None, None, None, 0), 'spg_set_bn_allreduce')
+    check(lib().spg_set_slot_allreduce(None, None, None, 1), 'spg_set_slot_allreduce')
     _SYNC_BN.clear()
 
 

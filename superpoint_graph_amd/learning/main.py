@@ -287,8 +287,10 @@ class Session:
             self.arena = FlatParameters(model, lazy_zero=True, host_counters=True)
             self.arena.attach_optimizer(optimizer)    # the Adam moments live in `optimizer.state` (checkpoint format kept)
         self.fused = None
-        # (not with synchronised BatchNorm: its all-reduce callbacks sit between producer and consumer launches -- the module path)
-        if self.arena is not None and getattr(args, 'fused_step', 1) and args.cuda and not getattr(args, 'sync_bn', 0):
+        # (with synchronised BatchNorm only in its slot form -- the all-reduces of the fixed-point statistics are issued by the library
+        #  itself between producer and consumer launches; the finalize-based form of rounds 1-4 needs the module path)
+        from .. import dist as _spd
+        if self.arena is not None and getattr(args, 'fused_step', 1) and args.cuda and (not getattr(args, 'sync_bn', 0) or _spd.sync_bn_mode() in (None, 'slots')):
             from .. import fused
             if fused.supports(model):
                 self.fused = fused.FusedStep(model, self.arena, class_weights=dbinfo['class_weights'],

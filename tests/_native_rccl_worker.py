@@ -45,7 +45,7 @@ def main():
     out0, g0 = run()
     for k, v in zip((14, 17, 18), old):
         L.spg_tune(k, v)
-    st = spd.enable_sync_bn(dev)
+    st = spd.enable_sync_bn(dev, mode='finalize')
     assert st.get('native') is True
     try:
         out1, g1 = run()
@@ -54,6 +54,18 @@ def main():
     assert torch.equal(out0, out1)
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+    # slot-synchronised BatchNorm (round 5): the library all-reduces the fixed-point statistics slots in place (ncclInt64) and
+    # the row counts come from the device buffer -- at one rank bit-identical to the plain per-rank step, every fast path kept
+    out2, g2 = run()
+    st = spd.enable_sync_bn(dev, mode='slots')
+    assert st.get('native') is True and spd.sync_bn_mode() == 'slots'
+    try:
+        out3, g3 = run()
+    finally:
+        spd.disable_sync_bn()
+    assert torch.equal(out2, out3)
+    for k in g2:
+        assert torch.equal(g2[k], g3[k]), k
     _lib.check(L.spg_rccl_destroy(), 'destroy')
     assert spd.native_rccl_world_size() == 0
     print('native rccl ok')

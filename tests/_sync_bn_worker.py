@@ -1,7 +1,9 @@
 """Worker of tests/test_gpu_dist.py: one of WORLD_SIZE data-parallel ranks (all on cuda:0, gloo rendezvous).
 Each rank takes one scene of the golden 2-scene batch, runs the train step with synchronised BatchNorm and the
 weighted gradient all-reduce, and compares against the REFERENCE's single-process results for the whole batch
-(tests/golden/s3dis_gru10_matrix.npz: logits, loss, every gradient, running statistics)."""
+(tests/golden/s3dis_gru10_matrix.npz: logits, loss, every gradient, running statistics).
+argv: sync (0 / 1), mode ('slots': the ranks all-reduce the exact fixed-point statistics slots, round 5; 'finalize': the fp64 sums of a
+finalize launch per layer, rounds 1-4), fused (1: the step as ONE library call, spg_train_step -- slots mode only)."""
 import os
 import sys
 import types
@@ -20,6 +22,8 @@ def main():
     from superpoint_graph_amd.flat import FlatParameters
     from superpoint_graph_amd.learning import ecc, pointnet
     sync = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    mode = sys.argv[2] if len(sys.argv) > 2 else 'slots'
+    fused = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     native = os.environ.get('SPG_NATIVE_RCCL', '0') == '1'         # multi-GPU node: one GPU per rank, the library's own RCCL communicator
     if native:
@@ -44,20 +48,27 @@ def main():
     cw = torch.from_numpy(g['class_weights']).to(dev)
 
     model = build_model(spec, state0).to(dev).train()
-    arena = FlatParameters(model)
-    state = spd.enable_sync_bn(dev) if sync else None
+    arena = FlatParameters(model, lazy_zero=bool(fused), host_counters=bool(fused))
+    state = spd.enable_sync_bn(dev, mode=mode) if sync else None
+    assert not sync or spd.sync_bn_mode() == mode
     model.ecc.set_info([gi], 1)
-    embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
     arena.zero_grad()
-    emb = embedder.run(model, None, flag, batch['clouds'][v0:v1].to(dev), batch['clouds_global'][v0:v1].to(dev))
-    logits = model.ecc(emb)
+    clouds_r, global_r = batch['clouds'][v0:v1].to(dev), batch['clouds_global'][v0:v1].to(dev)
     w = spd.loss_weight(labels, cw)
-    if sync:      # the backward couples the ranks: scale the loss first
-        loss = F.cross_entropy(logits, labels, weight=cw, reduction='sum')
+    if fused:
+        from superpoint_graph_amd.fused import FusedStep
+        step = FusedStep(model, arena, class_weights=cw, reduction='sum' if sync else 'mean')
+        loss, logits = step(flag, clouds_r, global_r, gi, labels)
     else:
-        loss = F.cross_entropy(logits, labels, weight=cw)
-    loss.backward()
-    embedder.bw_hook()
+        embedder = pointnet.CloudEmbedder(types.SimpleNamespace(cuda=1, ptn_mem_monger=1))
+        emb = embedder.run(model, None, flag, clouds_r, global_r)
+        logits = model.ecc(emb)
+        if sync:      # the backward couples the ranks: scale the loss first
+            loss = F.cross_entropy(logits, labels, weight=cw, reduction='sum')
+        else:
+            loss = F.cross_entropy(logits, labels, weight=cw)
+        loss.backward()
+        embedder.bw_hook()
     arena.allreduce(w, prescaled=bool(sync))
     torch.cuda.synchronize()
     if state is not None:
@@ -81,7 +92,7 @@ def main():
     sd = model.state_dict()
     err_run = max(maxrel(sd[k[7:]].double(), torch.from_numpy(g[k]).double()) for k in g.files
                   if k.startswith('state1/') and 'running' in k)
-    print(f'rank {rank} sync={sync}: logits {err_logits:.2e} loss {err_loss:.2e} worst grad {worst:.2e} ({worst_k}) '
+    print(f'rank {rank} sync={sync} mode={mode} fused={fused}: logits {err_logits:.2e} loss {err_loss:.2e} worst grad {worst:.2e} ({worst_k}) '
           f'running stats {err_run:.2e}', flush=True)
     if sync:
         assert err_logits < 1e-4 and err_loss < 1e-4 and worst < 5e-4 and err_run < 1e-5

@@ -20,13 +20,13 @@ def _free_port():
     return port
 
 
-def _run_world2(sync, native=False):
+def _run_world2(sync, native=False, mode='slots', fused=0):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY='0', SPG_NATIVE_RCCL='1' if native else '0')
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, '_sync_bn_worker.py'), str(sync)], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, '_sync_bn_worker.py'), str(sync), mode, str(fused)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -42,9 +42,13 @@ def _run_world2(sync, native=False):
     return outs
 
 
-def test_two_ranks_sync_bn_reproduce_single_process_reference(hip):
-    outs = _run_world2(1)
-    assert all('sync=1' in o for o in outs)
+@pytest.mark.parametrize('mode,fused', [('slots', 0), ('slots', 1), ('finalize', 0)])
+def test_two_ranks_sync_bn_reproduce_single_process_reference(hip, mode, fused):
+    """mode 'slots' (round 5): the ranks all-reduce the exact fixed-point statistics slots between producer and consumer launch --
+    statistics folds, fused convolution backward, one-pass first layers stay on, and (fused = 1) the whole step is ONE library call
+    (spg_train_step); mode 'finalize': the fp64 sums of a finalize launch per layer (rounds 1-4)."""
+    outs = _run_world2(1, mode=mode, fused=fused)
+    assert all(f'sync=1 mode={mode} fused={fused}' in o for o in outs)
 
 
 def test_two_ranks_local_bn_is_a_different_model(hip):
@@ -78,9 +82,12 @@ def test_rccl_collectives_single_rank_smoke(hip):
     assert out.returncode == 0 and 'rccl smoke ok' in out.stdout, (out.stdout + out.stderr)[-3000:]
 
 
-def test_sync_bn_world1_equals_local_bn_at_full_size(hip):
-    """At world size 1 the synchronised mode (reduce -> callback -> finish, here on top of the sliced reduction of the
-    large layers) must reproduce the fused finalize bit for bit: same fp64 sums, same finishing arithmetic."""
+@pytest.mark.parametrize('mode', ['finalize', 'slots'])
+def test_sync_bn_world1_equals_local_bn_at_full_size(hip, mode):
+    """At world size 1 the synchronised modes must reproduce the local step bit for bit.  'finalize' (reduce -> callback -> finish,
+    here on top of the sliced reduction of the large layers): same fp64 sums, same finishing arithmetic as the local finalize
+    path; 'slots' (round 5: the statistics slots themselves are all-reduced, the row counts come from a device buffer): the plain
+    per-rank step with every fast path on."""
     import types
 
     import torch
@@ -112,13 +119,14 @@ def test_sync_bn_world1_equals_local_bn_at_full_size(hip):
     #  the 64 / 128-input-channel layers -- spg_tune key 14, tests/test_gpu_bwdpair.py -- sums dW in another order)
     # ... and the first two convolutions / the first convolution's backward as the separate launches (keys 17, 18: round 5's one-pass
     # kernels take the first layer's statistics from the Gram matrix -- not bit-identical to sums over rounded outputs)
-    old = [hip.spg_tune(k, 1) for k in (14, 17, 18)]
+    keys = (14, 17, 18) if mode == 'finalize' else ()
+    old = [hip.spg_tune(k, 1) for k in keys]
     try:
         out0, g0, r0 = run()
     finally:
-        for k, v in zip((14, 17, 18), old):
+        for k, v in zip(keys, old):
             hip.spg_tune(k, v)
-    st = spd.enable_sync_bn(dev)
+    st = spd.enable_sync_bn(dev, mode=mode)
     try:
         out1, g1, r1 = run()
     finally:

@@ -36,11 +36,20 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert float(t) == 1.25
     # synchronised BatchNorm: fp64 all-reduce of a prefix view of the registered buffer, from inside the C callback
-    st = spd.enable_sync_bn(dev)
+    st = spd.enable_sync_bn(dev, mode='finalize')
     buf = spd._SYNC_BN['buf']
     buf[:7] = torch.arange(7, dtype=torch.float64, device=dev)
     dist.all_reduce(buf[:7], op=dist.ReduceOp.SUM)
     assert buf[:7].tolist() == list(range(7))
+    spd.disable_sync_bn()
+    # slot-synchronised BatchNorm: an int64 all-reduce of a zero-copy view of raw device memory, as the C callback does
+    st = spd.enable_sync_bn(dev, mode='slots')
+    words = torch.arange(11, dtype=torch.int64, device=dev)
+    view = torch.as_tensor(spd._DevicePtr(words.data_ptr(), words.numel()), device=dev)
+    dist.all_reduce(view, op=dist.ReduceOp.SUM)
+    assert words.tolist() == list(range(11)) and view.data_ptr() == words.data_ptr()
+    spd.slot_sync_count(0, 123); spd.slot_sync_count(1, 45)
+    assert spd._SYNC_BN['counts'].tolist() == [123.0, 45.0]
     spd.disable_sync_bn()
     dist.barrier()
     dist.destroy_process_group()
