@@ -376,12 +376,13 @@ int spg_set_bn_allreduce(spg_allreduce_fn fn, void* ctx, double* buf, long buf_d
  * behind every launch that produced such sums and before the launch that consumes them.  Integer sums are exact and
  * order-independent: every rank holds bit-identical statistics, whatever the rank count.  Everything built on the slots keeps
  * running (statistics folds, fused convolution backward, one-pass first layers, grouped launches, spg_train_step).
- * counts: DEVICE pointer to two doubles the caller keeps up to date (all-reduced) before every step -- embeddable superpoints
- * and superedges of all ranks; world: number of ranks (capacity check of the slots).  fn == NULL switches the mode off.
+ * The row counts the consumers divide by travel with the sums (a spare word of every slot array counts the rows of its producer
+ * launches), so the all-reduce delivers the rows of all ranks too.  world: number of ranks (capacity check of the slots; the
+ * BatchNorm parameter gradients, formed by every rank from the global sums, are divided by it).  fn == NULL switches the mode off.
  * All ranks must run the same launch sequence; a rank without edges cannot take part.  Mutually exclusive with
  * spg_set_bn_allreduce. */
 typedef int (*spg_slot_allreduce_fn)(void* ctx, unsigned long long* words, long nwords, void* stream);
-int spg_set_slot_allreduce(spg_slot_allreduce_fn fn, void* ctx, const double* counts, int world);
+int spg_set_slot_allreduce(spg_slot_allreduce_fn fn, void* ctx, int world);
 
 /* RCCL from inside the library: a communicator of the library's own, bootstrapped by the host --
  * rank 0 obtains 128 bytes with spg_rccl_unique_id and distributes them (any channel), every rank calls spg_rccl_init
@@ -395,9 +396,8 @@ int spg_rccl_world_size(void);
 int spg_rccl_allreduce_sum_f32(float* buf, long n, void* stream);
 int spg_rccl_sync_bn(double* buf, long buf_doubles);
 /* slot-synchronised BatchNorm (spg_set_slot_allreduce) through the library's communicator: the slots are summed in place as
- * 64-bit integers; counts = the caller's device buffer of two doubles (embeddable superpoints, superedges of ALL ranks), kept up
- * to date before every step -- spg_rccl_allreduce_sum_f64 is there for that; NULL switches the mode off */
-int spg_rccl_sync_slots(const double* counts);
+ * 64-bit integers (ncclInt64); on = 0 switches the mode off */
+int spg_rccl_sync_slots(int on);
 int spg_rccl_allreduce_sum_f64(double* buf, long n, void* stream);
 int spg_rccl_destroy(void);
 

@@ -238,7 +238,6 @@ static void fnet_forward_stages(const Plan& pl0, const float* edgefeats, int bn_
         SpgBnFold f; memset(&f, 0, sizeof(f));
         f.slots = p.slots; f.C = p.cout; f.update_times = bn_update_times; f.momentum = pl.cfg.bn_momentum; f.eps = pl.cfg.bn_eps;
         f.count = (double)pl.E; f.gamma = p.gamma; f.beta = p.beta; f.rm = p.rm; f.rv = p.rv;
-        if (spg_slot_sync_active()) { f.count_ptr = spg_slot_sync_counts() + 1; f.count_mul = 1.0; }      // superedges of ALL ranks
         f.mean = p.mean; f.rstd = p.rstd; f.s = p.s; f.t = p.t;
         g.fold = f;
       }
@@ -473,7 +472,7 @@ void eccrnn_backward_tail_stages(std::shared_ptr<BwdCtx> c, std::vector<SpgStage
         } else {
           SpgBnFoldBwd f; memset(&f, 0, sizeof(f));
           f.slots = prod.slots_bwd; f.C = prod.cout; f.count = (double)E; f.s = prod.s; f.mean = prod.mean; f.rstd = prod.rstd;
-          if (spg_slot_sync_active()) { f.count_ptr = spg_slot_sync_counts() + 1; f.count_mul = 1.0; f.grad_div = (double)spg_slot_sync_world(); }
+          if (spg_slot_sync_active()) f.grad_mul = 1.0 / (double)spg_slot_sync_world();
           f.consts = s.consts; f.dgamma = prod.dgamma; f.dbeta = prod.dbeta;
           c->pending = f;
         }

@@ -64,6 +64,18 @@ __device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int
 }
 
 
+// The rows behind a layer's sums travel WITH them: the spare word behind the flag word counts them (every producer launch adds
+// its rows once).  Under slot-synchronised BatchNorm the all-reduce of the slots therefore delivers the rows of ALL ranks to the
+// consumer -- no second collective, no host round trip; a single rank reads back its own count.  0 (a producer that does not
+// count): the caller's value.
+__device__ __forceinline__ void spg_slots_count_add(unsigned long long* slots, int C, long rows) {
+  __hip_atomic_fetch_add(slots + (size_t)SPG_FOLD_SLOTS * 4 * C + 1, (unsigned long long)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double spg_slots_count(const unsigned long long* slots, int C, double fallback) {
+  const unsigned long long n = slots[(size_t)SPG_FOLD_SLOTS * 4 * C + 1];
+  return n != 0ull ? (double)n : fallback;
+}
+
 // backward consumer prologue (weight-gradient kernels): sums (sum dz, sum dz * xhat) of the layer whose BatchNorm-backward
 // formula this launch's `a` operand applies -> consts [4][C] = {s, c1, mean, s * c2 * rstd}; workgroup 0 also writes the
 // BatchNorm parameter gradients.  All threads of the workgroup; ends with a workgroup barrier.
@@ -71,21 +83,21 @@ __device__ __forceinline__ void spg_slots_add_fwd(unsigned long long* slots, int
 __device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f, const bool first) {
   const int C = f.C;
   const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
+  const double cnt = spg_slots_count(f.slots, C, f.count);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double a = spg_fx_sum<8>(f.slots + c, (size_t)C, (size_t)4 * C);
     const double b = spg_fx_sum<8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
     if (bad) a = __builtin_nan("");
     const float ps = f.s[c], pmean = f.mean[c], prstd = f.rstd[c];
-    const double cnt = f.count_ptr != nullptr ? *f.count_ptr * f.count_mul : f.count;
     const double c1 = a / cnt, c2 = b / cnt;
     f.consts[0 * C + c] = ps;
     f.consts[1 * C + c] = (float)c1;
     f.consts[2 * C + c] = pmean;
     f.consts[3 * C + c] = (float)((double)ps * c2 * (double)prstd);
     if (first) {
-      const double gd = f.grad_div > 0.0 ? f.grad_div : 1.0;
-      if (f.dbeta) f.dbeta[c] = (float)(a / gd);
-      if (f.dgamma) f.dgamma[c] = (float)(b / gd);
+      const double gm = f.grad_mul > 0.0 ? f.grad_mul : 1.0;
+      if (f.dbeta) f.dbeta[c] = (float)(a * gm);
+      if (f.dgamma) f.dgamma[c] = (float)(b * gm);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -97,11 +109,11 @@ __device__ __forceinline__ void spg_bn_fold_bwd(const SpgBnFoldBwd& f, const boo
 __device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f, const bool first) {
   const int C = f.C;
   const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
+  const double M = spg_slots_count(f.slots, C, f.count);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     // every slot is an exact integer sum; the 8 slots are added exactly too (spg_fx_sum)
     double sx = spg_fx_sum<-8>(f.slots + c, (size_t)C, (size_t)4 * C);
     const double sxx = spg_fx_sum<-8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
-    const double M = f.count_ptr != nullptr ? *f.count_ptr * f.count_mul : f.count;
     if (bad) sx = __builtin_nan("");
     const double mean = sx / M;
     double m2 = sxx - M * mean * mean;

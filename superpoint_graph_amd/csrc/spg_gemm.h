@@ -27,12 +27,10 @@ struct SpgBnFold {
   const unsigned long long* slots;   // null: nothing to do
   int C, update_times;
   float momentum, eps;
-  double count;                      // rows behind the statistics
+  double count;                      // rows behind the statistics (used when the slots carry no row count: older producers)
   const float *gamma, *beta;
   float *rm, *rv;                    // running statistics (may be null)
   float *mean, *rstd, *s, *t;        // outputs [C]
-  const double* count_ptr;           // slot-synchronised BatchNorm: the rows of ALL ranks = *count_ptr * count_mul (else null: `count`)
-  double count_mul;
 };
 // backward: (sum dz, sum dz * xhat) of a layer -> the constants of the BatchNorm-backward prologue, finished by the first
 // launch that applies them (the layer's weight gradient); same slots layout
@@ -43,19 +41,17 @@ struct SpgBnFoldBwd {
   const float *s, *mean, *rstd;      // forward constants of the layer [C]
   float* consts;                     // out [4][C] = {s, c1, mean, s * c2 * rstd}
   float *dgamma, *dbeta;             // out [C] (may be null)
-  const double* count_ptr;           // slot-synchronised BatchNorm: see SpgBnFold
-  double count_mul;
-  double grad_div;                   // slot-synchronised BatchNorm: the sums are those of ALL ranks and every rank writes dgamma / dbeta,
-                                     // which the gradient all-reduce then adds up -- each writes sum / ranks (0 = 1: single rank)
+  double grad_mul;                   // slot-synchronised BatchNorm: the sums are those of ALL ranks and every rank writes dgamma / dbeta,
+                                     // which the gradient all-reduce then adds up -- each writes sum * (1 / ranks) (0 = 1: single rank)
 };
 // ---- slot-synchronised BatchNorm (round 5): data-parallel ranks normalise over the union of their batches by ALL-REDUCING THE
 // FIXED-POINT SLOTS THEMSELVES (int64 sums: exact and order-independent -- the synchronised statistics are bit-identical on every
 // rank and for every rank count) between the producer launch and the consumer launch.  Everything built on the slots keeps
 // working: the folds, the fused convolution backward, the one-pass first layers, grouped launches, riders, spg_train_step.  The
 // launch functions issue the collective themselves behind every launch that produced slots (behind the group's launch for a job
-// of a grouped launch); the row counts of the consumers come from a device buffer the host all-reduces once per step.
+// of a grouped launch).  The consumers' row counts travel WITH the sums: every producer launch adds its rows to the spare word
+// behind the slots' flag word (spg_fold.h: spg_slots_count_add), so the all-reduced slots carry the rows of all ranks.
 bool spg_slot_sync_active();
-const double* spg_slot_sync_counts();      // device [2]: superpoints, edges of all ranks (valid while the mode is active)
 int spg_slot_sync_world();
 // to be called behind a launch that added to `slots` (words int64): immediately, or behind the open group's launch (deferred)
 int spg_slot_sync_after(unsigned long long* slots, size_t words, hipStream_t stream, bool deferred);
@@ -79,6 +75,9 @@ struct SpgGemmParams {
                       // row-wave) and returned through spg_launch_gemm's stat_parts
   float* stat_cnt;    // forward: [parts] rows behind every partial (required with stat)
   unsigned long long* stat_slots;   // forward, instead of stat / stat_cnt: fixed-point slots of this layer (SpgBnFold above)
+  long stat_rows;     // rows this launch stands for in the statistics' row count (spg_fold.h: spg_slots_count_add); 0 = M.  (The data
+                      // gradient of the FC layer behind a max-pool has M = superpoints but feeds the statistics of the pooled layer over
+                      // ALL points.)
   SpgBnFold fold;     // forward: statistics of the layer that PRODUCED operand `a`, to be finished in this launch's prologue
   SpgBnFoldBwd fold_bwd;   // data gradient: BatchNorm-backward sums of the `a` operand's layer, finished in this launch's prologue
                            // too when the layer's weight gradient (which otherwise does it first) runs in the SAME grouped launch

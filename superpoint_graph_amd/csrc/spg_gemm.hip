@@ -631,6 +631,9 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
 
   // BatchNorm of the layer that produced operand `a`: its statistics arrive as fixed-point slots and are finished here (every
   // workgroup; spg_gemm.h) -- behind the barrier at its end the scale / shift arrays the staging pipes read exist
+  // the rows behind this launch's statistics travel with them (spg_fold.h): one workgroup counts them
+  if (p.stat_slots != nullptr && bx == 0 && by == 0 && threadIdx.x == 0)
+    spg_slots_count_add(p.stat_slots, WRED ? p.n_mask : p.N, p.stat_rows != 0 ? p.stat_rows : (long)p.M);
   // (round 5: on the full-tile path the fold runs BEHIND the issue of the first chunk's raw global loads -- they do not depend on
   //  the constants, only the staging arithmetic does -- so one global round trip of every folding launch hides behind the other)
   auto fold_now = [&]() __attribute__((always_inline)) {
@@ -1031,6 +1034,8 @@ __device__ __forceinline__ void spg_fewrow_sk_body(const SpgGemmParams& p, const
   float* red = reinterpret_cast<float*>(smem);        // [3][16][64] partial accumulators of waves 1..3
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
+  if (p.stat_slots != nullptr && bx == 0 && by == 0 && threadIdx.x == 0)
+    spg_slots_count_add(p.stat_slots, WRED ? p.n_mask : p.N, p.stat_rows != 0 ? p.stat_rows : (long)p.M);
   if constexpr (!WRED) {
     if (p.fold.slots != nullptr) spg_bn_fold_fwd(p.fold, bx == 0 && by == 0);
   } else {
@@ -2024,6 +2029,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
   // what every role does before its loop: (loaders: the first two tiles' loads, below) -- the constants of the dz prologue,
   // finished here from the layer's slots (ends with a barrier) or already there (finalize launch) -- constants and W into LDS
   auto prologue = [&]() __attribute__((always_inline)) {
+    if (g.stat_slots != nullptr && blockIdx.x == 0 && tid == 0) spg_slots_count_add(g.stat_slots, g.n_mask, g.stat_rows != 0 ? g.stat_rows : (long)g.M);
     if (g.fold_bwd.slots != nullptr) spg_bn_fold_bwd(g.fold_bwd, blockIdx.x == 0);
     if (tid < CQ) {
       kst[0 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c0 + 4 * tid); kst[1 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c1 + 4 * tid);
@@ -2378,18 +2384,17 @@ static int spg_sync_allreduce(long n, hipStream_t stream) {
 }
 
 // ---- slot-synchronised BatchNorm (spg_gemm.h) ----
-struct SpgSlotSync { spg_slot_allreduce_fn fn = nullptr; void* ctx = nullptr; const double* counts = nullptr; int world = 1; };
+struct SpgSlotSync { spg_slot_allreduce_fn fn = nullptr; void* ctx = nullptr; int world = 1; };
 static SpgSlotSync g_slot_sync;
-extern "C" int spg_set_slot_allreduce(spg_slot_allreduce_fn fn, void* ctx, const double* counts, int world) {
+extern "C" int spg_set_slot_allreduce(spg_slot_allreduce_fn fn, void* ctx, int world) {
   if (fn != nullptr) {
-    SPG_CHECK_ARG(counts != nullptr && world >= 1, "slot-synchronised BatchNorm needs the device row counts and the world size");
+    SPG_CHECK_ARG(world >= 1, "slot-synchronised BatchNorm needs the world size");
     SPG_CHECK_ARG(g_sync.fn == nullptr, "slot-synchronised BatchNorm and the finalize-based mode (spg_set_bn_allreduce) exclude each other");
   }
-  g_slot_sync.fn = fn; g_slot_sync.ctx = ctx; g_slot_sync.counts = fn ? counts : nullptr; g_slot_sync.world = fn ? world : 1;
+  g_slot_sync.fn = fn; g_slot_sync.ctx = ctx; g_slot_sync.world = fn ? world : 1;
   return 0;
 }
 bool spg_slot_sync_active() { return g_slot_sync.fn != nullptr; }
-const double* spg_slot_sync_counts() { return g_slot_sync.counts; }
 int spg_slot_sync_world() { return g_slot_sync.world; }
 static int slot_sync_now(unsigned long long* slots, size_t words, hipStream_t stream) {
   const int rc = g_slot_sync.fn(g_slot_sync.ctx, slots, (long)words, (void*)stream);

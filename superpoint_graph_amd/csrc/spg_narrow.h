@@ -4,7 +4,7 @@
 
 #define SPG_GRAM_MAXF 32      // point features (the cloud path of the general kernels has the same bound)
 // statistics slots of the Gram matrix of [x; 1]: [SPG_FOLD_SLOTS][2 limbs: hi, lo][npairs], npairs = (nfeat + 1)(nfeat + 2) / 2
-// (upper triangle, row-major), then a flag word -- same fixed-point format as the layers' slots (spg_fold.h, SH = -8)
+// (upper triangle, row-major), then a flag word and the row count -- same fixed-point format as the layers' slots (spg_fold.h, SH = -8)
 inline size_t spg_gram_slot_words(int nfeat) { const int c = nfeat + 1; return (size_t)SPG_FOLD_SLOTS * 2 * (c * (c + 1) / 2) + 8; }
 
 struct SpgGramParams {
@@ -19,8 +19,6 @@ struct SpgNarrowPairParams {
   const float* clouds; const float* stnT;
   int P, Ctot, nfeat, nblk;   // nblk = B * P / 32 blocks of 32 points
   double count;               // B * P: rows behind the first layer's statistics
-  const double* count_ptr;    // slot-synchronised BatchNorm: rows of ALL ranks = *count_ptr * count_mul (else null)
-  double count_mul;
   // first layer: y1 = W1 x + b1, train-mode BatchNorm from the Gram matrix
   const float *W1, *b1;       // [64, nfeat], [64] or null
   float* y1;                  // out [B * P, 64]

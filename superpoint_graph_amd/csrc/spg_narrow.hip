@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void spg_cloud_gram_kernel(const SpgGramParams
     __syncthreads();
   }
   const int npairs = Cg * (Cg + 1) / 2;
+  if (blockIdx.x == 0 && tid == 0)      // the rows behind the sums travel with them (spg_fold.h: spg_slots_count_add)
+    __hip_atomic_fetch_add(p.gram + (size_t)SPG_FOLD_SLOTS * 2 * npairs + 1, (unsigned long long)((long)p.B * P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned long long* slot = p.gram + (size_t)(blockIdx.x & (SPG_FOLD_SLOTS - 1)) * 2 * npairs;
   for (int pr = tid; pr < npairs; pr += 256) {
     int i = 0, rem = pr;
@@ -141,6 +143,8 @@ __global__ __launch_bounds__(256) void spg_cloud_gram16_kernel(const SpgGramPara
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[v] += red[w * 256 + v * 64 + lane];      // fixed order: deterministic
   const int npairs = Cg * (Cg + 1) / 2;
+  if (blockIdx.x == 0 && lane == 0)     // the rows behind the sums travel with them (spg_fold.h: spg_slots_count_add)
+    __hip_atomic_fetch_add(p.gram + (size_t)SPG_FOLD_SLOTS * 2 * npairs + 1, (unsigned long long)((long)p.B * P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned long long* slot = p.gram + (size_t)(blockIdx.x & (SPG_FOLD_SLOTS - 1)) * 2 * npairs;
   const int j = lane & 15;
 #pragma unroll
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(64 * NW) void spg_narrow_pair_fwd_kernel(const SpgN
 #pragma unroll
     for (int m = NW / 2; m >= 1; m >>= 1) { lin += spg_shfl_xor_d(lin, m); quad += spg_shfl_xor_d(quad, m); }
     // (the arithmetic of spg_bn_fold_fwd, spg_gemm.hip)
-    const double M = p.count_ptr != nullptr ? *p.count_ptr * p.count_mul : p.count;
+    const unsigned long long nrow = p.gram[(size_t)SPG_FOLD_SLOTS * 2 * npairs + 1];      // rows of all ranks (slot-synchronised BatchNorm), else this rank's
+    const double M = nrow != 0ull ? (double)nrow : p.count;
     mean = lin / M;
     m2 = quad - M * mean * mean;
     if (m2 < 0.0) m2 = 0.0;
@@ -414,6 +419,7 @@ __global__ __launch_bounds__(64 * NW) void spg_narrow_pair_fwd_kernel(const SpgN
     if (r == 0) xch[NW * SPG_NP_C * 2 + wave] = sn;
   }
   __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) spg_slots_count_add(p.slots2, SPG_NP_C, (long)p.nblk * 32);
   if (tid < SPG_NP_C) {
     float na = 0.f, mean_ = 0.f, m2_ = 0.f;
     for (int w = 0; w < NW; ++w) {
@@ -467,7 +473,8 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int nf = p.nfeat, Cg = nf + 1, npairs = Cg * (Cg + 1) / 2, P = p.P;
-  const double M = p.fold.count_ptr != nullptr ? *p.fold.count_ptr * p.fold.count_mul : (double)p.B * (double)P;      // rows behind the Gram matrix (all ranks)
+  const unsigned long long nrow = p.gram[(size_t)SPG_FOLD_SLOTS * 2 * npairs + 1];
+  const double M = nrow != 0ull ? (double)nrow : (double)p.B * (double)P;      // rows behind the Gram matrix (of all ranks under slot-synchronised BatchNorm)
 
   // ---- prologue: the layer's BatchNorm-backward constants (every workgroup finishes them from the exact sums; workgroup 0 also
   //      writes dgamma / dbeta), the mean of the input from the Gram slots, the small vectors of the data gradient ----
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
 #pragma unroll 1
       for (int jj = 0; jj < nf; ++jj) a = fma((double)p.W1[(long)c * nf + jj], Gs[jj * Cg + k] - Gs[jj * Cg + nf] * xk, a);      // Gc[jj][k]
       // (slot-synchronised BatchNorm: G is the Gram matrix of ALL ranks and every rank forms this term -- each contributes its share)
-      out[e] = (float)(-(double)cs[3 * SPG_NP_C + c] * a / (p.fold.grad_div > 0.0 ? p.fold.grad_div : 1.0));
+      out[e] = (float)(-(double)cs[3 * SPG_NP_C + c] * a * (p.fold.grad_mul > 0.0 ? p.fold.grad_mul : 1.0));
     }
     return;
   }

@@ -236,9 +236,6 @@ SpgBnFold fold_of(const Plan& pl, const Layer& prod, long count, int update_time
   f.slots = prod.slots; f.C = prod.cout; f.update_times = update_times; f.momentum = pl.cfg.bn_momentum; f.eps = pl.cfg.bn_eps;
   f.count = (double)count; f.gamma = prod.gamma; f.beta = prod.beta; f.rm = prod.rm; f.rv = prod.rv;
   f.mean = prod.mean; f.rstd = prod.rstd; f.s = prod.s; f.t = prod.t;
-  if (spg_slot_sync_active()) {      // rows of ALL ranks: superpoints (x points for the convolutions)
-    f.count_ptr = spg_slot_sync_counts(); f.count_mul = count == (long)pl.B ? 1.0 : (double)count / (double)pl.B;
-  }
   return f;
 }
 
@@ -288,7 +285,6 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
       SpgNarrowPairParams np; memset(&np, 0, sizeof(np));
       np.clouds = clouds; np.stnT = stnT; np.P = pl.P; np.Ctot = pl.cfg.nfeat; np.nfeat = l0.cin; np.nblk = (int)(pl.M / 32);
       np.count = (double)pl.M;
-      if (spg_slot_sync_active()) { np.count_ptr = spg_slot_sync_counts(); np.count_mul = (double)pl.P; }
       np.W1 = l0.W; np.b1 = l0.b; np.y1 = l0.y; np.gram = sg.gram; np.gamma1 = l0.gamma; np.beta1 = l0.beta; np.rm1 = l0.rm; np.rv1 = l0.rv;
       np.mean1 = l0.mean; np.rstd1 = l0.rstd; np.s1 = l0.s; np.t1 = l0.t;
       np.update_times = update_times; np.momentum = pl.cfg.bn_momentum; np.eps = pl.cfg.bn_eps;
@@ -423,10 +419,7 @@ SpgBnFoldBwd fold_bwd_of(const Plan& pl, const Layer& prod, long count, float* c
   SpgBnFoldBwd f; memset(&f, 0, sizeof(f));
   f.slots = prod.slots_bwd; f.C = prod.cout; f.count = (double)count; f.s = prod.s; f.mean = prod.mean; f.rstd = prod.rstd;
   f.consts = consts; f.dgamma = prod.dgamma; f.dbeta = prod.dbeta;
-  if (spg_slot_sync_active()) {
-    f.count_ptr = spg_slot_sync_counts(); f.count_mul = count == (long)pl.B ? 1.0 : (double)count / (double)pl.B;
-    f.grad_div = (double)spg_slot_sync_world();
-  }
+  if (spg_slot_sync_active()) f.grad_mul = 1.0 / (double)spg_slot_sync_world();
   return f;
 }
 
@@ -478,7 +471,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     g.Yp = first ? sg.pooled : prod.y; g.ldyp = first ? sg.ldpool : prod.ldy;
     g.ms = prod.s; g.mt = prod.t; g.mask_relu = 1; g.n_mask = prod.cout;
     g.mmean = prod.mean; g.mrstd = prod.rstd; g.stat = s.stat;
-    if (pl.fold) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; }
+    if (pl.fold) { g.stat = nullptr; g.stat_slots = prod.slots_bwd; g.stat_rows = first ? pl.M : (long)B; }
     if (grp.active()) g.fold_bwd = fold_k;
     int nparts = 0;
     SPG_TRY(spg_launch_gemm(g, st, &nparts));

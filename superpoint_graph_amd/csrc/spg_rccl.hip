@@ -102,10 +102,10 @@ extern "C" int spg_rccl_sync_bn(double* buf, long buf_doubles) {
   return spg_set_bn_allreduce(&bn_allreduce, nullptr, buf, buf_doubles);
 }
 
-extern "C" int spg_rccl_sync_slots(const double* counts) {
-  if (counts == nullptr) return spg_set_slot_allreduce(nullptr, nullptr, nullptr, 1);
+extern "C" int spg_rccl_sync_slots(int on) {
+  if (!on) return spg_set_slot_allreduce(nullptr, nullptr, 1);
   SPG_CHECK_ARG(g_comm != nullptr, "spg_rccl_init has not been called");
-  return spg_set_slot_allreduce(&slot_allreduce, nullptr, counts, g_world);
+  return spg_set_slot_allreduce(&slot_allreduce, nullptr, g_world);
 }
 
 extern "C" int spg_rccl_allreduce_sum_f64(double* buf, long n, void* stream) {
@@ -117,7 +117,7 @@ extern "C" int spg_rccl_allreduce_sum_f64(double* buf, long n, void* stream) {
 extern "C" int spg_rccl_destroy(void) {
   if (g_comm != nullptr) {
     (void)spg_set_bn_allreduce(nullptr, nullptr, nullptr, 0);
-    (void)spg_set_slot_allreduce(nullptr, nullptr, nullptr, 1);
+    (void)spg_set_slot_allreduce(nullptr, nullptr, 1);
     const int rc = g_api.CommDestroy(g_comm);
     g_comm = nullptr; g_world = 0; g_rank = -1;
     return nccl_check(rc, "ncclCommDestroy");

@@ -158,16 +158,15 @@ def _enable_slot_sync(device, group=None):
     """Slot-synchronised BatchNorm (include/spg_hip.h: spg_set_slot_allreduce): the ranks all-reduce the exact fixed-point
     statistics slots themselves (int64 sums) between producer and consumer launch -- synchronised statistics at the speed of the
     per-rank mode (statistics folds, fused convolution backward, one-pass first layers, spg_train_step all keep running), and
-    bit-identical on every rank.  The consumers' row counts come from `counts` (device, [superpoints, superedges] of all ranks),
-    refreshed before every forward by slot_sync_count()."""
+    bit-identical on every rank.  The consumers' row counts travel inside the slots (a spare word counts the producers' rows), so
+    there is nothing else to exchange."""
     import ctypes
     from ._lib import check, lib
-    counts = torch.zeros(2, dtype=torch.float64, device=device)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if lib().spg_rccl_world_size() > 0:
-        check(lib().spg_rccl_sync_slots(counts.data_ptr()), 'spg_rccl_sync_slots')
+        check(lib().spg_rccl_sync_slots(1), 'spg_rccl_sync_slots')
         state = {'calls': None, 'error': None, 'native': True, 'mode': 'slots'}
-        _SYNC_BN.update(cb=None, counts=counts, state=state, mode='slots', group=group, staged=False, native=True, world=lib().spg_rccl_world_size())
+        _SYNC_BN.update(cb=None, state=state, mode='slots', group=group, native=True)
         return state
     staged = dist.is_initialized() and dist.get_backend(group) == 'gloo'
     state = {'calls': 0, 'error': None, 'mode': 'slots'}
@@ -189,30 +188,9 @@ def _enable_slot_sync(device, group=None):
             return 1
 
     cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p)(_allreduce)
-    check(lib().spg_set_slot_allreduce(ctypes.cast(cb, ctypes.c_void_p), None, counts.data_ptr(), world), 'spg_set_slot_allreduce')
-    _SYNC_BN.update(cb=cb, counts=counts, state=state, mode='slots', group=group, staged=staged, native=False, world=world)
+    check(lib().spg_set_slot_allreduce(ctypes.cast(cb, ctypes.c_void_p), None, world), 'spg_set_slot_allreduce')
+    _SYNC_BN.update(cb=cb, state=state, mode='slots', group=group, native=False)
     return state
-
-
-def slot_sync_count(index: int, value: int):
-    """Slot-synchronised BatchNorm: this rank's row count of the coming forward (index 0: embeddable superpoints, 1: superedges) ->
-    the sum over the ranks in the device buffer the kernels read.  Asynchronous (stream order); a no-op in the other modes."""
-    if _SYNC_BN.get('mode') != 'slots':
-        return
-    from ._lib import check, lib
-    st = _SYNC_BN
-    c = st['counts'][index:index + 1]
-    c.fill_(float(value))
-    if st['native']:
-        if st['world'] > 1:
-            check(lib().spg_rccl_allreduce_sum_f64(c.data_ptr(), 1, torch.cuda.current_stream().cuda_stream), 'spg_rccl_allreduce_sum_f64')
-    elif dist.is_initialized() and dist.get_world_size(st['group']) > 1:
-        if st['staged']:
-            host = c.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=st['group'])
-            c.copy_(host)
-        else:
-            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=st['group'])
 
 
 def enable_sync_bn(device, group=None, max_channels: int = 1024, mode=None):
@@ -266,7 +244,7 @@ def enable_sync_bn(device, group=None, max_channels: int = 1024, mode=None):
 def disable_sync_bn():
     from ._lib import check, lib
     check(lib().spg_set_bn_allreduce(None, None, None, 0), 'spg_set_bn_allreduce')
-    check(lib().spg_set_slot_allreduce(None, None, None, 1), 'spg_set_slot_allreduce')
+    check(lib().spg_set_slot_allreduce(None, None, 1), 'spg_set_slot_allreduce')
     _SYNC_BN.clear()
 
 

@@ -159,9 +159,6 @@ class FusedStep:
         target = ops._req(target.contiguous(), torch.int64, 'target')
         ecc_cfg, _ = conv._cfg_for(gc_info, N)              # (+ the batch's scene boundaries for graphs above one round)
         b = self._buffers(plan, B, N, E, dev, ecc_cfg)
-        from . import dist as _spd
-        _spd.slot_sync_count(0, B)      # (slot-synchronised BatchNorm: row counts of all ranks; no-ops otherwise)
-        _spd.slot_sync_count(1, E)
         C = fc.out_features
         logits = torch.empty(N, C, dtype=torch.float32, device=dev)
         loss_buf = torch.empty(N + 2, dtype=torch.float32, device=dev)

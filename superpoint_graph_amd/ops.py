@@ -299,9 +299,6 @@ def pointnet_forward(cfg: PointNetCfg, clouds, clouds_global, groups: List[Seque
     if training and B <= 1:
         # torch.nn.BatchNorm1d raises for the FC layers ([1, C] / empty input) in training mode; so do we
         raise ValueError(f'Expected more than 1 value per channel when training, got input size [{B}, C]')
-    if training:      # (slot-synchronised BatchNorm: the embeddable superpoints of all ranks, for the statistics' row counts)
-        from . import dist as _spd
-        _spd.slot_sync_count(0, B)
     if B == 0:      # inference on a batch without a single embeddable superpoint: nothing to launch
         return (torch.zeros(0, cfg.fc[cfg.n_fc - 1], dtype=torch.float32, device=clouds.device),
                 PointNetState(cfg, 0, clouds, clouds_global, None, training, ext_transform))
@@ -394,9 +391,6 @@ def eccrnn_forward(cfg: EccRnnCfg, graph: DeviceGraph, h0, edgefeats, groups, tr
         raise ValueError(f'edgefeats must be [{E}, {cfg.fnet_widths[0]}], got {tuple(edgefeats.shape)}')
     if training and cfg.bnidx >= 0 and E == 1:
         raise ValueError('Expected more than 1 value per channel when training (filter-network BatchNorm over one edge)')
-    if training:      # (slot-synchronised BatchNorm: the superedges of all ranks)
-        from . import dist as _spd
-        _spd.slot_sync_count(1, E)
     nbytes = lib().spg_eccrnn_workspace_bytes(ctypes.byref(cfg), N, E, int(training))
     if nbytes == 0:
         raise RuntimeError('spg_eccrnn_workspace_bytes: ' + lib().spg_last_error().decode())

@@ -5,7 +5,7 @@
 # over the steady-state window (tools/prof_summary.py), (3)+(4) --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes
 # (never with other trace domains), each followed by the known-byte-count calibration of tools/pmc_calib.py.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -21,11 +21,13 @@ d = json.load(open('$OUT/${TAG}_bench.json'))
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline frac', d['roofline']['frac'], 'hbm_frac', d['roofline'].get('hbm_frac'))
 EOF2
 
-# the round's launch structures on the same box: module path ungrouped / grouped (both with separate backward launches), one-call
-# step, + fused convolution backward (key 14 off), + classifier / cross entropy inside the recurrence (key 15 off) = the default
-for V in "--fused-step 0 --tune 11:1,14:1" "--fused-step 0 --tune 14:1" "--fused-step 1 --tune 14:1,15:1" "--fused-step 1 --tune 15:1" "--fused-step 1"; do
+# the round's changes on the same box, interleaved (spg_tune keys 17 / 18: the one-pass first layers forward / backward as the
+# launches they replace; 16: weight-gradient leaves, an experiment that is off by default)
+for i in 1 2; do
+for V in "--tune 17:1,18:1" "--tune 18:1" "" "--tune 16:1" "--sync-bn 1"; do
   timeout 300 python $ROOT/bench.py --steps 40 --warmup 10 $STEPS $V 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('[$V]', round(d['ms_per_step'],4), 'min', round(d['ms_per_step_min'],4), 'median', round(d['ms_per_step_median'],4))"
+import json,sys; d=json.loads(sys.stdin.read()); print('[$V]', round(d['ms_per_step'],4), 'min', round(d['ms_per_step_min'],4), 'median', round(d['ms_per_step_median'],4), d['config']['batchnorm'])"
+done
 done > $OUT/${TAG}_ab_step_paths.txt
 cat $OUT/${TAG}_ab_step_paths.txt
 

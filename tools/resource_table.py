@@ -20,8 +20,9 @@ FIELDS = [('sgpr', r'TotalSGPRs'), ('vgpr', r'VGPRs'), ('agpr', r'AGPRs'), ('scr
 
 def table(src, extra=()):
     with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.abspath(src)
         r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Rpass-analysis=kernel-resource-usage', *extra,
-                            '-c', src, '-o', os.path.join(tmp, 'x.o')], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(src)))
+                            '-c', src, '-o', os.path.join(tmp, 'x.o')], capture_output=True, text=True, cwd=os.path.dirname(src))
     if r.returncode != 0:
         sys.exit(r.stderr[-3000:])
     blocks = re.split(r'remark: Function Name: ', r.stderr)[1:]
