@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (same guide; the opt-in precision modes only)
 
 
 def build_model(model_config, device, n_feat=14):
@@ -248,7 +249,7 @@ def other_workloads(args, log):
             d = json.loads(line)
             rf = d.get('roofline', {})
             out[name] = {'superpoints_per_s': d['value'], 'ms_per_step': d['ms_per_step'], 'dtype': d['dtype'].split(' ')[0],
-                         'workload': d['config']['workload'], 'roofline_bound': rf.get('bound'), 'roofline_frac': rf.get('frac'),
+                         'workload': d['config']['workload'], 'roofline_bound': rf.get('bound'), 'roofline_frac': rf.get('frac'), 'roofline_note': rf.get('bound_note'),
                          'roofline_unit': rf.get('unit'), 'roofline_achieved': rf.get('achieved'), 'dominant_frac_of_fp32_mfma_peak': rf.get('dominant_frac'),
                          'launches_per_step_gemm': rf.get('launches_per_step')}
             log(f'{name}: {d["value"]:.0f} superpoints/s, {d["ms_per_step"]:.3f} ms/step, roofline {rf.get("bound")} {rf.get("frac")}')
@@ -626,7 +627,14 @@ def main():
             # the bf16 modes move the wide GEMMs under the HBM roof (activations stay fp32 in memory: same bytes, less matrix
             # time): report the GEMM launches against HBM -- static traffic of the same launches ÷ their measured time
             gbs = traffic * launches.value / (ms.value * 1e-3) / 1e9
+            # (at ~0.25 of 8 TB/s that is the NEARER roof, not a bound -- the mode's GEMMs are limited by converting
+            # and splitting fp32 operands on the fly (VALU issue), so both fractions are reported and the note says so)
+            nprod = 3 if PREC == 3 else 1
             result['roofline'].update({'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
+                                       'mfma_bf16_frac': ach * nprod / PEAK_BF16_MFMA_TFLOPS,
+                                       'bound_note': 'nearer roof of two, neither is reached: fp32 operands are split into bf16 planes while '
+                                                     'staging (VALU issue bound); mfma_bf16_frac = %d bf16 products per fp32 product against the '
+                                                     'dense bf16 MFMA peak' % nprod,
                                        'fp32_equivalent_tflops': ach,
                                        'kernel': 'spg_rowgemm_kernel (bf16 MFMA 32x32x16, %s) + spg_wgrad_kernel' % args.precision})
         if dl.value > 0:

@@ -1500,6 +1500,13 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
   for (int r = p.R - 1; r >= -1; --r) {
     GruFwdState stf;            // issued before the wait for the neighbours' gradients: the loads are in flight while the wave polls
     if (saved && r >= 0) spg_px_load_state(reinterpret_cast<const f32x4*>(p.fsave) + ((long)j * p.R + r) * (SPG_PX_SAVE_F / 4) * 64 + lane, stf);
+    // the forward's aggregate and state of this iteration (phase 2 needs them) depend on nothing the wave waits for either: one L2
+    // round trip less between the neighbours' gradients and this node's granule (one workgroup per CU: the registers are there)
+    float a_pre = 0.f, h_pre = 0.f;
+    if (WPC == 1 && r >= 0 && lane < 32) {
+      a_pre = p.agg[(long)j * p.ldS + (long)r * 32 + lane];
+      h_pre = p.states[(long)j * p.ldS + (long)r * 32 + lane];
+    }
     // ---- phase 1: dH = d(out)/d(h^{r+1}) + dhdir + sum over the out-edges of W_e . G^{r+1}[dst] ----
     float dH = 0.f;
     if (lane < 32) {
@@ -1576,8 +1583,8 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
     // ---- phase 2: GRU recompute + backward of iteration r ----
     spg_node_sync<true>();
     if (lane < 32) {
-      sa[lane] = p.agg[(long)j * p.ldS + (long)r * 32 + lane];
-      sh[lane] = p.states[(long)j * p.ldS + (long)r * 32 + lane];
+      sa[lane] = WPC == 1 ? a_pre : p.agg[(long)j * p.ldS + (long)r * 32 + lane];
+      sh[lane] = WPC == 1 ? h_pre : p.states[(long)j * p.ldS + (long)r * 32 + lane];
     }
     spg_node_sync<true>();
     SpgGruBwdOut o;

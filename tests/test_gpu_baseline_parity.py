@@ -164,10 +164,13 @@ def _fused_train_step(spec, batch, state0, cw):
     return model, step, loss, logits, step.embeddings
 
 
-def _decision_conditioned(spec, batch, state0, cw, monkeypatch, free_run, fused=False):
+def _decision_conditioned(spec, batch, state0, cw, monkeypatch, free_run, fused=False, tol=1e-4, tie_tol=1e-4, loss_tol=1e-5):
     """free_run: also run the fp64 oracle with its OWN decisions (near-tie statistics against the unconditioned values, the
     unconditioned gradient error for the log) -- one more fp64 pass; the large configurations check the near-ties on the
-    values of the conditioned pass instead.  fused: the step under test is FusedStep (spg_train_step) instead of the modules."""
+    values of the conditioned pass instead.  fused: the step under test is FusedStep (spg_train_step) instead of the modules.
+    tol: bound on every gradient tensor (max-norm relative); tie_tol: how far from a tie (relative to the layer's largest value) a
+    decision may differ from the fp64 one; loss_tol -- the fp32 path's are the defaults, the opt-in precision modes state their own
+    (tests/test_gpu_precision.py).  -> (worst gradient error, its tensor)"""
     from superpoint_graph_amd import ops
     captured = {}
     if fused:
@@ -218,7 +221,7 @@ def _decision_conditioned(spec, batch, state0, cw, monkeypatch, free_run, fused=
             scale = float(h.abs().max())
             n_pool += d.numel(); n_pool_diff += int((gap > 0).sum())
             print(f'  {key}: {int((gap > 0).sum())} of {d.numel()} winners are not the fp64 maximum; worst gap {float(gap.max()):.2e} (scale {scale:.2e})')
-            assert float(gap.max()) <= 1e-4 * scale, key           # a different winner only on a near-tie
+            assert float(gap.max()) <= tie_tol * scale, key           # a different winner only on a near-tie
         else:
             v = rec[key].reshape(d.shape)                          # value the ReLU saw (fp64 oracle)
             differ = (v > 0) != d
@@ -226,8 +229,8 @@ def _decision_conditioned(spec, batch, state0, cw, monkeypatch, free_run, fused=
             worst = float(v[differ].abs().max()) if bool(differ.any()) else 0.0
             n_relu += d.numel(); n_relu_diff += int(differ.sum())
             print(f'  {key}: {int(differ.sum())} of {d.numel()} ReLU decisions differ; worst |v| there {worst:.2e} (scale {scale:.2e})')
-            assert worst <= 1e-4 * scale, key                      # a different side of zero only within round-off of zero
-            assert int(differ.sum()) <= 1e-3 * d.numel(), key
+            assert worst <= tie_tol * scale, key                      # a different side of zero only within round-off of zero
+            assert int(differ.sum()) <= 10 * tie_tol * d.numel(), key
     print(f'decisions: ReLU {n_relu_diff} / {n_relu} differ, max-pool {n_pool_diff} / {n_pool} differ')
     del rec
 
@@ -235,7 +238,7 @@ def _decision_conditioned(spec, batch, state0, cw, monkeypatch, free_run, fused=
     if free_run:
         st = {k: v.clone() for k, v in state0.items()}
         lc, _, _, g64 = O.train_step(batch, spec, st, cw, dtype=torch.float64, update_running_stats=False, dec=dec)
-    assert abs(float(loss) - float(lc)) <= 1e-5 * abs(float(lc))
+    assert abs(float(loss) - float(lc)) <= loss_tol * abs(float(lc))
     err, err_free = {}, {}
     for k, ref in g64.items():
         if not noise_grad(k, g64):
@@ -246,7 +249,8 @@ def _decision_conditioned(spec, batch, state0, cw, monkeypatch, free_run, fused=
           (worst, err[worst], max(err_free.values())))
     for k in sorted(err, key=err.get, reverse=True)[:8]:
         print(f'  {k}: conditioned {err[k]:.2e}  unconditioned {err_free[k]:.2e}')
-    assert err[worst] <= 1e-4, {k: e for k, e in err.items() if e > 1e-4}
+    assert err[worst] <= tol, {k: e for k, e in err.items() if e > tol}
+    return err[worst], worst
 
 
 def test_two_scene_batch_vs_reference_golden(hip, setup):

@@ -89,6 +89,24 @@ def test_bf16_train_step(hip, scene):
     assert e_emb < 8e-2 and e_log < 8e-2 and e_loss < 2e-2 and cos[0] > 0.9
 
 
+def test_split_bf16_decision_conditioned_gradients(hip, scene, monkeypatch):
+    """the SHARP gradient check in the split-bf16 mode.  The unconditioned bounds above (cosine / 0.15) are dominated
+    by ReLU / arg-max decisions that fall on the other side of a near-tie; here the fp64 oracle backward runs with the decisions the
+    HIP step in split-bf16 mode took, so what is left is the arithmetic of the mode itself: three bf16 products per fp32 product,
+    2^-16 per operand.  Stated bounds of THIS mode: every gradient tensor 1e-3 (fp32 MFMA: 1e-4; measured 2-3e-4), decisions differ
+    from the fp64 ones only within 1e-3 of the layer's scale, loss 1e-4."""
+    from superpoint_graph_amd import _lib
+    from test_gpu_baseline_parity import _decision_conditioned
+    spec, batch, state0, _ = scene
+    L = _lib.lib()
+    assert L.spg_tune(7, 3) >= 0
+    try:
+        worst, where = _decision_conditioned(spec, batch, state0, None, monkeypatch, free_run=False, tol=1e-3, tie_tol=1e-3, loss_tol=1e-4)
+    finally:
+        L.spg_tune(7, 0)
+    print(f'split-bf16, decision-conditioned: worst gradient tensor {where} {worst:.2e}')
+
+
 def test_modes_leave_default_untouched(hip, scene):
     """mode 0 after a detour through the bf16 modes: bit-identical to a run that never left it"""
     a = _step(scene, 0)
