@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64 * SPG_FCB_NW) void spg_first_conv_bwd_kernel(con
 
 bool spg_narrow_pair_supported(int nfeat, int c1, int c2, int P, long M) {
   return nfeat >= 1 && nfeat <= SPG_GRAM_MAXF && c1 == SPG_NP_C && c2 == SPG_NP_C && P >= 32 && P <= 128 && P % 32 == 0 && M > 0 &&
-         M * SPG_NP_C * 4 < (1L << 32) && M * (long)nfeat * 4 < (1L << 32) && spg_tune_get(SPG_TUNE_NO_NARROW_PAIR) != 1 && spg_gemm_precision() == 0;
+         M * SPG_NP_C * 4 < (1L << 32) && M * (long)nfeat * 4 < (1L << 32) && spg_tune_get(SPG_TUNE_NO_NARROW_PAIR) != 1;
 }
 
 int spg_launch_cloud_gram(const SpgGramParams& p, hipStream_t stream) {
@@ -686,7 +686,7 @@ int spg_launch_narrow_pair_fwd(const SpgNarrowPairParams& p, hipStream_t stream)
 
 bool spg_first_conv_bwd_supported(int nfeat, int c1, int P, long M) {
   return nfeat >= 2 && nfeat <= SPG_GRAM_MAXF && c1 == SPG_NP_C && P >= 32 && P <= 128 && P % 32 == 0 && M > 0 && M * SPG_NP_C * 4 < (1L << 32) &&
-         spg_tune_get(SPG_TUNE_NO_NARROW_PAIR) == 0 && !spg_tune_get(SPG_TUNE_NO_FIRST_CONV_BWD) && spg_gemm_precision() == 0;
+         spg_tune_get(SPG_TUNE_NO_NARROW_PAIR) == 0 && !spg_tune_get(SPG_TUNE_NO_FIRST_CONV_BWD);
 }
 
 static int fcb_grid(int B) {
