@@ -2217,7 +2217,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
 }
 
 bool spg_bwdpair_supported(const SpgGemmParams& g, const SpgOperand& b) {
-  if (g_tune[SPG_TUNE_NO_BWD_PAIR] || g_tune[SPG_TUNE_PRECISION] != 0) return false;
+  if (g_tune[SPG_TUNE_NO_BWD_PAIR]) return false;      // (also in the opt-in precision modes: the fused pair computes in fp32 MFMA)
   const int CI = g.N, CO = g.K;
   if (!(g.w_red && g.epi == SPG_EPI_BWD && ((CI == 64 && (CO == 64 || CO == 128)) || (CI == 128 && CO == 128)))) return false;
   const int IT = spg_bwdpair_rows(CI);
