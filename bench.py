@@ -336,6 +336,7 @@ def main():
                     help="arithmetic of the wide row-GEMMs: f32 = fp32 MFMA (default, the headline); bf16x3 = split-bf16 products (three "
                          "bf16 MFMAs per operand pair, fp32 accumulate, ~2^-16 per product); bf16 = bf16 operands.  A SEPARATE line: never "
                          "replaces the f32 headline (tolerances: tests/test_gpu_precision.py)")
+    ap.add_argument('--group-trace', type=int, default=0, help='tools: with an ATTRIBUTION build of the library (SPG_HIP_LIB), print the per-job time spans of the grouped launches of ONE step after the warm-up, and exit')
     ap.add_argument('--tune', default='', help='A/B switches of the library for experiments: comma-separated key:value pairs of spg_tune (include/spg_hip.h), e.g. 8:1 = per-iteration RNN-ECC launches, 9:1 = no side stream')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not run the two rocprofv3 PMC passes for roofline.traffic (use the committed file)')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
@@ -473,6 +474,39 @@ def main():
         step()
     barrier()
     log('warm-up done')
+    if args.group_trace:
+        import ctypes
+        L = _lib.lib()
+        MAXL, MAXJ = 64, 16
+        buf = torch.zeros(MAXL * MAXJ * 2, dtype=torch.int64, device=dev)
+        buf[0::2] = -1
+        if L.spg_group_trace(buf.data_ptr(), MAXL) != 0:
+            raise RuntimeError('--group-trace needs an attribution build of the library: make -C superpoint_graph_amd/csrc ATTRIBUTION=1, SPG_HIP_LIB=<that .so>')
+        step()
+        torch.cuda.synchronize()
+        n = L.spg_group_trace_read(None, 0)
+        ints = (ctypes.c_int * max(n, 1))()
+        L.spg_group_trace_read(ints, n)
+        L.spg_group_trace(None, 0)
+        t = buf.cpu().view(MAXL, MAXJ, 2)
+        kinds = {1: 'gemm', 2: 'wgrad', 3: 'colsum', 4: 'edge_wgrad', 5: 'pad', 6: 'zero', 7: 'reduce'}
+        pos, li = 0, 0
+        first = None
+        while pos < n:
+            nj, heavy = ints[pos], ints[pos + 1]
+            pos += 2
+            starts = [int(t[li, j, 0]) for j in range(nj)]
+            ends = [int(t[li, j, 1]) for j in range(nj)]
+            l0, l1 = min(starts), max(ends)
+            first = l0 if first is None else first
+            print(f'launch {li}: {"heavy" if heavy else "light"} {nj} jobs, starts at {(l0 - first) / 100:.1f} us, span {(l1 - l0) / 100:.1f} us')
+            for j in range(nj):
+                kind, var, gx, gy, gz, w = (ints[pos + k] for k in range(6))
+                pos += 6
+                print(f'    job {j}: {kinds.get(kind, kind)} variant {var} grid ({gx},{gy},{gz}) = {gx * gy * gz} wgs, weight {w}: '
+                      f'{(starts[j] - l0) / 100:6.1f} .. {(ends[j] - l0) / 100:6.1f} us')
+            li += 1
+        return
     # the timed region: EXACTLY K steps between barrier + synchronize on both sides, nothing else in the stream (round 5: the
     # per-step event pairs moved to a pass of their own below -- an event record is a marker packet that drains the queue's
     # pipeline, ~6 us per step that no training loop pays)

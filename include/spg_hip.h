@@ -470,6 +470,10 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * gradient + spg_stn_dT instead of the one-pass kernel of round 5 (spg_narrow.hip: the layer's raw output is linear in the cloud,
  * so its part of the BatchNorm-backward formula collapses onto the Gram matrix -- one pass over the incoming gradient and the
  * cloud; results agree at fp32 round-off, tests/test_gpu_narrow.py).
+ * key 19: 1 = the jobs of a grouped launch are ordered by workgroup length alone, as in round 4.  Default (round 5): the group's OWN
+ * jobs -- what the next launch of the stream waits for -- take the first workgroup slots, riders / riding reductions / leaves
+ * follow (bit-identical; -8.6 us per step: the job spans of an attribution build showed the FC head's data gradient starting 17 us
+ * into a 42 us launch, behind 581 riding weight-gradient workgroups; bench.py --group-trace).
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* ------------------------------------------------------------------------------------------------
@@ -553,6 +557,13 @@ int spg_ecc_persistent_errors(void);
  * per-iteration kernels, which cannot time out). */
 int spg_ecc_persistent_errors_clear(void);
 int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops);
+
+/* (new, tools only) Attribution builds of the library (make ATTRIBUTION=1): per-job time spans of the grouped launches -- buf: device
+ * memory [max_launches][16][2] unsigned long long, pre-filled (starts ~0, ends 0); null switches the recording off.  A production build
+ * returns -1.  spg_group_trace_read: the host-side log {njobs, heavy, njobs x {kind, variant, gx, gy, gz, weight}} per traced launch;
+ * returns the number of ints available.  (bench.py --group-trace) */
+int spg_group_trace(void* buf, int max_launches);
+int spg_group_trace_read(int* out, int max);
 
 #ifdef __cplusplus
 }

@@ -143,6 +143,8 @@ SIGNATURES = {
     'spg_rccl_allreduce_sum_f32': (_i, [_p, _l, _p]),
     'spg_rccl_sync_bn': (_i, [_p, _l]),
     'spg_rccl_sync_slots': (_i, [_i]),
+    'spg_group_trace': (_i, [_p, _i]),
+    'spg_group_trace_read': (_i, [_p, _i]),
     'spg_rccl_allreduce_sum_f64': (_i, [_p, _l, _p]),
     'spg_set_slot_allreduce': (_i, [_p, _p, _i]),
     'spg_rccl_destroy': (_i, []),

@@ -88,6 +88,10 @@ extern "C" int spg_tune(int key, int value) {
   return old;
 }
 
+namespace { thread_local int g_riding = 0; }
+struct SpgRidingScope { SpgRidingScope() { ++g_riding; } ~SpgRidingScope() { --g_riding; } };
+#define SPG_OWNER_WEIGHT 100000
+
 // per-(instantiation, shape) totals of the instrumented launches: up to `max` rows {tag, N, K, launches} / {ms, flops}
 extern "C" int spg_prof_read_shapes(int* keys, double* vals, int max) {
   std::lock_guard<std::mutex> lock(g_prof_mutex);
@@ -165,7 +169,8 @@ struct SpgJobHdr { int kind, variant, gx, gy, gz, offset, weight, bx0; };      /
 #define SPG_GROUP_ARENA_BYTES 3440
 #define SPG_GROUP_MAX_WGRAD_ROWS 65536      // weight gradients over more rows than this are never grouped
 struct SpgMultiArgs {
-  int njobs, pad[3];
+  int njobs, pad;
+  unsigned long long* trace;                // attribution build: per-job [min start, max end] of this launch (wall_clock64), or null
   int first_block[SPG_GROUP_MAX_JOBS];      // first workgroup of every job: ONE batch of scalar loads finds a workgroup's job
   SpgJobHdr hdr[SPG_GROUP_MAX_JOBS];
   alignas(16) unsigned char arena[SPG_GROUP_ARENA_BYTES];
@@ -1289,6 +1294,8 @@ static int launch_gemm_shape(const SpgGemmParams& p, hipStream_t stream, int* sp
     // OPT-IN (spg_tune key 12): measured no faster than the 32 x 128 kernel on the step (1.404 vs 1.401 ms, same box,
     // profiles/r04_splitk_experiment.txt) -- a link of an FC chain is dispatch + statistics fold + first loads + epilogue; the
     // chunk loop this form shortens is the smaller part, and without operand prefetch its chunks pay the memory latency each
+    // (round 5: also tried as the default for the one long reduction of the step, the data gradient of the filter network's last
+    // layer, K = 1024 -- 1.1949 vs 1.1947 ms: the group it rides in is not bounded by it)
     if (spg_tune_get(SPG_TUNE_SPLITK) && p.rows_per_tile == SPG_FC_ROWS && p.K >= SPG_SK_MIN_K && p.pool_out == nullptr)
       return launch_fewrow_sk<WRED, AMODE>(p, stream, sp);
   }
@@ -1849,6 +1856,7 @@ int spg_flush_reduce(SpgReduceQueue& q, hipStream_t stream) {
 // shadow of its group's other jobs (~3 TB/s measured: ~35 MB per 12 us group); the rest stays queued for the next call / the flush
 int spg_reduce_ride(SpgReduceQueue& q, hipStream_t stream, size_t max_bytes) {
   if (!spg_group_accepts(stream)) return 0;
+  SpgRidingScope riding;
   int kept = 0;
   size_t taken = 0;
   bool full = false;
@@ -2925,6 +2933,9 @@ __device__ __forceinline__ void spg_multi_body() {
   // scalar loads) -- instead of through the by-value parameter, which the compiler would copy to scratch (3.9 KB per lane)
   typedef __attribute__((address_space(4))) const SpgMultiArgs* spg_kernarg_ptr;
   const SpgMultiArgs& a = *(const SpgMultiArgs*)(spg_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+#ifdef SPG_ATTRIBUTION
+  const unsigned long long trace_t0 = wall_clock64();
+#endif
   // (independent loads, issued together: a dependent scan would pay one scalar-memory round trip per entry)
   int j = 0;
   const int nj = a.njobs;
@@ -2981,6 +2992,15 @@ __device__ __forceinline__ void spg_multi_body() {
     for (long i = (long)bx * 4 * SPG_THREADS + threadIdx.x; i < min(q.b, (long)(bx + 1) * 4 * SPG_THREADS); i += SPG_THREADS) q.dst[i] = 0.f;
   }
 #undef SPG_P
+#ifdef SPG_ATTRIBUTION
+  if (a.trace != nullptr) {      // span of the job = [earliest start, latest end] over its workgroups (tools: bench.py --group-trace)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicMin(a.trace + 2 * j, trace_t0);
+      atomicMax(a.trace + 2 * j + 1, (unsigned long long)wall_clock64());
+    }
+  }
+#endif
 }
 __global__ __launch_bounds__(SPG_THREADS, 2) void spg_multi_kernel(const SpgMultiArgs a_by_value) { spg_multi_body<true>(); }
 __global__ __launch_bounds__(SPG_THREADS, 4) void spg_multi_light_kernel(const SpgMultiArgs a_by_value) { spg_multi_body<false>(); }
@@ -3000,10 +3020,18 @@ struct SpgGroupState {
 };
 thread_local SpgGroupState g_grp;
 
+// attribution build: spans of the jobs of every grouped launch (spg_group_trace below)
+#ifdef SPG_ATTRIBUTION
+unsigned long long* g_trace_buf = nullptr;
+int g_trace_max = 0, g_trace_n = 0;
+#endif
+std::vector<int> g_trace_log;      // per traced launch: njobs, heavy, then per job {kind, variant, gx, gy, gz, weight}
+
 int group_flush() {
   SpgGroupState& g = g_grp;
   const int n = g.a.njobs;
   if (n == 0) return 0;
+  g.a.trace = nullptr;
   // launch order = block order: the jobs whose workgroups run longest go first, so that the tail of the launch consists of
   // short workgroups (measured: a 32-chunk data gradient behind 424 weight-gradient workgroups made its group slower than
   // the two separate launches).  Stable insertion sort by weight, descending (<= 12 entries); then the block ranges.
@@ -3021,6 +3049,17 @@ int group_flush() {
     ProfScope prof(g.st, g.flops, SPG_PROF_TAG(3, 32, 32, 0, 0, 0));
     // a group of ONE job gains nothing from the job table (its workgroups would pay the table's scalar loads on top of their
     // own: +1.5 us measured on a 16 us launch): it leaves as the stand-alone kernel
+#ifdef SPG_ATTRIBUTION
+    if (!(n == 1 && g.direct) && g_trace_buf != nullptr && g_trace_n < g_trace_max) {
+      g.a.trace = g_trace_buf + (size_t)g_trace_n * 2 * SPG_GROUP_MAX_JOBS;
+      ++g_trace_n;
+      g_trace_log.push_back(n); g_trace_log.push_back(g.heavy ? 1 : 0);
+      for (int i = 0; i < n; ++i) {
+        const SpgJobHdr& h = g.a.hdr[i];
+        for (int v : {h.kind, h.variant, h.gx, h.gy, h.gz, h.weight}) g_trace_log.push_back(v);
+      }
+    }
+#endif
     if (n == 1 && g.direct) rc = g.direct();
     else if (g.heavy) hipLaunchKernelGGL(spg_multi_kernel, dim3((unsigned)blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
     else hipLaunchKernelGGL(spg_multi_light_kernel, dim3((unsigned)blocks), dim3(SPG_THREADS), g.lds, g.st, g.a);
@@ -3035,6 +3074,24 @@ int group_flush() {
 }
 }  // namespace
 
+// Attribution builds (make ATTRIBUTION=1): from now on every grouped launch of this thread records, per job, the earliest start and
+// the latest end of its workgroups (100 MHz wall clock) into buf [max_launches][16 jobs][2] (device memory, pre-filled by the caller:
+// starts ~0, ends 0); buf = null switches it off.  spg_group_trace_read returns the host-side log (job kinds and grids per launch).
+extern "C" int spg_group_trace(void* buf, int max_launches) {
+#ifdef SPG_ATTRIBUTION
+  g_trace_buf = (unsigned long long*)buf; g_trace_max = buf != nullptr ? max_launches : 0; g_trace_n = 0; g_trace_log.clear();
+  return 0;
+#else
+  (void)buf; (void)max_launches;
+  return -1;
+#endif
+}
+extern "C" int spg_group_trace_read(int* out, int max) {
+  const int n = (int)g_trace_log.size();
+  for (int i = 0; i < n && i < max; ++i) out[i] = g_trace_log[i];
+  return n;
+}
+
 int spg_slot_sync_after(unsigned long long* slots, size_t words, hipStream_t stream, bool deferred) {
   if (!spg_slot_sync_active() || slots == nullptr || words == 0) return 0;
   if (deferred) { g_grp.syncs.emplace_back(slots, words); return 0; }
@@ -3047,6 +3104,10 @@ SpgGroupBypass::SpgGroupBypass(bool on) : on_(on) { if (on_) ++g_bypass; }
 SpgGroupBypass::~SpgGroupBypass() { if (on_) --g_bypass; }
 static bool spg_group_accepts(hipStream_t stream) { return g_grp.open && g_grp.st == stream && g_grp.rc == 0 && g_bypass == 0; }
 
+// Jobs that RIDE in somebody else's group (rider stages, riding reductions, leaves) while > 0: the group's own jobs -- the ones the
+// next launch of the stream waits for -- get the first workgroup slots of the launch (round 5: measured with the job spans of an
+// attribution build, bench.py --group-trace: the head's data gradient started 17 us into a 42 us launch, behind 581 workgroups of
+// riding weight gradients)
 // weight: relative duration of ONE workgroup of the job (sequential reduction chunks); decides the launch order
 static bool spg_group_add(int kind, int variant, const void* params, size_t bytes, dim3 grid, size_t lds, double flops, hipStream_t stream, int weight,
                           std::function<int()> direct, int bx0) {
@@ -3061,7 +3122,7 @@ static bool spg_group_add(int kind, int variant, const void* params, size_t byte
   }
   SpgJobHdr& h = g.a.hdr[g.a.njobs];
   h.kind = kind; h.variant = variant; h.gx = (int)grid.x; h.gy = (int)grid.y; h.gz = (int)grid.z;
-  h.offset = (int)g.used; h.weight = weight; h.bx0 = bx0;
+  h.offset = (int)g.used; h.weight = weight + ((g_riding > 0 || g_tune[SPG_TUNE_NO_OWNER_FIRST]) ? 0 : SPG_OWNER_WEIGHT); h.bx0 = bx0;
   g.direct = g.a.njobs == 0 ? std::move(direct) : nullptr;
   memcpy(g.a.arena + g.used, params, bytes);
   g.used += need;
@@ -3108,6 +3169,7 @@ static int riders_step(hipStream_t st) {
   if (g_rider_running || g_rider_next >= g_riders.size()) return 0;
   g_rider_running = true;
   SpgStage stage = std::move(g_riders[g_rider_next++]);
+  SpgRidingScope riding;
   const int rc = stage(st);
   g_rider_running = false;
   if (g_rider_next >= g_riders.size()) { g_riders.clear(); g_rider_next = 0; }
@@ -3141,6 +3203,7 @@ int spg_leaf_ride(hipStream_t stream, int launches_left) {
   for (size_t i = g_leaf_next; i < g_leaves.size(); ++i) total += g_leaves[i].cost;
   const double share = total / (launches_left > 1 ? launches_left : 1);
   double taken = 0.0;
+  SpgRidingScope riding;
   while (g_leaf_next < g_leaves.size() && (taken == 0.0 || taken + 0.5 * g_leaves[g_leaf_next].cost <= share)) {
     SpgLeaf leaf = std::move(g_leaves[g_leaf_next++]);
     taken += leaf.cost;
