@@ -22,9 +22,9 @@ print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline frac', d['roof
 EOF2
 
 # the round's changes on the same box, interleaved (spg_tune keys 17 / 18: the one-pass first layers forward / backward as the
-# launches they replace; 16: weight-gradient leaves, an experiment that is off by default)
+# launches they replace; 19: the round-4 job order of grouped launches; 16: weight-gradient leaves, an experiment that is off by default)
 for i in 1 2; do
-for V in "--tune 17:1,18:1" "--tune 18:1" "" "--tune 16:1" "--sync-bn 1"; do
+for V in "--tune 17:1,18:1,19:1" "--tune 18:1,19:1" "--tune 19:1" "" "--tune 16:1" "--sync-bn 1"; do
   timeout 300 python $ROOT/bench.py --steps 40 --warmup 10 $STEPS $V 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('[$V]', round(d['ms_per_step'],4), 'min', round(d['ms_per_step_min'],4), 'median', round(d['ms_per_step_median'],4), d['config']['batchnorm'])"
 done
