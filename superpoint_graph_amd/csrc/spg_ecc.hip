@@ -563,7 +563,7 @@ int spg_launch_ecc_step_fwd(const SpgEccStepFwd& p, hipStream_t stream) {
 // sw is the workgroup's padded copy of the cell weights.
 struct SpgGruBwdOut { float *dgi, *dgh, *dui, *duh, *dpre, *xg; long ld96, ld32; };
 
-template <bool WAVE>
+template <bool WAVE, int UNR = 8>
 __device__ __forceinline__ void spg_gru_backward_node(const SpgGruParams& G, const float* __restrict__ sw, float* sa, float* sh,
                                                       float* sx, float* sd, int lane, bool active, long j, float dH,
                                                       const SpgGruBwdOut& o, float& dh_acc, float& da,
@@ -641,7 +641,7 @@ __device__ __forceinline__ void spg_gru_backward_node(const SpgGruParams& G, con
     {
       const int c = lane & 31, q0 = 48 * (lane >> 5);
       float x0 = 0.f, x1 = 0.f, h0 = 0.f, h1 = 0.f;
-  #pragma unroll 8
+#pragma unroll UNR
       for (int q = q0; q < q0 + 48; q += 2) {
         x0 = fmaf(sw_ih[q * SPG_WLD + c], sa[q], x0);
         x1 = fmaf(sw_ih[(q + 1) * SPG_WLD + c], sa[q + 1], x1);
@@ -664,7 +664,7 @@ __device__ __forceinline__ void spg_gru_backward_node(const SpgGruParams& G, con
     spg_node_sync<WAVE>();
     if (G.ingate && lane < 32) {
       float g0 = 0.f, g1 = 0.f;
-  #pragma unroll 8
+#pragma unroll UNR
       for (int q = 0; q < 32; q += 2) {
         g0 = fmaf(sw_ig[q * SPG_WLD + lane], sd[q], g0);
         g1 = fmaf(sw_ig[(q + 1) * SPG_WLD + lane], sd[q + 1], g1);
@@ -1451,9 +1451,12 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
   const int ngroups = GROUPS ? p.groups.n : 1;
 #pragma nounroll
   for (int grp = 0; grp < ngroups; ++grp) {
-  const int lane = lane0 + spg_opaque_lane_zero();      // (see the forward kernel)
+  const int laneg = lane0 + spg_opaque_lane_zero();      // (see the forward kernel)
+  const int lane = laneg;
   const int gbase = p.groups.ptr[grp];
-  const int j = gbase + slot;
+  // the node is the same for all lanes of the wave: as a SCALAR, its row offsets into the dozen per-node arrays of the backward are
+  // scalar too (SGPR base + 32-bit lane offset) instead of 64-bit per-lane addresses that stay live across the iterations
+  const int j = __builtin_amdgcn_readfirstlane(gbase + slot);
   if (j >= p.groups.ptr[grp + 1]) continue;
   unsigned long long* gran = p.gran + ((long)grp * SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES - gbase) * 32;
   spg_node_sync<true>();
@@ -1498,6 +1501,9 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
                      __hip_atomic_load((const spg_gu32*)p.fsave_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == SPG_PX_SAVE_MAGIC;
   // iterations R-1 .. 0 produce G^r; the extra pass r = -1 only forms the gradient wrt h^0
   for (int r = p.R - 1; r >= -1; --r) {
+    // two workgroups per CU (256 registers per wave): the per-lane address arithmetic of an iteration must not be hoisted out of the
+    // iteration loop either -- it would stay live across the whole body
+    const int lane = laneg + (WPC == 2 ? spg_opaque_lane_zero() : 0);
     GruFwdState stf;            // issued before the wait for the neighbours' gradients: the loads are in flight while the wave polls
     if (saved && r >= 0) spg_px_load_state(reinterpret_cast<const f32x4*>(p.fsave) + ((long)j * p.R + r) * (SPG_PX_SAVE_F / 4) * 64 + lane, stf);
     // the forward's aggregate and state of this iteration (phase 2 needs them) depend on nothing the wave waits for either: one L2
@@ -1591,7 +1597,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
     o.dgi = p.dgi + (long)r * GW; o.dgh = p.dgh + (long)r * GW; o.dui = p.dui + (long)r * GW; o.duh = p.duh + (long)r * GW;
     o.dpre = p.dpre + (long)r * 32; o.xg = p.xg + (long)r * 32; o.ld96 = p.ld96; o.ld32 = p.ld32;
     float dh_acc, da;
-    spg_gru_backward_node<true>(p.gru, sw, sa, sh, sx, sd, lane, true, j, dH, o, dh_acc, da, saved ? &stf : nullptr);
+    spg_gru_backward_node<true, (WPC == 1 ? 8 : 2)>(p.gru, sw, sa, sh, sx, sd, lane, true, j, dH, o, dh_acc, da, saved ? &stf : nullptr);
     if (lane < 32) {
       dhdir = dh_acc;
       const float gc = da * invdeg;
