@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   //  stay live across the whole body, in registers the resident filters need)
   const int lane = lane0 + spg_opaque_lane_zero();
   const int gbase = p.groups.ptr[grp];
-  const int i = gbase + slot;
+  const int i = __builtin_amdgcn_readfirstlane(gbase + slot);      // (the wave's node as a scalar: see the backward kernel)
   if (i >= p.groups.ptr[grp + 1]) continue;
   // this group's granule region, addressed with GLOBAL node ids
   unsigned long long* gran = p.gran + ((long)grp * SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES - gbase) * 32;
