@@ -140,6 +140,8 @@ int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long row
 #define SPG_PX_WG_NODES 1024       // nodes per round with ONE 4-wave workgroup per CU (one wavefront per node, all co-resident)
 #define SPG_PX_MAX_NODES 2048      // nodes per round with two workgroups per CU (fewer register-resident filters, gate rows from LDS)
 #define SPG_PX_MAX_GROUPS 8        // rounds per launch: groups of whole connected components (scenes) of <= SPG_PX_MAX_NODES nodes
+#define SPG_PX_MULTI_MAX_NODES 16000      // one group above SPG_PX_MAX_NODES: several nodes per wavefront, iteration-major (spg_ecc.hip)
+inline bool spg_px_is_multi(int n_groups, int max_group) { return n_groups == 1 && max_group > SPG_PX_MAX_NODES; }
 struct SpgPxGroups {               // node ranges [ptr[g], ptr[g+1]) of the rounds; n = 1: the whole graph in one round
   int n;
   int ptr[SPG_PX_MAX_GROUPS + 1];
@@ -189,6 +191,7 @@ struct SpgEccPersistFwd {
   unsigned long long* gran; // [SPG_PX_MAX_GROUPS][SPG_PX_MAX_ITERS][SPG_PX_MAX_NODES][32] granules
   unsigned* ctl;            // {epoch base, workgroups done, error count, -}
   SpgPxGroups groups;
+  int gran_nodes;           // more nodes than wavefronts (one group above SPG_PX_MAX_NODES): nodes per iteration of the granule region (set by the launcher)
   float* fsave;             // [N][R][3 quads][64 lanes][4] forward internals kept for the backward (training), or null
   unsigned* fsave_tag;      // set to a magic word by the persistent forward when fsave was written
   SpgEccHead head;          // classifier + cross entropy behind the last iteration (head.W == nullptr: none)
@@ -211,6 +214,7 @@ struct SpgEccPersistBwd {
   unsigned long long* gran;
   unsigned* ctl;
   SpgPxGroups groups;
+  int gran_nodes;           // (see SpgEccPersistFwd)
   const float* fsave;       // forward internals (see SpgEccPersistFwd) -- used when *fsave_tag carries the magic word
   const unsigned* fsave_tag;
   SpgEccHead head;          // the head the forward launch ran (W == nullptr: none)

@@ -113,7 +113,8 @@ int make_plan(const spg_eccrnn_cfg* cfg, int N, int E, int training, void* ws, c
   // (12 x 64 floats each: 31 MB per 1000 nodes x 10 iterations) instead of the backward recomputing them on its critical path
   pl.fsave = nullptr; pl.fsave_tag = nullptr;
   pl.px = !pl.lstm && c.n_parts >= 0 && c.n_parts <= SPG_MAX_PARTS && spg_px_plan_groups(N, c.n_parts, c.part_ptr, &pl.groups);
-  if (pl.px && pl.training) {
+  // (more nodes than wavefronts -- one round above SPG_PX_MAX_NODES nodes: the backward recomputes the cell instead, spg_ecc.hip)
+  if (pl.px && pl.training && !spg_px_is_multi(pl.groups.n, N)) {
     pl.fsave_tag = cv.take<unsigned>(64);
     pl.fsave = cv.take<float>((size_t)N * pl.R * SPG_PX_SAVE_F * 64);
   }
@@ -275,7 +276,7 @@ static int eccrnn_recurrent_forward(Plan& pl, const void* graph_ws, const float*
     q.states = pl.states; q.ldS = pl.ldS; q.agg = pl.training ? pl.agg : nullptr;
     q.out = out; q.cat_all = pl.cfg.cat_all; q.ldo = pl.cfg.cat_all ? pl.ldS : 32; q.gru = pl.gru;
     q.fsave = pl.fsave; q.fsave_tag = pl.fsave_tag;
-    const bool with_head = head != nullptr && head_done != nullptr && head->nin == (pl.cfg.cat_all ? 32 * (pl.R + 1) : 32) &&
+    const bool with_head = head != nullptr && head_done != nullptr && !spg_px_is_multi(pl.groups.n, N) && head->nin == (pl.cfg.cat_all ? 32 * (pl.R + 1) : 32) &&
                            head->C <= SPG_PX_HEAD_MAXC && spg_px_head_lds_bytes(*head) <= SPG_PX_HEAD_LDS;
     if (with_head) q.head = *head;
     int err = 0;

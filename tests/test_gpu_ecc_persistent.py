@@ -48,7 +48,10 @@ def _run(net, gi, x, go, legacy):
 
 
 @pytest.mark.parametrize('config,n,e', [('gru_10_0,f_13', 1000, 5000), ('gru_10_0,f_13', 1003, 6000), ('gru_3_0_1_1_0,f_5', 37, 150),
-                                        ('gru_4_1,f_8', 1000, 5000), ('gru_2_1_0_0,f_8', 130, 700)])
+                                        ('gru_4_1,f_8', 1000, 5000), ('gru_2_1_0_0,f_8', 130, 700),
+                                        # one component above 2048 nodes (round 5): several nodes per wavefront, iteration-major
+                                        ('gru_10_0,f_13', 2100, 9000), ('gru_10_0,f_13', 5000, 25000), ('gru_4_1,f_8', 10000, 50000),
+                                        ('gru_3_0_1_1_0,f_5', 10000, 50000)])
 def test_persistent_recurrence_is_bit_identical_to_per_iteration_launches(hip, config, n, e):
     from superpoint_graph_amd.learning import ecc, graphnet
     idxn, degs = _graph(n, e, seed=n + e)
@@ -120,7 +123,8 @@ def _multi_scene(sizes, edges_per_node, seed):
 @pytest.mark.parametrize('config,sizes', [('gru_10_0,f_13', [1000, 1000]),                 # 2 scenes: one round, two workgroups per CU
                                           ('gru_10_0,f_13', [1000] * 5),                   # 3 rounds of <= 2048 nodes
                                           ('gru_4_1,f_8', [700, 900, 300, 1200, 50]),      # vector filters, ragged scenes
-                                          ('gru_3_0_1_1_0,f_5', [400, 300, 200, 100])])    # 1000 nodes in 4 scenes: still one round
+                                          ('gru_3_0_1_1_0,f_5', [400, 300, 200, 100]),     # 1000 nodes in 4 scenes: still one round
+                                          ('gru_4_1,f_8', [800] * 20)])                    # 10 rounds > 8: ONE group, several nodes per wavefront (round 5)
 def test_persistent_recurrence_multi_scene_batches(hip, config, sizes):
     """Batches of several scenes: up to 2048 nodes run as ONE round with two workgroups per CU, larger batches
     in rounds of whole scenes (the scene boundaries travel in spg_eccrnn_cfg.n_parts) -- bit-identical to the per-iteration
