@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
 // No head, no service workgroups, one group.  Granule region: [iteration][p.gran_nodes][32].
 #define SPG_PX_MULTI_NPW 8
 template <bool MATRIX>
-__global__ __launch_bounds__(256, 2) void spg_ecc_persist_fwd_multi_kernel(const SpgEccPersistFwd p) {
+__global__ __launch_bounds__(256, 3) void spg_ecc_persist_fwd_multi_kernel(const SpgEccPersistFwd p) {
   __shared__ float sw[(2 * 96 + 32) * SPG_WLD];
   __shared__ __attribute__((aligned(16))) float lds[4][3][32];
   __shared__ __attribute__((aligned(16))) float hsb[4][SPG_PX_CH * 32];
@@ -1937,10 +1937,10 @@ static int px_spare_wgs(int node_wgs, int wpc) {
 }
 
 // workgroups of an iteration-major launch: as many as stay resident with two per CU, no more than one wavefront per node
-static int px_multi_wgs(int nodes) {
+static int px_multi_wgs(int nodes, int wpc = 2) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 64;
-  const int cap = 2 * (cus - 4), need = spg_cdiv(nodes, 4);
+  const int cap = wpc * (cus - 4), need = spg_cdiv(nodes, 4);
   return need < cap ? need : cap;
 }
 
@@ -1999,7 +1999,7 @@ bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err
   p.gran_nodes = SPG_PX_MAX_NODES;
   if (spg_px_is_multi(p.groups.n, mg)) {      // more nodes than wavefronts: iteration-major, no head (the caller was told: head_done stays false)
     if (p.head.W != nullptr) { spg_set_error("persistent ECC forward: no head above %d nodes in one round", SPG_PX_MAX_NODES); *err = -1; return true; }
-    p.node_wgs = px_multi_wgs(mg);
+    p.node_wgs = px_multi_wgs(mg, 3);      // (the forward needs 168 registers and 52 KB of LDS: three workgroups per CU)
     p.gran_nodes = mg;
     p.fsave = nullptr;
     if (p.matrix) hipLaunchKernelGGL(spg_ecc_persist_fwd_multi_kernel<true>, dim3(p.node_wgs), dim3(256), 0, stream, p);
