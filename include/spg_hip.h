@@ -184,8 +184,10 @@ typedef struct spg_eccrnn_cfg {
   /* Per-batch hint (0 = unknown): the batched graph's nodes [part_ptr[k], part_ptr[k+1]) , k < n_parts, are closed under
    * edges -- the scenes of a batch (learning/spg.py:178-193 concatenates them with node offsets).  With it the
    * dataflow-synchronised GRU recurrence (all iterations in ONE launch) also serves batches of more than 2048 nodes: whole
-   * scenes are packed into rounds of <= 2048 nodes.  Without it (or when a scene alone exceeds a round) larger graphs take
-   * one launch per iteration.  Results are identical either way.  Must be the same in the workspace-size queries, the
+   * scenes are packed into rounds of <= 2048 nodes.  Without it (or when a scene alone exceeds a round, or more than 8 rounds
+   * are needed) graphs of up to 16 000 nodes run as ONE group with several nodes per wavefront, iteration-major (round 5:
+   * Semantic3D-scale scenes are one component of ~10 000 superpoints); beyond that, one launch per iteration.  Results are
+   * identical in all forms.  Must be the same in the workspace-size queries, the
    * forward and the backward of a batch. */
   int n_parts;
   int part_ptr[SPG_MAX_PARTS + 1];
@@ -441,7 +443,7 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * operand pair, ~2^-16 per product), 1 = bf16 operands; fp32 accumulation and fp32 tensors in every mode (tolerances:
  * tests/test_gpu_precision.py); key 8: 1 = run the GRU recurrence of spg_eccrnn_forward / _backward as one launch per
  * iteration instead of the persistent dataflow-synchronised launch (A/B timing and the equality test; the two forms give
- * bit-identical results); key 9: 1 = the recurrent cell's parameter-gradient launches of spg_eccrnn_backward go to a
+ * bit-identical results), 2 = only the iteration-major form for more nodes than wavefronts (round 5) is off; key 9: 1 = the recurrent cell's parameter-gradient launches of spg_eccrnn_backward go to a
  * library-owned side stream next to the filter network's backward chain (experiment; measured slower, off by default).
  * key 10: 1 = train-mode BatchNorm statistics of spg_pointnet_forward go through per-workgroup partials and a finalize launch
  * per layer (the pre-round-3 path, still used with synchronised BatchNorm) instead of fixed-point slots finished by the
