@@ -21,7 +21,7 @@ extern "C" const char* spg_last_error(void);
 void spg_set_error(const char* fmt, ...);
 // tuning knobs (process-global; defaults are the production values): see spg_tune in include/spg_hip.h
 enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_FIN_SLICE_MIN = 4, SPG_TUNE_NO_STAT_ACCUM = 5, SPG_TUNE_NO_HEAD_SERVICE = 6, SPG_TUNE_PRECISION = 7,
-       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_SIDE_STREAM = 9, SPG_TUNE_NO_BN_FOLD = 10, SPG_TUNE_NO_GROUP = 11, SPG_TUNE_SPLITK = 12, SPG_TUNE_NO_VEC_GENERIC = 13, SPG_TUNE_NO_BWD_PAIR = 14, SPG_TUNE_NO_ECC_HEAD = 15, SPG_TUNE_LEAVES = 16, SPG_TUNE_NO_NARROW_PAIR = 17, SPG_TUNE_NO_FIRST_CONV_BWD = 18, SPG_TUNE_NO_OWNER_FIRST = 19, SPG_TUNE_COUNT = 20 };
+       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_SIDE_STREAM = 9, SPG_TUNE_NO_BN_FOLD = 10, SPG_TUNE_NO_GROUP = 11, SPG_TUNE_SPLITK = 12, SPG_TUNE_NO_VEC_GENERIC = 13, SPG_TUNE_NO_BWD_PAIR = 14, SPG_TUNE_NO_ECC_HEAD = 15, SPG_TUNE_LEAVES = 16, SPG_TUNE_NO_NARROW_PAIR = 17, SPG_TUNE_NO_FIRST_CONV_BWD = 18, SPG_TUNE_NO_OWNER_FIRST = 19, SPG_TUNE_PX_SPIN_LIMIT = 20, SPG_TUNE_NO_ADAM_GUARD = 21, SPG_TUNE_COUNT = 22 };
 int spg_tune_get(int key);
 
 // Fork / join of a library-owned side stream (one per device, created on first use): a latency-bound chain of small-grid
@@ -469,6 +469,34 @@ __device__ __forceinline__ void spg_mfma_chunk_or(const f32x4* __restrict__ As, 
   }
 }
 
+// A out-major, B red-major, ONE 32 x 32 output block, over NG groups of 8 reduction indices (NG / 4 chunks of one LDS tile: the plane
+// and row formulas continue across chunk boundaries) with the fragment reads DEPTH groups ahead of their MFMAs.  A wave with one
+// accumulator chain (the data-gradient waves of spg_bwdpair_kernel) stalls on every exposed LDS round trip, and a chunk-by-chunk loop
+// exposes one per chunk; measured (round 6, profiles/r06_bwdpair_roles.txt): its 64 MFMAs of a tile took 9300 cycles next to the
+// weight-gradient wave's, 4400 with this loop.  Same MFMA order as NG / 4 calls of spg_mfma_chunk_or: bit-identical.
+template <int NG, int DEPTH>
+__device__ __forceinline__ void spg_mfma_tile_or(const f32x4* __restrict__ As, const float* __restrict__ Bs,
+                                                 int strideA, int strideB, int rowA, int colB, int h, f32x16& acc) {
+  constexpr int RING = DEPTH + 1;
+  f32x4 a[RING];
+  float b[RING][4];
+  auto fetch = [&](int slot, int g) __attribute__((always_inline)) {
+    a[slot] = As[(2 * g + h) * strideA + rowA];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[slot][s] = Bs[(8 * g + 4 * h + s) * strideB + colB];
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH && d < NG; ++d) fetch(d, d);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + DEPTH < NG) fetch((g + DEPTH) % RING, g + DEPTH);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g % RING][s], b[g % RING][s], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // both operands red-major
 template <int TI, int TJ>
 __device__ __forceinline__ void spg_mfma_chunk_rr(const float* __restrict__ As, const float* __restrict__ Bs,
@@ -520,12 +548,17 @@ __device__ __forceinline__ void spg_mfma_chunk_tr(const float* __restrict__ As, 
   }
 }
 
-// the same with the B operand finished on the fly: b = ReLU(raw * sc + sh), sc / sh of the lane's (fixed) channel
-template <int TI, int TA>
+// the same with the B operand finished on the fly: b = ReLU(raw * sc + sh), sc / sh of the lane's (fixed) channel.
+// The LDS operand reads run DEPTH k-steps ahead of the MFMAs that use them (register ring, pinned by scheduling barriers): left
+// to the compiler every k-step was `ds_read ...; s_waitcnt lgkmcnt; v_mfma` -- one exposed LDS round trip per TI MFMAs of the
+// weight-gradient waves of spg_bwdpair_kernel.  Same MFMA order, same values: bit-identical.
+// NK k-steps = 2 NK rows of the tile from row0 on (NK = SPG_KC / 2: one chunk; more: the row formulas continue across chunks).
+template <int TI, int TA, int NK = SPG_KC / 2, int DEPTH = (TI >= 4 ? 1 : 2)>
 __device__ __forceinline__ void spg_mfma_chunk_tr_aff(const float* __restrict__ As, const float* __restrict__ Bs,
                                                       int strideA4, int strideB, int row0, int colA, int colB, int h,
                                                       float sc, float sh, f32x16 (&acc)[TA][1]) {
   static_assert(TI <= TA, "accumulator array too small");
+  constexpr int RING = DEPTH + 1;
   int oa[TI];
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
@@ -533,14 +566,22 @@ __device__ __forceinline__ void spg_mfma_chunk_tr_aff(const float* __restrict__ 
     oa[i] = ((co >> 2) * strideA4 + row0 + h) * 4 + (co & 3);
   }
   const float* __restrict__ Bh = Bs + h * strideB + colB;
+  float a[RING][TI], braw[RING];
+  auto fetch = [&](int slot, int kk) __attribute__((always_inline)) {
 #pragma unroll
-  for (int kk = 0; kk < SPG_KC / 2; ++kk) {
-    float a[TI];
+    for (int i = 0; i < TI; ++i) a[slot][i] = As[oa[i] + 8 * kk];
+    braw[slot] = Bh[2 * kk * strideB];
+  };
 #pragma unroll
-    for (int i = 0; i < TI; ++i) a[i] = As[oa[i] + 8 * kk];
-    const float b = fmaxf(fmaf(Bh[2 * kk * strideB], sc, sh), 0.f);
+  for (int d = 0; d < DEPTH; ++d) fetch(d, d);
 #pragma unroll
-    for (int i = 0; i < TI; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b, acc[i][0], 0, 0, 0);
+  for (int kk = 0; kk < NK; ++kk) {
+    if (kk + DEPTH < NK) fetch((kk + DEPTH) % RING, kk + DEPTH);
+    __builtin_amdgcn_sched_barrier(0);
+    const float b = fmaxf(fmaf(braw[kk % RING], sc, sh), 0.f);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % RING][i], b, acc[i][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -997,7 +997,14 @@ __device__ __forceinline__ void spg_px_gather_granules_t(const unsigned long lon
         if (u < n) ok = ok && (unsigned)(x[k] >> 32) == tag;
       }
       const bool done = __all(ok);
-      if (done || spins > SPG_PX_SPIN_LIMIT) {
+      // (ctl[4]: a spin bound below the built-in one, set through spg_tune key 20 -- the fail-safe tests force a time-out with it;
+      //  0 = none.  Looked at every 32nd failed sweep only.)
+      bool give_up = spins > SPG_PX_SPIN_LIMIT;
+      if (!done && !give_up && (spins & 31u) == 31u) {
+        const unsigned lim = __hip_atomic_load((spg_gu32*)(ctl + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        give_up = lim != 0u && spins > lim;
+      }
+      if (done || give_up) {
         if (!done && lane == 0) atomicAdd(ctl + 2, 1u);      // never hang: flag the error and go on with what is there
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -1919,6 +1926,15 @@ static char* px_acquire(const SpgPxGroups& groups, int R, hipStream_t stream) {
     if (hipMemset(b, 0, px_bytes()) != hipSuccess) { (void)hipFree(b); return nullptr; }
     g_px_buf[dev] = b;
   }
+  {   // the test-only spin bound (spg_tune key 20) lives in the control block: ctl[4]
+    static int g_px_limit[SPG_MAX_DEVICES] = {0};
+    const int want = spg_tune_get(SPG_TUNE_PX_SPIN_LIMIT);
+    if (want != g_px_limit[dev]) {
+      const unsigned v = want > 0 ? (unsigned)want : 0u;
+      if (hipMemcpy((char*)g_px_buf[dev] + 4 * sizeof(unsigned), &v, sizeof(v), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+      g_px_limit[dev] = want;
+    }
+  }
   // one stream per device drives the persistent launches (they serialise on it); another stream takes the safe path
   if (!g_px_stream_set[dev]) { g_px_stream[dev] = stream; g_px_stream_set[dev] = true; }
   if (g_px_stream[dev] != stream) {
@@ -1952,15 +1968,43 @@ extern "C" int spg_ecc_persistent_errors(void) {
   return (int)ctl[2];
 }
 
+// The fail-safe of the optimiser step (spg_adam_clamp_kernel, spg_api.hip): device address of the control block's error word
+// (ctl[2]; ctl[3] counts the update launches that were withheld because of it), or null while the device has no exchange buffer
+// (no persistent launch has run: nothing can have timed out).
+unsigned* spg_px_guard_words() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES || g_px_buf[dev] == nullptr) return nullptr;
+  return (unsigned*)g_px_buf[dev] + 2;
+}
+
+extern "C" int spg_ecc_persistent_status(int* errors, int* withheld, int clear) {
+  if (errors) *errors = 0;
+  if (withheld) *withheld = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) { spg_set_error("spg_ecc_persistent_status: no current device"); return -1; }
+  if (g_px_buf[dev] == nullptr) return 0;
+  unsigned ctl[4] = {0, 0, 0, 0};
+  hipError_t e = hipMemcpy(ctl, g_px_buf[dev], sizeof(ctl), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { spg_set_error("spg_ecc_persistent_status: %s", hipGetErrorString(e)); return (int)e; }
+  if (errors) *errors = (int)ctl[2];
+  if (withheld) *withheld = (int)ctl[3];
+  if (clear && (ctl[2] != 0u || ctl[3] != 0u)) {
+    const unsigned zero[2] = {0u, 0u};
+    e = hipMemcpy((char*)g_px_buf[dev] + 2 * sizeof(unsigned), zero, sizeof(zero), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { spg_set_error("spg_ecc_persistent_status: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  return 0;
+}
+
 // reads AND clears the error word (one blocking 16-byte copy each way: call it where the host synchronises anyway)
 extern "C" int spg_ecc_persistent_errors_clear(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES || g_px_buf[dev] == nullptr) return 0;
   unsigned ctl[4] = {0, 0, 0, 0};
   if (hipMemcpy(ctl, g_px_buf[dev], sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (ctl[2] != 0u) {
-    const unsigned zero = 0u;
-    if (hipMemcpy((char*)g_px_buf[dev] + 2 * sizeof(unsigned), &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (ctl[2] != 0u || ctl[3] != 0u) {
+    const unsigned zero[2] = {0u, 0u};
+    if (hipMemcpy((char*)g_px_buf[dev] + 2 * sizeof(unsigned), zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return -1;
   }
   return (int)ctl[2];
 }

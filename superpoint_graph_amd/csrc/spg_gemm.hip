@@ -2002,6 +2002,23 @@ struct SpgBwdPairParams {
   float* partial;       // [grid][CO][CI]
 };
 #define SPG_PAIR_THREADS 1024
+#ifdef SPG_ATTRIBUTION
+// (attribution builds only: make ATTRIBUTION=1, tools/bwdpair_timing.py) shader cycles per role and phase, summed over one wave per
+// 256 threads of every role of every workgroup: [shape][role][phase]
+__device__ unsigned long long spg_pair_role_t[3][3][4];
+extern "C" int spg_pair_role_times(unsigned long long* out, int clear) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(spg_pair_role_t), sizeof(unsigned long long) * 36) != hipSuccess) return -1;
+  if (clear) { unsigned long long z[36] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(spg_pair_role_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#define SPG_T0() unsigned long long t__ = __builtin_readcyclecounter(), tp__[4] = {0, 0, 0, 0}
+#define SPG_TP(k) { const unsigned long long n__ = __builtin_readcyclecounter(); tp__[k] += n__ - t__; t__ = n__; }
+#define SPG_TEND(role) if ((threadIdx.x & 255) == 0) { const int sh__ = (CO == 128) + (CI == 128); for (int k__ = 0; k__ < 4; ++k__) atomicAdd(&spg_pair_role_t[sh__][role][k__], tp__[k__]); }
+#else
+#define SPG_T0()
+#define SPG_TP(k)
+#define SPG_TEND(role)
+#endif
 constexpr int spg_bwdpair_rows(int ci) { return 4096 / ci; }
 template <int CO, int CI>
 constexpr size_t spg_bwdpair_lds_bytes() {
@@ -2115,15 +2132,19 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
     store_tile(R0, tile, 0);
     if (tile + 2 * stride < ntile) load_tile(R0, tile + 2 * stride);
     __syncthreads();
+    SPG_T0();
     for (;;) {
       // tile k is being multiplied from buffer 0: tile k+1 (R1) -> buffer 1, then the loads of tile k+3 into R1
       int nxt = tile + stride;
       bool has_next = nxt < ntile;                // uniform
       if (has_next) {
         store_tile(R1, nxt, 1);
+        SPG_TP(0);
         if (nxt + 2 * stride < ntile) load_tile(R1, nxt + 2 * stride);
+        SPG_TP(1);
       }
       __syncthreads();
+      SPG_TP(2);
       if (!has_next) break;
       tile = nxt;
       // tile k+1 from buffer 1: tile k+2 (R0) -> buffer 0, then the loads of tile k+4 into R0
@@ -2131,13 +2152,17 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
       has_next = nxt < ntile;
       if (has_next) {
         store_tile(R0, nxt, 0);
+        SPG_TP(0);
         if (nxt + 2 * stride < ntile) load_tile(R0, nxt + 2 * stride);
+        SPG_TP(1);
       }
       __syncthreads();
+      SPG_TP(2);
       if (!has_next) break;
       tile = nxt;
     }
     __syncthreads();
+    SPG_TEND(2);
     return;
   }
 
@@ -2150,20 +2175,23 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
     sacc.s1 = f32x4{0.f, 0.f, 0.f, 0.f}; sacc.s2 = sacc.s1;
     __syncthreads();
     int buf = 0;
+    SPG_T0();
     for (;;) {
       const int nxt = tile + stride;
       const bool has_next = nxt < ntile;
       const f32x4* dz4 = smem + buf * BUF4;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[0][0][q] = 0.f;
-#pragma nounroll
-      for (int c = 0; c < CO / SPG_KC; ++c)
-        spg_mfma_chunk_or<1, 1>(dz4 + c * (SPG_KC / 4) * SA, wl + c * SPG_KC * SX, SA, SX, wi * 32 + r, wj * 32 + r, h, acc);
+      spg_mfma_tile_or<CO / 8, 2>(dz4, wl, SA, SX, wi * 32 + r, wj * 32 + r, h, acc[0][0]);
+      SPG_TP(0);
       spg_epilogue_bwd_vec_lds<IT, CI, WI, WJ>(g, acc, red, reinterpret_cast<const float*>(dz4 + CQ * SA), SX, (long)tile * IT, sacc);
+      SPG_TP(1);
       __syncthreads();
+      SPG_TP(2);
       if (!has_next) break;
       tile = nxt; buf ^= 1;
     }
+    SPG_TEND(0);
     // the workgroup's ONE statistics contribution (as at the end of a persistent data-gradient stream)
     constexpr int CW = 32, LPR = CW / 4;
     float* xch = red;                             // [2][CI][2]
@@ -2200,18 +2228,20 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
   const float xsc = reinterpret_cast<const float*>(kst + 4 * CQ)[wj * 32 + r], xsh = reinterpret_cast<const float*>(kst + 4 * CQ + XQ)[wj * 32 + r];
   __syncthreads();
   int buf = 0;
+  SPG_T0();
   for (;;) {
     const int nxt = tile + stride;
     const bool has_next = nxt < ntile;
     const float* dzf = reinterpret_cast<const float*>(smem + buf * BUF4);
     const float* xs = dzf + CQ * SA * 4;
-#pragma nounroll
-    for (int c = 0; c < IT / SPG_KC; ++c)
-      spg_mfma_chunk_tr_aff<TIW>(dzf, xs + c * SPG_KC * SX, SA, SX, c * SPG_KC, wi * (32 * TIW) + r, wj * 32 + r, h, xsc, xsh, acc);
+    spg_mfma_chunk_tr_aff<TIW, TIW, IT / 2>(dzf, xs, SA, SX, 0, wi * (32 * TIW) + r, wj * 32 + r, h, xsc, xsh, acc);
+    SPG_TP(0);
     __syncthreads();
+    SPG_TP(2);
     if (!has_next) break;
     tile = nxt; buf ^= 1;
   }
+  SPG_TEND(1);
   __syncthreads();
   float* pb = p.partial + (long)blockIdx.x * CO * CI;
   const int kl = wj * 32 + r;
