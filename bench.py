@@ -561,15 +561,15 @@ def main():
     # time-out carries on with stale states -- the number would still print; learning/main.py of this package checks the same)
     def self_check(where):
         torch.cuda.synchronize()
-        nerr = int(_lib.lib().spg_ecc_persistent_errors())
+        nerr, withheld = ops.persistent_ecc_status()       # (time-outs, optimiser updates the device withheld because of them)
         loss_v = float(exchange['loss'].item())
         if dp:                                   # SUM-reduced loss of this rank / its own normaliser = its mean loss
             w = float(exchange['w'].item())
             loss_v = loss_v / w if w > 0 else float('nan')
         gfin = bool(torch.isfinite(arena.flat.grad).all().item())
-        if nerr != 0 or not gfin or not np.isfinite(loss_v):
-            raise SystemExit(f'bench.py self-check FAILED after the {where}: persistent RNN-ECC time-outs {nerr}, loss {loss_v}, gradients finite {gfin}')
-        return {'loss': loss_v, 'persistent_errors': nerr, 'grads_finite': gfin, 'checked_after': where}
+        if nerr != 0 or withheld != 0 or not gfin or not np.isfinite(loss_v):
+            raise SystemExit(f'bench.py self-check FAILED after the {where}: persistent RNN-ECC time-outs {nerr}, optimiser updates withheld {withheld}, loss {loss_v}, gradients finite {gfin}')
+        return {'loss': loss_v, 'persistent_errors': nerr, 'updates_withheld': withheld, 'grads_finite': gfin, 'checked_after': where}
     check = self_check('timed region')
 
     wl = f'{args.model_config} fwd+bwd+Adam; {args.scenes} scene/GPU x {args.n_sp} sp x 128 pts x {args.n_feat} f, {args.n_edges} edges x 13 f'
@@ -725,6 +725,12 @@ def main():
             result['forward_only'] = forward_only(dev, flag, clouds_d, diam_d, GIs, args.n_feat)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.model_config, scenes, state0, n_feat=args.n_feat)
+        elif world > 1:      # (a reported baseline of rank 0 at N = 1 only; say so instead of leaving the key out)
+            result['cpu_baseline'] = {'skipped': 'n_gpus>1: the CPU baseline is timed by the N=1 run only'}
+            if 'roofline' in result and result['roofline'].get('traffic_source') != 'live':
+                result['roofline']['traffic_note'] = 'n_gpus>1: no live PMC passes; HBM bytes come from the N=1 run / the committed file'
+        else:
+            result['cpu_baseline'] = {'skipped': '--no-cpu-baseline'}
         if world == 1 and not args.no_extras:
             ow = other_workloads(args, log)
             result['other_workloads'] = ow

@@ -407,6 +407,8 @@ int spg_rccl_destroy(void);
  * Element-wise gradient clamp + Adam step on one flat parameter buffer: replaces the per-parameter loop
  * `p.grad.data.clamp_(-clip, clip)` (learning/main.py:210-212) and `optimizer.step()` of torch.optim.Adam
  * (learning/main.py:213, :433-437) by ONE launch.  `step` counts from 1.  grad_clip <= 0 disables the clamp.
+ * FAIL-SAFE (round 6): the launch is a no-op while the time-out word of the device's one-launch RNN-ECC recurrences is non-zero
+ * (spg_ecc_persistent_status) -- gradients computed from stale neighbour states never reach the parameters.
  * ---------------------------------------------------------------------------------------------- */
 int spg_adam_clamp_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, float grad_clip, int step, void* stream);
@@ -476,6 +478,10 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * jobs -- what the next launch of the stream waits for -- take the first workgroup slots, riders / riding reductions / leaves
  * follow (bit-identical; -8.6 us per step: the job spans of an attribution build showed the FC head's data gradient starting 17 us
  * into a 42 us launch, behind 581 riding weight-gradient workgroups; bench.py --group-trace).
+ * key 20: > 0 = a spin bound for the waits of the one-launch recurrences below the built-in one (tests only: tests/test_gpu_failsafe.py
+ * forces a time-out with it); 0 (default) = the built-in bound.
+ * key 21: 1 = spg_adam_clamp_step* ignore the time-out word of the one-launch recurrences (see spg_ecc_persistent_status); default 0:
+ * the update is withheld while the word is non-zero.
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* ------------------------------------------------------------------------------------------------
@@ -558,6 +564,15 @@ int spg_ecc_persistent_errors(void);
  * neighbour states, i.e. the ECC outputs / gradients of those steps are wrong (spg_tune key 8 = 1 selects the
  * per-iteration kernels, which cannot time out). */
 int spg_ecc_persistent_errors_clear(void);
+/* Fail-safe of the optimiser step (round 6).  The error word above is STICKY and lives on the device; spg_adam_clamp_step /
+ * spg_adam_clamp_step_scaled read it inside their launch and WITHHOLD the update while it is non-zero -- parameters and both moment
+ * buffers stay bit-identical -- counting the withheld launches.  No host synchronisation: a step whose recurrence timed out, and every
+ * step after it, changes nothing until the host has looked.  This call returns both counts (*errors: time-outs, *withheld: update
+ * launches skipped) and, with clear != 0, zeroes them; one blocking 16-byte copy each way, so call it where the host may wait
+ * (learning/main.py: every --ecc_check_every steps, at the end of an epoch, before a checkpoint).  The caller then switches to the
+ * per-iteration kernels (spg_tune key 8 = 1), takes `withheld` off its Adam step counter and repeats the batch(es) it still holds.
+ * The reference's only guard on this path is the NaN-loss check of learning/main.py:367. */
+int spg_ecc_persistent_status(int* errors, int* withheld, int clear);
 int spg_prof_read_tag(int tag, double* ms, long* launches, double* flops);
 
 /* (new, tools only) Attribution builds of the library (make ATTRIBUTION=1): per-job time spans of the grouped launches -- buf: device

@@ -106,6 +106,7 @@ SIGNATURES = {
     'spg_eccrnn_debug_offset': (_l, [ctypes.POINTER(EccRnnCfg), _i, _i, _i, _i, _i]),
     'spg_ecc_persistent_errors': (_i, []),
     'spg_ecc_persistent_errors_clear': (_i, []),
+    'spg_ecc_persistent_status': (_i, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _i]),
     'spg_eccrnn_backward': (_i, [ctypes.POINTER(EccRnnCfg), _i, _i, _p, _p, c_void_pp, _p, _p, c_void_pp, _p, _p, _p]),
     'spg_adam_clamp_step': (_i, [_p, _p, _p, _p, _l, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_float, _i, _p]),

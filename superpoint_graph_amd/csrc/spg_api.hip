@@ -568,8 +568,18 @@ int spg_linear_backward_deferred(const float* dY, long lddy, const float* X, lon
 // ---------------------------------------------------------------------------------------------
 __global__ void spg_adam_clamp_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                                      float clip, float bc1, float bc2_sqrt, const float* __restrict__ grad_div) {
+                                      float clip, float bc1, float bc2_sqrt, const float* __restrict__ grad_div,
+                                      unsigned* __restrict__ guard) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // Fail-safe (round 6): guard[0] = the persistent RNN-ECC launches' time-out count of this device.  Non-zero means a wave of the
+  // step whose gradients lie in `g` gave up waiting for a neighbour and went on with stale states: the gradients are WRONG, so the
+  // update is withheld -- parameters and moments stay bit-identical -- and guard[1] counts the withheld launch.  The word is sticky
+  // (only the host clears it: spg_ecc_persistent_status), so every later update is withheld too until the host has looked; no
+  // host synchronisation is involved.  One scalar load per wave.
+  if (guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (i == 0) atomicAdd(guard + 1, 1u);
+    return;
+  }
   if (i >= n) return;
   float gi = g[i];
   if (grad_div != nullptr) gi = gi / *grad_div;     // data-parallel normaliser (sum of the ranks' loss weights), still on the device
@@ -590,8 +600,9 @@ extern "C" int spg_adam_clamp_step_scaled(float* param, float* grad, float* exp_
   SPG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad argument");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  unsigned* guard = spg_tune_get(SPG_TUNE_NO_ADAM_GUARD) ? nullptr : spg_px_guard_words();
   hipLaunchKernelGGL(spg_adam_clamp_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, bc1, bc2_sqrt, grad_div);
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, bc1, bc2_sqrt, grad_div, guard);
   SPG_LAUNCH_CHECK();
   return 0;
 }

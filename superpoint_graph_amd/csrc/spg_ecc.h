@@ -242,3 +242,7 @@ struct SpgEccScatter {
   float* grad_emb;                // [B, 32]
   int B;
 };
+
+// device address of {error word, withheld-update counter} of the current device's persistent-launch control block, or null while
+// no persistent launch has run on it (spg_ecc.hip); read by the guarded optimiser step (spg_api.hip)
+unsigned* spg_px_guard_words();

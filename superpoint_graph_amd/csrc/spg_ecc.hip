@@ -980,7 +980,7 @@ __device__ __forceinline__ void spg_px_gather_plain(const float* __restrict__ X,
 // round -- a second hop latency on the path of the nodes that gate their neighbourhood
 template <int PER>
 __device__ __forceinline__ void spg_px_gather_granules_t(const unsigned long long* __restrict__ gran, unsigned tag, const int* ids,
-                                                         int n, int lane, float* hs, unsigned* ctl) {
+                                                         int n, int lane, float* hs, unsigned* ctl, unsigned limit) {
   const int half = lane >> 5, c = lane & 31;
   for (int p = 0; p < n; p += 2 * PER) {
     for (unsigned spins = 0;; ++spins) {
@@ -997,14 +997,7 @@ __device__ __forceinline__ void spg_px_gather_granules_t(const unsigned long lon
         if (u < n) ok = ok && (unsigned)(x[k] >> 32) == tag;
       }
       const bool done = __all(ok);
-      // (ctl[4]: a spin bound below the built-in one, set through spg_tune key 20 -- the fail-safe tests force a time-out with it;
-      //  0 = none.  Looked at every 32nd failed sweep only.)
-      bool give_up = spins > SPG_PX_SPIN_LIMIT;
-      if (!done && !give_up && (spins & 31u) == 31u) {
-        const unsigned lim = __hip_atomic_load((spg_gu32*)(ctl + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        give_up = lim != 0u && spins > lim;
-      }
-      if (done || give_up) {
+      if (done || spins > limit) {
         if (!done && lane == 0) atomicAdd(ctl + 2, 1u);      // never hang: flag the error and go on with what is there
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -1019,9 +1012,16 @@ __device__ __forceinline__ void spg_px_gather_granules_t(const unsigned long lon
 }
 
 __device__ __forceinline__ void spg_px_gather_granules(const unsigned long long* __restrict__ gran, unsigned tag, const int* ids,
-                                                       int n, int lane, float* hs, unsigned* ctl) {
-  if (n <= 8) spg_px_gather_granules_t<4>(gran, tag, ids, n, lane, hs, ctl);
-  else spg_px_gather_granules_t<8>(gran, tag, ids, n, lane, hs, ctl);
+                                                       int n, int lane, float* hs, unsigned* ctl, unsigned limit) {
+  if (n <= 8) spg_px_gather_granules_t<4>(gran, tag, ids, n, lane, hs, ctl, limit);
+  else spg_px_gather_granules_t<8>(gran, tag, ids, n, lane, hs, ctl, limit);
+}
+
+// the bound of the waits: the built-in one, or the (smaller) one of spg_tune key 20 in ctl[4] -- the fail-safe tests force a
+// time-out with it; read once per wave (a scalar load)
+__device__ __forceinline__ unsigned spg_px_spin_limit(const unsigned* ctl) {
+  const unsigned v = __hip_atomic_load((spg_gu32*)(ctl + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v != 0u && v < (unsigned)SPG_PX_SPIN_LIMIT ? v : (unsigned)SPG_PX_SPIN_LIMIT;
 }
 
 // the last workgroup to finish advances the epoch base past every tag this launch used and re-arms the counter
@@ -1263,6 +1263,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     if (p.head.reduction_mean) spg_px_head_wsum_partials(p.head, hd_part);
   }
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned spin_limit = spg_px_spin_limit(p.ctl);
   GruRowsLds wr;
   spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane0, wr);
   float* sa = lds[wave][0];
@@ -1343,7 +1344,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
       }
       spg_node_sync<true>();
       if (r == 0) spg_px_gather_plain(p.h0, 32, ids, n, lane, hs, p.h0_rows);
-      else spg_px_gather_granules(gran + (long)r * SPG_PX_MAX_NODES * 32, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl);
+      else spg_px_gather_granules(gran + (long)r * SPG_PX_MAX_NODES * 32, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl, spin_limit);
       spg_node_sync<true>();
       if constexpr (MATRIX) {
         if (c0 == 0) {
@@ -1446,6 +1447,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
   }
   spg_stage_cell_weights<GW>(p.gru, sw);
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned spin_limit = spg_px_spin_limit(p.ctl);
   float* sa = lds[wave][0];        // [32] aggregate   | later dgi [96]
   float* sh = lds[wave][1];        // [32] hidden      | later dgh [96]
   float* sx = lds[wave][2];        // [32] gated input
@@ -1537,7 +1539,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
           if (lane < n) { const int e = p.g.rev_eid[b0 + c0 + lane]; eis[lane] = e; ids[lane] = p.g.dst[e]; }
         }
         spg_node_sync<true>();
-        spg_px_gather_granules(gran + (long)(r + 1) * SPG_PX_MAX_NODES * 32, base + (unsigned)(r + 1) + 1u, ids, n, lane, hs, p.ctl);
+        spg_px_gather_granules(gran + (long)(r + 1) * SPG_PX_MAX_NODES * 32, base + (unsigned)(r + 1) + 1u, ids, n, lane, hs, p.ctl, spin_limit);
         spg_node_sync<true>();
         if constexpr (MATRIX) {
           if (c0 == 0) {
@@ -1640,6 +1642,7 @@ __global__ __launch_bounds__(256, 3) void spg_ecc_persist_fwd_multi_kernel(const
   const int S = (int)gridDim.x * 4, slot = (int)blockIdx.x * 4 + wave, N = p.g.N;
   spg_stage_cell_weights<96>(p.gru, sw);
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned spin_limit = spg_px_spin_limit(p.ctl);
   GruRowsLds wq;
   spg_gru_lds_rows<SPG_CELL_GRU>(sw, lane, wq);
   float* sa = lds[wave][0];
@@ -1688,7 +1691,7 @@ __global__ __launch_bounds__(256, 3) void spg_ecc_persist_fwd_multi_kernel(const
         }
         spg_node_sync<true>();
         if (r == 0) spg_px_gather_plain(p.h0, 32, ids, n, lane, hs, p.h0_rows);
-        else spg_px_gather_granules(p.gran + (long)r * GS, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl);
+        else spg_px_gather_granules(p.gran + (long)r * GS, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl, spin_limit);
         spg_node_sync<true>();
         if constexpr (MATRIX) {
           for (int u = 0; u < n; ++u) {
@@ -1749,6 +1752,7 @@ __global__ __launch_bounds__(256, 2) void spg_ecc_persist_bwd_multi_kernel(const
   const int S = (int)gridDim.x * 4, slot = (int)blockIdx.x * 4 + wave, N = p.g.N;
   spg_stage_cell_weights<GW>(p.gru, sw);
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned spin_limit = spg_px_spin_limit(p.ctl);
   float* sa = lds[wave][0];        // [32] aggregate   | later dgi [96]
   float* sh = lds[wave][1];        // [32] hidden      | later dgh [96]
   float* sx = lds[wave][2];        // [32] gated input
@@ -1796,7 +1800,7 @@ __global__ __launch_bounds__(256, 2) void spg_ecc_persist_bwd_multi_kernel(const
           spg_node_sync<true>();
           if (lane < n) { const int e = p.g.rev_eid[b0 + c0 + lane]; eis[lane] = e; ids[lane] = p.g.dst[e]; }
           spg_node_sync<true>();
-          spg_px_gather_granules(p.gran + (long)(r + 1) * GS, base + (unsigned)(r + 1) + 1u, ids, n, lane, hs, p.ctl);
+          spg_px_gather_granules(p.gran + (long)(r + 1) * GS, base + (unsigned)(r + 1) + 1u, ids, n, lane, hs, p.ctl, spin_limit);
           spg_node_sync<true>();
           if constexpr (MATRIX) {
             for (int u = 0; u < n; ++u) {
@@ -1952,7 +1956,26 @@ static int px_spare_wgs(int node_wgs, int wpc) {
   return spare > 0 ? spare : 0;
 }
 
-// workgroups of an iteration-major launch: as many as stay resident with two per CU, no more than one wavefront per node
+// Workgroups per CU the iteration-major kernels REALLY get (registers, LDS; a build for another gfx target or a device whose CUs
+// are partly masked gives fewer than the numbers they were written for): asked once per kernel.  A grid above what is resident
+// would leave waves spinning to their bound for workgroups that cannot start.
+template <class K>
+static int px_occupancy(K kernel, int want) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) return 0;
+  return n < want ? n : want;
+}
+static int px_multi_wpc(bool matrix, bool backward) {
+  static int cache[2][2] = {{-1, -1}, {-1, -1}};
+  int& c = cache[matrix ? 1 : 0][backward ? 1 : 0];
+  if (c < 0) {
+    if (backward) c = matrix ? px_occupancy(spg_ecc_persist_bwd_multi_kernel<true>, 2) : px_occupancy(spg_ecc_persist_bwd_multi_kernel<false>, 2);
+    else c = matrix ? px_occupancy(spg_ecc_persist_fwd_multi_kernel<true>, 3) : px_occupancy(spg_ecc_persist_fwd_multi_kernel<false>, 3);
+  }
+  return c;
+}
+
+// workgroups of an iteration-major launch: as many as stay resident with `wpc` per CU, no more than one wavefront per node
 static int px_multi_wgs(int nodes, int wpc = 2) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 64;
@@ -2043,7 +2066,9 @@ bool spg_launch_ecc_persist_fwd(SpgEccPersistFwd p, hipStream_t stream, int* err
   p.gran_nodes = SPG_PX_MAX_NODES;
   if (spg_px_is_multi(p.groups.n, mg)) {      // more nodes than wavefronts: iteration-major, no head (the caller was told: head_done stays false)
     if (p.head.W != nullptr) { spg_set_error("persistent ECC forward: no head above %d nodes in one round", SPG_PX_MAX_NODES); *err = -1; return true; }
-    p.node_wgs = px_multi_wgs(mg, 3);      // (the forward needs 168 registers and 52 KB of LDS: three workgroups per CU)
+    const int wpc_m = px_multi_wpc(p.matrix != 0, false);      // (the forward needs 168 registers and 52 KB of LDS: three workgroups per CU on gfx950)
+    if (wpc_m < 1 || (long)4 * px_multi_wgs(mg, wpc_m) * SPG_PX_MULTI_NPW < mg) return false;      // not resident enough: the per-iteration launches
+    p.node_wgs = px_multi_wgs(mg, wpc_m);
     p.gran_nodes = mg;
     p.fsave = nullptr;
     if (p.matrix) hipLaunchKernelGGL(spg_ecc_persist_fwd_multi_kernel<true>, dim3(p.node_wgs), dim3(256), 0, stream, p);
@@ -2072,7 +2097,9 @@ bool spg_launch_ecc_persist_bwd(SpgEccPersistBwd p, hipStream_t stream, int* err
   p.n_wgrad = 0;
   p.gran_nodes = SPG_PX_MAX_NODES;
   if (spg_px_is_multi(p.groups.n, mg)) {
-    p.node_wgs = px_multi_wgs(mg);
+    const int wpc_m = px_multi_wpc(p.matrix != 0, true);
+    if (wpc_m < 1 || (long)4 * px_multi_wgs(mg, wpc_m) * SPG_PX_MULTI_NPW < mg) return false;      // not resident enough: the per-iteration launches
+    p.node_wgs = px_multi_wgs(mg, wpc_m);
     p.gran_nodes = mg;
     p.fsave = nullptr; p.fsave_tag = nullptr;
     memset(&p.head, 0, sizeof(p.head));

@@ -316,6 +316,12 @@ int spg_eccrnn_forward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const void
   Plan pl;
   SPG_TRY(make_plan(cfg, N, E, training, workspace, params, pl));
   pl.fold = fnet_fold(pl);
+  // (as spg_pointnet.hip: with slot-synchronised BatchNorm the statistics MUST travel through the slots -- a rank that dropped to
+  //  per-rank finalize statistics because its own edge count exceeds the slots' capacity, or because spg_tune key 10 is set, would
+  //  issue a different number of slot all-reduces than its peers: a hang, or an unsynchronised model)
+  if (pl.training && spg_slot_sync_active() && E > 0)
+    for (const FLayer& l : pl.F)
+      SPG_CHECK_ARG(!l.bn || pl.fold, "slot-synchronised BatchNorm needs the filter network's statistics slots (spg_tune key 10 off, edges within the slots' capacity on every rank)");
   if (E == 0 && pl.training && spg_slot_sync_active())
     for (const FLayer& l : pl.F) SPG_CHECK_ARG(!l.bn, "slot-synchronised BatchNorm: a rank with an edge-less batch cannot take part in the filter-network statistics");
   if (E == 0 && pl.training && spg_sync_bn_active())
@@ -509,6 +515,9 @@ int spg_eccrnn_backward_phase(const spg_eccrnn_cfg* cfg, int N, int E, const voi
   Plan& pl = c->pl;
   SPG_TRY(make_plan(cfg, N, E, 1, workspace, params, pl));
   pl.fold = fnet_fold(pl);
+  if (spg_slot_sync_active() && E > 0)
+    for (const FLayer& l : pl.F)
+      SPG_CHECK_ARG(!l.bn || pl.fold, "slot-synchronised BatchNorm needs the filter network's statistics slots (spg_tune key 10 off, edges within the slots' capacity on every rank)");
   for (int i = 0; i < (int)pl.F.size(); ++i) {
     void* const* g = grads + 6 * i;
     pl.F[i].dW = (float*)g[0]; pl.F[i].db = (float*)g[1]; pl.F[i].dgamma = (float*)g[2]; pl.F[i].dbeta = (float*)g[3];

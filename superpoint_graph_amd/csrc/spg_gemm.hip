@@ -1880,6 +1880,9 @@ int spg_flush_deferred_reduce(hipStream_t stream) {
   return spg_flush_reduce(none, stream);
 }
 
+// (`used` only ever grows during a queue's life: a flush in the middle of a pass -- job table full -- sums and forgets the JOBS
+//  queued so far but never hands out their arena space again, so partial buffers captured by pending leaves (spg_queue_wgrad_leaf)
+//  stay theirs until the queue dies; a pass that needs more than the arena fails with an argument error instead of wrapping around)
 static int queue_take(SpgReduceQueue& q, size_t floats, float** out, hipStream_t stream) {
   if (q.njobs == SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(q, stream));
   SPG_CHECK_ARG(q.arena != nullptr && q.used + floats <= q.arena_floats, "reduction arena too small");
@@ -2408,7 +2411,10 @@ struct SpgSyncBn {
 static SpgSyncBn g_sync;
 
 extern "C" int spg_set_bn_allreduce(spg_allreduce_fn fn, void* ctx, double* buf, long buf_doubles) {
-  if (fn != nullptr) SPG_CHECK_ARG(buf != nullptr && buf_doubles >= 4, "synchronised BatchNorm needs a device buffer");
+  if (fn != nullptr) {
+    SPG_CHECK_ARG(buf != nullptr && buf_doubles >= 4, "synchronised BatchNorm needs a device buffer");
+    SPG_CHECK_ARG(!spg_slot_sync_active(), "the finalize-based synchronised BatchNorm and the slot-synchronised mode (spg_set_slot_allreduce) exclude each other");
+  }
   g_sync.fn = fn; g_sync.ctx = ctx; g_sync.buf = fn ? buf : nullptr; g_sync.ndoubles = fn ? buf_doubles : 0;
   return 0;
 }

@@ -18,9 +18,23 @@
 #include "spg_gemm.h"
 #include "spg_narrow.h"
 #include <limits.h>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace {
+// Which Gram-slot arrays (one per workspace and segment: the device address is the key) the LAST training forward filled
+// (spg_narrow.hip's one-pass first layers).  The backward of the first convolution takes its one-pass form only then: it used to
+// re-evaluate the forward's predicates (spg_tune keys 17 / 18, the fold, the shapes) -- had they changed in between (A/B tooling
+// toggling spg_tune), it would have read zeroed slots and written a wrong dW1 / dT without any error.
+std::mutex g_gram_mu;
+std::unordered_map<const void*, bool> g_gram_filled;
+void gram_record(const void* slots, bool filled) { std::lock_guard<std::mutex> lock(g_gram_mu); g_gram_filled[slots] = filled; }
+bool gram_recorded(const void* slots) {
+  std::lock_guard<std::mutex> lock(g_gram_mu);
+  auto it = g_gram_filled.find(slots);
+  return it != g_gram_filled.end() && it->second;
+}
 
 struct Layer {
   int cin = 0, cout = 0;
@@ -272,6 +286,7 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
                                          sg.pooled, sg.ldpool, nullptr, st));
   }
   size_t kfirst = 0;
+  if (pl.training && sg.gram != nullptr) gram_record(sg.gram, false);      // (set below when this forward fills the Gram slots)
   // train mode: the first two convolutions (cloud -> 64 -> 64) as ONE pass over the points -- the first layer's batch statistics
   // from the Gram matrix of the input, its raw output written once and never read back (spg_narrow.hip)
   if (!fused && pl.training && pl.fold && sg.gram != nullptr && sg.convs.size() > 2) {
@@ -291,6 +306,7 @@ int forward_segment(Plan& pl, Segment& sg, const float* clouds, const float* stn
       np.W2 = l1.W; np.b2 = l1.b; np.y2 = l1.y; np.slots2 = l1.slots;
       SPG_TRY(spg_launch_narrow_pair_fwd(np, st));
       SPG_TRY(spg_slot_sync_after(l1.slots, spg_fold_slot_words(l1.cout), st, false));
+      gram_record(sg.gram, true);
       kfirst = 2;
     }
   }
@@ -523,7 +539,7 @@ int backward_segment(Plan& pl, Segment& sg, BwdScratch& s, SpgReduceQueue& rq, S
     // The FIRST convolution behind a forward that left the Gram matrix of the input in the slots (spg_narrow.hip): weight gradient
     // and -- main segment behind an STN -- the gradient of the 2 x 2 transforms from ONE pass over the incoming gradient and the
     // cloud; the layer's raw output is not read (it is linear in the cloud: its part collapses onto the Gram matrix)
-    if (k == 0 && pl.fold && sg.gram != nullptr && sg.convs.size() > 2 && pending.slots != nullptr && cur.mode == SPG_PRO_BNBWD &&
+    if (k == 0 && pl.fold && sg.gram != nullptr && gram_recorded(sg.gram) && sg.convs.size() > 2 && pending.slots != nullptr && cur.mode == SPG_PRO_BNBWD &&
         cur.ld == l.cout && cur.c0 == s.consts && (!want_dxy || dT_out != nullptr) &&
         spg_narrow_pair_supported(l.cin, l.cout, pl.L[sg.convs[1]].cout, pl.P, pl.M) && spg_first_conv_bwd_supported(l.cin, l.cout, pl.P, pl.M)) {
       SpgFirstConvBwdParams fp; memset(&fp, 0, sizeof(fp));

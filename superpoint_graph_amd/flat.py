@@ -95,6 +95,17 @@ class FlatParameters:
                                                          torch.cuda.current_stream().cuda_stream), 'spg_adam_clamp_step')
         self._clear_written()
 
+    def rewind_steps(self, n):
+        """Takes n optimiser updates that the device WITHHELD (the fail-safe of spg_adam_clamp_step: a persistent RNN-ECC launch had
+        timed out -- ops.recover_persistent_ecc) off the host's step counter, so that Adam's bias correction continues from the
+        update the parameters have really seen."""
+        n = int(n)
+        if n <= 0 or not hasattr(self, '_t'):
+            return
+        self._t = max(self._t - n, 0)
+        if getattr(self, '_step_t', None) is not None:
+            self._step_t.fill_(float(self._t))
+
     def attach_optimizer(self, optimizer):
         """Keeps a `torch.optim.Adam` as the owner of the hyper-parameters (learning-rate schedulers keep working) and of the
         state dict (checkpoints stay in torch's format, both ways): its per-parameter moments become views of the arena's

@@ -119,6 +119,12 @@ def build_parser():
            'results as the module-level path; the filter network and the RNN-ECC parameter gradients travel next to PointNet\'s '
            'launches).  Active with --fused_optim 1 for the standard model (gru_R / lstm_R followed by f_K); otherwise the modules run')
     a('--max_train_iters', default=0, type=int, help='Stop every training epoch after this many batches (0 = whole epoch)')
+    a('--ecc_check_every', default=25, type=int,
+      help='Fail-safe of the one-launch RNN-ECC recurrences: their bounded waits raise a sticky device word when a neighbour state did '
+           'not arrive in time (GPU shared with another job, profiler); the clamp + Adam launch reads it and WITHHOLDS its update, so '
+           'wrong gradients never reach the parameters.  Every this many steps the host reads the word back (16 bytes, synchronises '
+           'the device), switches to the per-iteration kernels if it is set, corrects Adam\'s step count and repeats the batch at '
+           'hand.  0 = only at the end of an epoch / before a checkpoint (ops.check_persistent_ecc)')
     # data parallel (one process per GPU: `python -m torch.distributed.run --nproc-per-node N -m superpoint_graph_amd.learning.main ...`)
     a('--sync_bn', default=0, type=int, help='Data parallel: BatchNorm statistics over the scenes of ALL ranks (= the single-process '
       'batch of the reference); 0 = per-rank statistics')
@@ -388,10 +394,10 @@ class Session:
         self.model.train()
         loss_meter, acc_meter = meters.AverageValueMeter(), meters.ClassErrorMeter(accuracy=True)
         cm = metrics.ConfusionMatrix(self.dbinfo['classes'])
-        t0 = time.time()
-        for bidx, (targets, GIs, clouds_data) in enumerate(self._loader(self.train_dataset, True)):
-            t_loader = 1000 * (time.time() - t0)
-            t0 = time.time()
+
+        def step_batch(targets, GIs, clouds_data):
+            """zero_grad -> forward -> loss -> backward -> bw_hook -> [all-reduce] -> clamp + Adam (learning/main.py:199-213) of ONE batch
+            -> (loss of the whole batch, outputs, label_vec, label_mode), everything still on the device"""
             if self.arena is not None:
                 self.arena.zero_grad()
             else:
@@ -408,15 +414,7 @@ class Session:
                     self.arena.optimizer_step(grad_clip=a.grad_clip, grad_div=self.arena.normaliser)
                 else:
                     self.arena.optimizer_step(grad_clip=a.grad_clip)
-                t_trainer = 1000 * (time.time() - t0)
-                loss_meter.add(loss)
-                cm.count_predicted_batch_device(label_vec, outputs, label_mode)
-                _log_bounded(self.iter_log, (loss.clone(), t_trainer))
-                logging.debug('Batch loader time %f ms, trainer time %f ms.', t_loader, t_trainer)
-                t0 = time.time()
-                if a.max_train_iters and bidx + 1 >= a.max_train_iters:
-                    break
-                continue
+                return loss, outputs, label_vec, label_mode
             outputs, label_mode, label_vec = self._forward(targets, GIs, clouds_data)
             if self.dp:
                 # data parallel: back-propagate the SUM-reduced loss (gradients carry this rank's loss weight w_r), ONE all-reduce of
@@ -428,14 +426,7 @@ class Session:
                 self.arena.allreduce_sums(w, loss_sum)
                 loss = (self.arena.loss_sum / self.arena.normaliser).reshape(())       # the loss of the WHOLE batch (main.py:205)
                 self.arena.optimizer_step(grad_clip=a.grad_clip, grad_div=self.arena.normaliser)
-                t_trainer = 1000 * (time.time() - t0)
-                loss_meter.add(loss)
-                cm.count_predicted_batch_device(label_vec, outputs.detach(), label_mode)
-                _log_bounded(self.iter_log, (loss.clone(), t_trainer))
-                t0 = time.time()
-                if a.max_train_iters and bidx + 1 >= a.max_train_iters:
-                    break
-                continue
+                return loss, outputs.detach(), label_vec, label_mode
             loss = ops.cross_entropy(outputs, label_mode, weight=self.dbinfo['class_weights'])      # main.py:205
             loss.backward(self.arena.one if self.arena is not None else None)      # cached seed: no fill launch for ones_like(loss)
             self.embedder.bw_hook()
@@ -446,10 +437,27 @@ class Session:
                     for p in self.model.parameters():
                         p.grad.data.clamp_(-a.grad_clip, a.grad_clip)
                 self.optimizer.step()
+            return loss.detach(), outputs.detach(), label_vec, label_mode
+
+        t0 = time.time()
+        guard_every = int(getattr(a, 'ecc_check_every', 0) or 0) if (a.cuda and self.arena is not None) else 0
+        for bidx, (targets, GIs, clouds_data) in enumerate(self._loader(self.train_dataset, True)):
+            t_loader = 1000 * (time.time() - t0)
+            t0 = time.time()
+            loss, outputs, label_vec, label_mode = step_batch(targets, GIs, clouds_data)
+            if guard_every and (bidx + 1) % guard_every == 0:
+                # per-step fail-safe, host half (the device half: the clamp + Adam launch withholds its update while the one-launch
+                # RNN-ECC recurrences' time-out word is set).  One 16-byte read-back every `guard_every` steps.
+                withheld = ops.recover_persistent_ecc(self.arena)
+                if withheld:
+                    logging.warning('persistent RNN-ECC time-out: %d optimiser update(s) were withheld on the device (parameters untouched); '
+                                    'switched to the per-iteration kernels; repeating the current batch, %d earlier batch(es) of this window '
+                                    'are dropped', withheld, max(withheld - 1, 0))
+                    loss, outputs, label_vec, label_mode = step_batch(targets, GIs, clouds_data)
             t_trainer = 1000 * (time.time() - t0)
-            loss_meter.add(loss.detach())
-            cm.count_predicted_batch_device(label_vec, outputs.detach(), label_mode)   # filter_valid + argmax + counts, on the GPU
-            _log_bounded(self.iter_log, (loss.detach().clone(), t_trainer))
+            loss_meter.add(loss)
+            cm.count_predicted_batch_device(label_vec, outputs, label_mode)   # filter_valid + argmax + counts, on the GPU
+            _log_bounded(self.iter_log, (loss.clone(), t_trainer))
             logging.debug('Batch loader time %f ms, trainer time %f ms.', t_loader, t_trainer)
             t0 = time.time()
             if a.max_train_iters and bidx + 1 >= a.max_train_iters:

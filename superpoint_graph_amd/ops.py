@@ -432,31 +432,74 @@ def eccrnn_backward(state: EccRnnState, groups, grad_out, out_grads=None):
 # --------------------------------------------------------------------------------------------------
 # batch construction on the device
 # --------------------------------------------------------------------------------------------------
+def persistent_ecc_status(clear=False):
+    """(time-outs, withheld optimiser updates) of the dataflow-synchronised RNN-ECC launches of the current device
+    (include/spg_hip.h: spg_ecc_persistent_status).  The time-out word is sticky and read by the fused clamp + Adam launch itself: while
+    it is non-zero every update is WITHHELD (parameters / moments bit-identical), so nothing computed from stale neighbour states
+    reaches the model before the host has looked.  One blocking 16-byte copy: synchronises the device."""
+    e, w = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().spg_ecc_persistent_status(ctypes.byref(e), ctypes.byref(w), 1 if clear else 0), 'spg_ecc_persistent_status')
+    return int(e.value), int(w.value)
+
+
+def recover_persistent_ecc(arena=None, group=None):
+    """The per-step fail-safe's host half: reads and clears the status; when a recurrence has timed out, switches this process (every
+    rank of `group`: the decision is all-reduced) to the per-iteration kernels (spg_tune key 8, which cannot time out) and takes the
+    withheld updates off `arena`'s Adam step counter (FlatParameters.rewind_steps).  Returns the number of withheld updates (0:
+    nothing happened) -- the caller repeats the batches it still holds.  COLLECTIVE when a process group is initialised (every rank
+    must call it at the same step; group=False keeps it local)."""
+    errors, withheld = persistent_ecc_status(clear=True)
+    total = errors
+    if group is not False:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            on_gpu = dist.get_backend(group) == 'nccl'
+            t = torch.tensor([float(errors)], dtype=torch.float64, device=torch.device('cuda', torch.cuda.current_device()) if on_gpu else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            total = int(t.item())
+    if total == 0:
+        return 0
+    lib().spg_tune(8, 1)
+    if arena is not None and withheld:
+        arena.rewind_steps(withheld)
+    return max(withheld, 1)
+
+
 def check_persistent_ecc(what='training', group=None):
-    """Health check of the dataflow-synchronised RNN-ECC launches (include/spg_hip.h: spg_ecc_persistent_errors_clear): a
+    """Health check of the dataflow-synchronised RNN-ECC launches (include/spg_hip.h: spg_ecc_persistent_status): a
     wave whose bounded spin ran out (a peer workgroup was not resident in time: shared GPU, profiler, another stream holding
-    CUs) carried on with stale neighbour states.  Synchronises the device; call it where the host synchronises anyway (epoch
-    end, before a checkpoint).  Raises after clearing the counter and switching this process to the per-iteration kernels
-    (spg_tune key 8), so a caller that catches the error can repeat the affected work safely.  With an initialised process group
-    the count is summed over the ranks of `group` first (a collective: every rank must call it; group=False keeps it local)."""
-    n = lib().spg_ecc_persistent_errors_clear()
-    if n < 0:      # the counter could not be read (hipMemcpy failed): a different failure, not "-1 time-outs"
-        raise RuntimeError(f'spg_ecc_persistent_errors_clear failed during {what}: ' + lib().spg_last_error().decode())
-    total = n
+    CUs) carried on with stale neighbour states.  Since round 6 the fused optimiser launch WITHHOLDS its update while the time-out word
+    is set, so the parameters are never touched by such a step; this check is the last line (epoch end, before a checkpoint).
+    Synchronises the device.  Raises after clearing the counters and switching this process to the per-iteration kernels
+    (spg_tune key 8), so a caller that catches the error can repeat the affected work safely.
+    COLLECTIVE CONTRACT: with an initialised process group the count is summed over the ranks of `group` first -- EVERY rank of the
+    group must call it at the same point (a read failure on one rank is folded into the reduced value and raised on every rank, so no
+    rank is left alone in the collective); group=False keeps it local."""
+    failed = None
+    try:
+        n, withheld = persistent_ecc_status(clear=True)
+    except RuntimeError as exc:      # the counter could not be read: a different failure, not "-1 time-outs" -- but the collective still runs
+        failed, n, withheld = exc, 0, 0
+    total, any_failed = n, failed is not None
     if group is not False:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             # data parallel: every rank must take the same decision (one rank raising alone leaves the others in the next
             # collective until the RCCL time-out, and the ranks would run different kernels afterwards)
             on_gpu = dist.get_backend(group) == 'nccl'
-            t = torch.tensor([float(n)], dtype=torch.float64, device=torch.device('cuda', torch.cuda.current_device()) if on_gpu else 'cpu')
+            t = torch.tensor([float(n), 1.0 if failed is not None else 0.0], dtype=torch.float64,
+                             device=torch.device('cuda', torch.cuda.current_device()) if on_gpu else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            total = int(t.item())
+            total, any_failed = int(t[0].item()), bool(t[1].item() > 0)
+    if any_failed:
+        raise RuntimeError(f'the persistent RNN-ECC status could not be read during {what} on '
+                           + ('this rank: ' + str(failed) if failed is not None else 'another rank of the job'))
     if total == 0:
         return
     lib().spg_tune(8, 1)
-    raise RuntimeError(f'{total} persistent RNN-ECC spin time-out(s) ({n} on this rank) during {what}: the ECC outputs / gradients of the '
-                       'affected steps are wrong (a workgroup of the dataflow-synchronised launch was not resident in time).  The process '
+    raise RuntimeError(f'{total} persistent RNN-ECC spin time-out(s) ({n} on this rank; {withheld} optimiser update(s) withheld here) during '
+                       f'{what}: the ECC outputs / gradients of the affected steps are wrong (a workgroup of the dataflow-synchronised launch '
+                       'was not resident in time); the fused optimiser step withheld its updates from the first time-out on.  The process '
                        '(every rank of the job) now uses the per-iteration kernels (spg_tune key 8); repeat the work since the last check')
 
 

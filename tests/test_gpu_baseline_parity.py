@@ -77,6 +77,9 @@ def test_baseline_size_vs_reference_golden(hip, setup):
     #  first layers take the first BatchNorm's statistics from the exact Gram matrix instead of from rounded fp32 outputs: one
     #  max-pool winner of the 128 -> 256 layer now differs from the reference's fp32 run -- 3.4e-2 of that layer's weight gradient,
     #  1e-2 before.  The decision-conditioned tests below hold every tensor to 1e-4.)
+    # FROZEN (round 6): this bound is not to move again.  A kernel change that flips a further near-tie shows up
+    # as a COUNT in the conditioned test's log (`decisions: ReLU a / b differ, max-pool c / d differ`, run with -s;
+    # profiles/r06_parity_decisions.txt holds round 6's) and has to be argued there, not here.
     assert max(rest.values()) < 5e-2, {k: e for k, e in rest.items() if e >= 5e-2}
     sd = model.state_dict()
     for k in g.files:

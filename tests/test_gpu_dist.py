@@ -155,7 +155,7 @@ def test_bench_two_ranks_with_roofline_pass(hip):
     assert len(lines) == 1, out.stdout[-2000:]                        # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['superpoints_per_step'] == 400
-    assert 'roofline' in d and 'cpu_baseline' not in d
+    assert 'roofline' in d and 'skipped' in d['cpu_baseline'] and 'value' not in d['cpu_baseline']      # (N > 1: marked, not silently absent)
 
 
 @pytest.mark.parametrize('launcher', ['torchrun', 'self'])

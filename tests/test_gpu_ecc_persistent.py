@@ -80,8 +80,8 @@ def test_persistent_recurrence_is_bit_identical_to_per_iteration_launches(hip, c
 
 
 def test_persistent_recurrence_eval_mode_and_above_the_node_limit(hip):
-    """Inference (no aggregates kept) through the persistent launch; 1100 nodes exceed the resident-workgroup limit and take
-    the per-iteration path on their own -- same results either way."""
+    """Inference (no aggregates kept) through the persistent launch: 1000 nodes with one workgroup per CU, 1100 nodes with two
+    (since round 4; up to 2048 nodes per round) -- the same results as the per-iteration launches either way."""
     from superpoint_graph_amd.learning import ecc, graphnet
     for n, e in ((1000, 5000), (1100, 5000)):
         idxn, degs = _graph(n, e, seed=n)
