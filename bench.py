@@ -188,7 +188,7 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
                   for i in range(args.scenes)]
         samples = [spg.sample_from_scene(s, f'w{b}_{i}') for i, s in enumerate(scenes)]
         targets, _, (meta, flag, clouds, diam) = spg.eccpc_collate(samples)
-        batches.append((targets, [s[1] for s in samples], flag, clouds.pin_memory(), diam.pin_memory()))
+        batches.append((targets, [s[1] for s in samples], flag, clouds.pin_memory(), diam))
     from superpoint_graph_amd.learning.prefetch import SideStreamBatches
 
     def fresh_batches(n):
@@ -196,14 +196,33 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
         side stream by SideStreamBatches, so it overlaps the step in flight"""
         for it in range(n):
             targets, graphs, flag, clouds, diam = batches[it % nb]
-            gi = ecc.GraphConvInfo()
-            gi.set_batch_device(graphs, spg.cloud_edge_feats)      # edge list / features H2D + ordering + CSR on the device
             flag = flag.clone()                                    # a fresh batch object, as a collate produces it
-            pointnet.stage_flags(flag)                             # (eccpc_collate(device_batch=True) does this)
-            yield gi, flag, ops.upload(clouds, dev), ops.upload(diam, dev), ops.upload(targets[:, 0].contiguous(), dev)
+            if os.environ.get('SPG_TW_LEGACY'):                    # (A/B only: the round-5 sequence, one staging copy per vector)
+                gi = ecc.GraphConvInfo()
+                gi.set_batch_device(graphs, spg.cloud_edge_feats)
+                pointnet.stage_flags(flag)
+                yield gi, flag, ops.upload(clouds, dev), ops.upload(diam, dev), ops.upload(targets[:, 0].contiguous(), dev)
+                continue
+            # as eccpc_collate(device_batch=True): the edge list, the edge features, CloudEmbedder's two index vectors, the labels
+            # and the diameters travel in ONE staging copy (round 6; seven copies before), then ordering + CSR on the device
+            iv, slot = pointnet.flag_index_vectors(flag)
+            gi = ecc.GraphConvInfo()
+            gi.set_batch_device(graphs, spg.cloud_edge_feats, extras=[iv, slot, targets[:, 0].contiguous(), diam])
+            iv_d, slot_d, lab_d, diam_d = gi.extras_dev
+            pointnet.attach_staged_flags(flag, iv_d, slot_d)
+            yield gi, flag, ops.upload(clouds, dev), diam_d, lab_d
+
+    waited = [0.0]
 
     def run(n):
-        for gi, flag, c, d, lab in SideStreamBatches(fresh_batches(n)):
+        ssb = SideStreamBatches(fresh_batches(n))
+        try:
+            _run(ssb)
+        finally:
+            waited[0] += ssb.host_wait_seconds
+
+    def _run(ssb):
+        for gi, flag, c, d, lab in ssb:
             model.ecc.set_info([gi], 1)
             arena.zero_grad()
             if fstep is not None:
@@ -217,15 +236,37 @@ def trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, ite
             arena.adam_step(lr=1e-2, weight_decay=0.0, grad_clip=1.0)
     run(12)               # the side stream's allocator pool and the staging ring fill during the first batches
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(iters)
-    t_host = (time.perf_counter() - t0) / iters          # the host has enqueued everything: if this is close to dt the loop is host-bound
+    runs = []
+    for _ in range(3):    # (the window is bimodal on some boxes -- roughly one run in four lands 5-30 % above the others, with the
+        torch.cuda.synchronize()      # round-5 sequence as well --, so: three runs, the median is reported, all three are listed)
+        t0 = time.perf_counter()
+        run(iters)
+        th = (time.perf_counter() - t0) / iters          # the host over the WHOLE loop: once it runs ahead of the GPU by more than the
+        torch.cuda.synchronize()                         # hardware queue holds, its launches block -- this figure then tends to dt
+        runs.append(((time.perf_counter() - t0) / iters, th))
+    dt, t_host_long = sorted(runs)[1]
+    # the host's own cost of a fresh-batch step: short bursts from an idle GPU (12 steps = ~450 launches: they fit the queue, nothing
+    # blocks), median of 5
+    bursts = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        waited[0] = 0.0
+        t0 = time.perf_counter()
+        run(12)
+        t1 = time.perf_counter()
+        bursts.append(((t1 - t0 - waited[0]) / 12, (t1 - t0) / 12))
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    t_host, t_host_with_waits = sorted(bursts)[2]
     n = int(batches[0][2].numel())
-    log(f'trainer window: {dt * 1e3:.3f} ms/step (host enqueue {t_host * 1e3:.3f} ms/step)')
-    return {'ms_per_step': dt * 1e3, 'superpoints_per_s': n / dt, 'host_enqueue_ms_per_step': t_host * 1e3,
-            'what': 'fresh batch every step: pinned H2D of clouds/labels + GraphConvInfo.set_batch_device (edge list / features H2D, ordering by '
+    log(f'trainer window: {dt * 1e3:.3f} ms/step (host enqueue {t_host * 1e3:.3f} ms/step in 12-step bursts, {t_host_long * 1e3:.3f} over the {iters}-step loop)')
+    return {'ms_per_step': dt * 1e3, 'ms_per_step_runs': [r[0] * 1e3 for r in runs], 'superpoints_per_s': n / dt, 'host_enqueue_ms_per_step': t_host * 1e3,
+            'host_enqueue_ms_per_step_long_loop': t_host_long * 1e3, 'host_enqueue_plus_waits_ms_per_step': t_host_with_waits * 1e3,
+            'host_enqueue_how': 'host WORK per fresh-batch step: median of five 12-step bursts started on an idle GPU (the launches fit the hardware '
+                                'queue), minus the time SideStreamBatches spent waiting on the host for a batch under construction (it waits there '
+                                'instead of putting a cross-stream dependency on the training stream; ..._plus_waits includes it); the long-loop figure '
+                                'also includes the time the host waits for queue space once it is ahead of the GPU',
+
+            'what': 'fresh batch every step: pinned H2D of the clouds + ONE packed staging copy of everything else (edge list, edge features, index vectors, labels, diameters) + GraphConvInfo.set_batch_device (ordering by '
                     'target + CSR / reverse CSR as kernels), both on a side stream (SideStreamBatches, as the CLI does) + zero_grad..Adam '
                     '(learning/main.py:192-215)'}
 

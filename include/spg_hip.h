@@ -267,6 +267,14 @@ int spg_edge_features(const spg_edge_feature_specs* specs, const int64_t* edges,
 size_t spg_batch_graph_scratch_bytes(int N, int E, int F);
 int spg_batch_graph_build(const int64_t* edges_host, const float* feats_host, int N, int E, int F, int64_t* idxn, int64_t* degs,
                           float* feats_sorted, void* graph_ws, void* scratch, int32_t* error_flag, void* stream);
+/* (round 6) The same with the edge list and the edge features ALREADY on the device -- uploaded together with the batch's other
+ * small vectors by one spg_upload_packed: a fresh batch then costs the host two copies (the clouds, everything else) instead of
+ * seven (learning/main.py:189-203, learning/spg.py:178-193). */
+int spg_batch_graph_build_dev(const int64_t* edges_dev, const float* feats_dev, int N, int E, int F, int64_t* idxn, int64_t* degs,
+                              float* feats_sorted, void* graph_ws, void* scratch, int32_t* error_flag, void* stream);
+/* n host buffers -> one page-locked staging slot -> ONE asynchronous host-to-device copy: piece i lands at (char*)device + offsets[i]
+ * (the caller's layout: non-overlapping, inside `total` bytes).  Returns once the copy is enqueued; the host buffers may be re-used. */
+int spg_upload_packed(const void* const* host, const size_t* bytes, const size_t* offsets, int n, void* device, size_t total, void* stream);
 
 /* Host -> device upload of a small per-batch buffer (the reference's `.cuda()` of idxn / degs / edgefeats,
  * learning/ecc/GraphConvInfo.py:71-79, and of the clouds, learning/pointnet.py:150-152) WITHOUT a host stall: the bytes

@@ -119,6 +119,8 @@ SIGNATURES = {
     'spg_upload': (_i, [_p, _sz, _p, _p]),
     'spg_batch_graph_scratch_bytes': (_sz, [_i, _i, _i]),
     'spg_batch_graph_build': (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    'spg_batch_graph_build_dev': (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    'spg_upload_packed': (_i, [_p, _p, _p, _i, _p, _sz, _p]),
     'spg_spg_workspace_bytes': (_sz, [_i, _l]),
     'spg_spg_tet_edges': (_i, [_p, _l, _p, _p, _l, _p, _p]),
     'spg_spg_unique_edges': (_i, [_p, _l, _p, _p, _l, ctypes.c_float, _p, _p, _p, _p, _sz, _p]),

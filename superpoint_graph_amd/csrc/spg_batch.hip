@@ -209,12 +209,9 @@ StagingRing g_staging;
 
 }  // namespace
 
-static int upload_impl(const void* host, size_t bytes, void* device, void* stream) {
-  if (bytes == 0) return 0;
-  SPG_CHECK_ARG(host && device, "bad argument");
-  int dev = 0;
-  hipError_t rc = hipGetDevice(&dev);
-  if (rc != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) { spg_set_error("spg_upload: hipGetDevice failed"); return rc ? (int)rc : 1; }
+// a staging slot of the current device with room for `bytes`, free for the host to write (its last copy has left the buffer);
+// the ring's mutex is held only while the slot is chosen -- the caller owns the slot until it records `done` again
+static int staging_take(int dev, size_t bytes, StagingSlot** out) {
   std::lock_guard<std::mutex> lock(g_staging.mu);
   int idx;
   if (bytes <= kSmallBytes) {
@@ -224,6 +221,7 @@ static int upload_impl(const void* host, size_t bytes, void* device, void* strea
     idx = kSmallSlots + g_staging.next_large[dev];
     g_staging.next_large[dev] = (g_staging.next_large[dev] + 1) % kLargeSlots;
   }
+  hipError_t rc;
   if (g_staging.block[dev] == nullptr) {
     rc = hipHostMalloc(&g_staging.block[dev], kSmallSlots * kSmallInitial, hipHostMallocDefault);
     if (rc != hipSuccess) { g_staging.block[dev] = nullptr; spg_set_error("hipHostMalloc: %s", hipGetErrorString(rc)); return (int)rc; }
@@ -251,6 +249,19 @@ static int upload_impl(const void* host, size_t bytes, void* device, void* strea
     if (rc != hipSuccess) { s.buf = nullptr; spg_set_error("hipHostMalloc(%zu): %s", cap, hipGetErrorString(rc)); return (int)rc; }
     s.cap = cap; s.own = true;
   }
+  *out = &s;
+  return 0;
+}
+
+static int upload_impl(const void* host, size_t bytes, void* device, void* stream) {
+  if (bytes == 0) return 0;
+  SPG_CHECK_ARG(host && device, "bad argument");
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) { spg_set_error("spg_upload: hipGetDevice failed"); return rc ? (int)rc : 1; }
+  StagingSlot* sp = nullptr;
+  SPG_TRY(staging_take(dev, bytes, &sp));
+  StagingSlot& s = *sp;
   std::memcpy(s.buf, host, bytes);
   rc = hipMemcpyAsync(device, s.buf, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
   if (rc != hipSuccess) { spg_set_error("hipMemcpyAsync: %s", hipGetErrorString(rc)); return (int)rc; }
@@ -261,6 +272,31 @@ static int upload_impl(const void* host, size_t bytes, void* device, void* strea
 }
 
 extern "C" int spg_upload(const void* host, size_t bytes, void* device, void* stream) { return upload_impl(host, bytes, device, stream); }
+
+// Several small host buffers -> ONE staging slot -> ONE asynchronous copy into `device` (piece i lands at device + offsets[i];
+// the caller lays the pieces out: 256-byte aligned, non-overlapping, inside `total` bytes).  A fresh batch needs seven small
+// vectors on the device (edge list, edge features, CloudEmbedder's two index vectors, labels, diameters): as seven spg_upload
+// calls they cost the host ~0.1 ms each (memcpy + hipMemcpyAsync + event record) -- half of the fresh-batch loop's 1.0 ms of host
+// time per step (profiles/r06_tw_host_profile.txt).
+extern "C" int spg_upload_packed(const void* const* host, const size_t* bytes, const size_t* offsets, int n, void* device, size_t total,
+                                 void* stream) {
+  if (n <= 0 || total == 0) return 0;
+  SPG_CHECK_ARG(host && bytes && offsets && device, "bad argument");
+  for (int i = 0; i < n; ++i) SPG_CHECK_ARG((bytes[i] == 0 || host[i] != nullptr) && offsets[i] + bytes[i] <= total, "piece outside the packed buffer");
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess || dev < 0 || dev >= SPG_MAX_DEVICES) { spg_set_error("spg_upload_packed: hipGetDevice failed"); return rc ? (int)rc : 1; }
+  StagingSlot* sp = nullptr;
+  SPG_TRY(staging_take(dev, total, &sp));
+  for (int i = 0; i < n; ++i)
+    if (bytes[i]) std::memcpy((char*)sp->buf + offsets[i], host[i], bytes[i]);
+  rc = hipMemcpyAsync(device, sp->buf, total, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (rc != hipSuccess) { spg_set_error("hipMemcpyAsync: %s", hipGetErrorString(rc)); return (int)rc; }
+  rc = hipEventRecord(sp->done, (hipStream_t)stream);
+  if (rc != hipSuccess) { spg_set_error("hipEventRecord: %s", hipGetErrorString(rc)); return (int)rc; }
+  sp->pending = true;
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // spg_batch_graph_build: the whole batch construction of a SMALL batch in ONE launch
@@ -399,10 +435,11 @@ extern "C" size_t spg_batch_graph_scratch_bytes(int N, int E, int F) {
   return bg_al(e * 16) + bg_al(e * (size_t)(F > 0 ? F : 1) * 4) + 3 * bg_al(e * 4) + 256;
 }
 
-extern "C" int spg_batch_graph_build(const int64_t* edges_host, const float* feats_host, int N, int E, int F, int64_t* idxn, int64_t* degs,
-                                     float* feats_sorted, void* graph_ws, void* scratch, int32_t* error_flag, void* stream) {
+// inputs_on_device: edges / feats are DEVICE arrays already (uploaded with the batch's other small vectors by ONE spg_upload_packed)
+static int batch_graph_build_impl(const int64_t* edges_in, const float* feats_in, bool inputs_on_device, int N, int E, int F, int64_t* idxn,
+                                  int64_t* degs, float* feats_sorted, void* graph_ws, void* scratch, int32_t* error_flag, void* stream) {
   SPG_CHECK_ARG(N >= 1 && N <= kBgMaxNodes && E >= 0 && E <= kBgMaxEdges && F >= 0, "batch too large for the single-launch builder");
-  SPG_CHECK_ARG(degs && graph_ws && scratch && (E == 0 || (edges_host && idxn)) && (F == 0 || E == 0 || (feats_host && feats_sorted)), "null pointer");
+  SPG_CHECK_ARG(degs && graph_ws && scratch && (E == 0 || (edges_in && idxn)) && (F == 0 || E == 0 || (feats_in && feats_sorted)), "null pointer");
   const size_t e = (size_t)(E > 0 ? E : 1);
   char* w = (char*)scratch;
   BatchGraphArgs a;
@@ -411,9 +448,12 @@ extern "C" int spg_batch_graph_build(const int64_t* edges_host, const float* fea
   a.bucket_in = (int*)w; w += bg_al(e * 4);
   a.bucket_out = (int*)w; w += bg_al(e * 4);
   a.inv = (int*)w;
-  if (E > 0) {
-    SPG_TRY(upload_impl(edges_host, (size_t)E * 16, (void*)a.edges, stream));
-    if (F > 0) SPG_TRY(upload_impl(feats_host, (size_t)E * F * 4, (void*)a.feats, stream));
+  if (inputs_on_device) {
+    a.edges = edges_in;
+    a.feats = F > 0 ? feats_in : nullptr;
+  } else if (E > 0) {
+    SPG_TRY(upload_impl(edges_in, (size_t)E * 16, (void*)a.edges, stream));
+    if (F > 0) SPG_TRY(upload_impl(feats_in, (size_t)E * F * 4, (void*)a.feats, stream));
   }
   SpgGraph g = spg_graph_view(graph_ws, N, E);
   a.N = N; a.E = E; a.F = F; a.idxn = idxn; a.degs = degs; a.feats_sorted = feats_sorted;
@@ -428,4 +468,13 @@ extern "C" int spg_batch_graph_build(const int64_t* edges_host, const float* fea
     SPG_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int spg_batch_graph_build(const int64_t* edges_host, const float* feats_host, int N, int E, int F, int64_t* idxn, int64_t* degs,
+                                     float* feats_sorted, void* graph_ws, void* scratch, int32_t* error_flag, void* stream) {
+  return batch_graph_build_impl(edges_host, feats_host, false, N, E, F, idxn, degs, feats_sorted, graph_ws, scratch, error_flag, stream);
+}
+extern "C" int spg_batch_graph_build_dev(const int64_t* edges_dev, const float* feats_dev, int N, int E, int F, int64_t* idxn, int64_t* degs,
+                                         float* feats_sorted, void* graph_ws, void* scratch, int32_t* error_flag, void* stream) {
+  return batch_graph_build_impl(edges_dev, feats_dev, true, N, E, F, idxn, degs, feats_sorted, graph_ws, scratch, error_flag, stream);
 }

@@ -60,12 +60,15 @@ class GraphConvInfo(object):
         self._edge_indexes = torch.LongTensor(np.concatenate(edge_indexes).T)
         self._graph = None
 
-    def set_batch_device(self, graphs, edge_feat_func, device=None):
+    def set_batch_device(self, graphs, edge_feat_func, device=None, extras=None):
         """`set_batch` with the ordering work on the GPU (spg_set_batch): the host only concatenates the edge lists and
         edge attributes in their original order, counts the in-degrees (the contract keeps a host copy of `degs`;
         utils.get_edge_shards reads it) and checks the endpoints -- no device-to-host copy, no synchronisation.  Buffers
         come out device-resident; the order inside a target segment is the STABLE one (the reference's numpy argsort
-        leaves ties unspecified), everything else is identical to `set_batch`."""
+        leaves ties unspecified), everything else is identical to `set_batch`.
+        extras: further small HOST tensors of the batch (CloudEmbedder's index vectors, labels, diameters ...; None entries allowed):
+        they travel in the SAME staging copy as the edge list and the edge features (ops.upload_packed: one host-to-device copy per
+        batch instead of one per vector); their device versions are left in `self.extras_dev`, in the order given."""
         from ... import ops
         graphs = graphs if isinstance(graphs, (list, tuple)) else [graphs]
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
@@ -95,7 +98,19 @@ class GraphConvInfo(object):
         self._edge_indexes = None                                   # built on demand (get_pyg_buffers): only the pyg path reads it
         # a batch of a few scenes: ONE launch does the ordering by target, the edge-feature reordering and the CSR / reverse CSR,
         # fed from the host arrays through the staging ring (ops.batch_graph_build)
-        built = ops.batch_graph_build(torch.from_numpy(edges_h), feats if feats.dim() == 2 else None, p, dev) if feats.dim() == 2 else None
+        extras = list(extras) if extras is not None else []
+        self.extras_dev = [None] * len(extras)
+        edges_t = torch.from_numpy(edges_h)
+        if feats.dim() == 2 and not feats.is_cuda and ops.batch_graph_fits(p, int(edges_h.shape[0]), int(feats.shape[1])):
+            # ONE staging copy for everything small of this batch, then the single-launch builder on the device copies
+            packed = ops.upload_packed([edges_t, feats] + extras, dev)
+            self.extras_dev = packed[2:]
+            built = ops.batch_graph_build(packed[0], packed[1], p, dev)
+            self._idxn, self._degrees_gpu, self._edgefeats, self._graph, _err = built
+            return
+        if extras:
+            self.extras_dev = ops.upload_packed(extras, dev)
+        built = ops.batch_graph_build(edges_t, feats if feats.dim() == 2 else None, p, dev) if feats.dim() == 2 else None
         if built is not None:
             self._idxn, self._degrees_gpu, self._edgefeats, self._graph, _err = built
             return

@@ -164,6 +164,15 @@ def filter_valid(output, target, other=None):
     return output[idx, :], target[idx]
 
 
+def _labels_on_device(targets):
+    """(majority label, per-class point counts) of a batch on the device (learning/main.py:202-205): uploaded by the device collate in
+    the batch's one staging copy (learning/spg.py: eccpc_collate(device_batch=True)), or here."""
+    staged = getattr(targets, '_spg_labels_dev', None)
+    if staged is not None:
+        return staged
+    return tuple(ops.upload_packed([targets[:, 0].contiguous(), targets[:, 2:].contiguous()]))
+
+
 def _log_bounded(log, entry, keep=2048):
     """Per-batch records for tests and tools: 4-byte device scalars (clones -- a view would keep the loss kernel's whole
     [N+2] buffer alive), the oldest half dropped beyond `keep` entries so that a 350-epoch run does not grow without bound."""
@@ -381,8 +390,7 @@ class Session:
     def _forward(self, targets, GIs, clouds_data):
         self.model.ecc.set_info(GIs, self.args.cuda)
         # through the staging ring (ops.upload): a pageable `.cuda()` would stall the host until the previous step has drained
-        label_mode = ops.upload(targets[:, 0].contiguous()) if self.args.cuda else targets[:, 0].contiguous()
-        label_vec = ops.upload(targets[:, 2:].contiguous()) if self.args.cuda else targets[:, 2:].contiguous()
+        label_mode, label_vec = _labels_on_device(targets) if self.args.cuda else (targets[:, 0].contiguous(), targets[:, 2:].contiguous())
         embeddings = self.embedder.run(self.model, *clouds_data)
         outputs = self.model.ecc(embeddings)
         return outputs, label_mode, label_vec
@@ -405,8 +413,7 @@ class Session:
             if self.fused is not None and len(clouds_data[2]) > 1:
                 # forward + backward + bw_hook as one library call (learning/main.py:199-208); gradients land in the arena
                 self.model.ecc.set_info(GIs, a.cuda)
-                label_mode = ops.upload(targets[:, 0].contiguous())
-                label_vec = ops.upload(targets[:, 2:].contiguous())
+                label_mode, label_vec = _labels_on_device(targets)
                 loss, outputs = self.fused(clouds_data[1], clouds_data[2], clouds_data[3], GIs[0], label_mode)
                 if self.dp:
                     self.arena.allreduce_sums(self.fused.normaliser, loss)

@@ -347,6 +347,23 @@ class _ScatterEmbeddings(torch.autograd.Function):
         return ops.gather_rows(grad.contiguous(), ctx.idx_valid), None, None
 
 
+def flag_index_vectors(clouds_flag):
+    """HOST index vectors CloudEmbedder derives from `clouds_flag` (learning/pointnet.py:149,162,177-179): rows of the valid
+    superpoints, and the embedding row of every superpoint (-1 for the too-small ones) -> (idx_valid, slot_of_row), int64."""
+    valid = clouds_flag.eq(0)
+    idx_valid = torch.nonzero(valid).reshape(-1)
+    slot = torch.cumsum(valid.to(torch.int64), 0) - 1
+    slot[~valid] = -1
+    return idx_valid, slot
+
+
+def attach_staged_flags(clouds_flag, idx_valid_dev, slot_dev):
+    """The device copies of flag_index_vectors(clouds_flag), uploaded by the caller (a device collate packs them into the batch's one
+    staging copy: GraphConvInfo.set_batch_device(extras=...)), attached to the flag tensor for CloudEmbedder."""
+    clouds_flag._spg_staged = (idx_valid_dev, slot_dev)
+    return clouds_flag._spg_staged
+
+
 def stage_flags(clouds_flag):
     """Index vectors CloudEmbedder derives from `clouds_flag` (rows of the valid superpoints, embedding row of every
     superpoint), computed and uploaded on the CURRENT stream and attached to the flag tensor: a device collate calls this
@@ -355,12 +372,9 @@ def stage_flags(clouds_flag):
     staged = getattr(clouds_flag, '_spg_staged', None)
     if staged is None:
         dev = torch.device('cuda', torch.cuda.current_device())
-        valid = clouds_flag.eq(0)
-        idx_valid = torch.nonzero(valid).reshape(-1)
-        slot = torch.cumsum(valid.to(torch.int64), 0) - 1          # row of the embedding matrix, -1 for too-small superpoints
-        slot[~valid] = -1
+        idx_valid, slot = flag_index_vectors(clouds_flag)
         # (staging ring, non-blocking: a pageable H2D would stall the host until the stream has drained)
-        staged = clouds_flag._spg_staged = (ops.upload(idx_valid, dev), ops.upload(slot, dev))
+        staged = clouds_flag._spg_staged = tuple(ops.upload_packed([idx_valid, slot], dev))
     return staged
 
 

@@ -23,6 +23,7 @@ wait is a barrier packet: measured ~25 us each, tools/trainer_window_attrib.py),
 from __future__ import annotations
 
 import collections
+import time
 
 import torch
 
@@ -43,10 +44,18 @@ class SideStreamBatches:
     """for batch in SideStreamBatches(loader): ...  -- `loader` is any iterable whose `__next__` enqueues the batch's device work
     on the CURRENT stream (a `DataLoader` with `num_workers == 0` and a device collate, or a generator)."""
 
-    def __init__(self, loader, stream: 'torch.cuda.Stream | None' = None, fence_every: int = 4):
+    def __init__(self, loader, stream: 'torch.cuda.Stream | None' = None, fence_every: int = 4, host_wait: bool = True):
         self.loader = loader
         self.side = stream
         self.fence_every = max(1, int(fence_every))
+        # host_wait: a batch that is not built yet when its step is about to be enqueued is waited for on the HOST instead of with a
+        # cross-stream dependency on the training stream.  Round 6: with the batch's small vectors in one staging copy the host
+        # enqueues a fresh-batch step in 0.44 ms (0.50 before) -- far ahead of the GPU -- so `built.query()` was more often false and
+        # the loop paid the ~25 us pipeline drain of a stream wait on MORE steps than the slower host had (window 1.255 -> 1.30 ms on
+        # one box).  The build was enqueued a whole step earlier and runs next to the step in flight, so the host wait is short, and
+        # the training stream never sees a barrier packet.
+        self.host_wait = bool(host_wait)
+        self.host_wait_seconds = 0.0          # time the host spent WAITING for a build (not working): bench.py takes it off its enqueue figure
 
     def __len__(self):
         return len(self.loader)
@@ -92,5 +101,10 @@ class SideStreamBatches:
             batch, built = pending
             pending = build()                 # batch j+1 is under construction before step j is enqueued
             if not built.query():             # built a whole step ago: normally complete already -- then the training stream needs
-                main.wait_event(built)        # no cross-stream dependency at all (one costs ~25 us of pipeline drain)
+                if self.host_wait:            # no cross-stream dependency at all (one costs ~25 us of pipeline drain)
+                    t_w = time.perf_counter()
+                    built.synchronize()
+                    self.host_wait_seconds += time.perf_counter() - t_w
+                else:
+                    main.wait_event(built)
             yield batch

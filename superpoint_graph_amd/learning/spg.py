@@ -169,20 +169,33 @@ def eccpc_collate(batch, device_batch=False):
     targets, graphs, clouds_meta, clouds_flag, clouds, clouds_global = list(zip(*batch))
     targets = torch.cat([_as_tensor(t) for t in targets if t is not None], 0).long()
     graphs = [graph for graph in graphs if graph is not None]
-    if device_batch:
-        gi = ecc.GraphConvInfo()
-        gi.set_batch_device(graphs, cloud_edge_feats)
-        GIs = [gi]
-    else:
-        GIs = [ecc.GraphConvInfo(graphs, cloud_edge_feats)]
-    if len(clouds_meta[0]) > 0:
+    has_clouds = len(clouds_meta[0]) > 0
+    if has_clouds:
         clouds = torch.cat([_as_tensor(f) for f in clouds if f is not None], 0)
         clouds_global = torch.cat([_as_tensor(f) for f in clouds_global if f is not None], 0)
         clouds_flag = torch.cat([_as_tensor(f) for f in clouds_flag if f is not None], 0)
-        if device_batch:              # CloudEmbedder's index vectors travel with the batch (uploaded here, on the collate's stream)
-            from .pointnet import stage_flags
-            stage_flags(clouds_flag)
         clouds_meta = [item for sublist in clouds_meta if sublist is not None for item in sublist]
+    if device_batch:
+        # Everything small of the batch goes to the device in ONE staging copy together with the edge list and the edge features
+        # (GraphConvInfo.set_batch_device(extras=...)): CloudEmbedder's two index vectors, the label vectors the trainer uploads
+        # (learning/main.py:202-205: majority label / per-class point counts) and -- from a host-side loader -- the diameters.
+        from .pointnet import attach_staged_flags, flag_index_vectors
+        extras = [None, None, targets[:, 0].contiguous(), targets[:, 2:].contiguous(), None]
+        if has_clouds:
+            extras[0], extras[1] = flag_index_vectors(clouds_flag)
+            if not clouds_global.is_cuda and not clouds_global.is_pinned():
+                extras[4] = clouds_global
+        gi = ecc.GraphConvInfo()
+        gi.set_batch_device(graphs, cloud_edge_feats, extras=extras)
+        GIs = [gi]
+        dev_x = gi.extras_dev
+        if has_clouds:
+            attach_staged_flags(clouds_flag, dev_x[0], dev_x[1])
+            if dev_x[4] is not None:
+                clouds_global = dev_x[4]
+        targets._spg_labels_dev = (dev_x[2], dev_x[3])      # (label_mode, label_vec) on the device: learning/main.py uses them if present
+    else:
+        GIs = [ecc.GraphConvInfo(graphs, cloud_edge_feats)]
     return targets, GIs, (clouds_meta, clouds_flag, clouds, clouds_global)
 
 

@@ -64,6 +64,34 @@ def upload(host: torch.Tensor, device=None) -> torch.Tensor:
     return out
 
 
+def upload_packed(hosts, device=None):
+    """Several small host tensors -> ONE staging copy -> views of one device buffer (include/spg_hip.h: spg_upload_packed), in the
+    order given; None entries stay None.  What a fresh batch needs on the device besides its clouds travels this way (edge list,
+    edge features, CloudEmbedder's index vectors, labels, diameters): one memcpy-and-enqueue instead of one per vector."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.index is not None and device.index != torch.cuda.current_device():
+        raise RuntimeError(f'upload_packed: target cuda:{device.index} is not the current device cuda:{torch.cuda.current_device()}')
+    live = [(i, t.contiguous()) for i, t in enumerate(hosts) if t is not None]
+    for _, t in live:
+        if t.is_cuda:
+            raise TypeError('upload_packed takes host tensors')
+    n = len(live)
+    out = [None] * len(hosts)
+    if n == 0:
+        return out
+    ptrs, sizes, offs = (ctypes.c_void_p * n)(), (ctypes.c_size_t * n)(), (ctypes.c_size_t * n)()
+    total = 0
+    for k, (_, t) in enumerate(live):
+        nb = t.numel() * t.element_size()
+        ptrs[k], sizes[k], offs[k] = t.data_ptr() if nb else None, nb, total
+        total += (nb + 255) & ~255
+    buf = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
+    check(lib().spg_upload_packed(ptrs, sizes, offs, n, buf.data_ptr(), total, _stream()), 'spg_upload_packed')
+    for k, (i, t) in enumerate(live):
+        out[i] = buf[offs[k]:offs[k] + sizes[k]].view(t.dtype).view(t.shape)
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # graph structure
 # --------------------------------------------------------------------------------------------------
@@ -519,16 +547,22 @@ def set_batch(edges, n_nodes: int):
     return idxn, degs, perm, err
 
 
+def batch_graph_fits(n_nodes: int, n_edges: int, n_feat: int) -> bool:
+    """True when the single-launch batch builder serves a batch of this size (include/spg_hip.h: spg_batch_graph_scratch_bytes)."""
+    return n_edges > 0 and lib().spg_batch_graph_scratch_bytes(int(n_nodes), int(n_edges), int(n_feat)) > 0
+
+
 def batch_graph_build(edges_h: torch.Tensor, feats_h: Optional[torch.Tensor], n_nodes: int, device=None):
-    """The whole construction of a small batch in one launch (include/spg_hip.h: spg_batch_graph_build): HOST edges i64 [E, 2]
-    (batch node offsets applied) and HOST edge features f32 [E, F] -> (idxn, degs, feats_sorted, DeviceGraph, error flag) on the
+    """The whole construction of a small batch in one launch (include/spg_hip.h: spg_batch_graph_build / _dev): edges i64 [E, 2]
+    (batch node offsets applied) and edge features f32 [E, F], both on the HOST (uploaded here) or both on the DEVICE already -> (idxn, degs, feats_sorted, DeviceGraph, error flag) on the
     device, or None when the batch is too large for the single-workgroup builder (use set_batch + gather_rows + DeviceGraph)."""
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     E = int(edges_h.shape[0])
     F = 0 if feats_h is None else int(feats_h.shape[1])
     L = lib()
     nscratch = L.spg_batch_graph_scratch_bytes(n_nodes, E, F)
-    if nscratch == 0 or edges_h.is_cuda or (feats_h is not None and feats_h.is_cuda):
+    on_dev = edges_h.is_cuda
+    if nscratch == 0 or (feats_h is not None and feats_h.is_cuda != on_dev):
         return None
     edges_h = edges_h.contiguous()
     if edges_h.dtype != torch.int64:
@@ -543,7 +577,8 @@ def batch_graph_build(edges_h: torch.Tensor, feats_h: Optional[torch.Tensor], n_
     ws = torch.empty(L.spg_graph_workspace_bytes(n_nodes, n_nodes, E), dtype=torch.uint8, device=device)
     scratch = torch.empty(nscratch, dtype=torch.uint8, device=device)
     err = torch.empty(1, dtype=torch.int32, device=device)
-    check(L.spg_batch_graph_build(edges_h.data_ptr() if E else None, feats_h.data_ptr() if (feats_h is not None and E) else None, n_nodes, E, F,
+    # (inputs already on the device: uploaded with the batch's other small vectors by ONE upload_packed)
+    check((L.spg_batch_graph_build_dev if on_dev else L.spg_batch_graph_build)(edges_h.data_ptr() if E else None, feats_h.data_ptr() if (feats_h is not None and E) else None, n_nodes, E, F,
                                   _ptr(idxn) if E else None, _ptr(degs), _ptr(feats) if (feats is not None and E) else None, _ptr(ws),
                                   _ptr(scratch), _ptr(err), _stream()), 'spg_batch_graph_build')
     return idxn, degs, feats, DeviceGraph.from_workspace(ws, idxn, degs), err
