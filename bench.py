@@ -281,7 +281,7 @@ def other_workloads(args, log):
               '--no-extras', '--fused-step', str(args.fused_step)]
     sema = ['--n-sp', '10000', '--n-edges', '50000', '--n-feat', '11', '--model-config', 'gru_10,f_8']
     runs = {'s3dis_2_scenes_per_step_f32': ['--scenes', '2'], 's3dis_8_scenes_per_step_f32': ['--scenes', '8'],
-            'semantic3d_scale_f32': sema, 'semantic3d_scale_bf16x3': sema + ['--precision', 'bf16x3']}
+            'semantic3d_scale_f32': sema + ['--infer-line'], 'semantic3d_scale_bf16x3': sema + ['--precision', 'bf16x3']}
     out = {}
     for name, extra in runs.items():
         try:
@@ -293,11 +293,53 @@ def other_workloads(args, log):
                          'workload': d['config']['workload'], 'roofline_bound': rf.get('bound'), 'roofline_frac': rf.get('frac'), 'roofline_note': rf.get('bound_note'),
                          'roofline_unit': rf.get('unit'), 'roofline_achieved': rf.get('achieved'), 'dominant_frac_of_fp32_mfma_peak': rf.get('dominant_frac'),
                          'launches_per_step_gemm': rf.get('launches_per_step')}
+            if 'inference' in d:      # the evaluation forward at this scale (eval_final: 10 passes per scene)
+                out[name + '_inference'] = d['inference']
             log(f'{name}: {d["value"]:.0f} superpoints/s, {d["ms_per_step"]:.3f} ms/step, roofline {rf.get("bound")} {rf.get("frac")}')
         except Exception as e:      # a side measurement must never take the headline down
             out[name] = {'error': f'{type(e).__name__}: {e}'}
             log(f'{name}: failed ({e})')
     return out
+
+
+def inference_line(args, dev, model, flag, clouds_d, diam_d, GIs, iters=30):
+    """the evaluation forward of the FULL model of this run (learning/main.py:246-262; eval_final runs it 10
+    times per scene, :267-311) as ONE library call (spg_infer_step), with its roofline: algorithmic forward FLOP of the two
+    PointNet segments and the filter network / time against the fp32-MFMA peak (the fused inference stacks of DESIGN 4.7 are
+    MFMA-bound: activations never leave the CU)."""
+    from superpoint_graph_amd.flat import FlatParameters
+    from superpoint_graph_amd.fused import FusedStep
+    was_training = model.training
+    model.eval()
+    try:
+        step = FusedStep(model, FlatParameters(model, lazy_zero=True))
+        model.ecc.set_info(GIs, 1)
+        for _ in range(5):
+            step.infer(flag, clouds_d, diam_d, GIs[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            step.infer(flag, clouds_d, diam_d, GIs[0])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+    finally:
+        model.train(was_training)
+    B, P = int(clouds_d.shape[0]), int(clouds_d.shape[2])
+    ptn = model.ptn
+    conv_mac = lambda nin, widths: sum(a * b for a, b in zip([nin] + list(widths[:-1]), widths))
+    stn = ptn.stn if getattr(ptn, 'nfeat_stn', 0) > 0 else None
+    mac_pt = conv_mac(int(clouds_d.shape[1]), list(ptn._nf_conv)) + (conv_mac(stn._nfeat, list(stn._nf_conv)) if stn is not None else 0)
+    mac_sp = conv_mac(ptn._nf_conv[-1] + ptn._nfeat_global, list(ptn._nf_fc)) + (conv_mac(stn._nf_conv[-1], list(stn._nf_fc) + [stn._K * stn._K]) if stn is not None else 0)
+    E = int(GIs[0].get_buffers()[0].numel())
+    fnet = model.ecc.gconvs[0]._fnet
+    mac_edge = sum(m.weight.shape[0] * m.weight.shape[1] for m in fnet if hasattr(m, 'weight') and m.weight.dim() == 2)
+    gflop = 2.0 * (B * (P * mac_pt + mac_sp) + E * mac_edge) / 1e9
+    return {'workload': f'evaluation forward (running BatchNorm statistics) of {args.model_config} as ONE call (spg_infer_step): '
+                        f'{int(flag.numel())} superpoints x {P} pts x {int(clouds_d.shape[1])} f, {E} edges',
+            'ms': dt * 1e3, 'superpoints_per_s': int(flag.numel()) / dt, 'algorithmic_gflop': gflop,
+            'roofline': {'bound': 'mfma', 'achieved': gflop / dt / 1e3, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': gflop / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+                         'what': 'PointNet segments + filter network forward FLOP (the RNN-ECC iterations are latency / L2-bound and not counted) / wall time of the whole call'}}
 
 
 def forward_only(dev, flag, clouds_d, diam_d, GIs, n_feat, iters=40):
@@ -382,6 +424,7 @@ def main():
     ap.add_argument('--no-live-pmc', action='store_true', help='do not run the two rocprofv3 PMC passes for roofline.traffic (use the committed file)')
     ap.add_argument('--hipgraph', type=int, default=0, help='capture the step in a hipGraph (torch.cuda.CUDAGraph) and replay it')
     ap.add_argument('--fused-step', type=int, default=1, help='1 (default): forward + backward as ONE library call (superpoint_graph_amd/fused.py: spg_train_step; same kernels and results as the module path, tests/test_gpu_fused.py); 0: CloudEmbedder.run -> model.ecc -> cross_entropy -> backward -> bw_hook through the modules')
+    ap.add_argument('--infer-line', action='store_true', help='also time the evaluation forward of this run\'s model as one call (spg_infer_step) and report it with its roofline (`inference`)')
     ap.add_argument('--no-extras', action='store_true', help='skip the short runs of the other BASELINE.json configurations (2 / 8 scenes per step, Semantic3D scale in f32 and split-bf16) and the sustained repeat')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -758,6 +801,9 @@ def main():
         log(f'host enqueue of one step: {result["host_step_enqueue_ms"]:.3f} ms')
     if world == 1 and not args.no_trainer_window:
         result['trainer_window'] = trainer_window(args, dev, model, embedder, arena, seeds, n_classes, log, fstep=fstep)
+    if world == 1 and args.infer_line:
+        result['inference'] = inference_line(args, dev, model, flag, clouds_d, diam_d, GIs)
+        log(f'inference: {result["inference"]["ms"]:.3f} ms per forward, {result["inference"]["superpoints_per_s"]:.0f} superpoints/s, {result["inference"]["roofline"]["frac"]:.3f} of the fp32-MFMA peak')
     if world > 1:
         dist.barrier()
     if rank == 0:
