@@ -490,6 +490,9 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * forces a time-out with it); 0 (default) = the built-in bound.
  * key 21: 1 = spg_adam_clamp_step* ignore the time-out word of the one-launch recurrences (see spg_ecc_persistent_status); default 0:
  * the update is withheld while the word is non-zero.
+ * key 22: 1 = the pooled convolution of a PointNet segment with 128 -> 256 channels keeps its separate weight-gradient and
+ * data-gradient launches (+ finalize); default (round 6): the fused backward pair as two launches over the halves of its output
+ * channels (spg_gemm.hip: spg_queue_bwdpair; 196 -> 167 us on the unit scene; results agree at fp32 round-off, tests/test_gpu_bwdpair.py).
  * Returns the previous value, -1 for an unknown key. */
 int spg_tune(int key, int value);
 /* ------------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ extern "C" const char* spg_last_error(void);
 void spg_set_error(const char* fmt, ...);
 // tuning knobs (process-global; defaults are the production values): see spg_tune in include/spg_hip.h
 enum { SPG_TUNE_NO_PERSIST = 0, SPG_TUNE_DBG = 3, SPG_TUNE_FIN_SLICE_MIN = 4, SPG_TUNE_NO_STAT_ACCUM = 5, SPG_TUNE_NO_HEAD_SERVICE = 6, SPG_TUNE_PRECISION = 7,
-       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_SIDE_STREAM = 9, SPG_TUNE_NO_BN_FOLD = 10, SPG_TUNE_NO_GROUP = 11, SPG_TUNE_SPLITK = 12, SPG_TUNE_NO_VEC_GENERIC = 13, SPG_TUNE_NO_BWD_PAIR = 14, SPG_TUNE_NO_ECC_HEAD = 15, SPG_TUNE_LEAVES = 16, SPG_TUNE_NO_NARROW_PAIR = 17, SPG_TUNE_NO_FIRST_CONV_BWD = 18, SPG_TUNE_NO_OWNER_FIRST = 19, SPG_TUNE_PX_SPIN_LIMIT = 20, SPG_TUNE_NO_ADAM_GUARD = 21, SPG_TUNE_COUNT = 22 };
+       SPG_TUNE_NO_PERSIST_ECC = 8, SPG_TUNE_SIDE_STREAM = 9, SPG_TUNE_NO_BN_FOLD = 10, SPG_TUNE_NO_GROUP = 11, SPG_TUNE_SPLITK = 12, SPG_TUNE_NO_VEC_GENERIC = 13, SPG_TUNE_NO_BWD_PAIR = 14, SPG_TUNE_NO_ECC_HEAD = 15, SPG_TUNE_LEAVES = 16, SPG_TUNE_NO_NARROW_PAIR = 17, SPG_TUNE_NO_FIRST_CONV_BWD = 18, SPG_TUNE_NO_OWNER_FIRST = 19, SPG_TUNE_PX_SPIN_LIMIT = 20, SPG_TUNE_NO_ADAM_GUARD = 21, SPG_TUNE_NO_PAIR_SPLIT = 22, SPG_TUNE_COUNT = 23 };
 int spg_tune_get(int key);
 
 // Fork / join of a library-owned side stream (one per device, created on first use): a latency-bound chain of small-grid

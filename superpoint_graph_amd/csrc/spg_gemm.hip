@@ -1627,10 +1627,19 @@ static void wgrad_plan(long M, int N, int K, int* IT, int* JT, int* nsplit, int*
   *IT = it; *JT = jt; *rps = (int)rows; *nsplit = spg_cdiv(M, rows);
 }
 
+constexpr int spg_bwdpair_rows(int ci) { return 4096 / ci; }      // rows per tile of the fused backward pair (spg_bwdpair_kernel)
 size_t spg_wgrad_workspace_floats(long M, int N, int K) {
   int it, jt, ns, rps;
   wgrad_plan(M, N, K, &it, &jt, &ns, &rps);
-  const size_t w = (size_t)ns * N * K, c = (size_t)64 * N;   // also large enough for spg_launch_colsum over N columns
+  size_t w = (size_t)ns * N * K;
+  const size_t c = (size_t)64 * N;   // also large enough for spg_launch_colsum over N columns
+  // (the fused backward pair writes one partial per workgroup, one workgroup per CU: for the two-pass 128 -> 256 form that is a
+  //  little more than the split plan's own count -- spg_queue_bwdpair)
+  if (N == 256 && K == 128 && M >= spg_bwdpair_rows(K) && M % spg_bwdpair_rows(K) == 0) {
+    const long ntile = M / spg_bwdpair_rows(K);
+    const size_t w2 = (size_t)(ntile < spg_num_cus() ? ntile : spg_num_cus()) * N * K;
+    w = w2 > w ? w2 : w;
+  }
   return w > c ? w : c;
 }
 
@@ -1928,10 +1937,14 @@ int spg_queue_wgrad(SpgReduceQueue& q, SpgWgradParams p, float* dW, hipStream_t 
 
 // spg_epilogue_bwd_vec with the producer's raw output read from LDS (the tile the loaders staged: [IT][ldl] floats, all JT
 // channels) instead of from global memory: no load latency inside the epilogue -- its four waves are the only ones that run it
+// pass (uniform): 0 = the whole layer; 1 = the FIRST half of the layer's output channels of a two-launch pair (spg_queue_bwdpair:
+// 128 -> 256, whose weight matrix does not fit LDS): the partial data gradient is stored as it is -- no mask, no sums; 2 = the
+// SECOND half: the stored partial of pass 1 is added first (one dwordx4 load per output quad, issued before the staging), then
+// mask / sums / store as usual
 template <int IT, int JT, int WI, int WJ>
 __device__ __forceinline__ void spg_epilogue_bwd_vec_lds(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
                                                          float* __restrict__ red, const float* __restrict__ ylds, int ldl, long m0,
-                                                         SpgStatAcc<JT / WJ / 32>& sacc) {
+                                                         SpgStatAcc<JT / WJ / 32>& sacc, const int pass) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32, RW = IT / WI, CW = JT / WJ;
   constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR, NIT = SPG_EPI_PIECE_ROWS / RPI;
   const int tid = threadIdx.x + spg_opaque_zero(), lane = tid & 63, wave = (tid >> 6) & 3;
@@ -1947,6 +1960,16 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec_lds(const SpgGemmParams& p,
   float* yo = p.Y + (m0 + roww) * p.ldy + colw;
   const unsigned oo0 = (unsigned)lr * (unsigned)p.ldy + (unsigned)lc;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  f32x4 prev[TI * 2 * NIT];
+  if (pass == 2) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int u = 0; u < NIT; ++u)
+          prev[(2 * i + half) * NIT + u] = *reinterpret_cast<const f32x4*>(yo + oo0 + (unsigned)(32 * i + 16 * half + RPI * u) * (unsigned)p.ldy);
+  }
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -1959,13 +1982,16 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec_lds(const SpgGemmParams& p,
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
         f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * u) * LD + lc);
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(yl + (rb + RPI * u) * ldl);
+        if (pass == 2) v += prev[(2 * i + half) * NIT + u];
+        if (pass != 1) {
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(yl + (rb + RPI * u) * ldl);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float y = yv[e];
-          if (!(fmaf(y, sc[e], sh[e]) > 0.f)) v[e] = 0.f;
-          s1[e] += v[e];
-          s2[e] = fmaf(v[e], (y - mean[e]) * rstd[e], s2[e]);
+          for (int e = 0; e < 4; ++e) {
+            const float y = yv[e];
+            if (!(fmaf(y, sc[e], sh[e]) > 0.f)) v[e] = 0.f;
+            s1[e] += v[e];
+            s2[e] = fmaf(v[e], (y - mean[e]) * rstd[e], s2[e]);
+          }
         }
         *reinterpret_cast<f32x4*>(yo + oo0 + (unsigned)(rb + RPI * u) * (unsigned)p.ldy) = v;
       }
@@ -2003,6 +2029,11 @@ struct SpgBwdPairParams {
                         // stat_slots (producer), fold_bwd (this layer's sums -> constants, dgamma / dbeta; or none), ntile = M / IT
   SpgOperand b;         // the layer's input: AFFINE + ReLU over the producer's raw output (CI channels)
   float* partial;       // [grid][CO][CI]
+  int pass;             // 0: the whole layer in this launch; 1 / 2: first / second half of the layer's OUTPUT channels (a layer whose
+                        // weight matrix does not fit LDS, 128 -> 256): every pointer of `g` that is indexed by an output channel is
+                        // offset by the caller; pass 1 stores the partial data gradient raw, pass 2 adds it, masks, sums, stores;
+                        // the BatchNorm-backward fold (all CO channels of the layer) is pass 1's, the statistics contribution pass 2's
+  int pad_;
 };
 #define SPG_PAIR_THREADS 1024
 #ifdef SPG_ATTRIBUTION
@@ -2022,7 +2053,6 @@ extern "C" int spg_pair_role_times(unsigned long long* out, int clear) {
 #define SPG_TP(k)
 #define SPG_TEND(role)
 #endif
-constexpr int spg_bwdpair_rows(int ci) { return 4096 / ci; }
 template <int CO, int CI>
 constexpr size_t spg_bwdpair_lds_bytes() {
   return 2 * ((size_t)(CO / 4) * (spg_bwdpair_rows(CI) + 1) * 16 + (size_t)spg_bwdpair_rows(CI) * (CI + 4) * 4) + (size_t)CO * (CI + 4) * 4 +
@@ -2057,7 +2087,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
   // what every role does before its loop: (loaders: the first two tiles' loads, below) -- the constants of the dz prologue,
   // finished here from the layer's slots (ends with a barrier) or already there (finalize launch) -- constants and W into LDS
   auto prologue = [&]() __attribute__((always_inline)) {
-    if (g.stat_slots != nullptr && blockIdx.x == 0 && tid == 0) spg_slots_count_add(g.stat_slots, g.n_mask, g.stat_rows != 0 ? g.stat_rows : (long)g.M);
+    if (g.stat_slots != nullptr && p.pass != 1 && blockIdx.x == 0 && tid == 0) spg_slots_count_add(g.stat_slots, g.n_mask, g.stat_rows != 0 ? g.stat_rows : (long)g.M);
     if (g.fold_bwd.slots != nullptr) spg_bn_fold_bwd(g.fold_bwd, blockIdx.x == 0);
     if (tid < CQ) {
       kst[0 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c0 + 4 * tid); kst[1 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c1 + 4 * tid);
@@ -2187,7 +2217,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
       for (int q = 0; q < 16; ++q) acc[0][0][q] = 0.f;
       spg_mfma_tile_or<CO / 8, 2>(dz4, wl, SA, SX, wi * 32 + r, wj * 32 + r, h, acc[0][0]);
       SPG_TP(0);
-      spg_epilogue_bwd_vec_lds<IT, CI, WI, WJ>(g, acc, red, reinterpret_cast<const float*>(dz4 + CQ * SA), SX, (long)tile * IT, sacc);
+      spg_epilogue_bwd_vec_lds<IT, CI, WI, WJ>(g, acc, red, reinterpret_cast<const float*>(dz4 + CQ * SA), SX, (long)tile * IT, sacc, p.pass);
       SPG_TP(1);
       __syncthreads();
       SPG_TP(2);
@@ -2195,6 +2225,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
       tile = nxt; buf ^= 1;
     }
     SPG_TEND(0);
+    if (p.pass == 1) return;                      // (uniform) first half: nothing to contribute yet
     // the workgroup's ONE statistics contribution (as at the end of a persistent data-gradient stream)
     constexpr int CW = 32, LPR = CW / 4;
     float* xch = red;                             // [2][CI][2]
@@ -2260,13 +2291,15 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
 bool spg_bwdpair_supported(const SpgGemmParams& g, const SpgOperand& b) {
   if (g_tune[SPG_TUNE_NO_BWD_PAIR]) return false;      // (also in the opt-in precision modes: the fused pair computes in fp32 MFMA)
   const int CI = g.N, CO = g.K;
-  if (!(g.w_red && g.epi == SPG_EPI_BWD && ((CI == 64 && (CO == 64 || CO == 128)) || (CI == 128 && CO == 128)))) return false;
+  // (CI = 128, CO = 256 -- the pooled layer of the S3DIS / Semantic3D PointNet: two launches over the halves of its output channels)
+  if (!(g.w_red && g.epi == SPG_EPI_BWD && ((CI == 64 && (CO == 64 || CO == 128)) || (CI == 128 && (CO == 128 || (CO == 256 && !g_tune[SPG_TUNE_NO_PAIR_SPLIT])))))) return false;
   const int IT = spg_bwdpair_rows(CI);
   if (g.M < IT || g.M % IT != 0) return false;
   const SpgOperand& a = g.a;
   if (a.mode != SPG_PRO_BNBWD && a.mode != SPG_PRO_POOLBWD) return false;
   if (!spg_operand_vec_ok(a) || a.ld < CO) return false;
   if (a.mode == SPG_PRO_POOLBWD && (a.P != 128 || a.ldg < CO)) return false;
+  if (CO == 256 && g.fold_bwd.slots != nullptr && g.fold_bwd.C != CO) return false;      // (pass 1 finishes the constants of ALL channels)
   if (b.mode != SPG_PRO_AFFINE || !b.relu || b.c0 == nullptr || b.n_affine != CI || !spg_operand_vec_ok(b) || b.ld < CI) return false;
   if ((g.ldw & 3) != 0 || (((uintptr_t)g.W) & 15) != 0 || g.ldw < CI) return false;
   if (g.Y == nullptr || g.Yp == nullptr || (g.ldy & 3) != 0 || (g.ldyp & 3) != 0 || ((((uintptr_t)g.Y) | ((uintptr_t)g.Yp)) & 15) != 0) return false;
@@ -2297,7 +2330,7 @@ template <int AMODE>
 static int launch_bwdpair_shape(const SpgBwdPairParams& p, int grid, hipStream_t stream) {
   if (p.g.N == 64 && p.g.K == 64) return launch_bwdpair_t<64, 64, AMODE>(p, grid, stream);
   if (p.g.N == 64) return launch_bwdpair_t<128, 64, AMODE>(p, grid, stream);
-  return launch_bwdpair_t<128, 128, AMODE>(p, grid, stream);
+  return launch_bwdpair_t<128, 128, AMODE>(p, grid, stream);      // (also each half of a 128 -> 256 layer: p.pass 1 / 2)
 }
 
 // g: the data-gradient problem as for spg_launch_gemm (w_red = 1, epi = BWD, stat_slots, fold_bwd = this layer's pending sums or none);
@@ -2307,26 +2340,45 @@ int spg_queue_bwdpair(SpgReduceQueue& q, SpgGemmParams g, const SpgOperand& b, f
   const int IT = spg_bwdpair_rows(g.N);
   const int ntile = g.M / IT;
   const int grid = ntile < spg_num_cus() ? ntile : spg_num_cus();
-  SpgBwdPairParams p;
-  memset(&p, 0, sizeof(p));
   g.ntile = ntile; g.vec_store = 1; g.rows_per_tile = IT;
-  p.g = g; p.b = b;
-  if (q.njobs + 1 > SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(q, stream));
-  float* part = dW;
-  if (grid > 1) SPG_TRY(queue_take(q, (size_t)grid * g.K * g.N, &part, stream));
-  p.partial = part;
-  {
-    const double flops = 4.0 * (double)g.M * (double)g.K * (double)g.N;      // data gradient + weight gradient
-    ProfScope prof(stream, flops, SPG_PROF_TAG(4, 64, 64, g.a.mode, SPG_PRO_AFFINE, 1));
-    prof.r.M = g.M; prof.r.N = g.N; prof.r.K = g.K;
-    if (g.a.mode == SPG_PRO_BNBWD) SPG_TRY(launch_bwdpair_shape<SPG_PRO_BNBWD>(p, grid, stream));
-    else SPG_TRY(launch_bwdpair_shape<SPG_PRO_POOLBWD>(p, grid, stream));
+  // 128 -> 256 (the pooled layer): W (256 x 132 floats = 135 KB) does not fit LDS next to the tile buffers -- two launches of the
+  // 128 -> 128 kernel over the halves of the OUTPUT channels.  Each reads its half of (g, y) once and the layer's input once
+  // (twice in total: 65 MB more than a single pass would), its half of dW is complete; the data gradient is a sum over ALL output
+  // channels: pass 1 stores its partial, pass 2 adds it in its epilogue (65 MB more) and then masks / sums / stores.  Against the
+  // separate weight- and data-gradient launches (each applies the prologue to all of (g, y)): 0.52 -> 0.33 GB fetched, one launch
+  // chain of 2 instead of 3 (no finalize launch: the statistics leave through the slots).
+  const int npass = g.K == 256 ? 2 : 1, COh = g.K / npass;
+  for (int h = 0; h < npass; ++h) {
+    SpgBwdPairParams p;
+    memset(&p, 0, sizeof(p));
+    p.g = g; p.b = b;
+    p.pass = npass == 1 ? 0 : h + 1;
+    if (npass == 2) {
+      p.g.K = COh;
+      p.g.W = g.W + (long)h * COh * g.ldw;
+      p.g.a.X += h * COh; p.g.a.X2 += h * COh;                    // dz operand: channels [h COh, (h + 1) COh) of (g | pooled gradient, y)
+      if (p.g.a.aidx != nullptr) p.g.a.aidx += h * COh;
+      p.g.a.c0 += h * COh; p.g.a.c1 += h * COh; p.g.a.c2 += h * COh; p.g.a.c3 += h * COh;
+      if (h == 1) memset(&p.g.fold_bwd, 0, sizeof(p.g.fold_bwd));      // (pass 1 finished the constants of all channels)
+    }
+    float* dWh = dW + (long)h * COh * g.N;
+    if (q.njobs + 1 > SPG_MAX_REDUCE_JOBS) SPG_TRY(spg_flush_reduce(q, stream));
+    float* part = dWh;
+    if (grid > 1) SPG_TRY(queue_take(q, (size_t)grid * COh * g.N, &part, stream));
+    p.partial = part;
+    {
+      const double flops = 4.0 * (double)g.M * (double)COh * (double)g.N;      // data gradient + weight gradient
+      ProfScope prof(stream, flops, SPG_PROF_TAG(4, 64, 64, g.a.mode, SPG_PRO_AFFINE, 1));
+      prof.r.M = g.M; prof.r.N = g.N; prof.r.K = COh;
+      if (g.a.mode == SPG_PRO_BNBWD) SPG_TRY(launch_bwdpair_shape<SPG_PRO_BNBWD>(p, grid, stream));
+      else SPG_TRY(launch_bwdpair_shape<SPG_PRO_POOLBWD>(p, grid, stream));
+    }
+    if (grid > 1) {
+      SpgReduceJob& j = q.jobs[q.njobs++];
+      j.partial = part; j.out = dWh; j.nsplit = grid; j.n = COh * g.N;
+    }
   }
   SPG_TRY(spg_slot_sync_after(g.stat_slots, spg_fold_slot_words(g.n_mask), stream, false));      // (slot-synchronised BatchNorm)
-  if (grid > 1) {
-    SpgReduceJob& j = q.jobs[q.njobs++];
-    j.partial = part; j.out = dW; j.nsplit = grid; j.n = g.K * g.N;
-  }
   return 0;
 }
 

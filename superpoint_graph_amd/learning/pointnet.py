@@ -374,7 +374,10 @@ def stage_flags(clouds_flag):
         dev = torch.device('cuda', torch.cuda.current_device())
         idx_valid, slot = flag_index_vectors(clouds_flag)
         # (staging ring, non-blocking: a pageable H2D would stall the host until the stream has drained)
-        staged = clouds_flag._spg_staged = tuple(ops.upload_packed([idx_valid, slot], dev))
+        if clouds_flag.is_cuda:       # (a flag vector that lives on the device already: its index vectors do too)
+            staged = clouds_flag._spg_staged = (idx_valid, slot)
+        else:
+            staged = clouds_flag._spg_staged = tuple(ops.upload_packed([idx_valid, slot], dev))
     return staged
 
 

@@ -65,7 +65,9 @@ def test_fused_narrow_backward_matches_separate_launches(hip, tag):
     sep, n_sep = _run(hip, spec, batch, state0, cw, True)
     fus, n_fus = _run(hip, spec, batch, state0, cw, False)
     assert n_sep == 0
-    assert n_fus == (5 if tag == 's3dis_gru10_matrix' else 2), 'conv2 / conv3 / conv4 of the main network, conv2 / conv3 of the STN (where they have 64 / 128 input channels)'
+    # conv2 / conv3 / conv4 of the main network, conv2 / conv3 of the STN (where they have 64 / 128 input channels), and since round 6 the
+    # pooled layer conv5 (128 -> 256) as TWO launches over the halves of its output channels
+    assert n_fus == (7 if tag == 's3dis_gru10_matrix' else 2)
     worst = _compare(sep, fus, 2e-5)
     print(f'{tag}: {n_fus} fused launches, worst gradient difference {worst[1]:.2e} ({worst[0]})')
     again, _ = _run(hip, spec, batch, state0, cw, False)
@@ -91,6 +93,38 @@ def test_fused_narrow_backward_on_scenes(hip, n_sp, n_edges):
     state0 = {k: v.clone() for k, v in ref.state_dict().items()}
     sep, n_sep = _run(hip, spec, batch, state0, None, True)
     fus, n_fus = _run(hip, spec, batch, state0, None, False)
-    assert n_sep == 0 and n_fus == 5      # conv2 / conv3 of the STN, conv2 / conv3 / conv4 of the main network
+    assert n_sep == 0 and n_fus == 7      # conv2 / conv3 of the STN, conv2 / conv3 / conv4 of the main network, conv5 in two launches (round 6)
     worst = _compare(sep, fus, 2e-5)
     print(f'{n_sp} superpoints: worst gradient difference {worst[1]:.2e} ({worst[0]})')
+
+
+def test_pooled_layer_two_pass_pair_matches_its_separate_launches(hip):
+    """Round 6: the pooled layer conv5 (128 -> 256; its weight matrix does not fit LDS) runs the fused pair as TWO launches over the
+    halves of its output channels -- pass 1 stores its partial data gradient, pass 2 adds it and runs the epilogue.  Against the
+    same step with ONLY that layer on the separate weight- / data-gradient launches (spg_tune key 22 = 1; every other layer
+    fused on both sides): forward identical, every gradient within 2e-5 of its tensor's maximum, deterministic."""
+    from oracle import spg_oracle as O
+    from superpoint_graph_amd import synth
+    spec = O.ModelSpec()
+    col = synth.collate_numpy([synth.scene(9, n_sp=1000, n_edges=5000)])
+    idxn, degs, ef, _ = O.set_batch(col['edge_lists'], col['vcounts'], col['edge_feats'])
+    batch = dict(clouds_flag=torch.from_numpy(col['clouds_flag']), clouds=torch.from_numpy(col['clouds']),
+                 clouds_global=torch.from_numpy(col['clouds_global']), idxn=torch.from_numpy(idxn), degs=torch.from_numpy(degs),
+                 edgefeats=torch.from_numpy(ef), label_mode=torch.from_numpy(col['targets'][:, 0].copy()))
+    torch.manual_seed(4)
+    ref = build_model(spec)
+    with torch.no_grad():
+        ref.ptn.stn.proj.weight.normal_(0, 0.02)
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    old = hip.spg_tune(22, 1)
+    try:
+        one, n_one = _run(hip, spec, batch, state0, None, False)
+    finally:
+        hip.spg_tune(22, old)
+    two, n_two = _run(hip, spec, batch, state0, None, False)
+    assert n_one == 5 and n_two == 7
+    worst = _compare(one, two, 2e-5)
+    print(f'two-pass pooled layer: worst gradient difference {worst[1]:.2e} ({worst[0]})')
+    again, _ = _run(hip, spec, batch, state0, None, False)
+    for k in two[3]:
+        assert torch.equal(two[3][k], again[3][k]), k
