@@ -2292,7 +2292,9 @@ bool spg_bwdpair_supported(const SpgGemmParams& g, const SpgOperand& b) {
   if (g_tune[SPG_TUNE_NO_BWD_PAIR]) return false;      // (also in the opt-in precision modes: the fused pair computes in fp32 MFMA)
   const int CI = g.N, CO = g.K;
   // (CI = 128, CO = 256 -- the pooled layer of the S3DIS / Semantic3D PointNet: two launches over the halves of its output channels)
-  if (!(g.w_red && g.epi == SPG_EPI_BWD && ((CI == 64 && (CO == 64 || CO == 128)) || (CI == 128 && (CO == 128 || (CO == 256 && !g_tune[SPG_TUNE_NO_PAIR_SPLIT])))))) return false;
+  if (!(g.w_red && g.epi == SPG_EPI_BWD && ((CI == 64 && (CO == 64 || CO == 128)) || (CI == 128 && (CO == 128 || (CO == 256 && !g_tune[SPG_TUNE_NO_PAIR_SPLIT] && g_tune[SPG_TUNE_PRECISION] == 0)))))) return false;
+  // (not in the opt-in bf16 modes: there the pooled layer's stand-alone weight / data gradient run split-bf16 MFMA -- 50 + 65 us at the
+  //  unit scene's size against 167 us for the fp32 pair -- measured: Semantic3D scale split-bf16 1.44 -> 1.38 M superpoints/s with it)
   const int IT = spg_bwdpair_rows(CI);
   if (g.M < IT || g.M % IT != 0) return false;
   const SpgOperand& a = g.a;
