@@ -718,7 +718,8 @@ def main():
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                               'traffic_source': traffic_src, 'traffic_unit': 'HBM bytes per GEMM launch; ' + traffic_note,
                               'traffic_all_kernels_per_step': traffic_all,
-                              'kernel': 'spg_rowgemm_kernel + spg_wgrad_kernel (fp32 MFMA 32x32x2)',
+                              'kernel': 'spg_rowgemm_kernel + spg_bwdpair_kernel + spg_wgrad_kernel (fp32 MFMA 32x32x2)',
+                              'peak_note': 'gfx950 executes v_mfma_f32_32x32x2_f32 on the SIMD\'s fp32 lanes: a partner wave\'s VALU work ADDS to the matrix time instead of hiding behind it (profiles/r06_coissue_probe.txt: MFMA stream 3.53 ms + VALU stream 2.25 ms = 5.64 ms together; bf16 MFMA 6.98 -> 7.04 ms) -- the fused prologues / epilogues of these kernels are priced in MFMA time; under load the chip clocks ~2.0-2.1 GHz (shader cycles / kernel time, profiles/r06_bwdpair_roles.txt), the peak is quoted at 2.4 GHz',
                               'launches_per_step': launches.value / nprof, 'gemm_ms_per_step': ms.value / nprof,
                               'algorithmic_gflop_per_step': gflop_step,
                               'step_achieved': gflop_step / ms_per_step, 'step_frac': gflop_step / ms_per_step / PEAK_FP32_MFMA_TFLOPS}

@@ -5,7 +5,7 @@
 # over the steady-state window (tools/prof_summary.py), (3)+(4) --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes
 # (never with other trace domains), each followed by the known-byte-count calibration of tools/pmc_calib.py.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -21,10 +21,11 @@ d = json.load(open('$OUT/${TAG}_bench.json'))
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline frac', d['roofline']['frac'], 'hbm_frac', d['roofline'].get('hbm_frac'))
 EOF2
 
-# the round's changes on the same box, interleaved (spg_tune keys 17 / 18: the one-pass first layers forward / backward as the
-# launches they replace; 19: the round-4 job order of grouped launches; 16: weight-gradient leaves, an experiment that is off by default)
+# the round's changes on the same box, interleaved (spg_tune key 22: the pooled layer's backward as the separate weight- / data-gradient
+# launches of round 5 instead of the two-pass fused pair; key 14: no fused backward pairs at all; key 21: the optimiser's fail-safe read of
+# the recurrences' time-out word off; 17 / 18: the one-pass first layers off)
 for i in 1 2; do
-for V in "--tune 17:1,18:1,19:1" "--tune 18:1,19:1" "--tune 19:1" "" "--tune 16:1" "--sync-bn 1"; do
+for V in "--tune 14:1" "--tune 22:1" "" "--tune 21:1" "--tune 17:1,18:1" "--sync-bn 1"; do
   timeout 300 python $ROOT/bench.py --steps 40 --warmup 10 $STEPS $V 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('[$V]', round(d['ms_per_step'],4), 'min', round(d['ms_per_step_min'],4), 'median', round(d['ms_per_step_median'],4), d['config']['batchnorm'])"
 done
