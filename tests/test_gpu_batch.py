@@ -249,3 +249,34 @@ def test_set_batch_device_with_edgeless_graphs(sizes, empty):
     else:
         assert ef_d.shape[0] == 0
     dev.device_graph()          # the CSR exists (an edge-less batch is a valid graph: every node aggregates nothing)
+
+
+@pytest.mark.parametrize('sizes', [[300, 1, 120, 700], [4000, 3000]])
+def test_packed_upload_of_a_batch_equals_the_separate_uploads(hip, sizes):
+    """Round 6: everything small of a fresh batch travels in ONE staging copy (spg_upload_packed) -- the edge list and the edge
+    features for the single-launch builder (spg_batch_graph_build_dev) AND the batch's other vectors (`extras`): the buffers equal
+    those of the round-5 sequence (one spg_upload per vector) bit for bit, the extras arrive unchanged (dtype, shape, content), in
+    both the single-launch regime ([300, 1, 120, 700]) and above it ([4000, 3000]: the multi-launch path + a packed copy of the extras)."""
+    from superpoint_graph_amd import ops
+    from superpoint_graph_amd.learning import ecc, spg
+    graphs = _graphs(11, sizes)
+    n = sum(sizes)
+    rng = np.random.default_rng(5)
+    extras = [torch.from_numpy(rng.integers(0, n, 977)), None, torch.from_numpy(rng.integers(-100, 13, (n, 13))),
+              torch.from_numpy(rng.standard_normal(n).astype(np.float32)), torch.zeros(0, dtype=torch.int64)]
+    a = ecc.GraphConvInfo()
+    a.set_batch_device(graphs, spg.cloud_edge_feats)
+    b = ecc.GraphConvInfo()
+    b.set_batch_device(graphs, spg.cloud_edge_feats, extras=extras)
+    torch.cuda.synchronize()
+    for x, y in zip(a.get_buffers(), b.get_buffers()):
+        assert (x is None and y is None) or torch.equal(x.cpu(), y.cpu())
+    assert len(b.extras_dev) == len(extras) and b.extras_dev[1] is None
+    for h_, d_ in zip(extras, b.extras_dev):
+        if h_ is not None:
+            assert d_.is_cuda and d_.dtype == h_.dtype and d_.shape == h_.shape and torch.equal(d_.cpu(), h_)
+    # stand-alone form
+    ups = ops.upload_packed([extras[0], None, extras[3]])
+    assert ups[1] is None and torch.equal(ups[0].cpu(), extras[0]) and torch.equal(ups[2].cpu(), extras[3])
+    with pytest.raises(TypeError):
+        ops.upload_packed([ups[0]])
