@@ -426,6 +426,14 @@ int spg_adam_clamp_step(float* param, float* grad, float* exp_avg, float* exp_av
 int spg_adam_clamp_step_scaled(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                                float beta2, float eps, float weight_decay, float grad_clip, int step, const float* grad_div,
                                void* stream);
+/* (round 6) The same with a second, caller-supplied guard: *guard_all (a device float, may be null) != 0 withholds the update like the
+ * device's own time-out word does.  Data parallel: spg_ecc_persistent_flag writes this rank's flag (0 / 1) next to the gradients, the
+ * gradient all-reduce sums the flags, every rank passes the sum here -- one rank's time-out withholds the update on EVERY rank (the
+ * summed gradients contain its wrong ones), so the replicas stay identical (superpoint_graph_amd/flat.py: allreduce_sums). */
+int spg_adam_clamp_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, float grad_clip, int step, const float* grad_div,
+                                const float* guard_all, void* stream);
+int spg_ecc_persistent_flag(float* dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Instrumentation for bench.py: when enabled, every launch of the row-GEMM kernels is bracketed by

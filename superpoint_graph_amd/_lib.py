@@ -112,6 +112,9 @@ SIGNATURES = {
                                  ctypes.c_float, ctypes.c_float, _i, _p]),
     'spg_adam_clamp_step_scaled': (_i, [_p, _p, _p, _p, _l, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, _i, _p, _p]),
+    'spg_adam_clamp_step_guarded': (_i, [_p, _p, _p, _p, _l, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_float, _i, _p, _p, _p]),
+    'spg_ecc_persistent_flag': (_i, [_p, _p]),
     'spg_load_superpoints': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
     'spg_set_batch_workspace_bytes': (_sz, [_i, _i]),
     'spg_set_batch': (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),

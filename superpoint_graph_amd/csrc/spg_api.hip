@@ -569,15 +569,19 @@ int spg_linear_backward_deferred(const float* dY, long lddy, const float* X, lon
 __global__ void spg_adam_clamp_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
                                       float clip, float bc1, float bc2_sqrt, const float* __restrict__ grad_div,
-                                      unsigned* __restrict__ guard) {
+                                      unsigned* __restrict__ guard, const float* __restrict__ guard_all) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   // Fail-safe (round 6): guard[0] = the persistent RNN-ECC launches' time-out count of this device.  Non-zero means a wave of the
   // step whose gradients lie in `g` gave up waiting for a neighbour and went on with stale states: the gradients are WRONG, so the
   // update is withheld -- parameters and moments stay bit-identical -- and guard[1] counts the withheld launch.  The word is sticky
   // (only the host clears it: spg_ecc_persistent_status), so every later update is withheld too until the host has looked; no
   // host synchronisation is involved.  One scalar load per wave.
-  if (guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-    if (i == 0) atomicAdd(guard + 1, 1u);
+  // guard_all (data parallel): the ranks' time-out flags summed by the gradient all-reduce itself (FlatParameters.allreduce_sums) --
+  // the summed gradients contain the failed rank's wrong ones, so EVERY rank withholds, and the replicas stay identical.
+  const bool local_bad = guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  const bool any_bad = guard_all != nullptr && *guard_all != 0.f;
+  if (local_bad || any_bad) {
+    if (i == 0 && guard != nullptr) atomicAdd(guard + 1, 1u);
     return;
   }
   if (i >= n) return;
@@ -594,15 +598,34 @@ __global__ void spg_adam_clamp_kernel(float* __restrict__ p, float* __restrict__
   p[i] = p[i] - (lr / bc1) * (mi / denom);
 }
 
-extern "C" int spg_adam_clamp_step_scaled(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
-                                          float beta1, float beta2, float eps, float weight_decay, float grad_clip, int step,
-                                          const float* grad_div, void* stream) {
+extern "C" int spg_adam_clamp_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                                           float beta1, float beta2, float eps, float weight_decay, float grad_clip, int step,
+                                           const float* grad_div, const float* guard_all, void* stream) {
   SPG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad argument");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-  unsigned* guard = spg_tune_get(SPG_TUNE_NO_ADAM_GUARD) ? nullptr : spg_px_guard_words();
+  const bool off = spg_tune_get(SPG_TUNE_NO_ADAM_GUARD) != 0;
+  unsigned* guard = off ? nullptr : spg_px_guard_words();
   hipLaunchKernelGGL(spg_adam_clamp_kernel, dim3(spg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, bc1, bc2_sqrt, grad_div, guard);
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, bc1, bc2_sqrt, grad_div, guard, off ? nullptr : guard_all);
+  SPG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spg_adam_clamp_step_scaled(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                                          float beta1, float beta2, float eps, float weight_decay, float grad_clip, int step,
+                                          const float* grad_div, void* stream) {
+  return spg_adam_clamp_step_guarded(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_clip, step, grad_div, nullptr, stream);
+}
+
+// dst[0] = 1.0f if a one-launch recurrence of the current device has timed out since the host last cleared the word, else 0.0f --
+// enqueued on `stream`; the data-parallel exchange puts it next to the gradients so that the all-reduce sums the ranks' flags
+__global__ void spg_persistent_flag_kernel(const unsigned* __restrict__ guard, float* __restrict__ dst) {
+  dst[0] = (guard != nullptr && __hip_atomic_load(const_cast<unsigned*>(guard), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.f : 0.f;
+}
+extern "C" int spg_ecc_persistent_flag(float* dst, void* stream) {
+  SPG_CHECK_ARG(dst != nullptr, "null pointer");
+  hipLaunchKernelGGL(spg_persistent_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, spg_px_guard_words(), dst);
   SPG_LAUNCH_CHECK();
   return 0;
 }

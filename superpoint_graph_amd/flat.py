@@ -38,7 +38,8 @@ class FlatParameters:
             off += (p.numel() + 63) // 64 * 64
         self.numel = off
         data = torch.zeros(self.numel, dtype=dt, device=dev)
-        self._gbuf = torch.zeros(self.numel + 2, dtype=dt, device=dev)       # +2: loss-weight and loss-sum slots of the all-reduce
+        self._gbuf = torch.zeros(self.numel + 3, dtype=dt, device=dev)       # +3: loss-weight, loss-sum and time-out-flag slots of the all-reduce
+        self._guard_all = None               # set by allreduce_sums: the ranks' summed time-out flags (read by the next adam_step on the device)
         for p, off in zip(self.params, self._offsets):
             n = p.numel()
             data[off:off + n].copy_(p.data.reshape(-1))
@@ -89,10 +90,13 @@ class FlatParameters:
             self._t = 0
         self._resolve_stale()
         self._t += 1
-        _lib.check(_lib.lib().spg_adam_clamp_step_scaled(self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self._m.data_ptr(),
-                                                         self._v.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
-                                                         grad_clip, self._t, None if grad_div is None else grad_div.data_ptr(),
-                                                         torch.cuda.current_stream().cuda_stream), 'spg_adam_clamp_step')
+        guard_all = self._guard_all             # (one use: the flag belongs to the exchange of THIS step)
+        self._guard_all = None
+        _lib.check(_lib.lib().spg_adam_clamp_step_guarded(self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self._m.data_ptr(),
+                                                          self._v.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
+                                                          grad_clip, self._t, None if grad_div is None else grad_div.data_ptr(),
+                                                          None if guard_all is None else guard_all.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), 'spg_adam_clamp_step')
         self._clear_written()
 
     def rewind_steps(self, n):
@@ -159,9 +163,17 @@ class FlatParameters:
         self._gbuf[self.numel:self.numel + 1].copy_(weight.reshape(1), non_blocking=True)
         if loss_sum is not None:
             self._gbuf[self.numel + 1:self.numel + 2].copy_(loss_sum.detach().reshape(1), non_blocking=True)
+        # the fail-safe of the one-launch RNN-ECC recurrences across ranks: this rank's time-out flag (0 / 1, written on the device)
+        # travels as a third slot; the collective sums the flags and the clamp + Adam launch of EVERY rank withholds its update
+        # while the sum is non-zero -- the summed gradients contain the failed rank's wrong ones (include/spg_hip.h:
+        # spg_adam_clamp_step_guarded).  No host synchronisation.
+        if self._gbuf.is_cuda:
+            flag = self._gbuf[self.numel + 2:self.numel + 3]
+            _lib.check(_lib.lib().spg_ecc_persistent_flag(flag.data_ptr(), torch.cuda.current_stream().cuda_stream), 'spg_ecc_persistent_flag')
+            self._guard_all = flag
         native = _lib.lib().spg_rccl_world_size()
         if native > 1:
-            _lib.check(_lib.lib().spg_rccl_allreduce_sum_f32(self._gbuf.data_ptr(), self.numel + 2,
+            _lib.check(_lib.lib().spg_rccl_allreduce_sum_f32(self._gbuf.data_ptr(), self.numel + 3,
                                                              torch.cuda.current_stream().cuda_stream), 'spg_rccl_allreduce_sum_f32')
         elif dist.is_initialized() and dist.get_world_size(group) > 1:
             if dist.get_backend(group) == 'gloo' and self._gbuf.is_cuda:      # CPU-side test backend: staged through the host

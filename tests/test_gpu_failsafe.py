@@ -127,3 +127,39 @@ def test_guard_switch_and_epoch_end_check(hip):
     finally:
         hip.spg_tune(8, old8); hip.spg_tune(20, old20); hip.spg_tune(21, old21)
         ops.persistent_ecc_status(clear=True)
+
+
+def test_another_ranks_time_out_withholds_the_update_here(hip):
+    """Data parallel: the time-out flag travels as a slot of the gradient all-reduce (FlatParameters.allreduce_sums), the clamp + Adam
+    launch of every rank reads the SUM -- a rank whose own recurrence was fine withholds as well when another rank's was not (the
+    summed gradients contain that rank's wrong ones), so the replicas stay identical.  Simulated at world size 1 by writing the
+    summed flag a peer would have contributed."""
+    from superpoint_graph_amd import ops
+    from superpoint_graph_amd.learning import ecc
+    spec, batch, state0 = _scene()
+    ops.persistent_ecc_status(clear=True)
+    model, arena, step = _setup(spec, state0)
+    gi = ecc.GraphConvInfo.from_buffers(batch['idxn'].clone(), batch['degs'].clone(), batch['edgefeats'].clone())
+    model.ecc.set_info([gi], 1)
+
+    def one(flag_from_peer):
+        arena.zero_grad()
+        loss, _ = step(batch['clouds_flag'], batch['clouds'].to(DEV), batch['clouds_global'].to(DEV), gi, batch['label_mode'].to(DEV))
+        arena.allreduce_sums(step.normaliser, loss)
+        if flag_from_peer:
+            arena._gbuf[arena.numel + 2] += 1.0            # what the all-reduce would have added
+        arena.adam_step(lr=1e-3, grad_clip=1.0, grad_div=arena.normaliser)
+        torch.cuda.synchronize()
+
+    one(False)
+    p1, m1 = _params(model), arena._m.clone()
+    assert ops.persistent_ecc_status() == (0, 0)
+    one(True)
+    assert ops.persistent_ecc_status() == (0, 1)           # no local time-out, one update withheld
+    for k, v in _params(model).items():
+        assert torch.equal(v, p1[k]), k
+    assert torch.equal(arena._m, m1)
+    ops.persistent_ecc_status(clear=True)
+    one(False)                                             # the flag is per exchange: the next step goes through
+    assert any(not torch.equal(v, p1[k]) for k, v in _params(model).items())
+    assert ops.persistent_ecc_status() == (0, 0)
