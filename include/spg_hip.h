@@ -495,7 +495,8 @@ int spg_prof_read_shapes(int* keys, double* vals, int max);
  * follow (bit-identical; -8.6 us per step: the job spans of an attribution build showed the FC head's data gradient starting 17 us
  * into a 42 us launch, behind 581 riding weight-gradient workgroups; bench.py --group-trace).
  * key 20: > 0 = a spin bound for the waits of the one-launch recurrences below the built-in one (tests only: tests/test_gpu_failsafe.py
- * forces a time-out with it); 0 (default) = the built-in bound.
+ * forces a time-out with it); -1 = every wait reports a time-out at once, whether its data had arrived or not (deterministic on the
+ * smallest graphs: tests/test_gpu_main.py); 0 (default) = the built-in bound.
  * key 21: 1 = spg_adam_clamp_step* ignore the time-out word of the one-launch recurrences (see spg_ecc_persistent_status); default 0:
  * the update is withheld while the word is non-zero.
  * key 22: 1 = the pooled convolution of a PointNet segment with 128 -> 256 channels keeps its separate weight-gradient and

@@ -942,6 +942,7 @@ int spg_launch_copy2d(const float* src, long lds, float* dst, long ldd, long row
 #define SPG_PX_KMAX2B 2        // ... backward
 #define SPG_PX_CH 32           // edges gathered per pass (wave-private LDS staging)
 #define SPG_PX_SPIN_LIMIT 400000
+#define SPG_PX_SPIN_FORCED 0xffffffffu   // spg_tune key 20 = -1: every wait reports a time-out at once (tests; the data may or may not be stale)
 
 typedef __attribute__((address_space(1))) unsigned long long spg_gu64;
 typedef __attribute__((address_space(1))) unsigned spg_gu32;
@@ -997,8 +998,9 @@ __device__ __forceinline__ void spg_px_gather_granules_t(const unsigned long lon
         if (u < n) ok = ok && (unsigned)(x[k] >> 32) == tag;
       }
       const bool done = __all(ok);
-      if (done || spins > limit) {
-        if (!done && lane == 0) atomicAdd(ctl + 2, 1u);      // never hang: flag the error and go on with what is there
+      const bool forced = limit == SPG_PX_SPIN_FORCED;       // (uniform; the tests' deterministic time-out)
+      if (done || forced || spins > limit) {
+        if ((!done || forced) && lane == 0) atomicAdd(ctl + 2, 1u);   // never hang: flag the error and go on with what is there
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
           const int u = p + 2 * k + half;
@@ -1021,6 +1023,7 @@ __device__ __forceinline__ void spg_px_gather_granules(const unsigned long long*
 // time-out with it; read once per wave (a scalar load)
 __device__ __forceinline__ unsigned spg_px_spin_limit(const unsigned* ctl) {
   const unsigned v = __hip_atomic_load((spg_gu32*)(ctl + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v == SPG_PX_SPIN_FORCED) return v;
   return v != 0u && v < (unsigned)SPG_PX_SPIN_LIMIT ? v : (unsigned)SPG_PX_SPIN_LIMIT;
 }
 
@@ -1934,7 +1937,7 @@ static char* px_acquire(const SpgPxGroups& groups, int R, hipStream_t stream) {
     static int g_px_limit[SPG_MAX_DEVICES] = {0};
     const int want = spg_tune_get(SPG_TUNE_PX_SPIN_LIMIT);
     if (want != g_px_limit[dev]) {
-      const unsigned v = want > 0 ? (unsigned)want : 0u;
+      const unsigned v = want > 0 ? (unsigned)want : want == -1 ? SPG_PX_SPIN_FORCED : 0u;
       if (hipMemcpy((char*)g_px_buf[dev] + 4 * sizeof(unsigned), &v, sizeof(v), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
       g_px_limit[dev] = want;
     }
