@@ -102,6 +102,22 @@ __device__ __forceinline__ float spg_bnbwd_value(float a, float x, float b, floa
   return fmaf(a, x - b, -__fmul_rn(y - c, d));
 }
 
+// PACKED forms (round 6): gfx950 has two-wide fp32 VALU operations (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 on aligned
+// register pairs) and an fp32 MFMA shares the SIMD's issue with EVERY VALU operation -- a packed one costs what a plain one costs
+// (tools/probe/coissue_probe.hip: 8 v_fma_f32 or 8 v_pk_fma_f32 behind each MFMA: 108.2 cycles per MFMA either way), so the staging
+// and epilogue arithmetic of the fp32 GEMM kernels is written on float2 / float4 values where the elements are independent.
+// Element by element these are the SAME IEEE operations in the same order as the scalar forms above (bit-identical results).
+typedef float spg_f32x2 __attribute__((ext_vector_type(2)));
+typedef float spg_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ spg_f32x4 spg_fma4(spg_f32x4 a, spg_f32x4 b, spg_f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ spg_f32x2 spg_fma2(spg_f32x2 a, spg_f32x2 b, spg_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ spg_f32x4 spg_bnbwd_value4(spg_f32x4 a, spg_f32x4 x, spg_f32x4 b, spg_f32x4 y, spg_f32x4 c, spg_f32x4 d) {
+#pragma clang fp contract(off)
+  const spg_f32x4 t = (y - c) * d;          // (never contracted: see spg_bnbwd_value)
+  const spg_f32x4 u = x - b;
+  return __builtin_elementwise_fma(a, u, -t);
+}
+
 __device__ __forceinline__ float spg_fetch(const SpgOperand& d, long m, int c) {
   switch (d.mode) {
     case SPG_PRO_IDENT:
@@ -1014,18 +1030,14 @@ __device__ __forceinline__ f32x4 spg_finish_fast(const SpgQuad& q, const SpgRaw&
   if (MODE == SPG_PRO_IDENT) {
     v = r.x;
   } else if (MODE == SPG_PRO_AFFINE) {
+    const f32x4 t = spg_fma4(r.x, q.a, q.b);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(r.x[e], q.a[e], q.b[e]), lo);
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(t[e], lo);
   } else if (MODE == SPG_PRO_BNBWD) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = spg_bnbwd_value(q.a[e], r.x[e], q.b[e], r.y[e], q.c[e], q.d[e]);
+    v = spg_bnbwd_value4(q.a, r.x, q.b, r.y, q.c, q.d);
   } else {   // POOLBWD: the pooled gradient goes to the arg-max point of each (group, channel)
-    const float g0 = pai.x == pp ? px[0] : 0.f, g1 = pai.y == pp ? px[1] : 0.f;
-    const float g2 = pai.z == pp ? px[2] : 0.f, g3 = pai.w == pp ? px[3] : 0.f;
-    v[0] = spg_bnbwd_value(q.a[0], g0, q.b[0], r.y[0], q.c[0], q.d[0]);
-    v[1] = spg_bnbwd_value(q.a[1], g1, q.b[1], r.y[1], q.c[1], q.d[1]);
-    v[2] = spg_bnbwd_value(q.a[2], g2, q.b[2], r.y[2], q.c[2], q.d[2]);
-    v[3] = spg_bnbwd_value(q.a[3], g3, q.b[3], r.y[3], q.c[3], q.d[3]);
+    const f32x4 g = {pai.x == pp ? px[0] : 0.f, pai.y == pp ? px[1] : 0.f, pai.z == pp ? px[2] : 0.f, pai.w == pp ? px[3] : 0.f};
+    v = spg_bnbwd_value4(q.a, g, q.b, r.y, q.c, q.d);
   }
   return v;
 }

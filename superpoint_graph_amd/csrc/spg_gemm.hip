@@ -349,14 +349,26 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
       s += __shfl_xor(s, 32, 64);
       const float mean = s * inv;
       float m2 = 0.f;
+      if constexpr (FULL) {      // (the differences two at a time: v_pk_add_f32 on the accumulator pairs; the chain of FMAs as before)
+        const spg_f32x2 mean2 = {mean, mean};
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-          if (FULL || roww + 32 * i + spg_acc_row(q, h) < mvalid) {
-            const float d = acc[i][j][q] - mean;
-            m2 = fmaf(d, d, m2);
+          for (int q = 0; q < 16; q += 2) {
+            const spg_f32x2 d = spg_f32x2{acc[i][j][q], acc[i][j][q + 1]} - mean2;
+            m2 = fmaf(d[0], d[0], m2);
+            m2 = fmaf(d[1], d[1], m2);
           }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (roww + 32 * i + spg_acc_row(q, h) < mvalid) {
+              const float d = acc[i][j][q] - mean;
+              m2 = fmaf(d, d, m2);
+            }
+      }
       m2 += __shfl_xor(m2, 32, 64);
       if (sacc != nullptr) {             // persistent stream: merge into the running (rows, mean, M2) of this column
         const float na = sacc->n, nb = (float)nvw, nn = na + nb;
@@ -388,15 +400,21 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
       const float sg = (p.pool_sign != nullptr && p.pool_sign[colok ? col : 0] < 0.f) ? -1.f : 1.f;
       float kb = -FLT_MAX;
       int ib = INT_MAX;
+      const spg_f32x2 sg2 = {sg, sg};
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          // rows are visited in increasing order: a strict comparison keeps the FIRST extremum (torch's tie rule)
-          const int row = roww + 32 * i + spg_acc_row(q, h);
-          const float key = acc[i][j][q] * sg;
-          const bool gt = (FULL || row < mvalid) && key > kb;
-          kb = gt ? key : kb; ib = gt ? row : ib;
+        for (int q2 = 0; q2 < 16; q2 += 2) {
+          const spg_f32x2 key2 = spg_f32x2{acc[i][j][q2], acc[i][j][q2 + 1]} * sg2;      // (v_pk_mul_f32)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            // rows are visited in increasing order: a strict comparison keeps the FIRST extremum (torch's tie rule)
+            const int q = q2 + e;
+            const int row = roww + 32 * i + spg_acc_row(q, h);
+            const float key = key2[e];
+            const bool gt = (FULL || row < mvalid) && key > kb;
+            kb = gt ? key : kb; ib = gt ? row : ib;
+          }
         }
       const float ok = __shfl_xor(kb, 32, 64);
       const int oi = __shfl_xor(ib, 32, 64);
@@ -495,14 +513,16 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
         f32x4 v = *reinterpret_cast<const f32x4*>(st + (lr + RPI * u) * LD + lc);
+        const f32x4 y = use_y ? yv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (do_mask) {
+          const f32x4 act = spg_fma4(y, sc, sh);                                  // (packed: two channels per VALU operation)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float y = use_y ? yv[u][e] : 0.f;
-          if (do_mask && !(fmaf(y, sc[e], sh[e]) > 0.f)) v[e] = 0.f;
-          if (do_stats) {
-            s1[e] += v[e];
-            s2[e] = fmaf(v[e], (y - mean[e]) * rstd[e], s2[e]);
-          }
+          for (int e = 0; e < 4; ++e)
+            if (!(act[e] > 0.f)) v[e] = 0.f;
+        }
+        if (do_stats) {
+          s1 += v;
+          s2 = spg_fma4(v, (y - mean) * rstd, s2);
         }
         *reinterpret_cast<f32x4*>(yo + oo0 + (unsigned)(rb + RPI * u) * (unsigned)p.ldy) = v;
       }
@@ -729,6 +749,11 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
     // chunk are issued after the epilogue instead of under the last chunk -- nothing but the accumulators and the
     // loop-invariant offsets is then live across the epilogue (no spills)
     constexpr bool DEFER2 = WRED;
+    // Two workgroups share a CU (launch bounds); dispatched together they run the same phases at the same time -- both in the
+    // epilogue = no MFMA work on that CU.  The second round of workgroups (b >= 256 lands on the CU of b - 256) starts ~2 us late, so
+    // that one's epilogue falls under the other's chunk loop (A/B on one box, 2 x 2 runs: 1.153 -> 1.148 ms per step, 8 scenes
+    // 6.90 -> 6.86; 4 us the same, 8 us nothing).  Timing only: no effect on any result.
+    if (STREAM && !WRED && ((bx >> 8) & 1)) { __builtin_amdgcn_s_sleep(32); __builtin_amdgcn_s_sleep(32); }
     for (;;) {
       tile = __builtin_amdgcn_readfirstlane(tile);             // wave-uniform by construction: keep the tile stream in SGPRs
       m0 = (long)tile * p.rows_per_tile;
@@ -745,10 +770,12 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
           const float t = p.bias[col < p.N ? col : 0];
           bv = col < p.N ? t : 0.f;
         }
+        // (as 64-bit values: v_mov_b64, 8 instead of 16 VALU operations per 32 x 32 block)
+        typedef double spg_f64x8 __attribute__((ext_vector_type(8)));
+        const double bd = __builtin_bit_cast(double, spg_f32x2{bv, bv});
+        const spg_f64x8 b8 = {bd, bd, bd, bd, bd, bd, bd, bd};
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) acc[i][j][q] = bv;
+        for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_bit_cast(f32x16, b8);
       }
       // body(c, F, L): MFMAs of chunk c; finish chunk c+1 from set F; load chunk c+2 into set L (the one finished last
       // time).  Chunks nchunk, nchunk+1 are chunks 0, 1 of the NEXT tile of this workgroup (clamped re-loads of the last
@@ -1985,13 +2012,12 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec_lds(const SpgGemmParams& p,
         if (pass == 2) v += prev[(2 * i + half) * NIT + u];
         if (pass != 1) {
           const f32x4 yv = *reinterpret_cast<const f32x4*>(yl + (rb + RPI * u) * ldl);
+          const f32x4 act = spg_fma4(yv, sc, sh), xhat = (yv - mean) * rstd;      // (packed: two channels per VALU operation)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float y = yv[e];
-            if (!(fmaf(y, sc[e], sh[e]) > 0.f)) v[e] = 0.f;
-            s1[e] += v[e];
-            s2[e] = fmaf(v[e], (y - mean[e]) * rstd[e], s2[e]);
-          }
+          for (int e = 0; e < 4; ++e)
+            if (!(act[e] > 0.f)) v[e] = 0.f;
+          s1 += v;
+          s2 = spg_fma4(v, xhat, s2);
         }
         *reinterpret_cast<f32x4*>(yo + oo0 + (unsigned)(rb + RPI * u) * (unsigned)p.ldy) = v;
       }
@@ -2149,10 +2175,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
         } else {
           gv = R.pg[i];
         }
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = spg_bnbwd_value(ka[e], gv[e], kb[e], R.py[i][e], kc[e], kd[e]);
-        dz4[cq * SA + row] = v;
+        dz4[cq * SA + row] = spg_bnbwd_value4(ka, gv, kb, R.py[i], kc, kd);
       }
       // the producer's RAW output: the weight-gradient waves apply scale / shift / ReLU when they read their operand, the
       // data-gradient waves' epilogue needs the raw value (ReLU mask, xhat)

@@ -108,6 +108,40 @@ __global__ __launch_bounds__(THREADS, 1) void mixed(float* out, int n, const flo
   out[blockIdx.x * THREADS + tid] = res;
 }
 
+// the same with OTHER VALU operations behind each MFMA: OP 1 = v_pk_fma_f32 (two fp32 FMAs per lane), 2 = v_mov_b64, 3 = v_mov_b32,
+// 4 = v_max_f32, 5 = v_cndmask_b32 (round 6: is a packed operation charged like one plain operation?)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int KV, int THREADS, int OP>
+__global__ __launch_bounds__(THREADS, 1) void mixed_op(float* out, int n, const float* in) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+  const float a = in[lane], b = in[lane + 64];
+  f32x2 x[16];
+  for (int i = 0; i < 16; ++i) { x[i][0] = in[lane + i]; x[i][1] = in[lane + 32 + i]; }
+  const f32x2 m = {in[200 + lane], in[201 + lane]}, c = {in[300 + lane], in[301 + lane]};
+  for (int it = 0; it < n; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+          if constexpr (OP == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x[v]) : "v"(m), "v"(c));
+          else if constexpr (OP == 2) asm volatile("v_mov_b64 %0, %1" : "+v"(x[v]) : "v"(m));
+          else if constexpr (OP == 3) asm volatile("v_mov_b32 %0, %1" : "+v"(x[v][0]) : "v"(m[0]));
+          else if constexpr (OP == 4) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[v][0]) : "v"(m[0]));
+          else asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[v][0]) : "v"(m[0]));
+        }
+      }
+  }
+  float res = 0.f;
+  for (int i = 0; i < 4; ++i) for (int q = 0; q < 16; ++q) res += acc[i][q];
+  for (int i = 0; i < 16; ++i) res += x[i][0] + x[i][1];
+  out[blockIdx.x * THREADS + tid] = res;
+}
+
 template <class F>
 static float timeit(F&& launch) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -150,5 +184,13 @@ int main() {
   MIXED(4, 512, "2 waves/SIMD, k = 4");
   MIXED(8, 512, "2 waves/SIMD, k = 8");
   MIXED(16, 512, "2 waves/SIMD, k = 16");
+  printf("== mixed_op: 8 operations of another kind behind each MFMA, 1 wave/SIMD ==\n");
+#define MIXOP(OP, name) { const float ms = timeit([&] { hipLaunchKernelGGL((mixed_op<8, 256, OP>), dim3(blocks), dim3(256), 0, 0, out, 1000, in); }); \
+    const double cyc = ms * 1e-3 * 2.4e9 / (1000.0 * 64); printf("%-58s %8.3f ms  %6.1f cycles per MFMA per SIMD (at 2.4 GHz)\n", name, ms, cyc); fflush(stdout); }
+  MIXOP(1, "k = 8 v_pk_fma_f32");
+  MIXOP(2, "k = 8 v_mov_b64");
+  MIXOP(3, "k = 8 v_mov_b32");
+  MIXOP(4, "k = 8 v_max_f32");
+  MIXOP(5, "k = 8 v_cndmask_b32");
   return 0;
 }
