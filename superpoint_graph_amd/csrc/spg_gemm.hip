@@ -287,18 +287,31 @@ struct SpgStatAcc {
   float n;
   float a[TJ], b[TJ];        // forward: mean, M2 (lane = column); backward (vector epilogue): unused
   f32x4 s1, s2;              // backward vector epilogue: sum dz, sum dz*xhat of the lane's channel quad
+  float sg[TJ];              // forward, pooled layer: the BatchNorm scale of the lane's columns (its sign is what the pooling needs;
+  bool has_sg;               //   loop-invariant: loaded once by a persistent stream, has_sg says so)
 };
+// ROUND 6: this struct must stay in REGISTERS.  It used to reach the epilogues as `accum ? &sacc : nullptr`; a conditional address
+// defeats scalar replacement, the running statistics lived in scratch memory, and every scratch access is a VECTOR memory operation
+// behind an in-order counter: `s_waitcnt vmcnt` in front of the first one waited for the tile's sixteen global stores and for the
+// next tile's prefetched loads -- 7 000-12 000 cycles per tile in the "statistics" of a 16 384-cycle tile (tools/fwd_phase_timing.py,
+// profiles/r06_fwd_phase_timing.txt).  Now: always a reference, the choice is a separate flag.
 
 // BIAS_DONE: the accumulators were initialised with the bias (persistent fast path), nothing to add here
 template <int IT, int JT, int WI, int WJ, bool FULL, bool BIAS_DONE = false>
 __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
                                                  float* __restrict__ red, int tile, long m0, int mvalid, int n0,
-                                                 SpgStatAcc<JT / WJ / 32>* sacc = nullptr) {
+                                                 SpgStatAcc<JT / WJ / 32>& sacc, const bool accum, unsigned long long* edbg = nullptr) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
   const int tid = threadIdx.x + spg_opaque_zero(), lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
   const int colw = wj * (JT / WJ), roww = wi * (IT / WI);
+#ifdef SPG_ATTRIBUTION
+  unsigned long long et__ = __builtin_readcyclecounter();
+#define SPG_EP(k) if (edbg != nullptr) { const unsigned long long n__ = __builtin_readcyclecounter(); edbg[k] += n__ - et__; et__ = n__; }
+#else
+#define SPG_EP(k)
+#endif
   // ---- bias + store ----
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
@@ -331,6 +344,7 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
     spg_store_tile_vec<IT / WI, JT / WJ>(acc, red + wave * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ),
                                          p.Y + (m0 + roww) * p.ldy + n0 + colw, (unsigned)p.ldy, lane);
   }
+  SPG_EP(0);
   // ---- BatchNorm partials: every WAVE writes (mean, M2 = sum (y - mean)^2) of its own rows -- no LDS, no barrier;
   //      spg_bn_finalize_kernel combines the ntile*WI partials with Chan's formula ----
   const int nvw = min(max(mvalid - roww, 0), IT / WI);      // valid rows of this wave
@@ -370,11 +384,11 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
             }
       }
       m2 += __shfl_xor(m2, 32, 64);
-      if (sacc != nullptr) {             // persistent stream: merge into the running (rows, mean, M2) of this column
-        const float na = sacc->n, nb = (float)nvw, nn = na + nb;
-        const float delta = mean - sacc->a[j], f = nn > 0.f ? nb / nn : 0.f;
-        sacc->a[j] += delta * f;
-        sacc->b[j] += m2 + delta * delta * (na * f);
+      if (accum) {                       // persistent stream: merge into the running (rows, mean, M2) of this column
+        const float na = sacc.n, nb = (float)nvw, nn = na + nb;
+        const float delta = mean - sacc.a[j], f = nn > 0.f ? nb / nn : 0.f;
+        sacc.a[j] += delta * f;
+        sacc.b[j] += m2 + delta * delta * (na * f);
       } else if (h == 0 && (FULL || col < p.N)) {
         if (p.stat_slots != nullptr) {
           if (nvw > 0) spg_slots_add_fwd(p.stat_slots, p.N, col, (float)nvw, mean, m2);
@@ -384,20 +398,24 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
         }
       }
     }
-    if (sacc != nullptr) sacc->n += (float)nvw;
+    if (accum) sacc.n += (float)nvw;
     else if (lane == 0 && wj == 0 && n0 == 0 && p.stat_slots == nullptr) p.stat_cnt[part] = (float)nvw;
   }
+  SPG_EP(1);
   // ---- max-pool over the rows of the tile, fused (see SpgGemmParams): every lane keeps ONE extremum of its column --
   //      the maximum of key = v * sign, sign = -1 where the BatchNorm scale is negative -- with the first row that
   //      attains it; the two lane halves and then the WI row-waves of the workgroup are combined through LDS ----
   if (p.pool_out != nullptr) {
     float* xch = red + 4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ);        // [WI][JT] keys, [WI][JT] rows: behind the staging regions
     int* xci = reinterpret_cast<int*>(xch + WI * JT);
+    float* xsg = xch + 2 * WI * JT;                                      // [JT] signs
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
       const int cl = colw + 32 * j + r, col = n0 + cl;
       const bool colok = FULL || col < p.N;
-      const float sg = (p.pool_sign != nullptr && p.pool_sign[colok ? col : 0] < 0.f) ? -1.f : 1.f;
+      // (a persistent stream loaded the sign of its columns once, in front of its tile loop: a global load HERE sits behind the
+      //  tile's stores and the next tile's prefetch in the in-order vector-memory counter)
+      const float sg = sacc.has_sg ? (sacc.sg[j] < 0.f ? -1.f : 1.f) : ((p.pool_sign != nullptr && p.pool_sign[colok ? col : 0] < 0.f) ? -1.f : 1.f);
       float kb = -FLT_MAX;
       int ib = INT_MAX;
       const spg_f32x2 sg2 = {sg, sg};
@@ -419,8 +437,9 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
       const float ok = __shfl_xor(kb, 32, 64);
       const int oi = __shfl_xor(ib, 32, 64);
       if (ok > kb || (ok == kb && oi < ib)) { kb = ok; ib = oi; }
-      if (h == 0) { xch[wi * JT + cl] = kb; xci[wi * JT + cl] = ib; }
+      if (h == 0) { xch[wi * JT + cl] = kb; xci[wi * JT + cl] = ib; if (wi == 0) xsg[cl] = sg; }
     }
+    SPG_EP(2);
     __syncthreads();
     for (int cl = tid; cl < JT; cl += SPG_THREADS) {
       const int col = n0 + cl;
@@ -433,7 +452,7 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
         const int oi = xci[w * JT + cl];
         if (ok > kb || (ok == kb && oi < ib)) { kb = ok; ib = oi; }
       }
-      const float sg = (p.pool_sign != nullptr && p.pool_sign[col] < 0.f) ? -1.f : 1.f;
+      const float sg = xsg[cl];          // (the sign the row-waves used, through LDS: no second global load)
       p.pool_out[(long)tile * p.pool_ld + col] = kb * sg;
       if (p.pool_idx != nullptr) p.pool_idx[(long)tile * p.pool_ld + col] = ib;
     }
@@ -441,6 +460,7 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
       for (int e = tid; e < p.pool_nextra; e += SPG_THREADS)
         p.pool_out[(long)tile * p.pool_ld + p.N + e] = p.pool_extra[(long)tile * p.pool_nextra + e];
     __syncthreads();       // the exchange area is reused by the next tile of a persistent workgroup
+    SPG_EP(3);
   }
 }
 
@@ -475,7 +495,7 @@ __device__ __forceinline__ void spg_bwd_stat_store(const SpgGemmParams& p, f32x4
 template <int IT, int JT, int WI, int WJ>
 __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
                                                      float* __restrict__ red, int tile, long m0, int n0,
-                                                     SpgStatAcc<JT / WJ / 32>* sacc = nullptr) {
+                                                     SpgStatAcc<JT / WJ / 32>& sacc, const bool accum) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32, RW = IT / WI, CW = JT / WJ;
   constexpr int LD = CW + 8, LPR = CW / 4, RPI = 64 / LPR, NIT = SPG_EPI_PIECE_ROWS / RPI;
   static_assert(SPG_EPI_PIECE_ROWS % RPI == 0, "a piece is a whole number of store instructions");
@@ -528,8 +548,8 @@ __device__ __forceinline__ void spg_epilogue_bwd_vec(const SpgGemmParams& p, f32
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-  if (sacc != nullptr) {               // persistent stream: running sums, written once when the stream ends
-    sacc->s1 += s1; sacc->s2 += s2;
+  if (accum) {                         // persistent stream: running sums, written once when the stream ends
+    sacc.s1 += s1; sacc.s2 += s2;
   } else if (p.stat != nullptr || p.stat_slots != nullptr) {
     spg_bwd_stat_store<IT, JT, WI, WJ>(p, s1, s2, (long)tile * WI + wi, n0);
   }
@@ -608,17 +628,17 @@ __device__ __forceinline__ void spg_epilogue_bwd(const SpgGemmParams& p, f32x16 
 }
 
 // epilogue of one finished tile (all variants): `red` = LDS staging region that nobody reads any more
-// sacc != null (persistent streams: whole tiles, vector stores -- host): statistics are accumulated instead of written
+// accum (persistent streams: whole tiles, vector stores -- host): statistics are accumulated in `sacc` instead of written
 template <int IT, int JT, int WI, int WJ, bool WRED, bool FULL, bool BIAS_DONE>
 __device__ __forceinline__ void spg_tile_epilogue(const SpgGemmParams& p, f32x16 (&acc)[IT / WI / 32][JT / WJ / 32],
                                                   float* __restrict__ red, int tile, long m0, int mvalid, int n0,
-                                                  SpgStatAcc<JT / WJ / 32>* sacc = nullptr) {
+                                                  SpgStatAcc<JT / WJ / 32>& sacc, const bool accum, unsigned long long* edbg = nullptr) {
   if constexpr (!WRED) {      // forward kernels: weights [N,K]; backward (dgrad) kernels: untransposed weights [K,N]
-    if (mvalid == IT && n0 + JT <= p.N) spg_epilogue_fwd<IT, JT, WI, WJ, true, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0, sacc);
-    else spg_epilogue_fwd<IT, JT, WI, WJ, false, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0);
+    if (mvalid == IT && n0 + JT <= p.N) spg_epilogue_fwd<IT, JT, WI, WJ, true, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0, sacc, accum, edbg);
+    else spg_epilogue_fwd<IT, JT, WI, WJ, false, BIAS_DONE>(p, acc, red, tile, m0, mvalid, n0, sacc, false);
   } else {
     const bool full = mvalid == IT && n0 + JT <= p.N && (n0 + JT <= p.n_mask || (p.stat == nullptr && p.stat_slots == nullptr && !p.mask_relu));
-    if (FULL && full && p.vec_store) spg_epilogue_bwd_vec<IT, JT, WI, WJ>(p, acc, red, tile, m0, n0, sacc);
+    if (FULL && full && p.vec_store) spg_epilogue_bwd_vec<IT, JT, WI, WJ>(p, acc, red, tile, m0, n0, sacc, accum);
     else if (full) spg_epilogue_bwd<IT, JT, WI, WJ, true>(p, acc, red, tile, m0, mvalid, n0);
     else spg_epilogue_bwd<IT, JT, WI, WJ, false>(p, acc, red, tile, m0, mvalid, n0);
   }
@@ -638,6 +658,32 @@ __device__ __forceinline__ void spg_tile_epilogue(const SpgGemmParams& p, f32x16
 // the weights come pre-split (p.Wb, out-major for both the forward and -- pre-transposed -- the data gradient)
 // (bx, by): the workgroup's position in the launch grid -- blockIdx for a stand-alone launch, a virtual position inside its
 // job for a workgroup of a grouped launch (spg_multi_kernel below)
+#ifdef SPG_ATTRIBUTION
+// (attribution builds only; tools/fwd_phase_timing.py) shader cycles of wave 0 of every workgroup of the persistent forward streams,
+// by phase: [class][0 entry -> first chunk loop, 1 chunk loops, 2 epilogues, 3 last epilogue -> exit, 4 workgroups, 5 tiles];
+// class = 0: K 64, 1: K 128 / N 128, 2: N 256 (pooled layer), 3: K 64 with pooling (STN)
+__device__ unsigned long long spg_fwd_phase_t[4][14];
+extern "C" int spg_fwd_phase_times(unsigned long long* out, int clear) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(spg_fwd_phase_t), sizeof(unsigned long long) * 56) != hipSuccess) return -1;
+  if (clear) { unsigned long long z[56] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(spg_fwd_phase_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#define SPG_F0() unsigned long long ft__ = __builtin_readcyclecounter(), fp__[4] = {0, 0, 0, 0}, fn__ = 0, ep__[4] = {0, 0, 0, 0}, en__[4] = {0, 0, 0, 0}, et0__ = ft__
+#define SPG_FP(k) { const unsigned long long n__ = __builtin_readcyclecounter(); fp__[k] += n__ - ft__; ft__ = n__; }
+#define SPG_FTILE() ++fn__
+#define SPG_FN(k) { const unsigned long long n__ = __builtin_readcyclecounter(); en__[k] += n__ - et0__; et0__ = n__; }
+#define SPG_FN_FIRST(k) if (fn__ == 0) SPG_FN(k)
+#define SPG_FEND() if (STREAM && !WRED && threadIdx.x == 0) { const int c__ = p.N > 128 ? 2 : (p.K > 64 ? 1 : (p.pool_out != nullptr ? 3 : 0)); \
+    for (int k__ = 0; k__ < 4; ++k__) atomicAdd(&spg_fwd_phase_t[c__][k__], fp__[k__]); atomicAdd(&spg_fwd_phase_t[c__][4], 1ull); atomicAdd(&spg_fwd_phase_t[c__][5], fn__); for (int k__ = 0; k__ < 4; ++k__) { atomicAdd(&spg_fwd_phase_t[c__][6 + k__], ep__[k__]); atomicAdd(&spg_fwd_phase_t[c__][10 + k__], en__[k__]); } }
+#else
+#define SPG_F0()
+#define SPG_FP(k)
+#define SPG_FTILE()
+#define SPG_FN(k)
+#define SPG_FN_FIRST(k)
+#define SPG_FEND()
+#endif
+
 template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false, bool STREAM = false, int PREC = 0>
 __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const int bx, const int by) {
   constexpr int TI = IT / WI / 32, TJ = JT / WJ / 32;
@@ -647,6 +693,7 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
   f32x4* Bs = smem + (SPG_KC / 4) * (IT + 1);
   float* Bsr = reinterpret_cast<float*>(Bs);
 
+  SPG_F0();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wi = wave / WJ, wj = wave % WJ;
@@ -674,7 +721,7 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
   if constexpr (!(AMODE >= 0 && FULL)) fold_now();
 
   if constexpr (AMODE >= 0 && FULL) {
-    static_assert(4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) + 2 * WI * JT <= 4 * (A_F4 + B_F4), "epilogue staging + pooling exchange must fit one LDS buffer");
+    static_assert(4 * SPG_EPI_WAVE_FLOATS(IT / WI, JT / WJ) + 2 * WI * JT + JT <= 4 * (A_F4 + B_F4), "epilogue staging + pooling exchange must fit one LDS buffer");
     int tile = bx, ct = by;
     if (p.remap) {
       // XCD-aware item map (workgroup b runs on XCD b % 8): the column tiles of one row tile are consecutive workgroups
@@ -688,6 +735,25 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
     const int n0 = ct * JT;
     long m0 = (long)tile * p.rows_per_tile;
     int mvalid = (int)min((long)p.rows_per_tile, (long)p.M - m0);     // == IT for every tile of a multi-tile stream (host)
+    constexpr bool BIAS_IN_ACC = !WRED;
+    SpgStatAcc<TJ> sacc;                         // STREAM: statistics of this workgroup's tiles, one partial at the end
+    sacc.n = 0.f;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) { sacc.a[j] = 0.f; sacc.b[j] = 0.f; }
+    sacc.s1 = f32x4{0.f, 0.f, 0.f, 0.f}; sacc.s2 = sacc.s1;
+    // loop-invariant per-lane values of the workgroup's column tile, loaded ONCE and FIRST (in front of the tile's loads: their latency
+    // hides behind the BatchNorm fold): the bias the accumulators start from and (pooled layer) the sign of the BatchNorm scale -- a
+    // global load inside the tile loop waits, through the in-order vector-memory counter, for the previous tile's stores and the
+    // prefetched loads
+    float bias_v[TJ];          // (raw loaded values: nothing below may USE them before the first chunk is on its way -- a use is a wait)
+    sacc.has_sg = !WRED && p.pool_out != nullptr;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + wj * (JT / WJ) + 32 * j + r;
+      bias_v[j] = 0.f; sacc.sg[j] = 1.f;
+      if (BIAS_IN_ACC && p.bias != nullptr) bias_v[j] = p.bias[col < p.N ? col : 0];      // uniform
+      if (sacc.has_sg && p.pool_sign != nullptr) sacc.sg[j] = p.pool_sign[col < p.N ? col : 0];
+    }
     // two register sets: iteration c issues the global loads of chunk c+2 into one set (slots 0-2), then finishes chunk
     // c+1 from the other set (loaded during iteration c-1, i.e. a full chunk of MFMAs ago) into the idle LDS buffer
     SpgRowsFast<AMODE, IT> pa0, pa1;
@@ -723,7 +789,9 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
       for (int i = 0; i < NIA; ++i) pa0.load_part(p.a, m0, 0, i);
 #pragma unroll
       for (int i = 0; i < NIW; ++i) w_load(pw0, pwr0, pb0, 0, i);
+      SPG_FN(0);
       fold_now();                      // (ends with a workgroup barrier: the constants `prepare` reads exist behind it)
+      SPG_FN(1);
       pa0.prepare(p.a, tile, 0);
 #pragma unroll
       for (int i = 0; i < NIA; ++i) a_store(pa0, As, i);
@@ -737,23 +805,20 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
       for (int i = 0; i < NIW; ++i) w_load(pw1, pwr1, pb1, k1, i);
     }
     __syncthreads();
-    constexpr bool BIAS_IN_ACC = !WRED;
-    SpgStatAcc<TJ> sacc;                         // STREAM: statistics of this workgroup's tiles, one partial at the end
-    sacc.n = 0.f;
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) { sacc.a[j] = 0.f; sacc.b[j] = 0.f; }
-    sacc.s1 = f32x4{0.f, 0.f, 0.f, 0.f}; sacc.s2 = sacc.s1;
+    SPG_FN(2);
     const int tile0 = tile;                      // < rstride: index of this workgroup among those of its column tile
     const bool accum = STREAM && (p.stat != nullptr || p.stat_slots != nullptr) && p.stat_accum;
     // backward kernels (two operand streams + four constant arrays per register set): the loads of the next tile's SECOND
     // chunk are issued after the epilogue instead of under the last chunk -- nothing but the accumulators and the
     // loop-invariant offsets is then live across the epilogue (no spills)
-    constexpr bool DEFER2 = WRED;
+    constexpr bool DEFER2 = WRED;      // (tried for the forward as well, round 6: 1.139 -> 1.143 ms per step)
     // Two workgroups share a CU (launch bounds); dispatched together they run the same phases at the same time -- both in the
     // epilogue = no MFMA work on that CU.  The second round of workgroups (b >= 256 lands on the CU of b - 256) starts ~2 us late, so
     // that one's epilogue falls under the other's chunk loop (A/B on one box, 2 x 2 runs: 1.153 -> 1.148 ms per step, 8 scenes
     // 6.90 -> 6.86; 4 us the same, 8 us nothing).  Timing only: no effect on any result.
+#ifndef SPG_NO_STAGGER
     if (STREAM && !WRED && ((bx >> 8) & 1)) { __builtin_amdgcn_s_sleep(32); __builtin_amdgcn_s_sleep(32); }
+#endif
     for (;;) {
       tile = __builtin_amdgcn_readfirstlane(tile);             // wave-uniform by construction: keep the tile stream in SGPRs
       m0 = (long)tile * p.rows_per_tile;
@@ -764,12 +829,8 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
       // accumulators start from the bias (forward) / zero
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
-        float bv = 0.f;
-        if (BIAS_IN_ACC && p.bias != nullptr) {                  // uniform
-          const int col = n0 + wj * (JT / WJ) + 32 * j + r;
-          const float t = p.bias[col < p.N ? col : 0];
-          bv = col < p.N ? t : 0.f;
-        }
+        float bv = n0 + wj * (JT / WJ) + 32 * j + r < p.N ? bias_v[j] : 0.f;
+        asm volatile("" : "+v"(bv));      // (opaque per tile: the 16-register splat below must not be hoisted out of the tile loop -- it was, and spilled)
         // (as 64-bit values: v_mov_b64, 8 instead of 16 VALU operations per 32 x 32 block)
         typedef double spg_f64x8 __attribute__((ext_vector_type(8)));
         const double bd = __builtin_bit_cast(double, spg_f32x2{bv, bv});
@@ -824,6 +885,8 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
         if (!(STREAM && (SPG_DBG(p) & 32))) __syncthreads();      // (attribution switch: main loop without barriers)
       };
       const int reps = STREAM ? 1 + ((SPG_DBG(p) >> 8) & 15) : 1;      // (attribution switch: the chunk loop repeated -> steady-state rate)
+      SPG_FN_FIRST(3);
+      SPG_FP(fn__ == 0 ? 0 : 2);
       for (int rep = 0; rep < reps; ++rep)
       for (int c = 0; c < nchunk; c += 2) {
         // where the loads of chunk c+2 / c+3 come from: this tile, the next tile of the stream, or (at the very end) a
@@ -840,6 +903,7 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
       // Here (nchunk even when there is a next tile -- host): LDS buffer 0 holds chunk 0 of the next tile, set 1 its chunk
       // 1 (in flight); buffer 1 was read by the last chunk and is free: the epilogue stages through it.
       float* red = reinterpret_cast<float*>(smem + (A_F4 + B_F4));
+      SPG_FP(1); SPG_FTILE();
       if (STREAM && SPG_DBG(p)) {       // timing attribution only (spg_tune key 3; results are WRONG): parts of the epilogue off
         if (SPG_DBG(p) & 8) {
           if (acc[0][0][0] + acc[TI - 1][TJ - 1][5] == 123.456f) p.Y[0] = 0.f;
@@ -848,10 +912,14 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
           if (SPG_DBG(p) & 1) q.Y = nullptr;
           if (SPG_DBG(p) & 2) q.stat = nullptr;
           if (SPG_DBG(p) & 4) q.pool_out = nullptr;
-          spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(q, acc, red, tile, m0, mvalid, n0);
+          spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(q, acc, red, tile, m0, mvalid, n0, sacc, false);
         }
       } else
-      spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(p, acc, red, tile, m0, mvalid, n0, accum ? &sacc : nullptr);
+#ifdef SPG_ATTRIBUTION
+      spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(p, acc, red, tile, m0, mvalid, n0, sacc, accum, ep__);
+#else
+      spg_tile_epilogue<IT, JT, WI, WJ, WRED, true, BIAS_IN_ACC>(p, acc, red, tile, m0, mvalid, n0, sacc, accum);
+#endif
       if (!has_next) break;
       tile = nxt; m0 = m0n;
       if (DEFER2) {
@@ -863,6 +931,7 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
       }
       __syncthreads();          // the staging region is overwritten by the next chunk's finish stage
     }
+    SPG_FP(2);
     if (accum) {
       // The workgroup's ONE statistics partial: the WI row-waves hold (rows, mean, M2) / (sum, sum) of the same columns;
       // waves 1.. hand theirs to wave 0 through LDS (free now), which merges in fixed order and stores -- WI times fewer
@@ -936,6 +1005,7 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
         }
       }
     }
+    SPG_FP(3); SPG_FEND();
     return;
   }
 
@@ -1033,7 +1103,9 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
     }
   }
   float* red = reinterpret_cast<float*>(smem);  // LDS is free again after the last barrier
-  spg_tile_epilogue<IT, JT, WI, WJ, WRED, false, false>(p, acc, red, tile, m0, mvalid, n0);
+  SpgStatAcc<TJ> none;                          // (unused: one tile per workgroup, nothing accumulated)
+  none.has_sg = false;
+  spg_tile_epilogue<IT, JT, WI, WJ, WRED, false, false>(p, acc, red, tile, m0, mvalid, n0, none, false);
 }
 
 template <int IT, int JT, int WI, int WJ, bool WRED, int AMODE, bool FULL = false, bool STREAM = false, int PREC = 0>
@@ -1128,7 +1200,9 @@ __device__ __forceinline__ void spg_fewrow_sk_body(const SpgGemmParams& p, const
     for (int q = 0; q < 16; ++q) acc[q] += red[(w * 16 + q) * 64 + lane];
   f32x16 accs[1][1];
   accs[0][0] = acc;
-  spg_tile_epilogue<32, 32, 1, 1, WRED, false, false>(p, accs, red, bx, m0, mvalid, n0);
+  SpgStatAcc<1> none;
+  none.has_sg = false;
+  spg_tile_epilogue<32, 32, 1, 1, WRED, false, false>(p, accs, red, bx, m0, mvalid, n0, none, false);
 }
 
 template <bool WRED, int AMODE>

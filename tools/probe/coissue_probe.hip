@@ -76,6 +76,18 @@ __global__ __launch_bounds__(512, 1) void roles(float* out, int na, int nb, cons
       res += s[0] + s[1] + s[2] + s[3];
     } else if (BKIND == 4) {
       mfma32(nb);
+    } else if (BKIND >= 5) {      // 5 / 6 / 7: ONE / TWO / FOUR dependent chains of v_fma_f32 (the statistics of a GEMM epilogue are such chains)
+      constexpr int NC = BKIND == 5 ? 1 : (BKIND == 6 ? 2 : 4);
+      float x[NC];
+      for (int i = 0; i < NC; ++i) x[i] = in[lane + i];
+      const float m = in[200 + lane], c = in[300 + lane];
+      for (int it = 0; it < nb; ++it) {
+#pragma unroll
+        for (int u = 0; u < 64 / NC; ++u)
+#pragma unroll
+          for (int i = 0; i < NC; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(m), "v"(c));
+      }
+      for (int i = 0; i < NC; ++i) res += x[i];
     }
   }
   out[blockIdx.x * 512 + tid] = res;
@@ -168,6 +180,12 @@ int main() {
   ROLES(0, 3, 0, nbg, "B global loads alone");
   ROLES(1, 3, na, nbg, "A fp32 MFMA + B global loads");
   ROLES(1, 4, na, na, "A fp32 MFMA + B fp32 MFMA (expected: sum)");
+  ROLES(0, 5, 0, nbv / 4, "B ONE dependent chain of v_fma alone (4000 x 64)");
+  ROLES(1, 5, na, nbv / 4, "A fp32 MFMA + B one dependent chain");
+  ROLES(0, 6, 0, nbv / 4, "B TWO dependent chains alone (4000 x 64)");
+  ROLES(1, 6, na, nbv / 4, "A fp32 MFMA + B two dependent chains");
+  ROLES(0, 7, 0, nbv / 4, "B FOUR dependent chains alone (4000 x 64)");
+  ROLES(1, 7, na, nbv / 4, "A fp32 MFMA + B four dependent chains");
   ROLES(2, 0, 4 * na, 0, "A bf16 MFMA alone (8000 x 64 MFMAs per wave)");
   ROLES(2, 1, 4 * na, nbv, "A bf16 MFMA + B VALU fma");
   printf("== mixed: every wave runs MFMA + k VALU behind each MFMA; 1000 x 64 MFMAs per wave ==\n");
