@@ -242,6 +242,17 @@ static bool spg_group_add(int kind, int variant, const void* params, size_t byte
 // address computations are NOT hoisted out of the persistent tile loop (they would stay live across the main loop)
 __device__ __forceinline__ int spg_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 template <typename T> using spg_kernarg_ptr = __attribute__((address_space(4))) const T*;
+// Parameters are read where they lie (scalar loads at the point of use, see spg_rowgemm_kernel): at the start of a kernel every
+// 64-byte line of the block is a scalar-cache MISS, and the uses come one after the other -- load, wait, use, next load: nine misses
+// in a row for the 536 bytes of SpgGemmParams (tools/fwd_phase_timing.py: 5 400-6 900 cycles from the first instruction to the
+// first tile load).  One batch of dummy loads, one wait: the lines arrive together, the later loads hit.
+template <int BYTES>
+__device__ __forceinline__ void spg_touch_params(const spg_kernarg_ptr<unsigned> b) {
+  unsigned acc = 0;
+#pragma unroll
+  for (int o = 0; o < BYTES; o += 64) acc |= b[o / 4];
+  asm volatile("" :: "s"(acc));
+}
 #define SPG_EPI_PIECE_ROWS 16
 #define SPG_EPI_WAVE_FLOATS(RW, CW) (SPG_EPI_PIECE_ROWS * ((CW) + 8))
 
@@ -1115,6 +1126,7 @@ __global__ __launch_bounds__(SPG_THREADS, 2) void spg_rowgemm_kernel(const SpgGe
   // whole tile loop: the persistent instantiations spilled 74-123 SGPRs to VGPR lanes / scratch that way;
   // with the reference 10-46 (profiles/r05_kernel_resources.txt)
   const SpgGemmParams& p = *(const SpgGemmParams*)(spg_kernarg_ptr<SpgGemmParams>)__builtin_amdgcn_kernarg_segment_ptr();
+  spg_touch_params<(int)sizeof(SpgGemmParams)>((spg_kernarg_ptr<unsigned>)__builtin_amdgcn_kernarg_segment_ptr());
   spg_rowgemm_body<IT, JT, WI, WJ, WRED, AMODE, FULL, STREAM, PREC>(p, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -3118,8 +3130,7 @@ __device__ __forceinline__ void spg_multi_body() {
   extern __shared__ f32x4 smem[];
   // the job table is indexed dynamically: read it where it lies -- in the kernel-argument segment (constant address space,
   // scalar loads) -- instead of through the by-value parameter, which the compiler would copy to scratch (3.9 KB per lane)
-  typedef __attribute__((address_space(4))) const SpgMultiArgs* spg_kernarg_ptr;
-  const SpgMultiArgs& a = *(const SpgMultiArgs*)(spg_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  const SpgMultiArgs& a = *(const SpgMultiArgs*)(spg_kernarg_ptr<SpgMultiArgs>)__builtin_amdgcn_kernarg_segment_ptr();
 #ifdef SPG_ATTRIBUTION
   const unsigned long long trace_t0 = wall_clock64();
 #endif
@@ -3133,6 +3144,7 @@ __device__ __forceinline__ void spg_multi_body() {
   const int b = (int)blockIdx.x - a.first_block[j];
   const int bx = b % h.gx + h.bx0, by = (b / h.gx) % h.gy, bz = b / (h.gx * h.gy);
   const unsigned char* P = a.arena + h.offset;
+  // (touching the job's whole parameter block here, as spg_rowgemm_kernel does, costs 1 % of the step: the small jobs read few lines)
 #define SPG_P(T) (*reinterpret_cast<const T*>(P))
   if (h.kind == SPG_JOB_GEMM) {
     switch (h.variant) {
