@@ -16,6 +16,7 @@
 #pragma clang fp contract(off)
 #include "../../include/spg_hip.h"
 #include "spg_gemm.h"
+#include <type_traits>
 #include <float.h>
 #include <limits.h>
 #include <stdarg.h>
@@ -2198,7 +2199,21 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
 
   // what every role does before its loop: (loaders: the first two tiles' loads, below) -- the constants of the dz prologue,
   // finished here from the layer's slots (ends with a barrier) or already there (finalize launch) -- constants and W into LDS
-  auto prologue = [&]() __attribute__((always_inline)) {
+  auto prologue = [&](auto wload) __attribute__((always_inline)) {
+    // W does not depend on the fold: its loads are issued in front of it (round 6: they used to start behind the fold's barrier --
+    // two global round trips in a row at the head of every pair launch).  By the 512 threads of the matrix roles: their registers
+    // are free here, the loaders' hold two tiles in flight.
+    constexpr bool WLOAD = decltype(wload)::value;
+    constexpr int NWQ = CO * XQ / 512;
+    static_assert(CO * XQ % 512 == 0, "whole quads per thread");
+    f32x4 wq[NWQ];
+    if constexpr (WLOAD) {
+#pragma unroll
+      for (int k = 0; k < NWQ; ++k) {
+        const int i = tid + k * 512, co = i / XQ, q = i % XQ;
+        wq[k] = *reinterpret_cast<const f32x4*>(g.W + (long)co * g.ldw + 4 * q);
+      }
+    }
     if (g.stat_slots != nullptr && p.pass != 1 && blockIdx.x == 0 && tid == 0) spg_slots_count_add(g.stat_slots, g.n_mask, g.stat_rows != 0 ? g.stat_rows : (long)g.M);
     if (g.fold_bwd.slots != nullptr) spg_bn_fold_bwd(g.fold_bwd, blockIdx.x == 0);
     if (tid < CQ) {
@@ -2208,9 +2223,12 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
     if (tid < XQ) {
       kst[4 * CQ + tid] = *reinterpret_cast<const f32x4*>(p.b.c0 + 4 * tid); kst[4 * CQ + XQ + tid] = *reinterpret_cast<const f32x4*>(p.b.c1 + 4 * tid);
     }
-    for (int i = tid; i < CO * XQ; i += SPG_PAIR_THREADS) {
-      const int co = i / XQ, q = i % XQ;
-      *reinterpret_cast<f32x4*>(wl + co * SX + 4 * q) = *reinterpret_cast<const f32x4*>(g.W + (long)co * g.ldw + 4 * q);
+    if constexpr (WLOAD) {
+#pragma unroll
+      for (int k = 0; k < NWQ; ++k) {
+        const int i = tid + k * 512, co = i / XQ, q = i % XQ;
+        *reinterpret_cast<f32x4*>(wl + co * SX + 4 * q) = wq[k];
+      }
     }
     __syncthreads();                              // constants and W are in LDS
   };
@@ -2270,7 +2288,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
     };
     load_tile(R0, tile);                          // (no constant needed yet: in flight under the prologue)
     if (tile + stride < ntile) load_tile(R1, tile + stride);
-    prologue();
+    prologue(std::false_type{});
     store_tile(R0, tile, 0);
     if (tile + 2 * stride < ntile) load_tile(R0, tile + 2 * stride);
     __syncthreads();
@@ -2308,7 +2326,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
     return;
   }
 
-  prologue();
+  prologue(std::true_type{});
   if (role == 0) {
     // ---------------- data gradient ----------------
     f32x16 acc[1][1];
