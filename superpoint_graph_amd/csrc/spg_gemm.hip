@@ -2158,11 +2158,13 @@ extern "C" int spg_pair_role_times(unsigned long long* out, int clear) {
   if (clear) { unsigned long long z[36] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(spg_pair_role_t), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
-#define SPG_T0() unsigned long long t__ = __builtin_readcyclecounter(), tp__[4] = {0, 0, 0, 0}
+#define SPG_T0() unsigned long long t__ = __builtin_readcyclecounter(), tp__[4] = {0, 0, 0, t__ - tent__}
+#define SPG_TENTRY() const unsigned long long tent__ = __builtin_readcyclecounter()
 #define SPG_TP(k) { const unsigned long long n__ = __builtin_readcyclecounter(); tp__[k] += n__ - t__; t__ = n__; }
 #define SPG_TEND(role) if ((threadIdx.x & 255) == 0) { const int sh__ = (CO == 128) + (CI == 128); for (int k__ = 0; k__ < 4; ++k__) atomicAdd(&spg_pair_role_t[sh__][role][k__], tp__[k__]); }
 #else
 #define SPG_T0()
+#define SPG_TENTRY()
 #define SPG_TP(k)
 #define SPG_TEND(role)
 #endif
@@ -2184,6 +2186,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
   constexpr int TPG = 128 / IT;                                   // POOLBWD: tiles per group (P = 128 rows)
   static_assert((CO == 64 || CO == 128) && (CI == 64 || CI == 128) && IT * WJ * 32 == 4096 * (WJ * 32 / CI), "supported shapes");
   static_assert(NDZ >= 1 && NX >= 1 && IT % RDZ == 0 && IT % RX == 0, "loader map");
+  SPG_TENTRY();
   extern __shared__ f32x4 smem[];
   float* wl = reinterpret_cast<float*>(smem + 2 * BUF4);          // [CO][CI + 4]: red-major W (whole launch)
   float* red = wl + CO * SX;                                      // epilogue staging of the data-gradient waves
@@ -2286,9 +2289,14 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
 #pragma unroll
       for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(xs + (rx + RX * i) * SX + 4 * xq) = R.px[i];
     };
-    load_tile(R0, tile);                          // (no constant needed yet: in flight under the prologue)
-    if (tile + stride < ntile) load_tile(R1, tile + stride);
+    // (no constant needed yet: in flight under the prologue.  The widest shape -- 128 output, 64 input channels: 44 registers per
+    //  set -- keeps only ONE set in flight across the prologue: with both, the fold's arithmetic spilled 24 registers of in-flight
+    //  loads, i.e. waited for them, and the launch took 25 900 cycles from its first instruction to its first tile instead of 14 000)
+    constexpr bool LATE_R1 = 2 * sizeof(Regs) / 4 >= 64;
+    load_tile(R0, tile);
+    if (!LATE_R1 && tile + stride < ntile) load_tile(R1, tile + stride);
     prologue(std::false_type{});
+    if (LATE_R1 && tile + stride < ntile) load_tile(R1, tile + stride);
     store_tile(R0, tile, 0);
     if (tile + 2 * stride < ntile) load_tile(R0, tile + 2 * stride);
     __syncthreads();

@@ -44,8 +44,8 @@ def main():
             # summed over 256 workgroups x (1 wave for the matrix roles | 2 waves (tid % 256 == 0) for the loaders)
             div = n * launches[sh] * 256 * (2 if role == 2 else 1)
             v = [buf[(sh * 3 + role) * 4 + k] / div for k in range(4)]
-            tot = sum(v)
-            print('   %-16s total %8.0f cycles per launch and wave: ' % (rn, tot) + ', '.join('%s %.0f (%.0f%%)' % (phases[role][k], v[k], 100 * v[k] / max(tot, 1)) for k in range(3) if phases[role][k] != '-'))
+            tot = sum(v[:3])
+            print('   %-16s total %8.0f cycles per launch and wave: ' % (rn, tot) + ', '.join('%s %.0f (%.0f%%)' % (phases[role][k], v[k], 100 * v[k] / max(tot, 1)) for k in range(3) if phases[role][k] != '-') + ', entry -> loop %.0f' % v[3])
 
 if __name__ == '__main__':
     main()
