@@ -817,6 +817,10 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
       for (int i = 0; i < NIW; ++i) w_load(pw1, pwr1, pb1, k1, i);
     }
     __syncthreads();
+    // (the loop-invariant loads of the top become USABLE here: the compiler had moved the sign's compare right behind its load -- a
+    //  wait for a global round trip in front of the first tile load)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) asm volatile("" : "+v"(sacc.sg[j]), "+v"(bias_v[j]));
     SPG_FN(2);
     const int tile0 = tile;                      // < rstride: index of this workgroup among those of its column tile
     const bool accum = STREAM && (p.stat != nullptr || p.stat_slots != nullptr) && p.stat_accum;
