@@ -1244,6 +1244,27 @@ __device__ __forceinline__ void spg_px_head_wgrad(const SpgEccHead& hd, const fl
 // round).  Rounds (p.groups): wave slot s = 4 * blockIdx.x + wave owns node ptr[g] + s of group g for the whole recurrence, then
 // of group g + 1, ...; a group is a union of whole connected components, so everything a node waits for belongs to its own
 // group, whose waves are all resident and at this group or beyond -- no deadlock.  Every group has its own granule region.
+#ifdef SPG_ATTRIBUTION
+// (attribution builds only; tools/ecc_phase_timing.py) shader cycles of every node wave of the one-launch forward recurrence:
+// [0 rest of the entry, 1 own-state part, 2 waiting for + gathering the neighbours, 3 filters + mean, 4 input part + publish,
+//  5 head + exit, 6 waves, 7-10 inside the entry: up to the weight staging, cell weights, classifier weights + loss-weight partials,
+//  barrier + gate rows]
+__device__ unsigned long long spg_ecc_phase_t[12];
+extern "C" int spg_ecc_phase_times(unsigned long long* out, int clear) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(spg_ecc_phase_t), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
+  if (clear) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(spg_ecc_phase_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#define SPG_X0() unsigned long long xt__ = __builtin_readcyclecounter(), xp__[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SPG_XP(k) { const unsigned long long n__ = __builtin_readcyclecounter(); xp__[k] += n__ - xt__; xt__ = n__; }
+#define SPG_XEND() if ((threadIdx.x & 63) == 0) { for (int k__ = 0; k__ < 6; ++k__) atomicAdd(&spg_ecc_phase_t[k__], xp__[k__]); \
+    for (int k__ = 7; k__ < 11; ++k__) atomicAdd(&spg_ecc_phase_t[k__], xp__[k__]); if (xp__[4] != 0) atomicAdd(&spg_ecc_phase_t[6], 1ull); }
+#else
+#define SPG_X0()
+#define SPG_XP(k)
+#define SPG_XEND()
+#endif
+
 template <bool MATRIX, int KMAX, int WPC, bool GROUPS>
 __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const SpgEccPersistFwd p) {
   __shared__ float sw[(2 * 96 + 32) * SPG_WLD];
@@ -1252,10 +1273,13 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   __shared__ int idb[4][SPG_PX_CH];
   extern __shared__ __attribute__((aligned(16))) float swc[];      // the head's classifier rows [C][nin + 4] (SpgEccHead)
   __shared__ double hd_part[16];
+  SPG_X0();
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = blockIdx.x * 4 + wave;
   const bool with_head = p.head.W != nullptr;      // (uniform)
+  SPG_XP(7);
   spg_stage_cell_weights<96>(p.gru, sw);
+  SPG_XP(8);
   const int hd_ldw = p.head.nin + 4;
   if (with_head) {
     const int nq = p.head.nin >> 2;      // (nin = 32 or 32 (R + 1): whole quads; W is 16-byte aligned -- checked by the launcher)
@@ -1274,11 +1298,13 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   float* sx = lds[wave][2];
   float* hs = hsb[wave];
   int* ids = idb[wave];
+  SPG_XP(9);
   __syncthreads();            // the cell weights are in LDS; from here on the waves run on their own
   if (p.fsave_tag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *p.fsave_tag = SPG_PX_SAVE_MAGIC;
   using Rows = typename SpgPxRows<WPC == 1>::type;
   Rows wq;                    // this lane's gate rows: in registers for all iterations (WPC == 1) or read from LDS
   spg_px_rows_init(wq, wr);
+  SPG_XP(10);
   // (GROUPS = false: one round -- the loop and everything it costs in registers is compiled away)
   const int ngroups = GROUPS ? p.groups.n : 1;
 #pragma nounroll
@@ -1330,6 +1356,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     p.states[(long)i * p.ldS + lane] = hcur;
     if (p.cat_all) p.out[(long)i * p.ldo + lane] = hcur;
   }
+  SPG_XP(0);
   for (int r = 0; r < p.R; ++r) {
     // ---- what depends on the node's own state only (input gate, W_hh h, its normalisation): BEFORE waiting for the neighbours ----
     if (lane < 32) sh[lane] = hcur;
@@ -1339,6 +1366,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     if (with_head && p.cat_all) spg_px_head_accum(swc, hd_ldw, 32 * r, sh, lane, p.head.C, hlog);      // the classifier's share of h^r
     // ---- aggregate over the in-edges: mean of h_src (.) W_e ----
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    SPG_XP(1);
     for (int c0 = 0; c0 < deg; c0 += SPG_PX_CH) {
       const int n = min(SPG_PX_CH, deg - c0);
       if (deg > SPG_PX_CH) {
@@ -1349,6 +1377,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
       if (r == 0) spg_px_gather_plain(p.h0, 32, ids, n, lane, hs, p.h0_rows);
       else spg_px_gather_granules(gran + (long)r * SPG_PX_MAX_NODES * 32, base + (unsigned)r + 1u, ids, n, lane, hs, p.ctl, spin_limit);
       spg_node_sync<true>();
+      SPG_XP(2);
       if constexpr (MATRIX) {
         if (c0 == 0) {
 #pragma unroll
@@ -1399,6 +1428,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
       sa[lane] = a4[0] * invdeg;
     }
     spg_node_sync<true>();
+    SPG_XP(3);
     // ---- the input half of the GRU ----
     spg_gru_input_part<Rows, true>(p.gru, wq, sa, sx, lane, st);
     if (lane < 32) {
@@ -1412,6 +1442,7 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     }
     if (p.fsave != nullptr) spg_px_save_state(reinterpret_cast<f32x4*>(p.fsave) + ((long)i * p.R + r) * (SPG_PX_SAVE_F / 4) * 64 + lane, st);
     spg_node_sync<true>();      // sa / sh / sx are rewritten by the next iteration
+    SPG_XP(4);
   }
   // ---- the head: classifier + cross entropy of this node, and the gradient the backward recurrence starts from ----
   if (with_head) {
@@ -1421,8 +1452,10 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     const float wsum = p.head.reduction_mean ? spg_px_head_wsum_finish(hd_part) : 1.f;
     spg_px_head_node(p.head, swc, hd_ldw, wsum, i, lane, hlog, hs, hd_t, hd_w);
   }
+  SPG_XP(5);
   }      // groups
   spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
+  SPG_XEND();
 }
 
 template <bool MATRIX, int KMAX, int WPC, bool GROUPS>
