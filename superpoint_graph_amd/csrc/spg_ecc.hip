@@ -312,14 +312,24 @@ struct GruRowsReg {
 template <int GW>
 __device__ __forceinline__ void spg_stage_cell_weights(const SpgGruParams& G, float* __restrict__ sw) {
   constexpr int NQ = (2 * GW + 32) * 8;          // float4 pieces
-  for (int idx = threadIdx.x; idx < NQ; idx += SPG_THREADS) {
-    const int row = idx >> 3, q = idx & 7;
+  constexpr int NI = NQ / SPG_THREADS;
+  static_assert(NQ % SPG_THREADS == 0, "whole pieces per thread");
+  // ALL loads first, then the LDS writes (round 6): as one load-use loop the compiler kept its trips in order -- seven global round
+  // trips in a row at the head of the one-launch recurrences (tools/ecc_phase_timing.py: 8 900 cycles)
+  f32x4 v[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int idx = (int)threadIdx.x + k * SPG_THREADS, row = idx >> 3, q = idx & 7;
     const f32x4* src = row < GW ? reinterpret_cast<const f32x4*>(G.w_ih) + row * 8
                      : (row < 2 * GW ? reinterpret_cast<const f32x4*>(G.w_hh) + (row - GW) * 8
                                      : reinterpret_cast<const f32x4*>(G.ingate ? G.w_ig : G.w_ih) + (row - 2 * GW) * 8);
-    const f32x4 v = src[q];
+    v[k] = src[q];
+  }
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int idx = (int)threadIdx.x + k * SPG_THREADS, row = idx >> 3, q = idx & 7;
     float* d = sw + row * SPG_WLD + 4 * q;
-    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    d[0] = v[k][0]; d[1] = v[k][1]; d[2] = v[k][2]; d[3] = v[k][3];
   }
 }
 template <int CELL>
@@ -1055,16 +1065,56 @@ __device__ __forceinline__ void spg_px_rows_init(GruRowsLds& w, const GruRowsLds
 // workgroup barrier (spg_px_head_wsum_finish) -- the same value in every workgroup and every launch.
 __device__ __forceinline__ void spg_px_head_wsum_partials(const SpgEccHead& hd, double* part) {
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  // (per pass over 1024 nodes: the four labels, then the four class weights, then the four sums -- the loads of the four chains used to
+  //  follow each other, two dependent round trips each; the order of every sum is unchanged)
+  for (int i0 = 0; i0 < hd.N; i0 += 1024) {
+    int64_t t[4];
+    float w[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    for (int i = (int)threadIdx.x + 256 * q; i < hd.N; i += 1024) {
-      const int64_t t = hd.target[i];
-      if (t != hd.ignore_index && t >= 0 && t < hd.C) acc[q] += (double)(hd.class_weight ? hd.class_weight[t] : 1.f);
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + (int)threadIdx.x + 256 * q;
+      t[q] = hd.target[i < hd.N ? i : 0];
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = t[q] != hd.ignore_index && t[q] >= 0 && t[q] < hd.C;
+      w[q] = hd.class_weight ? hd.class_weight[ok ? t[q] : 0] : 1.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + (int)threadIdx.x + 256 * q;
+      if (i < hd.N && t[q] != hd.ignore_index && t[q] >= 0 && t[q] < hd.C) acc[q] += (double)w[q];
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     for (int off = 32; off >= 1; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
     if ((threadIdx.x & 63) == 0) part[(threadIdx.x >> 6) + 4 * q] = acc[q];
+  }
+}
+// the same for N <= 1024 (one pass) in two steps: the label loads are issued by `labels` (in front of other staging work), the sums
+// follow in `from_labels` -- one dependent round trip behind them instead of two
+__device__ __forceinline__ void spg_px_head_wsum_labels(const SpgEccHead& hd, int64_t (&t)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = (int)threadIdx.x + 256 * q;
+    t[q] = hd.target[i < hd.N ? i : 0];
+  }
+}
+__device__ __forceinline__ void spg_px_head_wsum_from_labels(const SpgEccHead& hd, const int64_t (&t)[4], double* part) {
+  float w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool ok = t[q] != hd.ignore_index && t[q] >= 0 && t[q] < hd.C;
+    w[q] = hd.class_weight ? hd.class_weight[ok ? t[q] : 0] : 1.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = (int)threadIdx.x + 256 * q;
+    double acc = 0.0;
+    if (i < hd.N && t[q] != hd.ignore_index && t[q] >= 0 && t[q] < hd.C) acc += (double)w[q];
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[(threadIdx.x >> 6) + 4 * q] = acc;
   }
 }
 __device__ __forceinline__ float spg_px_head_wsum_finish(const double* part) {
@@ -1283,11 +1333,26 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   const int hd_ldw = p.head.nin + 4;
   if (with_head) {
     const int nq = p.head.nin >> 2;      // (nin = 32 or 32 (R + 1): whole quads; W is 16-byte aligned -- checked by the launcher)
-    for (int e = threadIdx.x; e < p.head.C * nq; e += 256) {
-      const int c = e / nq, q = e - c * nq;
-      *reinterpret_cast<f32x4*>(swc + c * hd_ldw + 4 * q) = *reinterpret_cast<const f32x4*>(p.head.W + (long)c * p.head.nin + 4 * q);
+    const int ne = p.head.C * nq;
+    const bool one_pass = p.head.reduction_mean && p.head.N <= 1024;      // (uniform)
+    int64_t lab[4] = {0, 0, 0, 0};
+    if (one_pass) spg_px_head_wsum_labels(p.head, lab);                    // (in flight under the classifier rows)
+    const unsigned inv_nq = 0xffffffffu / (unsigned)nq + 1u;               // e / nq for e < 2^16 without a division per element
+    for (int e0 = threadIdx.x; e0 < ne; e0 += 4 * 256) {      // (four loads in flight per thread, then their LDS writes)
+      f32x4 v[4];
+      int cc[4], qq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = min(e0 + 256 * k, ne - 1);
+        cc[k] = ne < 65536 ? (int)__umulhi((unsigned)e, inv_nq) : e / nq; qq[k] = e - cc[k] * nq;
+        v[k] = *reinterpret_cast<const f32x4*>(p.head.W + (long)cc[k] * p.head.nin + 4 * qq[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (e0 + 256 * k < ne) *reinterpret_cast<f32x4*>(swc + cc[k] * hd_ldw + 4 * qq[k]) = v[k];
     }
-    if (p.head.reduction_mean) spg_px_head_wsum_partials(p.head, hd_part);
+    if (one_pass) spg_px_head_wsum_from_labels(p.head, lab, hd_part);
+    else if (p.head.reduction_mean) spg_px_head_wsum_partials(p.head, hd_part);
   }
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned spin_limit = spg_px_spin_limit(p.ctl);
@@ -1324,19 +1389,6 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   f32x4 wc[MATRIX ? KMAX : 1][4];
   float wv[KMAX];
   const int kb = lane >> 3;
-#pragma unroll
-  for (int u = 0; u < KMAX; ++u) {
-    wv[u] = 0.f;
-    if (u < deg) {
-      if constexpr (MATRIX) {
-        const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)(e0 + u) * 1024);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wc[u][q] = We[lane + 64 * q];
-      } else {
-        wv[u] = p.W[(long)(e0 + u) * 32 + (lane & 31)];
-      }
-    }
-  }
   if (deg <= SPG_PX_CH && lane < deg) ids[lane] = p.g.src[e0 + lane];
   float hlog = with_head && lane < p.head.C && p.head.b != nullptr ? p.head.b[lane] : 0.f;      // the head: logit of class `lane`
   // the node's label and its class weight: wave-uniform, fetched now (two dependent loads that would sit on the tail otherwise)
@@ -1355,6 +1407,22 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
     hcur = hrow >= 0 ? p.h0[hrow * 32 + lane] : 0.f;
     p.states[(long)i * p.ldS + lane] = hcur;
     if (p.cat_all) p.out[(long)i * p.ldo + lane] = hcur;
+  }
+  // the filter loads go LAST (round 6): 48 KB per wave from HBM.  The vector-memory counter is in-order -- in front of the small loads
+  // above (source ids, initial state, label) every use of one of those waited for all the filters; behind them the first iteration's
+  // own-state part and its gather run while the filters arrive.
+#pragma unroll
+  for (int u = 0; u < KMAX; ++u) {
+    wv[u] = 0.f;
+    if (u < deg) {
+      if constexpr (MATRIX) {
+        const f32x4* We = reinterpret_cast<const f32x4*>(p.W + (long)(e0 + u) * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wc[u][q] = We[lane + 64 * q];
+      } else {
+        wv[u] = p.W[(long)(e0 + u) * 32 + (lane & 31)];
+      }
+    }
   }
   SPG_XP(0);
   for (int r = 0; r < p.R; ++r) {
