@@ -208,18 +208,32 @@ __global__ __launch_bounds__(64 * NW) void spg_narrow_pair_fwd_kernel(const SpgN
   const float ga1 = p.gamma1 ? p.gamma1[c] : 1.f, be1 = p.beta1 ? p.beta1[c] : 0.f;
   float rm1 = 0.f, rv1 = 0.f;
   if (p.rm1 != nullptr && part == 0 && blockIdx.x == 0) { rm1 = p.rm1[c]; rv1 = p.rv1[c]; }
+  // (the Gram slots' flag and row-count words as well: the count used to be loaded behind the barrier below -- one more round trip)
+  const unsigned long long gram_bad = p.gram[(size_t)SPG_FOLD_SLOTS * 2 * npairs];
+  const unsigned long long nrow = p.gram[(size_t)SPG_FOLD_SLOTS * 2 * npairs + 1];      // rows of all ranks (slot-synchronised BatchNorm), else this rank's
 
   // ---- prologue: weights into LDS; the first layer's BatchNorm constants from the Gram matrix ----
   for (int i = tid; i < SPG_NP_C * 16; i += NT) {
     const int col = i >> 4, q = i & 15;
     W2s[q * 65 + col] = *reinterpret_cast<const f32x4*>(p.W2 + (long)col * SPG_NP_C + 4 * q);
   }
-  for (int i = tid; i < SPG_NP_C * SPG_NP_W1LD; i += NT) {
-    const int col = i / SPG_NP_W1LD, k = i - col * SPG_NP_W1LD;
-    W1s[i] = k < nf ? p.W1[(long)col * nf + k] : ((k == nf && p.b1 != nullptr) ? p.b1[col] : 0.f);
+  {   // (unconditional clamped loads, all in flight, then the selects: a conditional load per element kept the trips of this loop in order)
+    constexpr int NE1 = SPG_NP_C * SPG_NP_W1LD, NI1 = (NE1 + NT - 1) / NT;
+    float wv1[NI1], bv1[NI1];
+#pragma unroll
+    for (int u = 0; u < NI1; ++u) {
+      const int i = min(tid + u * NT, NE1 - 1), col = i / SPG_NP_W1LD, k = i - col * SPG_NP_W1LD;
+      wv1[u] = p.W1[(long)col * nf + (k < nf ? k : 0)];
+      bv1[u] = p.b1 != nullptr ? p.b1[col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NI1; ++u) {
+      const int i = tid + u * NT, col = i / SPG_NP_W1LD, k = i - col * SPG_NP_W1LD;
+      if (i < NE1) W1s[i] = k < nf ? wv1[u] : (k == nf ? bv1[u] : 0.f);
+    }
   }
   {
-    const bool bad = p.gram[(size_t)SPG_FOLD_SLOTS * 2 * npairs] != 0ull;
+    const bool bad = gram_bad != 0ull;
     for (int pr = tid; pr < npairs; pr += NT) {
       int i = 0, rem = pr;
       while (rem >= Cg - i) { rem -= Cg - i; ++i; }
@@ -245,7 +259,6 @@ __global__ __launch_bounds__(64 * NW) void spg_narrow_pair_fwd_kernel(const SpgN
 #pragma unroll
     for (int m = NW / 2; m >= 1; m >>= 1) { lin += spg_shfl_xor_d(lin, m); quad += spg_shfl_xor_d(quad, m); }
     // (the arithmetic of spg_bn_fold_fwd, spg_gemm.hip)
-    const unsigned long long nrow = p.gram[(size_t)SPG_FOLD_SLOTS * 2 * npairs + 1];      // rows of all ranks (slot-synchronised BatchNorm), else this rank's
     const double M = nrow != 0ull ? (double)nrow : p.count;
     mean = lin / M;
     m2 = quad - M * mean * mean;
