@@ -1327,6 +1327,16 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = blockIdx.x * 4 + wave;
   const bool with_head = p.head.W != nullptr;      // (uniform)
+  // ONE round (GROUPS = false): the node's row of the graph is requested in front of the weight staging -- the first link of the
+  // dependent chain row -> source ids / filters; its latency hides behind the staging loads (in-order counter: no extra wait)
+  int e0_early = 0, deg_early = 0;
+  float invdeg_early = 0.f;
+  if constexpr (!GROUPS) {
+    const int i0 = __builtin_amdgcn_readfirstlane(p.groups.ptr[0] + slot);
+    const int ic = i0 < p.groups.ptr[1] ? i0 : p.groups.ptr[0];
+    e0_early = p.g.rowptr[ic]; deg_early = p.g.rowptr[ic + 1] - e0_early;
+    invdeg_early = p.g.invdeg[ic];
+  }
   SPG_XP(7);
   spg_stage_cell_weights<96>(p.gru, sw);
   SPG_XP(8);
@@ -1383,8 +1393,8 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_fwd_kernel(const Spg
   // this group's granule region, addressed with GLOBAL node ids
   unsigned long long* gran = p.gran + ((long)grp * SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES - gbase) * 32;
   spg_node_sync<true>();      // (the wave's LDS regions were last read by the previous group's final iteration)
-  const int e0 = p.g.rowptr[i], deg = p.g.rowptr[i + 1] - e0;
-  const float invdeg = p.g.invdeg[i];
+  const int e0 = GROUPS ? p.g.rowptr[i] : e0_early, deg = GROUPS ? p.g.rowptr[i + 1] - e0 : deg_early;
+  const float invdeg = GROUPS ? p.g.invdeg[i] : invdeg_early;
   // resident for all iterations: the filters of the first KMAX in-edges
   f32x4 wc[MATRIX ? KMAX : 1][4];
   float wv[KMAX];
@@ -1549,6 +1559,14 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
     spg_px_finish(p.ctl, base, (unsigned)p.R + 2u);
     return;
   }
+  int b0_early = 0, odeg_early = 0;      // (see the forward kernel: the first link of row -> edge ids -> destinations -> filters)
+  float invdeg_early = 0.f;
+  if constexpr (!GROUPS) {
+    const int j0 = __builtin_amdgcn_readfirstlane(p.groups.ptr[0] + slot);
+    const int jc = j0 < p.groups.ptr[1] ? j0 : p.groups.ptr[0];
+    b0_early = p.g.rev_rowptr[jc]; odeg_early = p.g.rev_rowptr[jc + 1] - b0_early;
+    invdeg_early = p.g.invdeg[jc];
+  }
   spg_stage_cell_weights<GW>(p.gru, sw);
   const unsigned base = __hip_atomic_load((spg_gu32*)p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned spin_limit = spg_px_spin_limit(p.ctl);
@@ -1573,8 +1591,8 @@ __global__ __launch_bounds__(256, WPC) void spg_ecc_persist_bwd_kernel(const Spg
   if (j >= p.groups.ptr[grp + 1]) continue;
   unsigned long long* gran = p.gran + ((long)grp * SPG_PX_MAX_ITERS * SPG_PX_MAX_NODES - gbase) * 32;
   spg_node_sync<true>();
-  const int b0 = p.g.rev_rowptr[j], odeg = p.g.rev_rowptr[j + 1] - b0;
-  const float invdeg = p.g.invdeg[j];
+  const int b0 = GROUPS ? p.g.rev_rowptr[j] : b0_early, odeg = GROUPS ? p.g.rev_rowptr[j + 1] - b0 : odeg_early;
+  const float invdeg = GROUPS ? p.g.invdeg[j] : invdeg_early;
   // out-edge list (edge id, destination) and the filters of the first KMAX out-edges: resident for all iterations
   if (odeg <= SPG_PX_CH && lane < odeg) {
     const int e = p.g.rev_eid[b0 + lane];
