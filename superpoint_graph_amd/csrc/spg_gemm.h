@@ -18,9 +18,14 @@ enum { SPG_EPI_FWD = 0, SPG_EPI_BWD = 1 };
 // SH = -8 (|v| <= 2^52 per contribution, quantum 2^-36: a pre-BatchNorm rms of ~3e6 over a workgroup's 512 rows is still in
 // range), backward sums SH = +8 (|v| <= 2^36, quantum 2^-52: gradients are small numbers); spg_gemm.hip: spg_fx_split.  A non-finite contribution raises the flag word behind
 // the slots and the consumer then produces NaN statistics, as the arithmetic it replaces would.
-// Slot layout of one layer: int64 [8 slots][4 limbs: sum x hi, lo, sum x^2 hi, lo][C channels], then one flag word.
+// Slot layout of one layer: int64 [SPG_FOLD_SLOTS slots][4 limbs: sum x hi, lo, sum x^2 hi, lo][C channels], then one flag word.
 // Measured (tools/probe/bn_atomic_probe.hip): +0.3..0.6 us on the producer's tail at C = 64..256, ~1 us of consumer prologue.
-#define SPG_FOLD_SLOTS 8
+#ifndef SPG_FOLD_SLOTS      // (a power of two; -DSPG_FOLD_SLOTS=n builds a variant for A/Bs)
+// 4 since the end of round 6 (8 before): every consumer workgroup reads ALL slots of its channels in its prologue -- 16 instead of 32
+// loads per channel -- and the producers' atomics do not contend more at 4 (same box, interleaved: 8 slots 1.116 ms per step, 4 slots
+// 1.106, 2 slots 1.137).  The sums are exact integers: the slot count changes no bit of any result (tools/bitcheck.py).
+#define SPG_FOLD_SLOTS 4
+#endif
 #define SPG_FOLD_MAX_CONTRIBUTIONS (1L << 21)      // (a quarter of the representable count: 8 slots x 2^19)
 inline size_t spg_fold_slot_words(int C) { return (size_t)SPG_FOLD_SLOTS * 4 * C + 8; }
 struct SpgBnFold {
