@@ -111,7 +111,7 @@ __device__ __forceinline__ void spg_bn_fold_fwd(const SpgBnFold& f, const bool f
   const bool bad = f.slots[(size_t)SPG_FOLD_SLOTS * 4 * C] != 0ull;
   const double M = spg_slots_count(f.slots, C, f.count);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    // every slot is an exact integer sum; the 8 slots are added exactly too (spg_fx_sum)
+    // every slot is an exact integer sum; the slots are added exactly too (spg_fx_sum)
     double sx = spg_fx_sum<-8>(f.slots + c, (size_t)C, (size_t)4 * C);
     const double sxx = spg_fx_sum<-8>(f.slots + 2 * (size_t)C + c, (size_t)C, (size_t)4 * C);
     if (bad) sx = __builtin_nan("");

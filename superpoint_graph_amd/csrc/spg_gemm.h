@@ -8,9 +8,9 @@ enum { SPG_EPI_FWD = 0, SPG_EPI_BWD = 1 };
 // ---- BatchNorm statistics WITHOUT a finalize launch (round 3) ----------------------------------------------------------
 // Every small dependent launch of the step costs >= ~4.5 us whatever it computes, and a train-mode BatchNorm layer used to
 // cost two of them (finalize in the forward, finalize in the backward).  Instead the PRODUCER GEMM adds its per-workgroup
-// (sum x, sum x^2) as exactly associative 64-bit FIXED-POINT integers (fire-and-forget agent-scope atomics, 8 slots per
+// (sum x, sum x^2) as exactly associative 64-bit FIXED-POINT integers (fire-and-forget agent-scope atomics, SPG_FOLD_SLOTS slots per
 // channel so that at most ~64 workgroups meet on one address), and the CONSUMER GEMM -- the next layer, which needs the scale /
-// shift anyway -- sums the 8 slots per channel in its prologue, computes mean / rstd / scale / shift in float64 and writes
+// shift anyway -- sums the slots of a channel in its prologue, computes mean / rstd / scale / shift in float64 and writes
 // them (every workgroup writes the same bits; workgroup 0 also advances the running statistics).  Integer addition is
 // order-independent, so the result is deterministic (bit-identical from run to run) although the arrival order is not.
 // Representation of a double v: hi = floor(v * 2^SH), lo = frac(v * 2^SH) * 2^44 (both int64), up to 2^19 contributions per
@@ -26,7 +26,7 @@ enum { SPG_EPI_FWD = 0, SPG_EPI_BWD = 1 };
 // 1.106, 2 slots 1.137).  The sums are exact integers: the slot count changes no bit of any result (tools/bitcheck.py).
 #define SPG_FOLD_SLOTS 4
 #endif
-#define SPG_FOLD_MAX_CONTRIBUTIONS (1L << 21)      // (a quarter of the representable count: 8 slots x 2^19)
+#define SPG_FOLD_MAX_CONTRIBUTIONS ((long)SPG_FOLD_SLOTS << 17)      // (a quarter of the representable count: SPG_FOLD_SLOTS x 2^19)
 inline size_t spg_fold_slot_words(int C) { return (size_t)SPG_FOLD_SLOTS * 4 * C + 8; }
 struct SpgBnFold {
   const unsigned long long* slots;   // null: nothing to do
