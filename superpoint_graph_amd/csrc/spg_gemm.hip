@@ -828,13 +828,8 @@ __device__ __forceinline__ void spg_rowgemm_body(const SpgGemmParams& p, const i
     // chunk are issued after the epilogue instead of under the last chunk -- nothing but the accumulators and the
     // loop-invariant offsets is then live across the epilogue (no spills)
     constexpr bool DEFER2 = WRED;      // (tried for the forward as well, round 6: 1.139 -> 1.143 ms per step)
-    // Two workgroups share a CU (launch bounds); dispatched together they run the same phases at the same time -- both in the
-    // epilogue = no MFMA work on that CU.  The second round of workgroups (b >= 256 lands on the CU of b - 256) starts ~2 us late, so
-    // that one's epilogue falls under the other's chunk loop (A/B on one box, 2 x 2 runs: 1.153 -> 1.148 ms per step, 8 scenes
-    // 6.90 -> 6.86; 4 us the same, 8 us nothing).  Timing only: no effect on any result.
-#ifndef SPG_NO_STAGGER
-    if (STREAM && !WRED && ((bx >> 8) & 1)) { __builtin_amdgcn_s_sleep(32); __builtin_amdgcn_s_sleep(32); }
-#endif
+    // (a 2 us start offset for the second round of workgroups -- anti-phase of the two workgroups of a CU -- gained 0.4 % while the
+    //  streams' statistics still lived in scratch memory; with them in registers it measures 0.0 % at 1 and 8 scenes: removed)
     for (;;) {
       tile = __builtin_amdgcn_readfirstlane(tile);             // wave-uniform by construction: keep the tile stream in SGPRs
       m0 = (long)tile * p.rows_per_tile;
