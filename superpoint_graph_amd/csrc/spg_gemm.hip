@@ -2158,12 +2158,22 @@ extern "C" int spg_pair_role_times(unsigned long long* out, int clear) {
   return 0;
 }
 #define SPG_T0() unsigned long long t__ = __builtin_readcyclecounter(), tp__[4] = {0, 0, 0, t__ - tent__}
-#define SPG_TENTRY() const unsigned long long tent__ = __builtin_readcyclecounter()
+#define SPG_TENTRY() const unsigned long long tent__ = __builtin_readcyclecounter(); unsigned long long te__ = tent__, tq__[4] = {0, 0, 0, 0}
+#define SPG_TQ(k) { const unsigned long long n__ = __builtin_readcyclecounter(); tq__[k] += n__ - te__; te__ = n__; }
+#define SPG_TQEND() if (threadIdx.x == 0) { const int sh__ = (CO == 128) + (CI == 128); for (int k__ = 0; k__ < 4; ++k__) atomicAdd(&spg_pair_entry_t[sh__][k__], tq__[k__]); }
+__device__ unsigned long long spg_pair_entry_t[3][4];
+extern "C" int spg_pair_entry_times(unsigned long long* out, int clear) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(spg_pair_entry_t), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
+  if (clear) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(spg_pair_entry_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
 #define SPG_TP(k) { const unsigned long long n__ = __builtin_readcyclecounter(); tp__[k] += n__ - t__; t__ = n__; }
 #define SPG_TEND(role) if ((threadIdx.x & 255) == 0) { const int sh__ = (CO == 128) + (CI == 128); for (int k__ = 0; k__ < 4; ++k__) atomicAdd(&spg_pair_role_t[sh__][role][k__], tp__[k__]); }
 #else
 #define SPG_T0()
 #define SPG_TENTRY()
+#define SPG_TQ(k)
+#define SPG_TQEND()
 #define SPG_TP(k)
 #define SPG_TEND(role)
 #endif
@@ -2217,7 +2227,9 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
       }
     }
     if (g.stat_slots != nullptr && p.pass != 1 && blockIdx.x == 0 && tid == 0) spg_slots_count_add(g.stat_slots, g.n_mask, g.stat_rows != 0 ? g.stat_rows : (long)g.M);
+    SPG_TQ(0);
     if (g.fold_bwd.slots != nullptr) spg_bn_fold_bwd(g.fold_bwd, blockIdx.x == 0);
+    SPG_TQ(1);
     if (tid < CQ) {
       kst[0 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c0 + 4 * tid); kst[1 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c1 + 4 * tid);
       kst[2 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c2 + 4 * tid); kst[3 * CQ + tid] = *reinterpret_cast<const f32x4*>(g.a.c3 + 4 * tid);
@@ -2233,6 +2245,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
       }
     }
     __syncthreads();                              // constants and W are in LDS
+    SPG_TQ(2);
   };
 
   if (role >= 2) {
@@ -2341,6 +2354,7 @@ __global__ __launch_bounds__(SPG_PAIR_THREADS) void spg_bwdpair_kernel(const Spg
     sacc.n = 0.f; sacc.a[0] = 0.f; sacc.b[0] = 0.f;
     sacc.s1 = f32x4{0.f, 0.f, 0.f, 0.f}; sacc.s2 = sacc.s1;
     __syncthreads();
+    SPG_TQ(3); SPG_TQEND();
     int buf = 0;
     SPG_T0();
     for (;;) {

@@ -35,11 +35,15 @@ def main():
     for _ in range(n): run()
     torch.cuda.synchronize()
     h.spg_pair_role_times(buf, 0)
+    h.spg_pair_entry_times.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    eb = (ctypes.c_ulonglong * 12)()
+    h.spg_pair_entry_times(eb, 0)
     names = ['64->64 (x2 launches)', '64->128 (CO 128, CI 64; x2)', '128->128']
     launches = [2, 2, 1]
     phases = {0: ['mfma', 'epilogue', 'barrier wait', '-'], 1: ['mfma', '-', 'barrier wait', '-'], 2: ['finish+write tile (incl. data wait)', 'issue loads', 'barrier wait', '-']}
     for sh in range(3):
         print(names[sh])
+        print('   entry of the data-gradient wave 0 (cycles per launch and workgroup; includes the warm-up launches): up to the fold %.0f, fold %.0f, constants + W -> LDS + barrier %.0f, first tile ready %.0f' % tuple(eb[sh * 4 + k] / ((n + 5) * launches[sh] * 256) for k in range(4)))
         for role, rn in enumerate(['data gradient', 'weight gradient', 'loader']):
             # summed over 256 workgroups x (1 wave for the matrix roles | 2 waves (tid % 256 == 0) for the loaders)
             div = n * launches[sh] * 256 * (2 if role == 2 else 1)
