@@ -471,7 +471,8 @@ __device__ __forceinline__ void spg_epilogue_fwd(const SpgGemmParams& p, f32x16 
     if (n0 == 0 && p.pool_extra != nullptr)
       for (int e = tid; e < p.pool_nextra; e += SPG_THREADS)
         p.pool_out[(long)tile * p.pool_ld + p.N + e] = p.pool_extra[(long)tile * p.pool_nextra + e];
-    __syncthreads();       // the exchange area is reused by the next tile of a persistent workgroup
+    // (no barrier here any more: every caller follows the epilogue with a workgroup barrier before anything writes this LDS region
+    //  again -- the tile loop's own barrier, the one in front of the stream's final statistics merge -- or with nothing at all)
     SPG_EP(3);
   }
 }
