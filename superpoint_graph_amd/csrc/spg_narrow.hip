@@ -28,6 +28,10 @@
 namespace {
 
 #define SPG_NP_C 64                 // output channels of both layers
+// stores of the two raw outputs (y1 is read again by the backward pass only, y2 by the next layer and by the backward pass): NON-TEMPORAL,
+// as the row-GEMMs' outputs (spg_gemm.hip: spg_store_tile_vec_impl) -- same box, interleaved: y1 -0.2 %, y1 and y2 -0.55 % of the step
+#define SPG_NP_ST1(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#define SPG_NP_ST2(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #define SPG_NP_W1LD 33              // floats per row of the W1 copy in LDS (<= 32 input channels + pad)
 #define SPG_NP_A_SLOTS (16 * 33)    // float4 slots of one wave's activation tile: 16 planes (64 channels / 4) x (32 rows + 1)
 #define SPG_NP_W2_SLOTS (16 * 65)   // float4 slots of W2 in out-major layout: 16 planes x (64 columns + 1)
@@ -375,9 +379,9 @@ __global__ __launch_bounds__(64 * NW) void spg_narrow_pair_fwd_kernel(const SpgN
             // one store in the shadow of this MFMA: slots 0 .. 31 this block's y1, 32 .. 63 the previous block's y2
             const int slot = (gq * 4 + s) * 2 + j, e = slot & 31, ej = e >> 4, eq = e & 15, rl = (eq & 3) + 8 * (eq >> 2);
             if (slot < 32) {
-              if (eq < 8) y1a[rl * SPG_NP_C + 32 * ej] = acc[ej][eq]; else y1b[(rl - 16) * SPG_NP_C + 32 * ej] = acc[ej][eq];
+              SPG_NP_ST1(eq < 8 ? y1a + rl * SPG_NP_C + 32 * ej : y1b + (rl - 16) * SPG_NP_C + 32 * ej, acc[ej][eq]);
             } else if (have_prev) {
-              if (eq < 8) y2a[rl * SPG_NP_C + 32 * ej] = yprev[ej][eq]; else y2b[(rl - 16) * SPG_NP_C + 32 * ej] = yprev[ej][eq];
+              SPG_NP_ST2(eq < 8 ? y2a + rl * SPG_NP_C + 32 * ej : y2b + (rl - 16) * SPG_NP_C + 32 * ej, yprev[ej][eq]);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(64 * NW) void spg_narrow_pair_fwd_kernel(const SpgN
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int rl = (q & 3) + 8 * (q >> 2);
-        if (q < 8) y2a[rl * SPG_NP_C + 32 * j] = yprev[j][q]; else y2b[(rl - 16) * SPG_NP_C + 32 * j] = yprev[j][q];
+        SPG_NP_ST2(q < 8 ? y2a + rl * SPG_NP_C + 32 * j : y2b + (rl - 16) * SPG_NP_C + 32 * j, yprev[j][q]);
       }
   }
   // ONE statistics contribution per workgroup and column: the waves' triples meet in LDS (their tiles are free now) and wave 0
